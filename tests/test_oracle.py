@@ -1,0 +1,137 @@
+"""CPU: pin the oracle.
+
+* oracle.net  vs fixtures written by the REFERENCE's torch modules (tests/golden/make_golden.py).
+* oracle.mel  vs its own committed fixture (regression only -- the mel stage is "parity unpinned":
+  no librosa here, see oracle/mel.py) plus independent properties (float64 direct DFT, Parseval-type
+  checks, filterbank shape/normalisation facts that librosa documents).
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from nisqa_amd import synth
+from oracle import mel as omel, net as onet
+
+CLIPS = [('seed', 0, 1.0), ('seed', 1, 3.0), ('seed', 2, 10.0), ('seed', 3, 2.37),
+         ('edge', 'zeros', 0), ('edge', 'sine', 0), ('edge', 'min', 0), ('edge', 'max', 0)]
+
+
+def clip_pcm(i):
+    c = CLIPS[i]
+    return synth.synth_pcm16(c[1], c[2]) if c[0] == 'seed' else synth.edge_clip(c[1])
+
+
+def clip_spec(i):
+    return omel.melspec_db_from_audio(clip_pcm(i).astype(np.float32) / np.float32(32768.0), 48000)
+
+
+def test_synth_is_reproducible():
+    g = helpers.golden('mel_oracle.npz')
+    for i in (0, 3, 4, 5, 6):
+        assert zlib.crc32(clip_pcm(i).tobytes()) == int(g['pcm_crc32'][i])
+
+
+def test_mel_oracle_regression():
+    g = helpers.golden('mel_oracle.npz')
+    for i in (0, 3, 6):
+        np.testing.assert_allclose(clip_spec(i), g['mel_%d' % i], rtol=0, atol=2e-4)
+
+
+def test_mel_oracle_frame_and_segment_counts():
+    g = helpers.golden('mel_oracle.npz')
+    # 10 s @ 48 kHz -> 1001 frames -> 247 segments
+    assert int(g['n_frames'][2]) == 1001 and onet.n_wins_of(1001) == 247
+    assert int(g['n_frames'][6]) == 15 and onet.n_wins_of(15) == 1
+    assert onet.n_wins_of(int(g['n_frames'][7])) == 1300
+
+
+def test_stft_matches_direct_dft_float64():
+    rng = np.random.default_rng(5)
+    y = (rng.standard_normal(4000) * 0.1).astype(np.float32)
+    S = omel.stft_mag(y, 4096, 480, 960)
+    assert S.shape == (2049, 1 + 4000 // 480)
+    ypad = np.pad(y.astype(np.float64), 2048, mode='reflect')
+    w = omel.hann_periodic(960)
+    t = 3
+    fr = ypad[t * 480 + 1568: t * 480 + 1568 + 960] * w
+    for k in (0, 1, 7, 500, 1706, 2048):
+        ph = np.exp(-2j * np.pi * k * (np.arange(960) + 1568) / 4096.0)
+        assert abs(abs(np.sum(fr * ph)) - S[k, t]) < 1e-5 * max(1.0, S[k, t])
+
+
+def test_filterbank_properties():
+    fb = omel.mel_filterbank(48000, 4096, 48, 0.0, 20000.0)
+    assert fb.shape == (48, 2049) and fb.dtype == np.float32
+    nz = fb > 0
+    assert np.where(nz.any(0))[0].max() == 1706                    # SURVEY: <=1707 non-zero bins
+    assert (nz.sum(0) <= 2).all()                                   # triangles overlap pairwise only
+    # slaney norm: each triangle has (approximately) unit area in Hz
+    area = fb.sum(1) * (48000 / 4096.0)
+    assert np.allclose(area, 1.0, atol=0.05)
+    # 16 kHz audio with fmax 20000: bands above Nyquist are empty (librosa warns, result is zeros)
+    fb16 = omel.mel_filterbank(16000, 4096, 48, 0.0, 20000.0)
+    assert (fb16[-1] == 0).all() and fb16[0].any()
+
+
+def test_db_floor_and_clamp():
+    S = np.array([[0.0, 1e-6, 1e-4, 1.0, 100.0]], dtype=np.float32)
+    d = omel.amplitude_to_db(S)
+    assert np.allclose(d, [[-40.0, -40.0, -40.0, 0.0, 40.0]], atol=1e-4)   # max 40 -> floor -40
+    d2 = omel.amplitude_to_db(S[:, :4])
+    assert np.allclose(d2, [[-80.0, -80.0, -80.0, 0.0]], atol=1e-4)
+
+
+@pytest.mark.parametrize('name', ['dim_real', 'dim_rand', 'mos_real', 'mos_rand'])
+def test_net_oracle_matches_reference_fixture(name):
+    g = helpers.golden('net_%s.npz' % name)
+    if name.endswith('real'):
+        path = helpers.find_weights('nisqa.tar' if name.startswith('dim') else 'nisqa_mos_only.tar')
+        if path is None:
+            pytest.skip('real checkpoint not on this machine')
+        args, sd = helpers.load_checkpoint(path)
+    elif name == 'dim_rand':
+        args, sd = dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM')
+    else:
+        args, sd = dict(helpers.MOS_ARGS), helpers.random_state_dict(8, 'NISQA')
+    for i in range(len(CLIPS) - 1):              # the 52 s clip is covered by test_net_oracle_max_length
+        out, st = onet.predict_from_melspec(sd, args, clip_spec(i), return_stages=True)
+        assert st['n_wins'] == int(g['n_wins'][i])
+        np.testing.assert_allclose(out, g['out'][i], rtol=0, atol=2e-5)
+        if i in (0, 3, 6):
+            np.testing.assert_allclose(st['feat'], g['feat_%d' % i], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(st['td'], g['td_%d' % i], rtol=0, atol=2e-5)
+
+
+def test_net_oracle_max_length():
+    g = helpers.golden('net_dim_rand.npz')
+    args, sd = dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM')
+    out, st = onet.predict_from_melspec(sd, args, clip_spec(7), return_stages=True)
+    assert st['n_wins'] == 1300
+    np.testing.assert_allclose(out, g['out'][7], rtol=0, atol=5e-5)
+
+
+def test_segment_errors():
+    with pytest.raises(ValueError, match='too short'):
+        onet.segment_specs(np.zeros((48, 14), np.float32))
+    with pytest.raises(ValueError, match='must be odd'):
+        onet.segment_specs(np.zeros((48, 40), np.float32), seg_length=14)
+    with pytest.raises(ValueError, match='max_length'):
+        onet.segment_specs(np.zeros((48, 100), np.float32), max_length=5)
+
+
+def test_net_oracle_against_live_reference():
+    """Extra pin where the reference tree exists (build container): random clip, live modules."""
+    from oracle import ref_shim
+    if not ref_shim.reference_available():
+        pytest.skip('reference tree not present')
+    args, sd = dict(helpers.DIM_ARGS), helpers.random_state_dict(11, 'NISQA_DIM')
+    model, NL = ref_shim.build_reference_model(args, sd)
+    spec = (np.random.default_rng(3).standard_normal((48, 123)) * 20 - 40).astype(np.float32)
+    x, n = NL.segment_specs('t', spec, 15, 4, 1300)
+    with torch.no_grad():
+        ref = model(x.unsqueeze(0), torch.tensor([int(n)])).numpy()[0]
+    out = onet.predict_from_melspec(sd, args, spec)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
