@@ -1,0 +1,152 @@
+/*
+ * nisqa_hip.h -- C ABI of libnisqa_hip.so: the MI355X (gfx950) implementation of the NISQA
+ * predict hot path.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * The reference (gabrielmittag/NISQA) has no FFI of its own: its hot path is Python
+ * (SURVEY.md section 8b).  Each entry point below names the reference code it replaces, so a
+ * maintainer can bind it with ctypes from nisqa/NISQA_lib.py.
+ *
+ * Conventions
+ *   - every pointer marked [dev] is caller-owned DEVICE memory; the library never allocates or
+ *     frees caller memory and never synchronises the device;
+ *   - `stream` is the caller's hipStream_t (passed as void*); all work is enqueued on it;
+ *   - return value: 0 = NISQA_OK, otherwise a NISQA_ERR_* code; launch errors are reported as
+ *     NISQA_ERR_LAUNCH (query hipGetLastError for detail);
+ *   - shapes: B clips; clip b has len[b] samples, T[b] = 1 + len[b]/hop frames and
+ *     n[b] = ceil((T[b] - (seg_length-1)) / seg_hop) segments ("tokens");
+ *       frame_off[B+1] = exclusive prefix sum of T          (int32)
+ *       tok_off[B+1]   = exclusive prefix sum of round_up(n, 32)  (int32)  -- tokens are stored
+ *                        PADDED to 32 per clip so attention tiles never straddle clips;
+ *     TT = frame_off[B], NP = tok_off[B].
+ *   - the mel spectrogram is kept FRAME-MAJOR on the device: mel_tm[TT][n_mels]
+ *     (the reference's per-clip array is its transpose, [n_mels][T]).
+ */
+#ifndef NISQA_HIP_H
+#define NISQA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NISQA_OK 0
+#define NISQA_ERR_ARG 1        /* bad argument / unsupported configuration */
+#define NISQA_ERR_LAUNCH 2     /* a kernel launch failed */
+#define NISQA_ERR_WORKSPACE 3  /* workspace too small */
+
+#define NISQA_ABI_VERSION 1
+#define NISQA_N_MELS 48
+#define NISQA_SEG_LEN 15
+#define NISQA_N_FFT 4096
+#define NISQA_FEAT 384          /* AdaptCNN fan-out: 64 channels x 6 rows (NISQA_lib.py:681-684) */
+#define NISQA_DMODEL 64
+
+int nisqa_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Mel front end: replaces get_librosa_melspec (nisqa/NISQA_lib.py:2284-2331) after lb.load:
+ * centre/reflect-padded STFT (n_fft 4096, periodic hann of `win` samples), magnitude,
+ * slaney mel filterbank, amplitude_to_db(ref=1, amin=1e-4, top_db=80).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t n_fft;      /* must be 4096 */
+    int32_t hop;        /* int(sr * ms_hop_length), NISQA_lib.py:2308 */
+    int32_t win;        /* int(sr * ms_win_length) <= 1024, NISQA_lib.py:2309 */
+    int32_t n_mels;     /* must be 48 */
+    int32_t n_bins;     /* number of FFT bins with a non-zero mel weight (k = 0 .. n_bins-1), <= 2049 */
+    float   amin_sq;    /* amin^2 = 1e-8 */
+    float   top_db;     /* 80 */
+} nisqa_mel_cfg;
+
+/* Tables (all [dev]), built by the host from the checkpoint's ms_* arguments:
+ *   window[win]                 float  periodic hann
+ *   twiddle[4096][2]            float  (cos, -sin)(2*pi*k/4096)
+ *   band_start/len/woff[n_mels] int32  sparse rows of the mel filterbank: band m has non-zero
+ *                                      weights band_w[woff[m] .. woff[m]+len[m]) on bins
+ *                                      start[m] .. start[m]+len[m])
+ * pcm[dev] float mono samples of all clips back to back, clip b at [clip_off[b], clip_off[b+1]).
+ * Outputs: mel_tm[TT][48] UNCLAMPED dB, clip_max_enc[B] (must be zero-filled by the caller;
+ * receives an order-preserving uint32 encoding of the per-clip maximum dB).
+ */
+int nisqa_mel_db(const float* pcm, const int64_t* clip_off, const int32_t* frame_off,
+                 int32_t n_clips, int32_t total_frames, const nisqa_mel_cfg* cfg,
+                 const float* window, const float* twiddle,
+                 const int32_t* band_start, const int32_t* band_len, const int32_t* band_woff,
+                 const float* band_w,
+                 float* mel_tm, uint32_t* clip_max_enc, void* stream);
+
+/* Per-clip dB floor = max - top_db (the librosa top_db clamp, NISQA_lib.py:2330).  Writes
+ * clip_floor[B]; when clamp_in_place != 0 also applies max(x, floor) to mel_tm so that it equals
+ * the reference spectrogram (the CNN applies the floor on load, so the fused path passes 0). */
+int nisqa_mel_finalize(float* mel_tm, const int32_t* frame_off, int32_t n_clips,
+                       int32_t total_frames, const uint32_t* clip_max_enc, float top_db,
+                       float* clip_floor, int32_t clamp_in_place, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Framewise CNN: replaces segment_specs (NISQA_lib.py:2239-2282) + Framewise.forward /
+ * AdaptCNN.forward (NISQA_lib.py:487-502, 688-710).  Segments are never materialised: token
+ * k of clip b reads frames [frame_off[b] + k*seg_hop, +15) of mel_tm directly.
+ * Weights: `cnn_w` is the packed blob produced by nisqa_amd.weights.pack_adapt_cnn (layout in
+ * DESIGN.md); BatchNorm (eval) is folded into the conv weights/biases.
+ * Output feat[NP][384] in the reference's flatten order (channel*6 + row, NISQA_lib.py:706);
+ * rows of padding tokens are left untouched.  p3_ws: scratch [NP][18][64] floats.
+ * ------------------------------------------------------------------------------------------ */
+int nisqa_cnn_adapt(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                    const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                    int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
+                    float* p3_ws, float* feat, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Time dependency: replaces SelfAttention.forward + 2 x SelfAttentionLayer.forward
+ * (NISQA_lib.py:988-996, 1025-1040): Linear 384->64, LayerNorm, then per layer masked
+ * single-head attention (d=64, scale 1/8), out-proj, residual+LN, FFN(ReLU), residual+LN.
+ * td_w: packed blob from nisqa_amd.weights.pack_self_att.  ws: scratch, 6*NP*64 floats
+ * (q, k, v-transposed; double-buffered across layers).  x_out[NP][64].
+ * ------------------------------------------------------------------------------------------ */
+int nisqa_td_selfatt(const float* feat, const int32_t* tok_off, const int32_t* n_wins,
+                     int32_t n_clips, int32_t total_tok_padded, int32_t n_layers,
+                     const float* td_w, float* ws, float* x_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling heads: replaces n_heads x PoolAttFF.forward (NISQA_lib.py:1171-1183) and the
+ * torch.cat of NISQA_DIM.forward (NISQA_lib.py:265-266).  n_heads = 5 (NISQA_DIM: mos, noi,
+ * dis, col, loud) or 1 (NISQA).  pool_w: packed blob from nisqa_amd.weights.pack_pool_att.
+ * ws: scratch 2*NP*8 floats.  out[B][n_heads].
+ * ------------------------------------------------------------------------------------------ */
+int nisqa_pool_att(const float* x, const int32_t* tok_off, const int32_t* n_wins,
+                   int32_t n_clips, int32_t total_tok_padded, int32_t n_heads,
+                   const float* pool_w, float* ws, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole forward for one batch: replaces the body of the per-batch step of predict_dim /
+ * predict_mos (NISQA_lib.py:1420-1467): PCM in, [B][n_heads] out.  Internally the calls above,
+ * carving scratch out of `ws` (size from nisqa_workspace_bytes).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* window; const float* twiddle;
+    const int32_t* band_start; const int32_t* band_len; const int32_t* band_woff; const float* band_w;
+    const float* cnn_w; const float* td_w; const float* pool_w;
+    int32_t n_layers; int32_t n_heads; int32_t seg_hop;
+} nisqa_model_dev;
+
+size_t nisqa_workspace_bytes(int32_t n_clips, int32_t total_frames, int32_t total_tok_padded);
+
+int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, const int32_t* frame_off,
+                        const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                        int32_t total_frames, int32_t total_tok_padded,
+                        const nisqa_mel_cfg* cfg, const nisqa_model_dev* model,
+                        void* ws, size_t ws_bytes, float* out, void* stream);
+
+/* int16 PCM -> float32 (x / 32768), the soundfile scaling lb.load applies (NISQA_lib.py:2304). */
+int nisqa_pcm16_to_f32(const int16_t* pcm16, float* pcm, int64_t n, void* stream);
+
+/* Self-test of the MFMA fragment maps the kernels rely on: D = A(32xK) * B(Kx32) with
+ * v_mfma_f32_32x32x2_f32, a/b/d [dev] row-major.  Used by tests only. */
+int nisqa_selftest_mfma(const float* a, const float* b, float* d, int32_t k, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NISQA_HIP_H */

@@ -1,0 +1,78 @@
+// libnisqa_hip.so: ABI glue -- version, workspace carving, the whole-batch forward and the MFMA
+// fragment-map self-test.  See include/nisqa_hip.h for the contract.
+#include "common.hpp"
+#include "../../include/nisqa_hip.h"
+
+extern "C" int nisqa_abi_version(void) { return NISQA_ABI_VERSION; }
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct ws_plan {
+    size_t mel, cmax, cfloor, p3, feat, td, x, pool, total;
+};
+
+static ws_plan plan_ws(int32_t n_clips, int32_t total_frames, int32_t np) {
+    ws_plan p;
+    size_t o = 0;
+    p.mel = o;    o += align256((size_t)total_frames * NISQA_N_MELS * 4);
+    p.cmax = o;   o += align256((size_t)n_clips * 4);
+    p.cfloor = o; o += align256((size_t)n_clips * 4);
+    p.p3 = o;     o += align256((size_t)np * 18 * 64 * 4);
+    p.feat = o;   o += align256((size_t)np * NISQA_FEAT * 4);
+    p.td = o;     o += align256((size_t)np * 64 * 6 * 4);
+    p.x = o;      o += align256((size_t)np * 64 * 4);
+    p.pool = o;   o += align256((size_t)np * 8 * 2 * 4);
+    p.total = o;
+    return p;
+}
+
+extern "C" size_t nisqa_workspace_bytes(int32_t n_clips, int32_t total_frames, int32_t total_tok_padded) {
+    if (n_clips <= 0 || total_frames <= 0 || total_tok_padded <= 0) return 0;
+    return plan_ws(n_clips, total_frames, total_tok_padded).total;
+}
+
+extern "C" int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, const int32_t* frame_off,
+                                   const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                                   int32_t total_frames, int32_t total_tok_padded, const nisqa_mel_cfg* cfg,
+                                   const nisqa_model_dev* model, void* ws, size_t ws_bytes, float* out, void* stream) {
+    if (!cfg || !model || !ws || n_clips <= 0 || total_frames <= 0 || total_tok_padded <= 0) return NISQA_ERR_ARG;
+    const ws_plan p = plan_ws(n_clips, total_frames, total_tok_padded);
+    if (ws_bytes < p.total) return NISQA_ERR_WORKSPACE;
+    char* w = (char*)ws;
+    float* mel = (float*)(w + p.mel);
+    uint32_t* cmax = (uint32_t*)(w + p.cmax);
+    float* cfloor = (float*)(w + p.cfloor);
+    float* p3 = (float*)(w + p.p3);
+    float* feat = (float*)(w + p.feat);
+    float* td = (float*)(w + p.td);
+    float* x = (float*)(w + p.x);
+    float* pool = (float*)(w + p.pool);
+    if (hipMemsetAsync(cmax, 0, (size_t)n_clips * 4, (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH;
+    int rc = nisqa_mel_db(pcm, clip_off, frame_off, n_clips, total_frames, cfg, model->window, model->twiddle,
+                          model->band_start, model->band_len, model->band_woff, model->band_w, mel, cmax, stream);
+    if (rc) return rc;
+    rc = nisqa_mel_finalize(mel, frame_off, n_clips, total_frames, cmax, cfg->top_db, cfloor, 0, stream);
+    if (rc) return rc;
+    rc = nisqa_cnn_adapt(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
+                         model->cnn_w, p3, feat, stream);
+    if (rc) return rc;
+    rc = nisqa_td_selfatt(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w, td, x, stream);
+    if (rc) return rc;
+    return nisqa_pool_att(x, tok_off, n_wins, n_clips, total_tok_padded, model->n_heads, model->pool_w, pool, out, stream);
+}
+
+// D[32][32] = A[32][k] * B[k][32] with the fragment maps of common.hpp (k even)
+__global__ __launch_bounds__(64) void selftest_mfma_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ d, int k) {
+    const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+    f32x16 acc = zero16();
+    for (int kk = 0; kk < k; kk += 2) acc = mfma32(a[i * k + kk + h], b[(kk + h) * 32 + i], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[NQ_DROW(r, h) * 32 + i] = acc[r];
+}
+
+extern "C" int nisqa_selftest_mfma(const float* a, const float* b, float* d, int32_t k, void* stream) {
+    if (k <= 0 || (k & 1)) return NISQA_ERR_ARG;
+    hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, d, k);
+    return hipGetLastError() == hipSuccess ? NISQA_OK : NISQA_ERR_LAUNCH;
+}

@@ -1,0 +1,63 @@
+// Shared device helpers for the NISQA gfx950 kernels.
+//
+// Matrix work uses v_mfma_f32_32x32x2_f32 (f32 in / f32 accumulate, bitwise an fmaf chain), so the
+// network keeps the reference's fp32 arithmetic.  Fragment maps (wave64), lane l:
+//   A (32 x 2): A[i = l & 31][k = l >> 5]            one VGPR
+//   B (2 x 32): B[k = l >> 5][j = l & 31]            one VGPR
+//   D (32 x 32): reg r of lane l = D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l & 31]
+// Throughout the kernels a K-step covers 8 consecutive k: lane half h = l>>5 loads the float4
+// k = 8s+4h .. 8s+4h+3 for its row/col, and MFMA kk of the step pairs k = 8s+kk (h=0) with
+// k = 8s+4+kk (h=1).  Weight fragments are pre-packed on the host in exactly that order
+// ([step][tile][lane][4] floats) so every wave-load is one contiguous 1 KiB read.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NQ_DEV static __device__ __forceinline__
+
+NQ_DEV f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+NQ_DEV f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// D-fragment row of register r for lane half hf
+#define NQ_DROW(r, hf) (((r) & 3) + 8 * ((r) >> 2) + 4 * (hf))
+
+// Largest b in [0, n) with off[b] <= p   (off is an exclusive prefix sum, off[n] > p).
+NQ_DEV int find_segment(const int32_t* __restrict__ off, int n, int p) {
+    int lo = 0, hi = n;            // invariant: off[lo] <= p < off[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (off[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// order-preserving float <-> uint32 (for atomicMax on floats of either sign)
+NQ_DEV uint32_t enc_ordered(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+NQ_DEV float dec_ordered(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+NQ_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+NQ_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}

@@ -1,0 +1,53 @@
+// Packed-weight blob layouts shared by the kernels (device side) and mirrored in
+// nisqa_amd/weights.py (host side).  All offsets are in floats and multiples of 4.
+#pragma once
+
+// ---- AdaptCNN blob ("cnn_w") -------------------------------------------------------------
+// conv1: folded weights w1[16][9] (c_out, tap = dy*3+dx) and bias t1[16]  (VALU path)
+// conv2..6: MFMA B-fragments wf[tap][step][ntile][lane][4] and bias t[c_out]
+//   value(tap, s, nt, lane, kk) = W[n = (lane&31) + 32*nt][c = 8*s + 4*(lane>>5) + kk][tap] * bn_scale[n]
+#define CNN_W1 0
+#define CNN_T1 (CNN_W1 + 16 * 9)
+#define CNN_WF2 (CNN_T1 + 16)
+#define CNN_T2 (CNN_WF2 + 9 * 2 * 1 * 256)
+#define CNN_WF3 (CNN_T2 + 32)
+#define CNN_T3 (CNN_WF3 + 9 * 4 * 2 * 256)
+#define CNN_WF4 (CNN_T3 + 64)
+#define CNN_T4 (CNN_WF4 + 9 * 8 * 2 * 256)
+#define CNN_WF5 (CNN_T4 + 64)
+#define CNN_T5 (CNN_WF5 + 9 * 8 * 2 * 256)
+#define CNN_WF6 (CNN_T5 + 64)
+#define CNN_T6 (CNN_WF6 + 9 * 8 * 2 * 256)
+#define CNN_W_FLOATS (CNN_T6 + 64)
+
+// ---- self-attention blob ("td_w") ----------------------------------------------------------
+// A-fragments af[step][mtile][lane][4]:
+//   value(s, mt, lane, kk) = W[row = (lane&31) + 32*mt][k = 8*s + 4*(lane>>5) + kk]
+// proj: W = linear.weight [64][384] (48 steps, 2 mtiles); then vectors of 64.
+#define TD_PROJ_AF 0
+#define TD_PROJ_B (TD_PROJ_AF + 48 * 2 * 256)
+#define TD_LN0_G (TD_PROJ_B + 64)
+#define TD_LN0_B (TD_LN0_G + 64)
+#define TD_LAYER0 (TD_LN0_B + 64)
+// per layer (offsets relative to the layer base)
+#define TDL_QKV_AF 0                              /* in_proj_weight [192][64]: 8 steps, 6 mtiles */
+#define TDL_QKV_B (TDL_QKV_AF + 8 * 6 * 256)      /* 192 */
+#define TDL_OUT_AF (TDL_QKV_B + 192)              /* out_proj.weight [64][64]: 8 steps, 2 mtiles */
+#define TDL_OUT_B (TDL_OUT_AF + 8 * 2 * 256)
+#define TDL_LN1_G (TDL_OUT_B + 64)
+#define TDL_LN1_B (TDL_LN1_G + 64)
+#define TDL_FF1_AF (TDL_LN1_B + 64)               /* linear1.weight [64][64] */
+#define TDL_FF1_B (TDL_FF1_AF + 8 * 2 * 256)
+#define TDL_FF2_AF (TDL_FF1_B + 64)               /* linear2.weight [64][64] */
+#define TDL_FF2_B (TDL_FF2_AF + 8 * 2 * 256)
+#define TDL_LN2_G (TDL_FF2_B + 64)
+#define TDL_LN2_B (TDL_LN2_G + 64)
+#define TDL_FLOATS (TDL_LN2_B + 64)
+
+// ---- pooling blob ("pool_w"), per head ------------------------------------------------------
+#define PL_W1_AF 0                                /* linear1.weight [128][64]: 8 steps, 4 mtiles */
+#define PL_B1 (PL_W1_AF + 8 * 4 * 256)            /* 128 */
+#define PL_W2 (PL_B1 + 128)                       /* linear2.weight [128] */
+#define PL_W3 (PL_W2 + 128)                       /* linear3.weight [64] */
+#define PL_B2 (PL_W3 + 64)                        /* linear2.bias, linear3.bias, pad, pad */
+#define PL_FLOATS (PL_B2 + 4)

@@ -1,0 +1,196 @@
+"""Device engine: owns the packed weights / tables on one GPU and drives libnisqa_hip.so.
+
+PyTorch is used only for device memory, streams and H2D/D2H copies; all arithmetic of the hot
+path (mel front end, AdaptCNN, self-attention, attention pooling) runs in the HIP kernels behind
+the C ABI (include/nisqa_hip.h).  No fallback: constructing the engine without a GPU or without
+the built library raises.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from . import weights as _w
+from .melbank import MelTables
+
+SEG_LEN = 15
+TOK_PAD = 32
+
+
+class BatchPlan(object):
+    """Host-side shape metadata of one batch (the only thing the host computes per batch)."""
+
+    def __init__(self, lengths, hop, seg_hop, max_segments, names=None):
+        lengths = np.asarray(lengths, dtype=np.int64).reshape(-1)
+        self.n_clips = int(len(lengths))
+        if self.n_clips == 0:
+            raise ValueError('empty batch')
+        self.lengths = lengths
+        self.T = (1 + lengths // hop).astype(np.int64)             # librosa centre framing
+        n_full = self.T - (SEG_LEN - 1)                              # NISQA_lib.py:2256
+        for i in np.nonzero(n_full < 1)[0]:
+            raise ValueError(
+                'Sample too short. Only {} windows available but seg_length={}. '
+                'Consider zero padding the audio sample. File: {}'.format(
+                    int(self.T[i]), SEG_LEN, names[i] if names is not None else i))
+        n = -(-n_full // seg_hop) if seg_hop > 1 else n_full        # NISQA_lib.py:2271-2273
+        if max_segments is not None:
+            for i in np.nonzero(n > max_segments)[0]:
+                raise ValueError('n_wins {} > max_length {} --- {}. Increase max window length ms_max_segments!'.format(
+                    int(n[i]), max_segments, names[i] if names is not None else i))
+        self.n_wins = n.astype(np.int32)
+        self.clip_off = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        self.frame_off = np.concatenate([[0], np.cumsum(self.T)]).astype(np.int32)
+        npad = (n + TOK_PAD - 1) // TOK_PAD * TOK_PAD
+        self.tok_off = np.concatenate([[0], np.cumsum(npad)]).astype(np.int32)
+        self.total_samples = int(self.clip_off[-1])
+        self.total_frames = int(self.frame_off[-1])
+        self.total_tok = int(self.tok_off[-1])
+        self.dev = None
+
+    def to(self, device):
+        if self.dev is None or self.dev['device'] != device:
+            self.dev = {
+                'device': device,
+                'clip_off': torch.from_numpy(self.clip_off).to(device),
+                'frame_off': torch.from_numpy(self.frame_off).to(device),
+                'tok_off': torch.from_numpy(self.tok_off).to(device),
+                'n_wins': torch.from_numpy(self.n_wins).to(device),
+            }
+        return self.dev
+
+    def token_index(self):
+        """Indices (into the padded token axis) of the valid tokens, clip by clip."""
+        return np.concatenate([self.tok_off[b] + np.arange(self.n_wins[b]) for b in range(self.n_clips)])
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class HipNisqa(object):
+    """nisqa.tar / nisqa_mos_only.tar (CNN-SA-AP) on one MI355X."""
+
+    def __init__(self, args, state_dict, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError('nisqa_amd: no GPU visible (torch.cuda.is_available() is False); '
+                               'the HIP engine has no CPU fallback')
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
+        self.args = args
+        a = args
+        if a.get('cnn_model') != 'adapt' or a.get('td') != 'self_att' or a.get('pool') != 'att' \
+                or a.get('td_2') not in (None, 'skip') or a.get('td_sa_pos_enc'):
+            raise NotImplementedError(
+                'HIP engine covers cnn_model=adapt / td=self_att / pool=att (nisqa.tar, nisqa_mos_only.tar); got '
+                'cnn_model={} td={} td_2={} pool={}'.format(a.get('cnn_model'), a.get('td'), a.get('td_2'), a.get('pool')))
+        if a['ms_seg_length'] != SEG_LEN or a['ms_n_mels'] != 48 or list(a['cnn_pool_1']) != [24, 7] \
+                or list(a['cnn_pool_2']) != [12, 5] or list(a['cnn_pool_3']) != [6, 3] \
+                or a['td_sa_nhead'] != 1 or a['td_sa_d_model'] != 64 or not a.get('pool_att_h'):
+            raise NotImplementedError('HIP engine is built for the nisqa.tar geometry (15-frame segments, 48 mels, '
+                                      'pools 24x7/12x5/6x3, 1 head, d_model 64)')
+        if a.get('ms_sr') is not None:
+            raise NotImplementedError('ms_sr resampling is not implemented (all shipped checkpoints use ms_sr=None)')
+        self.seg_hop = int(a['ms_seg_hop_length'])
+        self.max_segments = a['ms_max_segments']
+        self.n_layers = int(a['td_sa_num_layers'])
+        self.dim = a['model'] == 'NISQA_DIM'
+        heads = ['pool_layers.%d.model.' % h for h in range(5)] if self.dim else ['pool.model.']
+        self.n_heads = len(heads)
+        up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        self.cnn_w = up(_w.pack_adapt_cnn(state_dict))
+        self.td_w = up(_w.pack_self_att(state_dict, self.n_layers))
+        self.pool_w = up(_w.pack_pool_att(state_dict, heads))
+        self._mel = {}
+        self._ws = None
+
+    # -- tables -----------------------------------------------------------------------------
+    def mel_tables(self, sr):
+        sr = int(sr)
+        if sr not in self._mel:
+            a = self.args
+            t = MelTables(sr, a['ms_n_fft'], a['ms_hop_length'], a['ms_win_length'], a['ms_n_mels'], a['ms_fmax'])
+            up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+            d = {'host': t, 'window': up(t.window), 'twiddle': up(t.twiddle), 'band_start': up(t.band_start),
+                 'band_len': up(t.band_len), 'band_woff': up(t.band_woff), 'band_w': up(t.band_w)}
+            d['cfg'] = _lib.MelCfg(t.n_fft, t.hop, t.win, t.n_mels, t.n_bins, 1e-8, 80.0)
+            d['model'] = _lib.ModelDev(_ptr(d['window']), _ptr(d['twiddle']), _ptr(d['band_start']), _ptr(d['band_len']),
+                                       _ptr(d['band_woff']), _ptr(d['band_w']), _ptr(self.cnn_w), _ptr(self.td_w),
+                                       _ptr(self.pool_w), self.n_layers, self.n_heads, self.seg_hop)
+            self._mel[sr] = d
+        return self._mel[sr]
+
+    def plan(self, lengths, sr, names=None):
+        return BatchPlan(lengths, self.mel_tables(sr)['host'].hop, self.seg_hop, self.max_segments, names)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- whole forward --------------------------------------------------------------------------
+    def forward_pcm(self, pcm, plan, sr):
+        """pcm: float32 device tensor [plan.total_samples] -> device tensor [B, n_heads]."""
+        assert pcm.dtype == torch.float32 and pcm.is_cuda and pcm.numel() == plan.total_samples
+        mt = self.mel_tables(sr)
+        d = plan.to(self.device)
+        need = self.lib.nisqa_workspace_bytes(plan.n_clips, plan.total_frames, plan.total_tok)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        out = torch.empty((plan.n_clips, self.n_heads), dtype=torch.float32, device=self.device)
+        rc = self.lib.nisqa_predict_batch(_ptr(pcm), _ptr(d['clip_off']), _ptr(d['frame_off']), _ptr(d['tok_off']),
+                                          _ptr(d['n_wins']), plan.n_clips, plan.total_frames, plan.total_tok,
+                                          ctypes.byref(mt['cfg']), ctypes.byref(mt['model']), _ptr(self._ws),
+                                          self._ws.numel(), _ptr(out), self._stream())
+        _lib.check(rc, 'nisqa_predict_batch')
+        return out
+
+    def pcm16_to_f32(self, pcm16):
+        out = torch.empty(pcm16.numel(), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nisqa_pcm16_to_f32(_ptr(pcm16), _ptr(out), pcm16.numel(), self._stream()), 'nisqa_pcm16_to_f32')
+        return out
+
+    # -- stage-by-stage API (parity tests, profiling) ---------------------------------------------
+    def mel(self, pcm, plan, sr, clamp=True):
+        """-> (mel_tm [TT,48] dB, clip_floor [B]); with clamp the top_db floor is applied in place."""
+        mt = self.mel_tables(sr)
+        d = plan.to(self.device)
+        mel = torch.empty((plan.total_frames, 48), dtype=torch.float32, device=self.device)
+        cmax = torch.zeros(plan.n_clips, dtype=torch.int32, device=self.device)
+        floor = torch.empty(plan.n_clips, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nisqa_mel_db(_ptr(pcm), _ptr(d['clip_off']), _ptr(d['frame_off']), plan.n_clips,
+                                         plan.total_frames, ctypes.byref(mt['cfg']), _ptr(mt['window']),
+                                         _ptr(mt['twiddle']), _ptr(mt['band_start']), _ptr(mt['band_len']),
+                                         _ptr(mt['band_woff']), _ptr(mt['band_w']), _ptr(mel), _ptr(cmax),
+                                         self._stream()), 'nisqa_mel_db')
+        _lib.check(self.lib.nisqa_mel_finalize(_ptr(mel), _ptr(d['frame_off']), plan.n_clips, plan.total_frames,
+                                               _ptr(cmax), 80.0, _ptr(floor), 1 if clamp else 0, self._stream()),
+                   'nisqa_mel_finalize')
+        return mel, floor
+
+    def cnn(self, mel_tm, clip_floor, plan):
+        d = plan.to(self.device)
+        p3 = torch.empty((plan.total_tok, 18, 64), dtype=torch.float32, device=self.device)
+        feat = torch.zeros((plan.total_tok, 384), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nisqa_cnn_adapt(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']),
+                                            _ptr(clip_floor), plan.n_clips, plan.total_tok, self.seg_hop,
+                                            _ptr(self.cnn_w), _ptr(p3), _ptr(feat), self._stream()), 'nisqa_cnn_adapt')
+        return feat, p3
+
+    def td(self, feat, plan):
+        d = plan.to(self.device)
+        ws = torch.empty(plan.total_tok * 64 * 6, dtype=torch.float32, device=self.device)
+        x = torch.zeros((plan.total_tok, 64), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nisqa_td_selfatt(_ptr(feat), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
+                                             plan.total_tok, self.n_layers, _ptr(self.td_w), _ptr(ws), _ptr(x),
+                                             self._stream()), 'nisqa_td_selfatt')
+        return x
+
+    def pool(self, x, plan):
+        d = plan.to(self.device)
+        ws = torch.empty(plan.total_tok * 16, dtype=torch.float32, device=self.device)
+        out = torch.empty((plan.n_clips, self.n_heads), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nisqa_pool_att(_ptr(x), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips, plan.total_tok,
+                                           self.n_heads, _ptr(self.pool_w), _ptr(ws), _ptr(out), self._stream()),
+                   'nisqa_pool_att')
+        return out

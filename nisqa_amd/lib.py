@@ -1,0 +1,80 @@
+"""ctypes binding of libnisqa_hip.so (the C ABI of include/nisqa_hip.h).
+
+The product path has no fallback: if the shared library is missing this module raises at load
+time (build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C nisqa_amd/csrc``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnisqa_hip.so')
+
+NISQA_OK, NISQA_ERR_ARG, NISQA_ERR_LAUNCH, NISQA_ERR_WORKSPACE = 0, 1, 2, 3
+ABI_VERSION = 1
+
+c_p = ctypes.c_void_p
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+
+
+class MelCfg(ctypes.Structure):
+    """nisqa_mel_cfg"""
+    _fields_ = [('n_fft', c_i32), ('hop', c_i32), ('win', c_i32), ('n_mels', c_i32), ('n_bins', c_i32),
+                ('amin_sq', ctypes.c_float), ('top_db', ctypes.c_float)]
+
+
+class ModelDev(ctypes.Structure):
+    """nisqa_model_dev"""
+    _fields_ = [('window', c_p), ('twiddle', c_p), ('band_start', c_p), ('band_len', c_p), ('band_woff', c_p),
+                ('band_w', c_p), ('cnn_w', c_p), ('td_w', c_p), ('pool_w', c_p),
+                ('n_layers', c_i32), ('n_heads', c_i32), ('seg_hop', c_i32)]
+
+
+# name -> (restype, argtypes); every symbol include/nisqa_hip.h declares
+SYMBOLS = {
+    'nisqa_abi_version': (ctypes.c_int, []),
+    'nisqa_mel_db': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, ctypes.POINTER(MelCfg), c_p, c_p, c_p, c_p, c_p, c_p,
+                                    c_p, c_p, c_p]),
+    'nisqa_mel_finalize': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_p, ctypes.c_float, c_p, c_i32, c_p]),
+    'nisqa_cnn_adapt': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'nisqa_td_selfatt': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'nisqa_pool_att': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'nisqa_workspace_bytes': (ctypes.c_size_t, [c_i32, c_i32, c_i32]),
+    'nisqa_predict_batch': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, ctypes.POINTER(MelCfg),
+                                           ctypes.POINTER(ModelDev), c_p, ctypes.c_size_t, c_p, c_p]),
+    'nisqa_pcm16_to_f32': (ctypes.c_int, [c_p, c_p, c_i64, c_p]),
+    'nisqa_selftest_mfma': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library with typed entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            'nisqa_amd: HIP library not built: %s is missing (run __graft_entry__.build() or '
+            '`make -C nisqa_amd/csrc`); there is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nisqa_abi_version() != ABI_VERSION:
+        raise RuntimeError('nisqa_amd: libnisqa_hip.so ABI %d != expected %d' % (lib.nisqa_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+class NisqaHipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != NISQA_OK:
+        names = {1: 'NISQA_ERR_ARG', 2: 'NISQA_ERR_LAUNCH', 3: 'NISQA_ERR_WORKSPACE'}
+        raise NisqaHipError('%s failed: %s' % (what, names.get(rc, rc)))

@@ -1,0 +1,88 @@
+"""Host-side constant tables of the mel front end (product code; numpy, float64 then float32).
+
+Mirrors what librosa 0.8.1 builds inside ``lb.feature.melspectrogram`` for the reference's call
+(nisqa/NISQA_lib.py:2311-2328): periodic hann window, slaney-normalised triangular mel filterbank
+(htk=False) -- here exported in sparse row form because each FFT bin touches at most two bands --
+plus the 4096-point twiddle table the FFT kernel indexes.
+"""
+import numpy as np
+
+
+def _hz_to_mel(f):
+    f = np.asanyarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    if f.ndim:
+        big = f >= min_log_hz
+        mels[big] = min_log_mel + np.log(f[big] / min_log_hz) / logstep
+    elif f >= min_log_hz:
+        mels = min_log_mel + np.log(f / min_log_hz) / logstep
+    return mels
+
+
+def _mel_to_hz(m):
+    m = np.asanyarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    freqs = f_sp * m
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    big = m >= min_log_mel
+    freqs[big] = min_log_hz * np.exp(logstep * (m[big] - min_log_mel))
+    return freqs
+
+
+def slaney_filterbank(sr, n_fft, n_mels, fmin, fmax):
+    """Dense [n_mels, 1+n_fft//2] float32 filterbank (librosa.filters.mel, htk=False, norm='slaney')."""
+    n_bins = 1 + n_fft // 2
+    fb = np.zeros((n_mels, n_bins), dtype=np.float32)
+    fftfreqs = np.linspace(0, float(sr) / 2, n_bins, endpoint=True)
+    edges = _mel_to_hz(np.linspace(_hz_to_mel(fmin), _hz_to_mel(fmax), n_mels + 2))
+    width = np.diff(edges)
+    ramps = np.subtract.outer(edges, fftfreqs)
+    for m in range(n_mels):
+        fb[m] = np.maximum(0, np.minimum(-ramps[m] / width[m], ramps[m + 2] / width[m + 1]))
+    fb *= (2.0 / (edges[2:n_mels + 2] - edges[:n_mels]))[:, np.newaxis]
+    return fb
+
+
+class MelTables(object):
+    """All constant arrays nisqa_mel_db needs, as numpy (upload once per model)."""
+
+    def __init__(self, sr, n_fft, hop_s, win_s, n_mels, fmax):
+        if int(n_fft) != 4096:
+            raise NotImplementedError('HIP mel front end supports ms_n_fft=4096 only (got {})'.format(n_fft))
+        if int(n_mels) != 48:
+            raise NotImplementedError('HIP mel front end supports ms_n_mels=48 only (got {})'.format(n_mels))
+        self.sr = int(sr)
+        self.n_fft = int(n_fft)
+        self.hop = int(sr * hop_s)                 # NISQA_lib.py:2308
+        self.win = int(sr * win_s)                 # NISQA_lib.py:2309
+        if not (2 <= self.win <= 1024):
+            raise NotImplementedError(
+                'HIP mel front end needs 2 <= win_length <= 1024 samples (sr {} gives {})'.format(sr, self.win))
+        self.n_mels = int(n_mels)
+        n = np.arange(self.win, dtype=np.float64)
+        self.window = (0.5 - 0.5 * np.cos(2.0 * np.pi * n / self.win)).astype(np.float32)
+        k = np.arange(4096, dtype=np.float64)
+        self.twiddle = np.stack([np.cos(2 * np.pi * k / 4096), -np.sin(2 * np.pi * k / 4096)], 1).astype(np.float32)
+        fb = slaney_filterbank(self.sr, self.n_fft, self.n_mels, 0.0, float(fmax))
+        start = np.zeros(self.n_mels, np.int32)
+        length = np.zeros(self.n_mels, np.int32)
+        woff = np.zeros(self.n_mels, np.int32)
+        w = []
+        o = 0
+        for m in range(self.n_mels):
+            nz = np.nonzero(fb[m])[0]
+            if len(nz):
+                start[m], length[m] = nz[0], nz[-1] - nz[0] + 1
+                w.append(fb[m, nz[0]:nz[-1] + 1])
+            woff[m] = o
+            o += int(length[m])
+        self.band_start, self.band_len, self.band_woff = start, length, woff
+        self.band_w = np.concatenate(w).astype(np.float32) if w else np.zeros(1, np.float32)
+        self.n_bins = int((start + length).max()) if o else 1
+        self.dense = fb

@@ -1,0 +1,174 @@
+"""Pack an unchanged NISQA ``model_state_dict`` into the device blobs the HIP kernels read.
+
+Layouts mirror ``csrc/layout.hpp`` (tests/test_host.py checks the two agree):
+
+* conv B-fragments  wf[tap][step][ntile][lane][4]:
+      W[n = (lane&31)+32*ntile][c = 8*step + 4*(lane>>5) + kk][dy][dx] * bn_scale[n],  tap = dy*3+dx
+* linear A-fragments af[step][mtile][lane][4]:
+      W[row = (lane&31)+32*mtile][k = 8*step + 4*(lane>>5) + kk]
+
+BatchNorm (eval, running statistics; reference NISQA_lib.py:690-705) is folded in float64:
+scale = gamma / sqrt(var + 1e-5), w' = w * scale, t = (conv_bias - mean) * scale + beta.
+"""
+import numpy as np
+
+BN_EPS = 1e-5
+
+# ---- offsets (floats), identical to csrc/layout.hpp ------------------------------------------
+CNN_W1 = 0
+CNN_T1 = CNN_W1 + 16 * 9
+CNN_WF2 = CNN_T1 + 16
+CNN_T2 = CNN_WF2 + 9 * 2 * 1 * 256
+CNN_WF3 = CNN_T2 + 32
+CNN_T3 = CNN_WF3 + 9 * 4 * 2 * 256
+CNN_WF4 = CNN_T3 + 64
+CNN_T4 = CNN_WF4 + 9 * 8 * 2 * 256
+CNN_WF5 = CNN_T4 + 64
+CNN_T5 = CNN_WF5 + 9 * 8 * 2 * 256
+CNN_WF6 = CNN_T5 + 64
+CNN_T6 = CNN_WF6 + 9 * 8 * 2 * 256
+CNN_W_FLOATS = CNN_T6 + 64
+
+TD_PROJ_AF = 0
+TD_PROJ_B = TD_PROJ_AF + 48 * 2 * 256
+TD_LN0_G = TD_PROJ_B + 64
+TD_LN0_B = TD_LN0_G + 64
+TD_LAYER0 = TD_LN0_B + 64
+TDL_QKV_AF = 0
+TDL_QKV_B = TDL_QKV_AF + 8 * 6 * 256
+TDL_OUT_AF = TDL_QKV_B + 192
+TDL_OUT_B = TDL_OUT_AF + 8 * 2 * 256
+TDL_LN1_G = TDL_OUT_B + 64
+TDL_LN1_B = TDL_LN1_G + 64
+TDL_FF1_AF = TDL_LN1_B + 64
+TDL_FF1_B = TDL_FF1_AF + 8 * 2 * 256
+TDL_FF2_AF = TDL_FF1_B + 64
+TDL_FF2_B = TDL_FF2_AF + 8 * 2 * 256
+TDL_LN2_G = TDL_FF2_B + 64
+TDL_LN2_B = TDL_LN2_G + 64
+TDL_FLOATS = TDL_LN2_B + 64
+
+PL_W1_AF = 0
+PL_B1 = PL_W1_AF + 8 * 4 * 256
+PL_W2 = PL_B1 + 128
+PL_W3 = PL_W2 + 128
+PL_B2 = PL_W3 + 64
+PL_FLOATS = PL_B2 + 4
+
+
+def _np(sd, key):
+    v = sd[key]
+    if hasattr(v, 'detach'):
+        v = v.detach().cpu().numpy()
+    return np.asarray(v, dtype=np.float64)
+
+
+_LANE = np.arange(64)
+
+
+def conv_b_fragments(wf):
+    """wf [cout][cin][3][3] (already BN-scaled) -> flat [9][S][NT][64][4] float32."""
+    cout, cin = wf.shape[:2]
+    S, NT = cin // 8, cout // 32
+    w9 = wf.reshape(cout, cin, 9)
+    tap = np.arange(9)[:, None, None, None, None]
+    s = np.arange(S)[None, :, None, None, None]
+    nt = np.arange(NT)[None, None, :, None, None]
+    lane = _LANE[None, None, None, :, None]
+    kk = np.arange(4)[None, None, None, None, :]
+    n = (lane & 31) + 32 * nt
+    c = 8 * s + 4 * (lane >> 5) + kk
+    return w9[n, c, tap].astype(np.float32).reshape(-1)
+
+
+def linear_a_fragments(w):
+    """w [rows][K] -> flat [K/8][rows/32][64][4] float32."""
+    rows, K = w.shape
+    S, MT = K // 8, rows // 32
+    s = np.arange(S)[:, None, None, None]
+    mt = np.arange(MT)[None, :, None, None]
+    lane = _LANE[None, None, :, None]
+    kk = np.arange(4)[None, None, None, :]
+    return w[(lane & 31) + 32 * mt, 8 * s + 4 * (lane >> 5) + kk].astype(np.float32).reshape(-1)
+
+
+def fold_bn(sd, pfx, i):
+    w = _np(sd, pfx + 'conv%d.weight' % i)
+    b = _np(sd, pfx + 'conv%d.bias' % i)
+    scale = _np(sd, pfx + 'bn%d.weight' % i) / np.sqrt(_np(sd, pfx + 'bn%d.running_var' % i) + BN_EPS)
+    t = (b - _np(sd, pfx + 'bn%d.running_mean' % i)) * scale + _np(sd, pfx + 'bn%d.bias' % i)
+    return w * scale[:, None, None, None], t
+
+
+def pack_adapt_cnn(sd, pfx='cnn.model.'):
+    """AdaptCNN (cnn_model='adapt', 16/32/64 channels, 3x3 kernels, no fc) -> float32 [CNN_W_FLOATS]."""
+    shapes = [(16, 1), (32, 16), (64, 32), (64, 64), (64, 64), (64, 64)]
+    for i, (co, ci) in enumerate(shapes, 1):
+        if tuple(sd[pfx + 'conv%d.weight' % i].shape) != (co, ci, 3, 3):
+            raise NotImplementedError('HIP AdaptCNN kernel is built for the nisqa.tar geometry; conv%d is %s'
+                                      % (i, tuple(sd[pfx + 'conv%d.weight' % i].shape)))
+    if pfx + 'fc.weight' in sd:
+        raise NotImplementedError('cnn_fc_out_h is not supported by the HIP AdaptCNN kernel')
+    blob = np.zeros(CNN_W_FLOATS, np.float32)
+    w, t = fold_bn(sd, pfx, 1)
+    blob[CNN_W1:CNN_W1 + 144] = w.reshape(16, 9).astype(np.float32).reshape(-1)
+    blob[CNN_T1:CNN_T1 + 16] = t
+    for i, (wo, to) in zip(range(2, 7), [(CNN_WF2, CNN_T2), (CNN_WF3, CNN_T3), (CNN_WF4, CNN_T4),
+                                          (CNN_WF5, CNN_T5), (CNN_WF6, CNN_T6)]):
+        w, t = fold_bn(sd, pfx, i)
+        fr = conv_b_fragments(w)
+        blob[wo:wo + fr.size] = fr
+        blob[to:to + t.size] = t
+    return blob
+
+
+def pack_self_att(sd, n_layers, pfx='time_dependency.model.'):
+    """SelfAttention (d_model 64, 1 head, sa_h 64, input 384) -> float32 blob."""
+    if tuple(sd[pfx + 'linear.weight'].shape) != (64, 384):
+        raise NotImplementedError('HIP self-attention kernel needs Linear 384->64')
+    blob = np.zeros(TD_LAYER0 + n_layers * TDL_FLOATS, np.float32)
+
+    def put(off, arr):
+        arr = np.asarray(arr, np.float32).reshape(-1)
+        blob[off:off + arr.size] = arr
+
+    put(TD_PROJ_AF, linear_a_fragments(_np(sd, pfx + 'linear.weight')))
+    put(TD_PROJ_B, _np(sd, pfx + 'linear.bias'))
+    put(TD_LN0_G, _np(sd, pfx + 'norm1.weight'))
+    put(TD_LN0_B, _np(sd, pfx + 'norm1.bias'))
+    for l in range(n_layers):
+        p = pfx + 'layers.%d.' % l
+        base = TD_LAYER0 + l * TDL_FLOATS
+        if tuple(sd[p + 'self_attn.in_proj_weight'].shape) != (192, 64) or \
+                tuple(sd[p + 'linear1.weight'].shape) != (64, 64):
+            raise NotImplementedError('HIP self-attention kernel needs d_model=64, nhead=1, sa_h=64')
+        put(base + TDL_QKV_AF, linear_a_fragments(_np(sd, p + 'self_attn.in_proj_weight')))
+        put(base + TDL_QKV_B, _np(sd, p + 'self_attn.in_proj_bias'))
+        put(base + TDL_OUT_AF, linear_a_fragments(_np(sd, p + 'self_attn.out_proj.weight')))
+        put(base + TDL_OUT_B, _np(sd, p + 'self_attn.out_proj.bias'))
+        put(base + TDL_LN1_G, _np(sd, p + 'norm1.weight'))
+        put(base + TDL_LN1_B, _np(sd, p + 'norm1.bias'))
+        put(base + TDL_FF1_AF, linear_a_fragments(_np(sd, p + 'linear1.weight')))
+        put(base + TDL_FF1_B, _np(sd, p + 'linear1.bias'))
+        put(base + TDL_FF2_AF, linear_a_fragments(_np(sd, p + 'linear2.weight')))
+        put(base + TDL_FF2_B, _np(sd, p + 'linear2.bias'))
+        put(base + TDL_LN2_G, _np(sd, p + 'norm2.weight'))
+        put(base + TDL_LN2_B, _np(sd, p + 'norm2.bias'))
+    return blob
+
+
+def pack_pool_att(sd, head_prefixes):
+    """PoolAttFF heads (64 -> 128 -> 1 scores, 64 -> 1 output) -> float32 [n_heads * PL_FLOATS]."""
+    blob = np.zeros(len(head_prefixes) * PL_FLOATS, np.float32)
+    for h, p in enumerate(head_prefixes):
+        if tuple(sd[p + 'linear1.weight'].shape) != (128, 64):
+            raise NotImplementedError('HIP pooling kernel needs pool_att_h=128 on d=64')
+        base = h * PL_FLOATS
+        fr = linear_a_fragments(_np(sd, p + 'linear1.weight'))
+        blob[base + PL_W1_AF: base + PL_W1_AF + fr.size] = fr
+        blob[base + PL_B1: base + PL_B1 + 128] = _np(sd, p + 'linear1.bias')
+        blob[base + PL_W2: base + PL_W2 + 128] = _np(sd, p + 'linear2.weight').reshape(-1)
+        blob[base + PL_W3: base + PL_W3 + 64] = _np(sd, p + 'linear3.weight').reshape(-1)
+        blob[base + PL_B2] = _np(sd, p + 'linear2.bias').reshape(-1)[0]
+        blob[base + PL_B2 + 1] = _np(sd, p + 'linear3.bias').reshape(-1)[0]
+    return blob
