@@ -1,0 +1,269 @@
+"""Host-side mirror of the reference's hot-path interface in nisqa/NISQA_lib.py: same names,
+argument meaning and error behaviour, with the arithmetic moved to the HIP engine.
+
+  SpeechQualityDataset  (reference NL:2052-2236)  file table + ms_* parameters; items are read here,
+                                                   spectrograms are computed on the GPU
+  predict_mos / predict_dim (NL:1420-1467)        batching loop: WAV ingest -> device -> HIP forward
+  NISQA / NISQA_DIM     (NL:29-268)                parameter containers with the reference's
+                                                   state_dict keys; forward() runs the HIP path
+
+Out of scope here (raise NotImplementedError): training, evaluation metrics, NISQA_DE,
+alternative blocks no shipped checkpoint uses.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pandas as pd; pd.options.mode.chained_assignment = None
+import torch
+import torch.nn as nn
+
+from . import dist as _dist
+from .wavio import read_wav
+
+
+# ---------------------------------------------------------------------------------------------
+# Parameter containers: identical module tree / state_dict keys as the reference so that
+# nisqa.tar loads with load_state_dict(strict=True) (NISQA_model.py:1023).
+# ---------------------------------------------------------------------------------------------
+class _Params(nn.Module):
+    """Leaf holding named tensors (weights as Parameters, running stats as buffers)."""
+
+    def __init__(self, shapes, buffers=()):
+        super().__init__()
+        for name, shape in shapes.items():
+            self.register_parameter(name, nn.Parameter(torch.zeros(shape), requires_grad=False))
+        for name, shape, dtype in buffers:
+            self.register_buffer(name, torch.zeros(shape, dtype=dtype))
+
+
+def _conv(cout, cin, kh, kw):
+    return _Params({'weight': (cout, cin, kh, kw), 'bias': (cout,)})
+
+
+def _bn(c):
+    return _Params({'weight': (c,), 'bias': (c,)},
+                   [('running_mean', (c,), torch.float32), ('running_var', (c,), torch.float32),
+                    ('num_batches_tracked', (), torch.int64)])
+
+
+def _lin(cout, cin):
+    return _Params({'weight': (cout, cin), 'bias': (cout,)})
+
+
+class _AdaptCNNParams(nn.Module):
+    def __init__(self, c1, c2, c3, kernel_size, pool_3):
+        super().__init__()
+        kh, kw = (kernel_size, kernel_size) if isinstance(kernel_size, int) else tuple(kernel_size)
+        chans = [1, c1, c2, c3, c3, c3, c3]
+        for i in range(1, 7):
+            k_w = pool_3[1] if i == 6 else kw                       # NL:625, NL:672-676
+            setattr(self, 'conv%d' % i, _conv(chans[i], chans[i - 1], kh, k_w))
+            setattr(self, 'bn%d' % i, _bn(chans[i]))
+        self.fan_out = c3 * pool_3[0]
+
+
+class _SALayerParams(nn.Module):
+    def __init__(self, d, h):
+        super().__init__()
+        self.self_attn = nn.Module()
+        self.self_attn.register_parameter('in_proj_weight', nn.Parameter(torch.zeros(3 * d, d), requires_grad=False))
+        self.self_attn.register_parameter('in_proj_bias', nn.Parameter(torch.zeros(3 * d), requires_grad=False))
+        self.self_attn.out_proj = _lin(d, d)
+        self.linear1 = _lin(h, d)
+        self.linear2 = _lin(d, h)
+        self.norm1 = _Params({'weight': (d,), 'bias': (d,)})
+        self.norm2 = _Params({'weight': (d,), 'bias': (d,)})
+
+
+class _SelfAttentionParams(nn.Module):
+    def __init__(self, input_size, d, layers, h):
+        super().__init__()
+        self.norm1 = _Params({'weight': (d,), 'bias': (d,)})
+        self.linear = _lin(d, input_size)
+        self.layers = nn.ModuleList([_SALayerParams(d, h) for _ in range(layers)])
+
+
+class _PoolAttFFParams(nn.Module):
+    def __init__(self, d, h):
+        super().__init__()
+        self.linear1 = _lin(h, d)
+        self.linear2 = _lin(1, h)
+        self.linear3 = _lin(1, d)
+
+
+class _Wrap(nn.Module):
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+
+class _NisqaBase(nn.Module):
+    """Shared by NISQA and NISQA_DIM: builds the parameter tree, owns the (lazy) HIP engine."""
+
+    def __init__(self, n_heads, **kw):
+        super().__init__()
+        g = lambda k, d=None: kw.get(k, d)
+        if g('cnn_model', 'adapt') != 'adapt' or g('td', 'self_att') != 'self_att' or g('pool', 'att') != 'att' \
+                or g('td_2', 'skip') not in (None, 'skip') or not g('pool_att_h', 128):
+            raise NotImplementedError(
+                'nisqa_amd accelerates the CNN-SA-AP path (cnn_model=adapt, td=self_att, td_2=skip, pool=att with '
+                'pool_att_h); got cnn_model={} td={} td_2={} pool={}'.format(
+                    g('cnn_model'), g('td'), g('td_2'), g('pool')))
+        self._hp = dict(kw)
+        self.cnn = _Wrap(_AdaptCNNParams(g('cnn_c_out_1', 16), g('cnn_c_out_2', 32), g('cnn_c_out_3', 64),
+                                         g('cnn_kernel_size', 3), g('cnn_pool_3', [6, 3])))
+        d = g('td_sa_d_model', 64)
+        self.time_dependency = _Wrap(_SelfAttentionParams(self.cnn.model.fan_out, d, g('td_sa_num_layers', 2),
+                                                          g('td_sa_h', 64)))
+        if n_heads == 5:
+            self.pool_layers = nn.ModuleList([_Wrap(_PoolAttFFParams(d, g('pool_att_h', 128))) for _ in range(5)])
+        else:
+            self.pool = _Wrap(_PoolAttFFParams(d, g('pool_att_h', 128)))
+        self._engine = None
+        self._engine_args = None
+
+    def bind_args(self, args):
+        """Give the module the checkpoint's args (ms_* front-end parameters live there, NISQA_model.py:941-942)."""
+        self._engine_args = args
+        self._engine = None
+        return self
+
+    def engine(self, device=None):
+        if self._engine is None:
+            from .engine import HipNisqa
+            if self._engine_args is None:
+                raise RuntimeError('bind_args(checkpoint_args) must be called before the HIP engine is built')
+            self._engine = HipNisqa(self._engine_args, self.state_dict(), device)
+        return self._engine
+
+    def forward(self, x, n_wins):
+        """Reference inner operator model(x[B,L,1,48,15], n_wins[B]) -> [B, heads] (NL:137-142, NL:260-268)."""
+        raise NotImplementedError(
+            'segment-tensor entry point is not wired yet: use predict_dim/predict_mos (PCM in) or '
+            'engine().forward_pcm; see DESIGN.md section "what comes next"')
+
+
+class NISQA(_NisqaBase):
+    def __init__(self, **kw):
+        super().__init__(1, **kw)
+        self.name = 'NISQA'
+
+
+class NISQA_DIM(_NisqaBase):
+    def __init__(self, **kw):
+        super().__init__(5, **kw)
+        self.name = 'NISQA_DIM'
+
+
+# ---------------------------------------------------------------------------------------------
+# Dataset mirror
+# ---------------------------------------------------------------------------------------------
+class SpeechQualityDataset(object):
+    """File table of the reference dataset (NL:2052-2236).  Same constructor arguments; loading a
+    waveform replaces ``_load_spec`` (the spectrogram itself is produced on the GPU)."""
+
+    def __init__(self, df, df_con=None, data_dir='', folder_column='', filename_column='filename', mos_column='MOS',
+                 seg_length=15, max_length=None, to_memory=False, to_memory_workers=0, transform=None,
+                 seg_hop_length=1, ms_n_fft=1024, ms_hop_length=80, ms_win_length=170, ms_n_mels=32, ms_sr=48e3,
+                 ms_fmax=16e3, ms_channel=None, double_ended=False, filename_column_ref=None, dim=False):
+        if double_ended:
+            raise NotImplementedError('double-ended (NISQA_DE) datasets are out of scope')
+        if transform is not None:
+            raise NotImplementedError('spectrogram transforms are not supported on the HIP path')
+        self.df, self.df_con, self.data_dir = df, df_con, data_dir
+        self.filename_column, self.mos_column = filename_column, mos_column
+        self.seg_length, self.seg_hop_length, self.max_length = seg_length, seg_hop_length, max_length
+        self.ms_n_fft, self.ms_hop_length, self.ms_win_length = ms_n_fft, ms_hop_length, ms_win_length
+        self.ms_n_mels, self.ms_sr, self.ms_fmax, self.ms_channel = ms_n_mels, ms_sr, ms_fmax, ms_channel
+        self.dim = dim
+
+    def __len__(self):
+        return len(self.df)
+
+    def file_path(self, index):
+        return os.path.join(self.data_dir, self.df[self.filename_column].iloc[index])   # NL:2132
+
+    def load_audio(self, index):
+        """(samples, sr) of item ``index``; raises ValueError('Could not load file ...') like NL:2305-2306."""
+        return read_wav(self.file_path(index), self.ms_channel)
+
+    def labels(self, n):
+        """predict_only labels: NaN rows like NL:2217-2231."""
+        return np.full((n, 5 if self.dim else 1), np.nan, dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# Batching loop
+# ---------------------------------------------------------------------------------------------
+def _predict(model, ds, bs, dev, num_workers):
+    """Shared body of predict_mos / predict_dim: returns y_hat [N, heads] float32 for ALL items of ds
+    (clip-sharded over ranks when torch.distributed is initialised, then gathered)."""
+    if ds.mos_column != 'predict_only':
+        raise NotImplementedError('only predict_only datasets are supported (evaluation is out of scope)')
+    dev = torch.device(dev)
+    if dev.type != 'cuda':
+        raise RuntimeError('nisqa_amd has no CPU path: device {} requested but the hot path runs only as HIP kernels '
+                           'on an MI355X'.format(dev))
+    eng = model.engine(dev if dev.index is not None else None)
+    n = len(ds)
+    lo, hi = _dist.shard_range(n)
+    bs = max(1, int(bs))
+    heads = eng.n_heads
+    y_local = np.zeros((hi - lo, heads), dtype=np.float32)
+    pool = ThreadPoolExecutor(max_workers=max(1, int(num_workers))) if num_workers and num_workers > 0 else None
+    try:
+        def load_batch(s):
+            idx = list(range(s, min(s + bs, hi)))
+            items = list(pool.map(ds.load_audio, idx)) if pool else [ds.load_audio(i) for i in idx]
+            return idx, items
+
+        starts = list(range(lo, hi, bs))
+        nxt = load_batch(starts[0]) if starts else None
+        for bi, s in enumerate(starts):
+            idx, items = nxt
+            fut = None
+            if bi + 1 < len(starts) and pool is not None:          # overlap ingest of the next batch
+                fut = pool.submit(load_batch, starts[bi + 1])
+            by_sr = {}
+            for i, (y, sr) in zip(idx, items):
+                by_sr.setdefault(sr, []).append((i, y))
+            pending = []
+            for sr, grp in by_sr.items():                          # files of one rate share the mel tables
+                plan = eng.plan([len(y) for _, y in grp], sr, names=[ds.file_path(i) for i, _ in grp])
+                if all(y.dtype == np.int16 for _, y in grp):
+                    host = torch.from_numpy(np.concatenate([y for _, y in grp])).pin_memory()
+                    pcm = eng.pcm16_to_f32(host.to(eng.device, non_blocking=True))
+                else:
+                    host = torch.from_numpy(np.concatenate(
+                        [y.astype(np.float32) / np.float32(32768.0) if y.dtype == np.int16 else y for _, y in grp]))
+                    pcm = host.pin_memory().to(eng.device, non_blocking=True)
+                pending.append(([i for i, _ in grp], eng.forward_pcm(pcm, plan, sr)))
+            for ids, out in pending:
+                y_local[np.asarray(ids) - lo] = out.cpu().numpy()
+            if bi + 1 < len(starts):
+                nxt = fut.result() if fut is not None else load_batch(starts[bi + 1])
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True)
+    return _dist.gather_rows(y_local, n, lo, hi, dev)
+
+
+def predict_mos(model, ds, bs, dev, num_workers=0):
+    """predict_mos (NL:1420-1439): fills ds.df['mos_pred'] (float64 like NL:1438), returns (y_hat, y)."""
+    y_hat = _predict(model, ds, bs, dev, num_workers)[:, :1]
+    y = ds.labels(len(ds))[:, :1]
+    ds.df['mos_pred'] = y_hat.astype(dtype=float)
+    return y_hat, y
+
+
+def predict_dim(model, ds, bs, dev, num_workers=0):
+    """predict_dim (NL:1441-1467): fills mos/noi/dis/col/loud_pred columns, returns (y_hat, y)."""
+    y_hat = _predict(model, ds, bs, dev, num_workers)
+    y = ds.labels(len(ds))
+    ds.df['mos_pred'] = y_hat[:, 0].reshape(-1, 1)
+    ds.df['noi_pred'] = y_hat[:, 1].reshape(-1, 1)
+    ds.df['dis_pred'] = y_hat[:, 2].reshape(-1, 1)
+    ds.df['col_pred'] = y_hat[:, 3].reshape(-1, 1)
+    ds.df['loud_pred'] = y_hat[:, 4].reshape(-1, 1)
+    return y_hat, y

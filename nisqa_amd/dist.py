@@ -1,0 +1,48 @@
+"""Clip sharding across GPUs: one process per GPU, contiguous index ranges,
+no data-path collective; one all_gather of the [N/world, heads] result rows at the end (RCCL when
+the process group's backend is "nccl", gloo in the CPU tests).  Replaces nn.DataParallel
+(reference NISQA_model.py:56-57)."""
+import numpy as np
+import torch
+
+
+def _dist_on():
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
+def world():
+    if _dist_on():
+        return torch.distributed.get_rank(), torch.distributed.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n, rank, world_size):
+    """Contiguous, balanced [lo, hi) of rank's share of n items (first n % world ranks get one extra)."""
+    base, rem = divmod(int(n), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_range(n):
+    r, w = world()
+    return shard_bounds(n, r, w)
+
+
+def gather_rows(local, n, lo, hi, dev):
+    """All ranks get the full [n, C] array assembled from every rank's [hi-lo, C] rows."""
+    r, w = world()
+    if w == 1:
+        return local
+    C = local.shape[1]
+    cap = -(-n // w)                                    # rows per rank, padded to the largest shard
+    backend = torch.distributed.get_backend()
+    tdev = torch.device(dev) if backend == 'nccl' else torch.device('cpu')
+    buf = torch.zeros((cap, C), dtype=torch.float32, device=tdev)
+    buf[:hi - lo] = torch.from_numpy(local).to(tdev)
+    parts = [torch.empty_like(buf) for _ in range(w)]
+    torch.distributed.all_gather(parts, buf)
+    out = np.zeros((n, C), dtype=np.float32)
+    for k in range(w):
+        a, b = shard_bounds(n, k, w)
+        out[a:b] = parts[k][:b - a].cpu().numpy()
+    return out
