@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py -- clips/sec of the NISQA predict hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE pass of the whole hot path (PCM -> mel -> AdaptCNN -> self-attention -> pooling
+heads -> [B,5] rows) over one batch of synthetic input already resident in HBM.  Workload at every N:
+BASELINE.json configs[1] per GPU -- nisqa.tar architecture (NISQA_DIM, random-init weights: there
+are no checkpoints on the GPU box), bs = 64 clips of 10 s / 48 kHz synthetic audio (SURVEY.md
+section 8d generator).  Weak scaling: each rank owns its own 64-clip batch (clips shard with no
+data-path collective); the only exchange is the final all_gather of result rows, inside the timed
+region.  value = clips all ranks processed / max-over-ranks wall time.
+
+Extra objects on the JSON line (see DESIGN.md "Measurement"):
+  roofline     dominant kernel (cnn_front_kernel, conv1-4 + pools): algorithmic FLOPs per launch /
+               its mean launch duration measured with HIP events recorded inside the timed region
+               on the launch stream, against the dense fp32 MFMA peak (157.3 TFLOP/s).
+  cpu_baseline the CPU oracle (a port of the reference path: numpy mel restatement + torch-CPU
+               network) timed on this box's host cores over a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from nisqa_amd import synth                      # noqa: E402
+
+BATCH = 64
+SECONDS = 10.0
+SR = 48000
+N_DISTINCT = 16          # distinct synthetic clips per rank (tiled to BATCH); generation is host-bound
+
+# Algorithmic FLOPs per 10 s clip (247 segments), SURVEY.md section 8a / BASELINE.md:
+FLOP_CONV1_4 = (51.2 + 382.4 + 546.3 + 1092.6) * 1e6      # what one cnn_front_kernel launch does, per clip
+FLOP_TOTAL = 2.93e9                                          # whole path incl. mel in FFT form
+PEAK_F32_MFMA = 157.3                                        # TFLOP/s, MI355X_MICROARCH.md
+
+
+def cpu_baseline(n_clips=6):
+    """Oracle (CPU port of the reference path) on a bounded sample; returns the JSON object."""
+    from oracle import mel as omel, net as onet
+    args, sd = dict(synth.DIM_ARGS), synth.random_state_dict(7, 'NISQA_DIM')
+    clips = [synth.synth_pcm16(2000 + i, SECONDS).astype(np.float32) / np.float32(32768.0) for i in range(n_clips)]
+    onet.predict_from_melspec(sd, args, omel.melspec_db_from_audio(clips[0][:SR], SR))   # warm-up
+    t0 = time.perf_counter()
+    t_mel = 0.0
+    for y in clips:
+        t1 = time.perf_counter()
+        spec = omel.melspec_db_from_audio(y, SR)
+        t_mel += time.perf_counter() - t1
+        onet.predict_from_melspec(sd, args, spec)
+    dt = time.perf_counter() - t0
+    return {'value': round(n_clips / dt, 3), 'unit': 'clips/s', 'cores': int(torch.get_num_threads()),
+            'kind': 'port',
+            'sample': '%d x 10 s clips, oracle.mel (numpy restatement of librosa 0.8.1) + oracle.net (torch CPU fp32), '
+                      'one clip at a time; %.2f s total, mel share %.0f%%; host has %d cores'
+                      % (n_clips, dt, 100.0 * t_mel / dt, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                             % (a.gpus, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from nisqa_amd.engine import HipNisqa
+    eng = HipNisqa(dict(synth.DIM_ARGS), synth.random_state_dict(7, 'NISQA_DIM'), dev)
+
+    # synthetic batch, resident in HBM before the timed region
+    base = [synth.synth_pcm16(1000 * rank + i, SECONDS) for i in range(N_DISTINCT)]
+    pcm16 = np.concatenate([base[i % N_DISTINCT] for i in range(BATCH)])
+    plan = eng.plan([len(base[0])] * BATCH, SR)
+    pcm = eng.pcm16_to_f32(torch.from_numpy(pcm16).to(dev))
+    plan.to(dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        out = eng.forward_pcm(pcm, plan, SR)
+    barrier()
+
+    evs = []
+    for _ in range(a.steps):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        for x in e:
+            x.record()                     # forces handle creation; re-recorded inside the library
+        evs.append(e)
+    barrier()
+    t0 = time.perf_counter()
+    outs = []
+    for s in range(a.steps):
+        outs.append(eng.forward_pcm(pcm, plan, SR, stage_events=evs[s]))
+    if world > 1:                           # the path's one exchange step: gather the MOS rows
+        rows = torch.cat(outs, 0)
+        parts = [torch.empty_like(rows) for _ in range(world)]
+        torch.distributed.all_gather(parts, rows)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        torch.distributed.barrier()
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        assert torch.isfinite(outs[-1]).all()
+        names = ['mel', 'cnn_front', 'cnn_back', 'selfatt', 'pool']
+        stage_ms = {n: float(np.mean([evs[s][i].elapsed_time(evs[s][i + 1]) for s in range(a.steps)]))
+                    for i, n in enumerate(names)}
+        front_s = stage_ms['cnn_front'] * 1e-3
+        achieved = FLOP_CONV1_4 * BATCH / front_s / 1e12
+        clips = BATCH * a.steps * world
+        res = {
+            'metric': 'clips/sec (10 s, 48 kHz)', 'value': round(clips / dt, 2), 'unit': 'clips/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic 48 kHz / 10 s PCM16 clips (SURVEY 8d generator), random-init nisqa.tar architecture',
+            'config': {'workload': 'predict_dir nisqa.tar (NISQA_DIM CNN-SA-AP) bs=64 per GPU, 10 s synthetic 48 kHz '
+                                   'clips, PCM resident in HBM', 'batch_clips_per_gpu': BATCH,
+                       'segments_per_batch': int(plan.n_wins.sum()), 'frames_per_batch': plan.total_frames,
+                       'parallelism': 'clip-sharded x%d, final all_gather of MOS rows' % world},
+            'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
+            'roofline': {'kernel': 'cnn_front_kernel (conv1-4 + pools, fp32 MFMA)', 'bound': 'mfma',
+                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / PEAK_F32_MFMA, 4), 'traffic': None,
+                         'flop_per_launch': FLOP_CONV1_4 * BATCH, 'avg_launch_ms': round(stage_ms['cnn_front'], 4),
+                         'whole_path_tflops': round(FLOP_TOTAL * clips / dt / 1e12 / world, 2)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

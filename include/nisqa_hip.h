@@ -97,6 +97,14 @@ int nisqa_cnn_adapt(const float* mel_tm, const int32_t* frame_off, const int32_t
                     const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                     int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
                     float* p3_ws, float* feat, void* stream);
+/* The two launches of nisqa_cnn_adapt separately (conv1-4 + pools -> p3_ws; conv5-6 -> feat). */
+int nisqa_cnn_front(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                    const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                    int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
+                    float* p3_ws, void* stream);
+int nisqa_cnn_back(const float* p3_ws, const int32_t* tok_off, const int32_t* n_wins,
+                   int32_t n_clips, int32_t total_tok_padded, const float* cnn_w,
+                   float* feat, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Time dependency: replaces SelfAttention.forward + 2 x SelfAttentionLayer.forward
@@ -129,6 +137,10 @@ typedef struct {
     const int32_t* band_start; const int32_t* band_len; const int32_t* band_woff; const float* band_w;
     const float* cnn_w; const float* td_w; const float* pool_w;
     int32_t n_layers; int32_t n_heads; int32_t seg_hop;
+    /* optional profiling hook: NULL, or 6 caller-created hipEvent_t recorded on `stream` at the stage
+     * boundaries of nisqa_predict_batch: [0] start, [1] after mel, [2] after the conv1-4 kernel,
+     * [3] after the conv5-6 kernel, [4] after self-attention, [5] after pooling */
+    void* const* stage_events;
 } nisqa_model_dev;
 
 size_t nisqa_workspace_bytes(int32_t n_clips, int32_t total_frames, int32_t total_tok_padded);

@@ -47,18 +47,30 @@ extern "C" int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, co
     float* td = (float*)(w + p.td);
     float* x = (float*)(w + p.x);
     float* pool = (float*)(w + p.pool);
+    void* const* ev = model->stage_events;
+#define NQ_STAGE(i) do { if (ev && hipEventRecord((hipEvent_t)ev[i], (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH; } while (0)
     if (hipMemsetAsync(cmax, 0, (size_t)n_clips * 4, (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH;
+    NQ_STAGE(0);
     int rc = nisqa_mel_db(pcm, clip_off, frame_off, n_clips, total_frames, cfg, model->window, model->twiddle,
                           model->band_start, model->band_len, model->band_woff, model->band_w, mel, cmax, stream);
     if (rc) return rc;
     rc = nisqa_mel_finalize(mel, frame_off, n_clips, total_frames, cmax, cfg->top_db, cfloor, 0, stream);
     if (rc) return rc;
-    rc = nisqa_cnn_adapt(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
-                         model->cnn_w, p3, feat, stream);
+    NQ_STAGE(1);
+    rc = nisqa_cnn_front(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
+                         model->cnn_w, p3, stream);
     if (rc) return rc;
+    NQ_STAGE(2);
+    rc = nisqa_cnn_back(p3, tok_off, n_wins, n_clips, total_tok_padded, model->cnn_w, feat, stream);
+    if (rc) return rc;
+    NQ_STAGE(3);
     rc = nisqa_td_selfatt(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w, td, x, stream);
     if (rc) return rc;
-    return nisqa_pool_att(x, tok_off, n_wins, n_clips, total_tok_padded, model->n_heads, model->pool_w, pool, out, stream);
+    NQ_STAGE(4);
+    rc = nisqa_pool_att(x, tok_off, n_wins, n_clips, total_tok_padded, model->n_heads, model->pool_w, pool, out, stream);
+    if (rc) return rc;
+    NQ_STAGE(5);
+    return NISQA_OK;
 }
 
 // D[32][32] = A[32][k] * B[k][32] with the fragment maps of common.hpp (k even)

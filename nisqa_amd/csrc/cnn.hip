@@ -21,6 +21,7 @@
 //     segments per wave (72 / 24 rows of the 32-row MFMA tile).
 #include "common.hpp"
 #include "layout.hpp"
+#include "../../include/nisqa_hip.h"
 
 #define FRONT_ACT_BYTES 15360            /* max(A1 10752 + input 2880, A3 15360) */
 #define FRONT_ZERO_OFF FRONT_ACT_BYTES   /* 256 B of zeros: target of out-of-image taps */
@@ -364,15 +365,30 @@ __global__ __launch_bounds__(64) void cnn_back_kernel(
     }
 }
 
+extern "C" int nisqa_cnn_front(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                               const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                               int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w, float* p3_ws,
+                               void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0) return 1;
+    hipLaunchKernelGGL(cnn_front_kernel, dim3(total_tok_padded), dim3(64), FRONT_LDS_BYTES, (hipStream_t)stream,
+                       mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, p3_ws);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" int nisqa_cnn_back(const float* p3_ws, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                              int32_t total_tok_padded, const float* cnn_w, float* feat, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31)) return 1;
+    hipLaunchKernelGGL(cnn_back_kernel, dim3(total_tok_padded / 4), dim3(64), BACK_LDS_BYTES, (hipStream_t)stream,
+                       p3_ws, tok_off, n_wins, n_clips, cnn_w, feat);
+    return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
 extern "C" int nisqa_cnn_adapt(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
                                const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                                int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
                                float* p3_ws, float* feat, void* stream) {
-    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0) return 1;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(cnn_front_kernel, dim3(total_tok_padded), dim3(64), FRONT_LDS_BYTES, st, mel_tm, frame_off,
-                       tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, p3_ws);
-    hipLaunchKernelGGL(cnn_back_kernel, dim3(total_tok_padded / 4), dim3(64), BACK_LDS_BYTES, st, p3_ws, tok_off,
-                       n_wins, n_clips, cnn_w, feat);
-    return hipGetLastError() == hipSuccess ? 0 : 2;
+    int rc = nisqa_cnn_front(mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, total_tok_padded, seg_hop,
+                             cnn_w, p3_ws, stream);
+    if (rc) return rc;
+    return nisqa_cnn_back(p3_ws, tok_off, n_wins, n_clips, total_tok_padded, cnn_w, feat, stream);
 }

@@ -118,7 +118,7 @@ class HipNisqa(object):
             d['cfg'] = _lib.MelCfg(t.n_fft, t.hop, t.win, t.n_mels, t.n_bins, 1e-8, 80.0)
             d['model'] = _lib.ModelDev(_ptr(d['window']), _ptr(d['twiddle']), _ptr(d['band_start']), _ptr(d['band_len']),
                                        _ptr(d['band_woff']), _ptr(d['band_w']), _ptr(self.cnn_w), _ptr(self.td_w),
-                                       _ptr(self.pool_w), self.n_layers, self.n_heads, self.seg_hop)
+                                       _ptr(self.pool_w), self.n_layers, self.n_heads, self.seg_hop, None)
             self._mel[sr] = d
         return self._mel[sr]
 
@@ -129,8 +129,11 @@ class HipNisqa(object):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     # -- whole forward --------------------------------------------------------------------------
-    def forward_pcm(self, pcm, plan, sr):
-        """pcm: float32 device tensor [plan.total_samples] -> device tensor [B, n_heads]."""
+    def forward_pcm(self, pcm, plan, sr, stage_events=None):
+        """pcm: float32 device tensor [plan.total_samples] -> device tensor [B, n_heads].
+
+        stage_events: optional list of 6 recorded-once torch.cuda.Event(enable_timing=True); they are
+        re-recorded at the stage boundaries (profiling hook of nisqa_model_dev)."""
         assert pcm.dtype == torch.float32 and pcm.is_cuda and pcm.numel() == plan.total_samples
         mt = self.mel_tables(sr)
         d = plan.to(self.device)
@@ -138,9 +141,14 @@ class HipNisqa(object):
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
         out = torch.empty((plan.n_clips, self.n_heads), dtype=torch.float32, device=self.device)
+        model = mt['model']
+        if stage_events is not None:
+            arr = (ctypes.c_void_p * 6)(*[ctypes.c_void_p(e.cuda_event) for e in stage_events])
+            model = _lib.ModelDev.from_buffer_copy(mt['model'])
+            model.stage_events = ctypes.cast(arr, ctypes.c_void_p)
         rc = self.lib.nisqa_predict_batch(_ptr(pcm), _ptr(d['clip_off']), _ptr(d['frame_off']), _ptr(d['tok_off']),
                                           _ptr(d['n_wins']), plan.n_clips, plan.total_frames, plan.total_tok,
-                                          ctypes.byref(mt['cfg']), ctypes.byref(mt['model']), _ptr(self._ws),
+                                          ctypes.byref(mt['cfg']), ctypes.byref(model), _ptr(self._ws),
                                           self._ws.numel(), _ptr(out), self._stream())
         _lib.check(rc, 'nisqa_predict_batch')
         return out

@@ -28,7 +28,7 @@ class ModelDev(ctypes.Structure):
     """nisqa_model_dev"""
     _fields_ = [('window', c_p), ('twiddle', c_p), ('band_start', c_p), ('band_len', c_p), ('band_woff', c_p),
                 ('band_w', c_p), ('cnn_w', c_p), ('td_w', c_p), ('pool_w', c_p),
-                ('n_layers', c_i32), ('n_heads', c_i32), ('seg_hop', c_i32)]
+                ('n_layers', c_i32), ('n_heads', c_i32), ('seg_hop', c_i32), ('stage_events', c_p)]
 
 
 # name -> (restype, argtypes); every symbol include/nisqa_hip.h declares
@@ -38,6 +38,8 @@ SYMBOLS = {
                                     c_p, c_p, c_p]),
     'nisqa_mel_finalize': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_p, ctypes.c_float, c_p, c_i32, c_p]),
     'nisqa_cnn_adapt': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'nisqa_cnn_front': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
+    'nisqa_cnn_back': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_td_selfatt': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_pool_att': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_workspace_bytes': (ctypes.c_size_t, [c_i32, c_i32, c_i32]),
