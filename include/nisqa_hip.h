@@ -55,7 +55,8 @@ typedef struct {
     int32_t hop;        /* int(sr * ms_hop_length), NISQA_lib.py:2308 */
     int32_t win;        /* int(sr * ms_win_length) <= 1024, NISQA_lib.py:2309 */
     int32_t n_mels;     /* must be 48 */
-    int32_t n_bins;     /* number of FFT bins with a non-zero mel weight (k = 0 .. n_bins-1), <= 2049 */
+    int32_t n_bins;     /* number of FFT bins with a non-zero mel weight (k = 0 .. n_bins-1), <= 2048 */
+    int32_t w_floats;   /* length of band_w (total non-zero filterbank weights), <= 4100 */
     float   amin_sq;    /* amin^2 = 1e-8 */
     float   top_db;     /* 80 */
 } nisqa_mel_cfg;

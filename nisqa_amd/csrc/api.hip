@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64) void selftest_mfma_kernel(const float* __restri
 
 extern "C" int nisqa_selftest_mfma(const float* a, const float* b, float* d, int32_t k, void* stream) {
     if (k <= 0 || (k & 1)) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, b, d, k);
-    return hipGetLastError() == hipSuccess ? NISQA_OK : NISQA_ERR_LAUNCH;
+    return NQ_LAUNCH_STATUS();
 }

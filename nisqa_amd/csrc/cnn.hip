@@ -370,17 +370,19 @@ extern "C" int nisqa_cnn_front(const float* mel_tm, const int32_t* frame_off, co
                                int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w, float* p3_ws,
                                void* stream) {
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0) return 1;
+    NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(cnn_front_kernel, dim3(total_tok_padded), dim3(64), FRONT_LDS_BYTES, (hipStream_t)stream,
                        mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, p3_ws);
-    return hipGetLastError() == hipSuccess ? 0 : 2;
+    return NQ_LAUNCH_STATUS();
 }
 
 extern "C" int nisqa_cnn_back(const float* p3_ws, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
                               int32_t total_tok_padded, const float* cnn_w, float* feat, void* stream) {
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31)) return 1;
+    NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(cnn_back_kernel, dim3(total_tok_padded / 4), dim3(64), BACK_LDS_BYTES, (hipStream_t)stream,
                        p3_ws, tok_off, n_wins, n_clips, cnn_w, feat);
-    return hipGetLastError() == hipSuccess ? 0 : 2;
+    return NQ_LAUNCH_STATUS();
 }
 
 extern "C" int nisqa_cnn_adapt(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,

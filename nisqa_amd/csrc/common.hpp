@@ -61,3 +61,8 @@ NQ_DEV float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+
+// hipGetLastError() is sticky per thread and PyTorch routinely leaves benign errors behind (e.g.
+// hipPointerGetAttributes on pageable host memory).  Clear it before our launches, read it after.
+#define NQ_LAUNCH_BEGIN() (void)hipGetLastError()
+#define NQ_LAUNCH_STATUS() (hipGetLastError() == hipSuccess ? 0 : 2)

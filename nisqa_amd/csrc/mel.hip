@@ -2,18 +2,24 @@
 // (reference nisqa/NISQA_lib.py:2308-2331; arithmetic of librosa 0.8.1 stft / filters.mel /
 // amplitude_to_db restated in oracle/mel.py).
 //
-// One wave computes one STFT frame end to end (window -> FFT -> |.| -> mel -> dB):
-//   * the hann window has `win` <= 1024 non-zero taps inside the 4096-sample frame, so after a
-//     (magnitude-preserving) circular shift the real sequence is supported on [0, 1024).  Packed as
-//     z[n] = x[2n] + i x[2n+1] (n < 512) the 2048-point complex FFT collapses to FOUR 512-point
-//     FFTs of z[n] * W2048^(r n), r = 0..3, giving Z[4m + r]: the three outer radix-4 stages of a
-//     4096-point transform are never executed (pruned input);
+// One wave computes one STFT frame end to end (window -> FFT -> |.| -> mel -> dB) and walks over
+// FRAMES_PER_WAVE consecutive frames with all per-lane constants resident in registers:
+//   * pruned FFT: the hann window has `win` <= 1024 non-zero taps inside the 4096-sample frame, so
+//     after a (magnitude-preserving) circular shift the real sequence is supported on [0, 1024).
+//     Packed as z[n] = x[2n] + i x[2n+1] (n < 512) the 2048-point complex FFT collapses to FOUR
+//     512-point FFTs of z[n] * W2048^(r n), r = 0..3, giving Z[4m + r]: the three outer radix-4
+//     stages of a 4096-point transform are never executed;
 //   * each 512-point FFT is radix 8x8x8 with 8 complex values per lane and two wave-private LDS
-//     transposes (padded strides 72 / 80 B-rows: conflict free for ds_write_b64 / ds_read_b128);
-//   * the real-input recombination, magnitude, sparse (two-triangles-per-bin) slaney filterbank as
-//     48 wavefront reductions, 10*log10(max(amin^2, S^2)) and the per-clip running maximum
-//     (order-preserving atomicMax) all stay in the same wave; the only HBM traffic is the 960
-//     input samples (coalesced, L2-shared between overlapping frames) and 48 output floats.
+//     transposes (row strides 72 complex / 80 B: conflict free for ds_write_b64 / ds_read_b128);
+//     every twiddle is either a per-lane register loaded once per wave or a compile-time constant;
+//   * real-input recombination X[K] = (Z[K] + conj Z[2048-K])/2 - i W4096^K (Z[K] - conj Z[2048-K])/2:
+//     the partner of Z_r[k] is Z_(4-r)[511-k] (Z_0[512-k] for r = 0), i.e. the SAME register index
+//     mirrored in lane 63-l (64-l): a lane shuffle, no spectrum buffer;
+//   * slaney filterbank in sparse form (each bin feeds <= 2 triangles): 4 bands per pass, one per
+//     16-lane row, weights shared in LDS by the workgroup, row totals by DPP butterflies;
+//   * 10*log10(max(amin^2, S^2)), coalesced 192-byte store per frame, running per-clip maximum kept
+//     in a register and published with one order-preserving atomicMax per wave and clip;
+//   * the next frame's samples are prefetched while the current frame is transformed.
 // The top_db clamp needs the per-clip maximum, i.e. a reduction over every frame of the clip; it
 // is applied by the consumer (the CNN loads max(x, floor)) or by nisqa_mel_finalize in place.
 #include "common.hpp"
@@ -47,134 +53,231 @@ NQ_DEV void dft8(c32 (&v)[8]) {
     v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
 }
 
-#define MEL_Z_BYTES (4 * 520 * 8)          /* Z[K] at ((K&3)*520 + (K>>2)) complex */
-#define MEL_B1_OFF MEL_Z_BYTES             /* exchange 1: [p][72] complex */
-#define MEL_B2_OFF (MEL_B1_OFF + 8 * 72 * 8) /* exchange 2: 64 rows of 80 B */
-#define MEL_MAG_OFF MEL_Z_BYTES            /* magnitudes alias the exchange buffers */
-#define MEL_LDS_BYTES (MEL_B2_OFF + 64 * 80)
+// exp(-2 pi i m / 32) and exp(-2 pi i m / 16) as (cos, -sin)
+__device__ constexpr float W32C[32] = {1.000000000e+00f, 9.807852804e-01f, 9.238795325e-01f, 8.314696123e-01f, 7.071067812e-01f, 5.555702330e-01f, 3.826834324e-01f, 1.950903220e-01f, 6.123233996e-17f, -1.950903220e-01f, -3.826834324e-01f, -5.555702330e-01f, -7.071067812e-01f, -8.314696123e-01f, -9.238795325e-01f, -9.807852804e-01f, -1.000000000e+00f, -9.807852804e-01f, -9.238795325e-01f, -8.314696123e-01f, -7.071067812e-01f, -5.555702330e-01f, -3.826834324e-01f, -1.950903220e-01f, -1.836970199e-16f, 1.950903220e-01f, 3.826834324e-01f, 5.555702330e-01f, 7.071067812e-01f, 8.314696123e-01f, 9.238795325e-01f, 9.807852804e-01f};
+__device__ constexpr float W32S[32] = {-0.000000000e+00f, -1.950903220e-01f, -3.826834324e-01f, -5.555702330e-01f, -7.071067812e-01f, -8.314696123e-01f, -9.238795325e-01f, -9.807852804e-01f, -1.000000000e+00f, -9.807852804e-01f, -9.238795325e-01f, -8.314696123e-01f, -7.071067812e-01f, -5.555702330e-01f, -3.826834324e-01f, -1.950903220e-01f, -1.224646799e-16f, 1.950903220e-01f, 3.826834324e-01f, 5.555702330e-01f, 7.071067812e-01f, 8.314696123e-01f, 9.238795325e-01f, 9.807852804e-01f, 1.000000000e+00f, 9.807852804e-01f, 9.238795325e-01f, 8.314696123e-01f, 7.071067812e-01f, 5.555702330e-01f, 3.826834324e-01f, 1.950903220e-01f};
+__device__ constexpr float W16C[16] = {1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f, 6.123233996e-17f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f, -1.000000000e+00f, -9.238795325e-01f, -7.071067812e-01f, -3.826834324e-01f, -1.836970199e-16f, 3.826834324e-01f, 7.071067812e-01f, 9.238795325e-01f};
+__device__ constexpr float W16S[16] = {-0.000000000e+00f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f, -1.000000000e+00f, -9.238795325e-01f, -7.071067812e-01f, -3.826834324e-01f, -1.224646799e-16f, 3.826834324e-01f, 7.071067812e-01f, 9.238795325e-01f, 1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f};
 
-__global__ __launch_bounds__(64) void mel_frame_kernel(
+#define MEL_WAVES 4
+#define MEL_EXCH_BYTES 5120            /* exchange 1 [8][72] complex (4608 B) and exchange 2 64 x 80 B alias */
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+NQ_DEV float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
+NQ_DEV c32 shfl_c(c32 v, int src) { return cmk(__shfl(v.x, src), __shfl(v.y, src)); }
+
+// |X[K]| for K = 4k + r from za = Z[K], zb = Z[2048-K], W4096^K = wl * wc (per-lane x constant part;
+// applied one after the other so that nothing loop-invariant can be hoisted into 64 extra registers)
+NQ_DEV float xmag(c32 za, c32 zb, c32 wl, c32 wc) {
+    const float ar = za.x + zb.x, ai = za.y - zb.y;     // Za + conj(Zb)
+    const c32 d = cmul(cmk(za.x - zb.x, za.y + zb.y), wl);   // (Za - conj(Zb)) * wl
+    const float wr = wc.x * d.x - wc.y * d.y, wi = wc.x * d.y + wc.y * d.x;
+    const float xr = 0.5f * (ar + wi), xi = 0.5f * (ai - wr);
+    return sqrtf(xr * xr + xi * xi);
+}
+
+struct mel_twiddles {
+    c32 a[4];   // W2048^(r l), r = 1..3 (a[0] unused)
+    c32 b[8];   // W512^(l p)
+    c32 c[8];   // W64^((l&7) q1)
+    c32 d[4];   // W4096^(4 l + r)
+};
+
+// 512-point FFT of u[a] = z[l + 64 a] * W2048^(r (l + 64 a)); returns Z_r[l + 64 q2] in u[q2]
+template <int R>
+NQ_DEV void fft512(c32 (&u)[8], const c32 (&z)[8], const mel_twiddles& tw, char* exch, int lane) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        if (R == 0 || a == 0) u[a] = z[a];
+        else u[a] = cmul(z[a], cmk(W32C[(R * a) & 31], W32S[(R * a) & 31]));     // W2048^(64 R a) = W32^(R a)
+    }
+    dft8(u);                                                // over a -> p
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        if (p != 0) u[p] = cmul(u[p], tw.b[p]);               // W512^(l p)
+        if (R != 0) u[p] = cmul(u[p], tw.a[R]);               // W2048^(R l): per-lane part of the pre-twiddle
+    }
+    c32* b1 = (c32*)exch;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) b1[p * 72 + lane] = u[p];
+    __builtin_amdgcn_wave_barrier();
+    const int pq = lane >> 3, j1 = lane & 7;
+#pragma unroll
+    for (int j2 = 0; j2 < 8; ++j2) u[j2] = b1[pq * 72 + j1 + 8 * j2];
+    __builtin_amdgcn_wave_barrier();
+    dft8(u);                                                // over j2 -> q1
+#pragma unroll
+    for (int q1 = 1; q1 < 8; ++q1) u[q1] = cmul(u[q1], tw.c[q1]);
+#pragma unroll
+    for (int q1 = 0; q1 < 8; ++q1) *(c32*)(exch + (pq + 8 * q1) * 80 + j1 * 8) = u[q1];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 t4 = *(const f32x4*)(exch + lane * 80 + q * 16);
+        u[2 * q] = cmk(t4[0], t4[1]);
+        u[2 * q + 1] = cmk(t4[2], t4[3]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    dft8(u);                                                // over j1 -> q2 ; k = lane + 64 q2
+}
+
+__global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
     const float* __restrict__ pcm, const int64_t* __restrict__ clip_off,
-    const int32_t* __restrict__ frame_off, int n_clips, nisqa_mel_cfg cfg,
-    const float* __restrict__ window, const float2* __restrict__ tw,
+    const int32_t* __restrict__ frame_off, int n_clips, int total_frames, int frames_per_wave,
+    nisqa_mel_cfg cfg, int mag_stride, int w_floats,
+    const float* __restrict__ window, const float2* __restrict__ twg,
     const int32_t* __restrict__ band_start, const int32_t* __restrict__ band_len,
     const int32_t* __restrict__ band_woff, const float* __restrict__ band_w,
     float* __restrict__ mel_tm, uint32_t* __restrict__ clip_max_enc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x;
-    const int f = blockIdx.x;
-    const int b = find_segment(frame_off, n_clips, f);
-    const int t = f - frame_off[b];
-    const int64_t c0 = clip_off[b];
-    const int L = (int)(clip_off[b + 1] - c0);
-    const float* y = pcm + c0;
-    // first windowed sample of frame t in clip coordinates (librosa: centre pad n_fft/2, window
-    // centre-padded by (n_fft - win)/2)
-    const int start = t * cfg.hop - cfg.n_fft / 2 + (cfg.n_fft - cfg.win) / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* wlds = (float*)smem;                                   // shared sparse filterbank weights
+    const int w_bytes = (w_floats * 4 + 15) & ~15;
+    const int per_wave = MEL_EXCH_BYTES + mag_stride * 16;
+    char* exch = smem + w_bytes + wave * per_wave;
+    float* mag = (float*)(exch + MEL_EXCH_BYTES);                 // |X[K]| at (K&3)*mag_stride + (K>>2)
+    for (int i = tid; i < w_floats; i += 64 * MEL_WAVES) wlds[i] = band_w[i];
+    __syncthreads();
 
-    // ---- windowed, reflect-padded samples, packed as complex pairs: lane holds n = lane + 64 a
-    c32 z[8];
+    // ---- per-lane constants, loaded once per wave
+    mel_twiddles tw;
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const int n = lane + 64 * a;
-        float v[2];
+    for (int r = 1; r < 4; ++r) { const float2 w = twg[(2 * r * lane) & 4095]; tw.a[r] = cmk(w.x, w.y); }
+    tw.a[0] = cmk(1.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) { const float2 w = twg[(8 * lane * p) & 4095]; tw.b[p] = cmk(w.x, w.y); }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const float2 w = twg[(64 * (lane & 7) * q) & 4095]; tw.c[q] = cmk(w.x, w.y); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float2 w = twg[4 * lane + r]; tw.d[r] = cmk(w.x, w.y); }
+    float win[8][2];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int m = 2 * n + e;
-            float s = 0.f;
-            if (m < cfg.win) {
-                int i = start + m;
+            const int m = 2 * (lane + 64 * a) + e;
+            win[a][e] = m < cfg.win ? window[m] : 0.f;
+        }
+    // band tables of this lane's DPP row: pass ps handles band 4*ps + row
+    const int row = lane >> 4, l16 = lane & 15;
+    int bsl[12], bwo[12];                                          // (start | len << 16), weight offset
+#pragma unroll
+    for (int ps = 0; ps < 12; ++ps) {
+        const int bnd = 4 * ps + row;
+        bsl[ps] = band_start[bnd] | (band_len[bnd] << 16); bwo[ps] = band_woff[bnd];
+    }
+
+    const int f_begin = (blockIdx.x * MEL_WAVES + wave) * frames_per_wave;
+    const int f_end = min(f_begin + frames_per_wave, total_frames);
+    if (f_begin >= f_end) return;
+    const int start0 = -cfg.n_fft / 2 + (cfg.n_fft - cfg.win) / 2;   // first windowed sample of frame 0
+
+    int b = find_segment(frame_off, n_clips, f_begin);
+    float runmax = -3.0e38f;
+
+    // raw (unwindowed) samples of frame f, reflect-padded like np.pad(mode='reflect')
+    auto load_frame = [&](int f, int bb, float (&raw)[8][2]) {
+        const int64_t c0 = clip_off[bb];
+        const int L = (int)(clip_off[bb + 1] - c0);
+        const float* y = pcm + c0;
+        const int s0 = (f - frame_off[bb]) * cfg.hop + start0;
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                int i = s0 + 2 * (lane + 64 * a) + e;
                 i = i < 0 ? -i : i;
                 i = i >= L ? 2 * (L - 1) - i : i;
                 i = min(max(i, 0), L - 1);
-                s = y[i] * window[m];
+                raw[a][e] = y[i];
             }
-            v[e] = s;
+    };
+
+    float raw[8][2];
+    load_frame(f_begin, b, raw);
+    for (int f = f_begin; f < f_end; ++f) {
+        c32 z[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) z[a] = cmk(raw[a][0] * win[a][0], raw[a][1] * win[a][1]);
+        // prefetch the next frame (clip may change)
+        const int fn = f + 1;
+        int bn = b;
+        if (fn < f_end) {
+            while (fn >= frame_off[bn + 1]) ++bn;
+            load_frame(fn, bn, raw);
         }
-        z[a] = cmk(v[0], v[1]);
-    }
 
-    c32* zbuf = (c32*)smem;
-    c32* b1 = (c32*)(smem + MEL_B1_OFF);
-    char* b2 = smem + MEL_B2_OFF;
-
+        c32 u[8], u1[8];
+        const int mir = 63 - lane;
+        // r = 0: partner Z_0[512 - k] = lane (64 - l) & 63, register 7 - q2 (lane 0: register (8 - q2) & 7)
+        fft512<0>(u, z, tw, exch, lane);
+        {
+            const int src = (64 - lane) & 63;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        c32 u[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            if (r == 0) {
-                u[a] = z[a];
-            } else {
-                const float2 w = tw[(2 * r * (lane + 64 * a)) & 4095];
-                u[a] = cmul(z[a], cmk(w.x, w.y));
+            for (int q2 = 0; q2 < 8; ++q2) {
+                c32 zb = shfl_c(u[7 - q2], src);
+                if (lane == 0) zb = u[(8 - q2) & 7];
+                if (lane + 64 * q2 < mag_stride)
+                    mag[0 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tw.d[0], cmk(W16C[q2], W16S[q2]));
             }
         }
-        dft8(u);                                            // over a -> p
+        // r = 2: partner Z_2[511 - k] = lane 63 - l, register 7 - q2
+        fft512<2>(u, z, tw, exch, lane);
 #pragma unroll
-        for (int p = 1; p < 8; ++p) {
-            const float2 w = tw[(8 * lane * p) & 4095];     // W512^(j p)
-            u[p] = cmul(u[p], cmk(w.x, w.y));
+        for (int q2 = 0; q2 < 8; ++q2) {
+            const c32 zb = shfl_c(u[7 - q2], mir);
+            if (lane + 64 * q2 < mag_stride)
+                mag[2 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tw.d[2], cmk(W16C[q2], W16S[q2]));
         }
+        // r = 1 and r = 3 are each other's partners
+        fft512<1>(u1, z, tw, exch, lane);
+        fft512<3>(u, z, tw, exch, lane);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) b1[p * 72 + lane] = u[p];
-        __syncthreads();
-        const int pq = lane >> 3, j1 = lane & 7;
-#pragma unroll
-        for (int j2 = 0; j2 < 8; ++j2) u[j2] = b1[pq * 72 + j1 + 8 * j2];
-        dft8(u);                                            // over j2 -> q1
-#pragma unroll
-        for (int q1 = 1; q1 < 8; ++q1) {
-            const float2 w = tw[(64 * j1 * q1) & 4095];     // W64^(j1 q1)
-            u[q1] = cmul(u[q1], cmk(w.x, w.y));
+        for (int q2 = 0; q2 < 8; ++q2) {
+            const c32 z3m = shfl_c(u[7 - q2], mir), z1m = shfl_c(u1[7 - q2], mir);
+            const c32 w16 = cmk(W16C[q2], W16S[q2]);
+            if (lane + 64 * q2 < mag_stride) {
+                mag[1 * mag_stride + lane + 64 * q2] = xmag(u1[q2], z3m, tw.d[1], w16);
+                mag[3 * mag_stride + lane + 64 * q2] = xmag(u[q2], z1m, tw.d[3], w16);
+            }
         }
-#pragma unroll
-        for (int q1 = 0; q1 < 8; ++q1) *(c32*)(b2 + (pq + 8 * q1) * 80 + j1 * 8) = u[q1];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 t4 = *(const f32x4*)(b2 + lane * 80 + q * 16);
-            u[2 * q] = cmk(t4[0], t4[1]);
-            u[2 * q + 1] = cmk(t4[2], t4[3]);
-        }
-        dft8(u);                                            // over j1 -> q2 ; k = lane + 64 q2
-#pragma unroll
-        for (int q2 = 0; q2 < 8; ++q2) zbuf[r * 520 + lane + 64 * q2] = u[q2];   // K = 4k + r
-        __syncthreads();
-    }
+        __builtin_amdgcn_wave_barrier();
 
-    // ---- real-input recombination + magnitude for the bins that carry mel weight
-    float* mag = (float*)(smem + MEL_MAG_OFF);
-    for (int K = lane; K < cfg.n_bins; K += 64) {
-        const int Ka = K & 2047, Kb = (2048 - K) & 2047;
-        const c32 za = zbuf[(Ka & 3) * 520 + (Ka >> 2)];
-        const c32 zb = zbuf[(Kb & 3) * 520 + (Kb >> 2)];
-        const float2 w = tw[K];
-        const float ar = za.x + zb.x, ai = za.y - zb.y;     // Za + conj(Zb)
-        const float dr = za.x - zb.x, di = za.y + zb.y;     // Za - conj(Zb)
-        const float wr = w.x * dr - w.y * di, wi = w.x * di + w.y * dr;
-        const float xr = 0.5f * (ar + wi), xi = 0.5f * (ai - wr);
-        mag[K] = sqrtf(xr * xr + xi * xi);
+        // ---- sparse slaney filterbank: 4 bands per pass (one per 16-lane row)
+        float mine = 0.f;
+#pragma unroll
+        for (int ps = 0; ps < 12; ++ps) {
+            float part = 0.f;
+            const int bst = bsl[ps] & 0xffff, bln = bsl[ps] >> 16;
+            for (int q = l16; q < bln; q += 16) {
+                const int K = bst + q;
+                part = fmaf(wlds[bwo[ps] + q], mag[(K & 3) * mag_stride + (K >> 2)], part);
+            }
+            part = row16_sum(part);
+            if (l16 == ps) mine = part;                 // lane 16*row + ps holds band 4*ps + row
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- amplitude_to_db(ref=1, amin=1e-4): 10*log10(max(amin^2, S^2)); running per-clip max
+        if (l16 < 12) {
+            const float db = 10.0f * log10f(fmaxf(cfg.amin_sq, mine * mine));
+            mel_tm[(size_t)f * NISQA_N_MELS + 4 * l16 + row] = db;
+            runmax = fmaxf(runmax, db);
+        }
+        if (bn != b || fn >= f_end) {                   // wave-uniform: publish this clip's maximum
+            const float m = wave_max(runmax);
+            if (lane == 0) atomicMax(clip_max_enc + b, enc_ordered(m));
+            runmax = -3.0e38f;
+            b = bn;
+        }
     }
-    __syncthreads();
-
-    // ---- sparse slaney filterbank: one wavefront reduction per band
-    float mine = 0.f;
-    for (int m = 0; m < cfg.n_mels; ++m) {
-        const int st = band_start[m], ln = band_len[m], wo = band_woff[m];
-        float part = 0.f;
-        for (int q = lane; q < ln; q += 64) part = fmaf(band_w[wo + q], mag[st + q], part);
-        part = wave_sum(part);
-        if (lane == m) mine = part;
-    }
-    // ---- amplitude_to_db(ref=1, amin=1e-4): 10*log10(max(amin^2, S^2)); running per-clip max
-    float db = -3.0e38f;
-    if (lane < cfg.n_mels) {
-        db = 10.0f * log10f(fmaxf(cfg.amin_sq, mine * mine));
-        mel_tm[(size_t)f * cfg.n_mels + lane] = db;
-    }
-    db = wave_max(db);
-    if (lane == 0) atomicMax(clip_max_enc + b, enc_ordered(db));
 }
 
 __global__ void mel_floor_kernel(const uint32_t* __restrict__ clip_max_enc, float top_db, int n_clips,
@@ -206,30 +309,44 @@ extern "C" int nisqa_mel_db(const float* pcm, const int64_t* clip_off, const int
                             const int32_t* band_len, const int32_t* band_woff, const float* band_w,
                             float* mel_tm, uint32_t* clip_max_enc, void* stream) {
     if (!cfg || cfg->n_fft != NISQA_N_FFT || cfg->n_mels != NISQA_N_MELS || cfg->win < 2 || cfg->win > 1024 ||
-        cfg->hop < 1 || cfg->n_bins < 1 || cfg->n_bins > 2049 || n_clips <= 0 || total_frames <= 0)
+        cfg->hop < 1 || cfg->n_bins < 1 || cfg->n_bins > 2048 || cfg->w_floats < 1 || cfg->w_floats > 4100 ||
+        n_clips <= 0 || total_frames <= 0)
         return NISQA_ERR_ARG;
-    hipLaunchKernelGGL(mel_frame_kernel, dim3(total_frames), dim3(64), MEL_LDS_BYTES, (hipStream_t)stream, pcm,
-                       clip_off, frame_off, n_clips, *cfg, window, (const float2*)twiddle, band_start, band_len,
-                       band_woff, band_w, mel_tm, clip_max_enc);
-    return hipGetLastError() == hipSuccess ? NISQA_OK : NISQA_ERR_LAUNCH;
+    const int w_floats = cfg->w_floats;
+    NQ_LAUNCH_BEGIN();
+    // LDS: shared band weights + per wave (FFT exchange 5120 B + magnitudes 4 planes x mag_stride floats);
+    // mag_stride >= ceil(n_bins/4) and == 8 (mod 32) keeps the band-sum reads bank-conflict free
+    int mag_stride = (cfg->n_bins + 3) / 4;
+    mag_stride += (8 - (mag_stride & 31) + 32) & 31;
+    const int w_bytes = (w_floats * 4 + 15) & ~15;
+    const size_t lds = (size_t)w_bytes + MEL_WAVES * (MEL_EXCH_BYTES + mag_stride * 16);
+    const int frames_per_wave = 8;
+    const int per_wg = MEL_WAVES * frames_per_wave;
+    hipLaunchKernelGGL(mel_frame_kernel, dim3((total_frames + per_wg - 1) / per_wg), dim3(64 * MEL_WAVES), lds,
+                       (hipStream_t)stream, pcm, clip_off, frame_off, n_clips, total_frames, frames_per_wave, *cfg,
+                       mag_stride, w_floats, window, (const float2*)twiddle, band_start, band_len, band_woff, band_w,
+                       mel_tm, clip_max_enc);
+    return NQ_LAUNCH_STATUS();
 }
 
 extern "C" int nisqa_mel_finalize(float* mel_tm, const int32_t* frame_off, int32_t n_clips, int32_t total_frames,
                                   const uint32_t* clip_max_enc, float top_db, float* clip_floor,
                                   int32_t clamp_in_place, void* stream) {
     if (n_clips <= 0 || total_frames <= 0) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(mel_floor_kernel, dim3((n_clips + 63) / 64), dim3(64), 0, (hipStream_t)stream, clip_max_enc,
                        top_db, n_clips, clip_floor);
     if (clamp_in_place)
         hipLaunchKernelGGL(mel_clamp_kernel, dim3(total_frames), dim3(64), 0, (hipStream_t)stream, mel_tm, frame_off,
                            n_clips, total_frames, clip_floor);
-    return hipGetLastError() == hipSuccess ? NISQA_OK : NISQA_ERR_LAUNCH;
+    return NQ_LAUNCH_STATUS();
 }
 
 extern "C" int nisqa_pcm16_to_f32(const int16_t* pcm16, float* pcm, int64_t n, void* stream) {
     if (n <= 0) return NISQA_ERR_ARG;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(pcm16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, pcm16, pcm, n);
-    return hipGetLastError() == hipSuccess ? NISQA_OK : NISQA_ERR_LAUNCH;
+    return NQ_LAUNCH_STATUS();
 }

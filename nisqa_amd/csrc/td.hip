@@ -313,6 +313,7 @@ extern "C" int nisqa_td_selfatt(const float* feat, const int32_t* tok_off, const
     float* kb[2] = {ws + sz, ws + 4 * sz};
     float* vb[2] = {ws + 2 * sz, ws + 5 * sz};
     const int tiles = np / 32;
+    NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(td_proj_kernel, dim3(tiles), dim3(64), 0, st, feat, tok_off, n_wins, n_clips, np, td_w, x_out,
                        qb[0], kb[0], vb[0]);
     for (int l = 0; l < n_layers; ++l) {
@@ -323,7 +324,7 @@ extern "C" int nisqa_td_selfatt(const float* feat, const int32_t* tok_off, const
                            (const float*)x_out, (const float*)qb[c], (const float*)kb[c], (const float*)vb[c], x_out,
                            qb[nx], kb[nx], vb[nx]);
     }
-    return hipGetLastError() == hipSuccess ? NISQA_OK : NISQA_ERR_LAUNCH;
+    return NQ_LAUNCH_STATUS();
 }
 
 extern "C" int nisqa_pool_att(const float* x, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
@@ -334,9 +335,10 @@ extern "C" int nisqa_pool_att(const float* x, const int32_t* tok_off, const int3
     hipStream_t st = (hipStream_t)stream;
     float* sc = ws;
     float* yv = ws + (size_t)total_tok_padded * 8;
+    NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(pool_score_kernel, dim3(total_tok_padded / 32), dim3(64), 0, st, x, tok_off, n_wins, n_clips,
                        n_heads, pool_w, sc, yv);
     hipLaunchKernelGGL(pool_final_kernel, dim3(n_clips), dim3(64), 0, st, tok_off, n_wins, n_heads,
                        (const float*)sc, (const float*)yv, out);
-    return hipGetLastError() == hipSuccess ? NISQA_OK : NISQA_ERR_LAUNCH;
+    return NQ_LAUNCH_STATUS();
 }

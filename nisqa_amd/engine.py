@@ -115,7 +115,7 @@ class HipNisqa(object):
             up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
             d = {'host': t, 'window': up(t.window), 'twiddle': up(t.twiddle), 'band_start': up(t.band_start),
                  'band_len': up(t.band_len), 'band_woff': up(t.band_woff), 'band_w': up(t.band_w)}
-            d['cfg'] = _lib.MelCfg(t.n_fft, t.hop, t.win, t.n_mels, t.n_bins, 1e-8, 80.0)
+            d['cfg'] = _lib.MelCfg(t.n_fft, t.hop, t.win, t.n_mels, t.n_bins, int(t.band_w.size), 1e-8, 80.0)
             d['model'] = _lib.ModelDev(_ptr(d['window']), _ptr(d['twiddle']), _ptr(d['band_start']), _ptr(d['band_len']),
                                        _ptr(d['band_woff']), _ptr(d['band_w']), _ptr(self.cnn_w), _ptr(self.td_w),
                                        _ptr(self.pool_w), self.n_layers, self.n_heads, self.seg_hop, None)

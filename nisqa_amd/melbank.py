@@ -85,4 +85,6 @@ class MelTables(object):
         self.band_start, self.band_len, self.band_woff = start, length, woff
         self.band_w = np.concatenate(w).astype(np.float32) if w else np.zeros(1, np.float32)
         self.n_bins = int((start + length).max()) if o else 1
+        if self.n_bins > 2048:
+            raise NotImplementedError('mel filterbank reaches the Nyquist bin; not supported by the HIP front end')
         self.dense = fb
