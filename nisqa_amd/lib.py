@@ -20,7 +20,7 @@ c_i64 = ctypes.c_int64
 
 class MelCfg(ctypes.Structure):
     """nisqa_mel_cfg"""
-    _fields_ = [('n_fft', c_i32), ('hop', c_i32), ('win', c_i32), ('n_mels', c_i32), ('n_bins', c_i32), ('w_floats', c_i32),
+    _fields_ = [('n_fft', c_i32), ('hop', c_i32), ('win', c_i32), ('n_mels', c_i32), ('n_bins', c_i32),
                 ('w_floats', c_i32), ('amin_sq', ctypes.c_float), ('top_db', ctypes.c_float)]
 
 
