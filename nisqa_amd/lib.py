@@ -57,6 +57,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  It must be
+    # mapped BEFORE libnisqa_hip.so so that our DT_NEEDED libamdhip64.so.7 binds to that same runtime; loaded
+    # the other way round the process ends up with two HIP runtimes and torch's streams/pointers are foreign.
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(
             'nisqa_amd: HIP library not built: %s is missing (run __graft_entry__.build() or '
