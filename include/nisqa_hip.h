@@ -55,8 +55,8 @@ typedef struct {
     int32_t hop;        /* int(sr * ms_hop_length), NISQA_lib.py:2308 */
     int32_t win;        /* int(sr * ms_win_length) <= 1024, NISQA_lib.py:2309 */
     int32_t n_mels;     /* must be 48 */
-    int32_t n_bins;     /* number of FFT bins with a non-zero mel weight (k = 0 .. n_bins-1), <= 2048 */
-    int32_t w_floats;   /* length of band_w (total non-zero filterbank weights), <= 4100 */
+    int32_t n_bins;     /* number of FFT bins with a non-zero mel weight (k = 0 .. n_bins-1), <= 2049 */
+    int32_t w_floats;   /* length of band_w (padded filterbank weights), <= 8192 */
     float   amin_sq;    /* amin^2 = 1e-8 */
     float   top_db;     /* 80 */
 } nisqa_mel_cfg;
@@ -64,9 +64,10 @@ typedef struct {
 /* Tables (all [dev]), built by the host from the checkpoint's ms_* arguments:
  *   window[win]                 float  periodic hann
  *   twiddle[4096][2]            float  (cos, -sin)(2*pi*k/4096)
- *   band_start/len/woff[n_mels] int32  sparse rows of the mel filterbank: band m has non-zero
- *                                      weights band_w[woff[m] .. woff[m]+len[m]) on bins
- *                                      start[m] .. start[m]+len[m])
+ *   band_start/len/woff[n_mels] int32  sparse rows of the mel filterbank: band m has weights
+ *                                      band_w[woff[m] .. woff[m]+len[m]) on bins start[m] .. ;
+ *                                      len[m] is zero-padded to a multiple of 16 and equal for
+ *                                      the four bands 4p .. 4p+3 of a pass (see melbank.py)
  * pcm[dev] float mono samples of all clips back to back, clip b at [clip_off[b], clip_off[b+1]).
  * Outputs: mel_tm[TT][48] UNCLAMPED dB, clip_max_enc[B] (must be zero-filled by the caller;
  * receives an order-preserving uint32 encoding of the per-clip maximum dB).

@@ -168,12 +168,13 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
         }
     // band tables of this lane's DPP row: pass ps handles band 4*ps + row
     const int row = lane >> 4, l16 = lane & 15;
-    int bsl[12], bwo[12];                                          // (start | len << 16), weight offset
+    int bst[12], bwo[12];                                          // first bin, weight offset (+ this lane)
 #pragma unroll
     for (int ps = 0; ps < 12; ++ps) {
         const int bnd = 4 * ps + row;
-        bsl[ps] = band_start[bnd] | (band_len[bnd] << 16); bwo[ps] = band_woff[bnd];
+        bst[ps] = band_start[bnd] + l16; bwo[ps] = band_woff[bnd] + l16;
     }
+    const int kmax = 4 * mag_stride - 1;
 
     const int f_begin = (blockIdx.x * MEL_WAVES + wave) * frames_per_wave;
     const int f_end = min(f_begin + frames_per_wave, total_frames);
@@ -228,6 +229,8 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
                 if (lane + 64 * q2 < mag_stride)
                     mag[0 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tw.d[0], cmk(W16C[q2], W16S[q2]));
             }
+            if (lane == 0 && 512 < mag_stride) mag[512] = fabsf(u[0].x - u[0].y);   // Nyquist bin X[2048] = Re Z0 - Im Z0
+
         }
         // r = 2: partner Z_2[511 - k] = lane 63 - l, register 7 - q2
         fft512<2>(u, z, tw, exch, lane);
@@ -255,11 +258,13 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
         float mine = 0.f;
 #pragma unroll
         for (int ps = 0; ps < 12; ++ps) {
+            // padded length is the same for the 4 bands of a pass (zero weights beyond a band's support)
+            const int nit = __builtin_amdgcn_readfirstlane(band_len[4 * ps]) >> 4;
             float part = 0.f;
-            const int bst = bsl[ps] & 0xffff, bln = bsl[ps] >> 16;
-            for (int q = l16; q < bln; q += 16) {
-                const int K = bst + q;
-                part = fmaf(wlds[bwo[ps] + q], mag[(K & 3) * mag_stride + (K >> 2)], part);
+#pragma unroll 4
+            for (int it = 0; it < nit; ++it) {
+                const int K = min(bst[ps] + 16 * it, kmax);
+                part = fmaf(wlds[bwo[ps] + 16 * it], mag[(K & 3) * mag_stride + (K >> 2)], part);
             }
             part = row16_sum(part);
             if (l16 == ps) mine = part;                 // lane 16*row + ps holds band 4*ps + row
@@ -309,7 +314,7 @@ extern "C" int nisqa_mel_db(const float* pcm, const int64_t* clip_off, const int
                             const int32_t* band_len, const int32_t* band_woff, const float* band_w,
                             float* mel_tm, uint32_t* clip_max_enc, void* stream) {
     if (!cfg || cfg->n_fft != NISQA_N_FFT || cfg->n_mels != NISQA_N_MELS || cfg->win < 2 || cfg->win > 1024 ||
-        cfg->hop < 1 || cfg->n_bins < 1 || cfg->n_bins > 2048 || cfg->w_floats < 1 || cfg->w_floats > 4100 ||
+        cfg->hop < 1 || cfg->n_bins < 1 || cfg->n_bins > 2049 || cfg->w_floats < 1 || cfg->w_floats > 8192 ||
         n_clips <= 0 || total_frames <= 0)
         return NISQA_ERR_ARG;
     const int w_floats = cfg->w_floats;

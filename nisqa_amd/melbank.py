@@ -70,21 +70,24 @@ class MelTables(object):
         k = np.arange(4096, dtype=np.float64)
         self.twiddle = np.stack([np.cos(2 * np.pi * k / 4096), -np.sin(2 * np.pi * k / 4096)], 1).astype(np.float32)
         fb = slaney_filterbank(self.sr, self.n_fft, self.n_mels, 0.0, float(fmax))
+        # Sparse rows for the kernel: band m covers bins [start[m], start[m] + len[m]) with weights
+        # band_w[woff[m] : woff[m] + len[m]].  The kernel sums four consecutive bands per pass (one per 16-lane
+        # row) with a wave-uniform trip count, so len is PADDED (zero weights) to the pass maximum rounded up
+        # to 16 and is identical for the four bands of a pass.
         start = np.zeros(self.n_mels, np.int32)
-        length = np.zeros(self.n_mels, np.int32)
-        woff = np.zeros(self.n_mels, np.int32)
-        w = []
-        o = 0
+        true_len = np.zeros(self.n_mels, np.int32)
         for m in range(self.n_mels):
             nz = np.nonzero(fb[m])[0]
             if len(nz):
-                start[m], length[m] = nz[0], nz[-1] - nz[0] + 1
-                w.append(fb[m, nz[0]:nz[-1] + 1])
-            woff[m] = o
-            o += int(length[m])
-        self.band_start, self.band_len, self.band_woff = start, length, woff
-        self.band_w = np.concatenate(w).astype(np.float32) if w else np.zeros(1, np.float32)
-        self.n_bins = int((start + length).max()) if o else 1
-        if self.n_bins > 2048:
-            raise NotImplementedError('mel filterbank reaches the Nyquist bin; not supported by the HIP front end')
+                start[m], true_len[m] = nz[0], nz[-1] - nz[0] + 1
+        length = np.zeros(self.n_mels, np.int32)
+        for ps in range(self.n_mels // 4):
+            length[4 * ps:4 * ps + 4] = max(16, -(-int(true_len[4 * ps:4 * ps + 4].max()) // 16) * 16)
+        woff = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.int32)
+        w = np.zeros(int(length.sum()), np.float32)
+        for m in range(self.n_mels):
+            w[woff[m]:woff[m] + true_len[m]] = fb[m, start[m]:start[m] + true_len[m]]
+        self.band_start, self.band_len, self.band_woff, self.band_w = start, length, woff, w
+        self.true_len = true_len
+        self.n_bins = int((start + true_len).max()) if true_len.any() else 1
         self.dense = fb

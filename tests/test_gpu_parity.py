@@ -83,6 +83,24 @@ def test_mel_matches_oracle(eng_rand, batch):
             assert np.abs(got - g['mel_%d' % i]).max() < 2e-3
 
 
+@pytest.mark.parametrize('sr', [16000, 44100, 8000, 22050])
+def test_mel_other_sample_rates(eng_rand, sr):
+    """ms_sr=None: hop/win/filterbank follow the file's native rate (NISQA_lib.py:2308-2309); at 16 kHz and
+    below the upper mel bands lie above Nyquist (empty filters -> -80 dB floor) and the Nyquist bin carries weight."""
+    pcm = [synth.synth_pcm16(40, 1.3, sr=sr), synth.synth_pcm16(41, 0.7, sr=sr)]
+    flat = np.concatenate(pcm).astype(np.float32) / np.float32(32768.0)
+    plan = eng_rand.plan([len(p) for p in pcm], sr)
+    mel, floor = eng_rand.mel(torch.from_numpy(flat).to(eng_rand.device), plan, sr, clamp=True)
+    mel = mel.cpu().numpy()
+    for n, p in enumerate(pcm):
+        ref = omel.melspec_db_from_audio(p.astype(np.float32) / np.float32(32768.0), sr)
+        got = mel[plan.frame_off[n]:plan.frame_off[n + 1]].T
+        assert got.shape == ref.shape
+        err = np.abs(got - ref).max()
+        print('sr', sr, 'clip', n, 'max|d|', err)
+        assert err < 2e-3
+
+
 def test_pcm16_conversion(eng_rand):
     p = clip_pcm(0)
     d = eng_rand.pcm16_to_f32(torch.from_numpy(p).to(eng_rand.device))
