@@ -202,10 +202,11 @@ def _predict(model, ds, bs, dev, num_workers):
     if ds.mos_column != 'predict_only':
         raise NotImplementedError('only predict_only datasets are supported (evaluation is out of scope)')
     dev = torch.device(dev)
-    if dev.type != 'cuda':
+    if model._engine is None and dev.type != 'cuda':
         raise RuntimeError('nisqa_amd has no CPU path: device {} requested but the hot path runs only as HIP kernels '
                            'on an MI355X'.format(dev))
     eng = model.engine(dev if dev.index is not None else None)
+    pin = eng.device.type == 'cuda'
     n = len(ds)
     lo, hi = _dist.shard_range(n)
     bs = max(1, int(bs))
@@ -232,12 +233,12 @@ def _predict(model, ds, bs, dev, num_workers):
             for sr, grp in by_sr.items():                          # files of one rate share the mel tables
                 plan = eng.plan([len(y) for _, y in grp], sr, names=[ds.file_path(i) for i, _ in grp])
                 if all(y.dtype == np.int16 for _, y in grp):
-                    host = torch.from_numpy(np.concatenate([y for _, y in grp])).pin_memory()
-                    pcm = eng.pcm16_to_f32(host.to(eng.device, non_blocking=True))
+                    host = torch.from_numpy(np.concatenate([y for _, y in grp]))
+                    pcm = eng.pcm16_to_f32((host.pin_memory() if pin else host).to(eng.device, non_blocking=True))
                 else:
                     host = torch.from_numpy(np.concatenate(
                         [y.astype(np.float32) / np.float32(32768.0) if y.dtype == np.int16 else y for _, y in grp]))
-                    pcm = host.pin_memory().to(eng.device, non_blocking=True)
+                    pcm = (host.pin_memory() if pin else host).to(eng.device, non_blocking=True)
                 pending.append(([i for i, _ in grp], eng.forward_pcm(pcm, plan, sr)))
             for ids, out in pending:
                 y_local[np.asarray(ids) - lo] = out.cpu().numpy()

@@ -1,0 +1,174 @@
+"""Drop-in for the reference's ``nisqa/NISQA_model.py`` on the predict path: same class name,
+constructor argument dict, attributes (``.args .dev .model .ds_val``), printed lines, result frame
+and ``NISQA_results.csv`` -- with the hot path behind it running as HIP kernels on an MI355X.
+
+Only what ``run_predict.py`` reaches is implemented (reference NISQA_model.py:26-39, 54-81,
+732-847, 928-1051).  ``train()`` / ``evaluate()`` raise NotImplementedError (out of scope,
+SURVEY.md section 2 rows 16-19).
+"""
+import datetime
+import os
+from glob import glob
+
+import pandas as pd; pd.options.mode.chained_assignment = None
+import torch
+import yaml
+
+from . import NISQA_lib as NL
+
+
+class nisqaModel(object):
+    """Loads the checkpoint and the dataset table; ``predict()`` returns the frame the reference returns."""
+
+    def __init__(self, args):
+        self.args = args
+        if 'mode' not in self.args:
+            self.args['mode'] = 'main'
+        self.runinfos = {}
+        self._getDevice()
+        self._loadModel()
+        self._loadDatasets()
+        self.args['now'] = datetime.datetime.today()
+        if self.args['mode'] == 'main':
+            print(yaml.dump(self.args, default_flow_style=None, sort_keys=False))
+
+    def train(self):
+        raise NotImplementedError('training is out of scope of nisqa_amd (inference hot path only)')
+
+    def evaluate(self, mapping='first_order', do_print=True, do_plot=False):
+        raise NotImplementedError('evaluation metrics are out of scope of nisqa_amd (inference hot path only)')
+
+    def predict(self):
+        """reference NISQA_model.py:54-81"""
+        print('---> Predicting ...')
+        # tr_parallel (nn.DataParallel in the reference, NISQA_model.py:56-57) is superseded: launch one
+        # process per GPU with torchrun and the clips are sharded across ranks (nisqa_amd/dist.py).
+        if self.args['dim'] == True:  # noqa: E712  (mirrors the reference's comparison)
+            y_val_hat, y_val = NL.predict_dim(self.model, self.ds_val, self.args['tr_bs_val'], self.dev,
+                                              num_workers=self.args['tr_num_workers'])
+        else:
+            y_val_hat, y_val = NL.predict_mos(self.model, self.ds_val, self.args['tr_bs_val'], self.dev,
+                                              num_workers=self.args['tr_num_workers'])
+        from . import dist as _dist
+        rank, _ = _dist.world()
+        if self.args['output_dir']:
+            self.ds_val.df['model'] = self.args['name']
+            if rank == 0:
+                self.ds_val.df.to_csv(os.path.join(self.args['output_dir'], 'NISQA_results.csv'), index=False)
+        if rank == 0:
+            print(self.ds_val.df.to_string(index=False))
+        return self.ds_val.df
+
+    # ---- datasets (reference NISQA_model.py:732-847) ---------------------------------------------
+    def _loadDatasets(self):
+        if self.args['mode'] == 'predict_file':
+            self._loadDatasetsFile()
+        elif self.args['mode'] == 'predict_dir':
+            self._loadDatasetsFolder()
+        elif self.args['mode'] == 'predict_csv':
+            self._loadDatasetsCSVpredict()
+        elif self.args['mode'] == 'main':
+            raise NotImplementedError('mode "main" (training / evaluation datasets) is out of scope of nisqa_amd')
+        else:
+            raise NotImplementedError('mode not available')
+
+    def _dataset(self, df, df_con, data_dir, filename_column, to_memory):
+        a = self.args
+        return NL.SpeechQualityDataset(
+            df, df_con=df_con, data_dir=data_dir, filename_column=filename_column, mos_column='predict_only',
+            seg_length=a['ms_seg_length'], max_length=a['ms_max_segments'], to_memory=to_memory,
+            to_memory_workers=None, seg_hop_length=a['ms_seg_hop_length'], transform=None,
+            ms_n_fft=a['ms_n_fft'], ms_hop_length=a['ms_hop_length'], ms_win_length=a['ms_win_length'],
+            ms_n_mels=a['ms_n_mels'], ms_sr=a['ms_sr'], ms_fmax=a['ms_fmax'], ms_channel=a['ms_channel'],
+            double_ended=a['double_ended'], dim=a['dim'], filename_column_ref=a.get('csv_ref'))
+
+    def _loadDatasetsFolder(self):
+        files = glob(os.path.join(self.args['data_dir'], '*.wav'))
+        files = [os.path.basename(f) for f in files]
+        df_val = pd.DataFrame(files, columns=['deg'])
+        print('# files: {}'.format(len(df_val)))
+        if len(df_val) == 0:
+            raise ValueError('No wav files found in data_dir')
+        self.ds_val = self._dataset(df_val, None, self.args['data_dir'], 'deg', None)
+
+    def _loadDatasetsFile(self):
+        data_dir = os.path.dirname(self.args['deg'])
+        file_name = os.path.basename(self.args['deg'])
+        df_val = pd.DataFrame([file_name], columns=['deg'])
+        self.ds_val = self._dataset(df_val, None, data_dir, 'deg', None)
+
+    def _loadDatasetsCSVpredict(self):
+        csv_file_path = os.path.join(self.args['data_dir'], self.args['csv_file'])
+        dfile = pd.read_csv(csv_file_path)
+        if 'csv_con' in self.args:
+            dcon = pd.read_csv(os.path.join(self.args['data_dir'], self.args['csv_con']))
+        else:
+            dcon = None
+        self.ds_val = self._dataset(dfile, dcon, self.args['data_dir'], self.args['csv_deg'], False)
+
+    # ---- model (reference NISQA_model.py:928-1030) -------------------------------------------------
+    def _loadModel(self):
+        if self.args['pretrained_model']:
+            if os.path.isabs(self.args['pretrained_model']):
+                model_path = os.path.join(self.args['pretrained_model'])
+            else:
+                model_path = os.path.join(os.getcwd(), self.args['pretrained_model'])
+            checkpoint = torch.load(model_path, map_location='cpu')   # packed to device blobs by the engine
+            checkpoint['args'].update(self.args)                      # caller keys win (NISQA_model.py:941)
+            self.args = checkpoint['args']
+        else:
+            raise NotImplementedError('nisqa_amd needs --pretrained_model (inference only)')
+
+        if self.args['model'] == 'NISQA_DIM':
+            self.args['dim'] = True
+            self.args['csv_mos_train'] = None
+            self.args['csv_mos_val'] = None
+        else:
+            self.args['dim'] = False
+        if self.args['model'] == 'NISQA_DE':
+            self.args['double_ended'] = True
+        else:
+            self.args['double_ended'] = False
+            self.args['csv_ref'] = None
+
+        keys = ['ms_seg_length', 'ms_n_mels', 'cnn_model', 'cnn_c_out_1', 'cnn_c_out_2', 'cnn_c_out_3',
+                'cnn_kernel_size', 'cnn_dropout', 'cnn_pool_1', 'cnn_pool_2', 'cnn_pool_3', 'cnn_fc_out_h',
+                'td', 'td_sa_d_model', 'td_sa_nhead', 'td_sa_pos_enc', 'td_sa_num_layers', 'td_sa_h',
+                'td_sa_dropout', 'td_lstm_h', 'td_lstm_num_layers', 'td_lstm_dropout', 'td_lstm_bidirectional',
+                'td_2', 'td_2_sa_d_model', 'td_2_sa_nhead', 'td_2_sa_pos_enc', 'td_2_sa_num_layers', 'td_2_sa_h',
+                'td_2_sa_dropout', 'td_2_lstm_h', 'td_2_lstm_num_layers', 'td_2_lstm_dropout',
+                'td_2_lstm_bidirectional', 'pool', 'pool_att_h', 'pool_att_dropout']
+        self.model_args = {k: self.args[k] for k in keys}
+
+        print('Model architecture: ' + self.args['model'])
+        if self.args['model'] == 'NISQA':
+            self.model = NL.NISQA(**self.model_args)
+        elif self.args['model'] == 'NISQA_DIM':
+            self.model = NL.NISQA_DIM(**self.model_args)
+        elif self.args['model'] == 'NISQA_DE':
+            raise NotImplementedError('NISQA_DE (double-ended) is out of scope of nisqa_amd')
+        else:
+            raise NotImplementedError('Model not available')
+
+        missing_keys, unexpected_keys = self.model.load_state_dict(checkpoint['model_state_dict'], strict=True)
+        print('Loaded pretrained model from ' + self.args['pretrained_model'])
+        if missing_keys:
+            print('missing_keys:')
+            print(missing_keys)
+        if unexpected_keys:
+            print('unexpected_keys:')
+            print(unexpected_keys)
+        self.model.bind_args(self.args)
+
+    def _getDevice(self):
+        """reference NISQA_model.py:1032-1051 (one GPU per process: LOCAL_RANK picks it under torchrun)"""
+        if torch.cuda.is_available():
+            self.dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        else:
+            self.dev = torch.device('cpu')
+        if 'tr_device' in self.args:
+            if self.args['tr_device'] == 'cpu':
+                self.dev = torch.device('cpu')
+            elif self.args['tr_device'] == 'cuda':
+                self.dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        print('Device: {}'.format(self.dev))

@@ -1,0 +1,396 @@
+"""CPU tests of the host side: packed layouts vs the device header, plan arithmetic, WAV ingest vs the
+oracle's decoder, the C-ABI library (loads, exports every declared symbol -- no compute without a GPU),
+the nisqaModel / run_predict plumbing, and the clip-sharded predict loop under gloo (world_size 2)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+import helpers
+from nisqa_amd import synth, weights as W, wavio
+from nisqa_amd.engine import BatchPlan
+from nisqa_amd.melbank import MelTables
+from oracle import mel as omel, net as onet
+
+ROOT = helpers.ROOT
+
+
+# ---- layouts ---------------------------------------------------------------------------------------
+def _header_defines(path):
+    env = {}
+    for line in open(path):
+        m = re.match(r'#define\s+(\w+)\s+(.+?)\s*(/\*.*)?$', line)
+        if m and not m.group(2).startswith('"'):
+            try:
+                env[m.group(1)] = int(eval(m.group(2), {}, env))
+            except Exception:
+                pass
+    return env
+
+
+def test_layout_header_matches_python():
+    env = _header_defines(os.path.join(ROOT, 'nisqa_amd', 'csrc', 'layout.hpp'))
+    names = [n for n in dir(W) if re.match(r'(CNN|TD|TDL|PL)_', n)]
+    assert len(names) > 30
+    for n in names:
+        assert env[n] == getattr(W, n), n
+        assert getattr(W, n) % 4 == 0, n                    # float4-aligned
+
+
+def test_conv_fragments_roundtrip():
+    rng = np.random.default_rng(0)
+    w = rng.standard_normal((64, 32, 3, 3))
+    fr = W.conv_b_fragments(w).reshape(9, 4, 2, 64, 4)
+    for tap, s, nt, lane, kk in [(0, 0, 0, 0, 0), (8, 3, 1, 63, 3), (4, 2, 1, 37, 1), (5, 1, 0, 31, 2)]:
+        n, c = (lane & 31) + 32 * nt, 8 * s + 4 * (lane >> 5) + kk
+        assert fr[tap, s, nt, lane, kk] == np.float32(w[n, c, tap // 3, tap % 3])
+    # emulate the MFMA k-pairing: step s, mfma kk pairs k = 8s+kk (h=0) with 8s+4+kk (h=1) -> every k once
+    seen = sorted(8 * s + 4 * h + kk for s in range(4) for h in range(2) for kk in range(4))
+    assert seen == list(range(32))
+
+
+def test_linear_fragments_roundtrip():
+    rng = np.random.default_rng(1)
+    w = rng.standard_normal((192, 64))
+    fr = W.linear_a_fragments(w).reshape(8, 6, 64, 4)
+    x = rng.standard_normal(64)
+    y = np.zeros(192)
+    for s in range(8):
+        for mt in range(6):
+            for lane in range(64):
+                for kk in range(4):
+                    y[(lane & 31) + 32 * mt] += fr[s, mt, lane, kk] * x[8 * s + 4 * (lane >> 5) + kk]
+    np.testing.assert_allclose(y, w.astype(np.float32).astype(np.float64) @ x, atol=1e-5)
+
+
+def test_bn_fold_matches_batchnorm():
+    sd = synth.random_state_dict(3)
+    wf, t = W.fold_bn(sd, 'cnn.model.', 2)
+    x = torch.randn(2, 16, 8, 5)
+    ref = torch.nn.functional.batch_norm(
+        torch.nn.functional.conv2d(x, sd['cnn.model.conv2.weight'], sd['cnn.model.conv2.bias'], padding=1),
+        sd['cnn.model.bn2.running_mean'], sd['cnn.model.bn2.running_var'], sd['cnn.model.bn2.weight'],
+        sd['cnn.model.bn2.bias'], False, 0.0, 1e-5)
+    got = torch.nn.functional.conv2d(x, torch.from_numpy(wf).float(), torch.from_numpy(t).float(), padding=1)
+    assert (ref - got).abs().max() < 1e-5
+    assert (sd['cnn.model.bn2.weight'] < 0).any()           # negative gammas are exercised
+
+
+def test_pack_sizes_and_unsupported_geometry():
+    sd = synth.random_state_dict(7)
+    assert W.pack_adapt_cnn(sd).shape == (W.CNN_W_FLOATS,)
+    assert W.pack_self_att(sd, 2).shape == (W.TD_LAYER0 + 2 * W.TDL_FLOATS,)
+    assert W.pack_pool_att(sd, ['pool_layers.%d.model.' % h for h in range(5)]).shape == (5 * W.PL_FLOATS,)
+    bad = dict(sd)
+    bad['cnn.model.conv3.weight'] = torch.zeros(48, 32, 3, 3)
+    with pytest.raises(NotImplementedError):
+        W.pack_adapt_cnn(bad)
+
+
+# ---- mel tables -------------------------------------------------------------------------------------
+@pytest.mark.parametrize('sr', [48000, 44100, 16000, 8000])
+def test_mel_tables_match_oracle_filterbank(sr):
+    t = MelTables(sr, 4096, 0.01, 0.02, 48, 20000)
+    fb = omel.mel_filterbank(sr, 4096, 48, 0.0, 20000.0)
+    np.testing.assert_array_equal(t.dense, fb)
+    assert t.hop == int(sr * 0.01) and t.win == int(sr * 0.02)
+    for m in range(48):
+        row = np.zeros(2049 + 400, np.float32)
+        row[t.band_start[m]:t.band_start[m] + t.band_len[m]] = t.band_w[t.band_woff[m]:t.band_woff[m] + t.band_len[m]]
+        np.testing.assert_array_equal(row[:2049], fb[m])
+        assert t.band_len[m] % 16 == 0 and t.band_len[m] == t.band_len[4 * (m // 4)]
+    np.testing.assert_allclose(t.window, omel.hann_periodic(t.win).astype(np.float32))
+    assert t.n_bins == (np.nonzero(fb.any(0))[0].max() + 1)
+
+
+def test_mel_tables_reject_unsupported():
+    with pytest.raises(NotImplementedError):
+        MelTables(48000, 2048, 0.01, 0.02, 48, 20000)
+    with pytest.raises(NotImplementedError):
+        MelTables(96000, 4096, 0.01, 0.02, 48, 20000)       # 1920-sample window > 1024
+
+
+# ---- plan ---------------------------------------------------------------------------------------------
+def test_batch_plan_counts_and_errors():
+    p = BatchPlan([480000, 14 * 480, 144000], 480, 4, 1300)
+    assert list(p.T) == [1001, 15, 301]
+    assert list(p.n_wins) == [247, 1, 72] == [onet.n_wins_of(int(t)) for t in p.T]
+    assert list(p.tok_off) == [0, 256, 288, 384] and p.total_tok == 384
+    assert list(p.frame_off) == [0, 1001, 1016, 1317]
+    assert len(p.token_index()) == 247 + 1 + 72
+    with pytest.raises(ValueError, match='Sample too short'):
+        BatchPlan([14 * 480 - 1], 480, 4, 1300, names=['x.wav'])
+    with pytest.raises(ValueError, match='Increase max window length ms_max_segments'):
+        BatchPlan([(1301 * 4 + 14) * 480], 480, 4, 1300)
+    p1 = BatchPlan([20 * 480], 480, 1, 6000)                 # seg_hop 1 (nisqa_tts geometry)
+    assert list(p1.n_wins) == [7]
+
+
+# ---- WAV ingest -----------------------------------------------------------------------------------------
+def _cases(tmp_path):
+    rng = np.random.default_rng(4)
+    mono16 = (rng.standard_normal(5000) * 3000).astype(np.int16)
+    st16 = (rng.standard_normal((5000, 2)) * 3000).astype(np.int16)
+    f32 = (rng.standard_normal((4000, 2)) * 0.2).astype(np.float32)
+    i32 = (rng.standard_normal(3000) * 1e8).astype(np.int32)
+    u8 = rng.integers(0, 255, 3000).astype(np.uint8)
+    out = {}
+    for name, data, sr in [('mono16', mono16, 48000), ('st16', st16, 44100), ('f32', f32, 16000),
+                           ('i32', i32, 8000), ('u8', u8, 22050)]:
+        p = str(tmp_path / (name + '.wav'))
+        synth.write_wav(p, data, sr)
+        out[name] = p
+    return out
+
+
+def test_wav_ingest_matches_oracle_decoder(tmp_path):
+    files = _cases(tmp_path)
+    for name, path in files.items():
+        y, sr = wavio.read_wav(path)
+        yo, sro = omel.load_wav(path)
+        assert sr == sro
+        if y.dtype == np.int16:
+            assert name == 'mono16'
+            y = y.astype(np.float32) / np.float32(32768.0)
+        np.testing.assert_array_equal(y, yo)
+    y, _ = wavio.read_wav(files['st16'], ms_channel=1)
+    yo, _ = omel.load_wav(files['st16'], ms_channel=1)
+    np.testing.assert_array_equal(y, yo)
+
+
+def test_wav_24bit_and_errors(tmp_path):
+    v = np.array([0, 1, -1, 8388607, -8388608, 123456], dtype=np.int32)
+    raw = b''.join(int(x & 0xFFFFFF).to_bytes(3, 'little') for x in v)
+    import struct
+    hdr = b'RIFF' + struct.pack('<I', 36 + len(raw)) + b'WAVE' + b'fmt ' + struct.pack('<IHHIIHH', 16, 1, 1, 48000, 144000, 3, 24) \
+        + b'data' + struct.pack('<I', len(raw))
+    p = tmp_path / 'p24.wav'
+    p.write_bytes(hdr + raw)
+    y, sr = wavio.read_wav(str(p))
+    np.testing.assert_allclose(y, v / 8388608.0, atol=1e-7)
+    bad = tmp_path / 'bad.wav'
+    bad.write_bytes(b'not a wav')
+    with pytest.raises(ValueError, match='Could not load file'):
+        wavio.read_wav(str(bad))
+    with pytest.raises(ValueError, match='Could not load file'):
+        wavio.read_wav(str(tmp_path / 'missing.wav'))
+
+
+# ---- C ABI ------------------------------------------------------------------------------------------------
+def test_library_exports_every_declared_symbol():
+    from nisqa_amd import lib
+    hdr = open(os.path.join(ROOT, 'include', 'nisqa_hip.h')).read()
+    declared = set(re.findall(r'\b(nisqa_[a-z0-9_]+)\s*\(', hdr))
+    assert declared == set(lib.SYMBOLS), declared ^ set(lib.SYMBOLS)
+    if not os.path.isfile(lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    L = lib.load()                                           # loads, binds every symbol, checks the ABI version
+    assert L.nisqa_abi_version() == 1
+    assert L.nisqa_workspace_bytes(64, 64064, 16384) > 64064 * 48 * 4
+    assert L.nisqa_workspace_bytes(0, 1, 1) == 0
+    out = subprocess.check_output(['nm', '-D', '--defined-only', lib.LIB_PATH]).decode()
+    exported = set(re.findall(r' T (nisqa_\w+)', out))
+    assert declared <= exported
+
+
+def test_abi_argument_validation_without_gpu():
+    from nisqa_amd import lib
+    L = lib.load()
+    cfg = lib.MelCfg(2048, 480, 960, 48, 1707, 4032, 1e-8, 80.0)      # wrong n_fft -> rejected before any launch
+    assert L.nisqa_mel_db(None, None, None, 1, 10, cfg, None, None, None, None, None, None, None, None, None) == lib.NISQA_ERR_ARG
+    assert L.nisqa_cnn_adapt(None, None, None, None, None, 1, 33, 4, None, None, None, None) == lib.NISQA_ERR_ARG
+    assert L.nisqa_pool_att(None, None, None, 1, 32, 9, None, None, None, None) == lib.NISQA_ERR_ARG
+
+
+def test_engine_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from nisqa_amd.engine import HipNisqa
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        HipNisqa(dict(synth.DIM_ARGS), synth.random_state_dict(7))
+
+
+# ---- nisqaModel / CLI plumbing -------------------------------------------------------------------------------
+class FakeEngine(object):
+    """Test double for the device engine: same interface, deterministic per-clip numbers on the CPU."""
+
+    def __init__(self, heads):
+        self.n_heads, self.device = heads, torch.device('cpu')
+
+    def plan(self, lengths, sr, names=None):
+        return BatchPlan(lengths, int(sr * 0.01), 4, 1300, names)
+
+    def pcm16_to_f32(self, t):
+        return t.to(torch.float32) / 32768.0
+
+    def forward_pcm(self, pcm, plan, sr):
+        rows = []
+        for b in range(plan.n_clips):
+            seg = pcm[plan.clip_off[b]:plan.clip_off[b + 1]]
+            rows.append(torch.stack([seg.abs().mean() * (h + 1) + plan.n_wins[b] for h in range(self.n_heads)]))
+        return torch.stack(rows).float()
+
+
+@pytest.fixture()
+def wav_dir(tmp_path):
+    d = tmp_path / 'wavs'
+    d.mkdir()
+    for i in range(5):
+        synth.write_wav(str(d / ('c%d.wav' % i)), synth.synth_pcm16(i, 0.3 + 0.1 * i), 48000)
+    pd.DataFrame({'name': ['c%d.wav' % i for i in (3, 1, 4)], 'db': ['x', 'y', 'z']}).to_csv(d / 'list.csv', index=False)
+    return d
+
+
+def _ckpt(tmp_path, model='NISQA_DIM'):
+    args = dict(synth.DIM_ARGS if model == 'NISQA_DIM' else synth.MOS_ARGS)
+    args.update({'pretrained_model': False, 'tr_bs_val': 1, 'tr_num_workers': 0, 'tr_device': 'cuda'})
+    p = tmp_path / ('%s.tar' % model)
+    torch.save({'args': args, 'model_state_dict': synth.random_state_dict(7 if model == 'NISQA_DIM' else 8, model)}, p)
+    return str(p)
+
+
+def _args(mode, ckpt, **kw):
+    a = {'mode': mode, 'pretrained_model': ckpt, 'deg': None, 'data_dir': None, 'output_dir': None, 'csv_file': None,
+         'csv_deg': None, 'num_workers': 0, 'bs': 2, 'ms_channel': None, 'tr_bs_val': 2, 'tr_num_workers': 0}
+    a.update(kw)
+    return a
+
+
+def test_nisqa_model_predict_dir_and_csv_plumbing(tmp_path, wav_dir, capsys):
+    from nisqa_amd.NISQA_model import nisqaModel
+    ck = _ckpt(tmp_path)
+    out_dir = tmp_path / 'out'
+    out_dir.mkdir()
+    m = nisqaModel(_args('predict_dir', ck, data_dir=str(wav_dir), output_dir=str(out_dir)))
+    assert m.args['dim'] is True and m.args['ms_seg_hop_length'] == 4 and m.args['name'] == 'rand_dim'
+    assert len(m.ds_val) == 5 and list(m.ds_val.df.columns) == ['deg']
+    m.model._engine = FakeEngine(5)
+    df = m.predict()
+    assert list(df.columns) == ['deg', 'mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred', 'model']
+    csv = pd.read_csv(out_dir / 'NISQA_results.csv')
+    assert list(csv.columns) == list(df.columns) and len(csv) == 5 and (csv['model'] == 'rand_dim').all()
+    txt = capsys.readouterr().out
+    assert 'Model architecture: NISQA_DIM' in txt and '---> Predicting ...' in txt and '# files: 5' in txt
+    # predict_csv keeps the caller's columns and CSV order
+    m2 = nisqaModel(_args('predict_csv', ck, data_dir=str(wav_dir), csv_file='list.csv', csv_deg='name'))
+    m2.model._engine = FakeEngine(5)
+    df2 = m2.predict()
+    assert list(df2['name']) == ['c3.wav', 'c1.wav', 'c4.wav'] and list(df2['db']) == ['x', 'y', 'z']
+    by_name = dict(zip(df['deg'], df['mos_pred']))
+    assert [by_name[n] for n in df2['name']] == pytest.approx(list(df2['mos_pred']))
+    assert 'model' not in df2.columns                        # only written when output_dir is set (NISQA_model.py:74-75)
+
+
+def test_nisqa_model_predict_file_mos_only_and_errors(tmp_path, wav_dir):
+    from nisqa_amd.NISQA_model import nisqaModel
+    ck = _ckpt(tmp_path, 'NISQA')
+    m = nisqaModel(_args('predict_file', ck, deg=str(wav_dir / 'c2.wav')))
+    assert m.args['dim'] is False and len(m.ds_val) == 1
+    m.model._engine = FakeEngine(1)
+    df = m.predict()
+    assert list(df.columns) == ['deg', 'mos_pred'] and df['mos_pred'].dtype == np.float64   # NISQA_lib.py:1438
+    empty = tmp_path / 'empty'
+    empty.mkdir()
+    with pytest.raises(ValueError, match='No wav files found in data_dir'):
+        nisqaModel(_args('predict_dir', ck, data_dir=str(empty)))
+    with pytest.raises(NotImplementedError):
+        nisqaModel(_args('nope', ck))
+    short = tmp_path / 'short.wav'
+    synth.write_wav(str(short), synth.synth_pcm16(1, 0.05), 48000)
+    ms = nisqaModel(_args('predict_file', ck, deg=str(short)))
+    ms.model._engine = FakeEngine(1)
+    with pytest.raises(ValueError, match='Sample too short'):
+        ms.predict()
+
+
+def test_predict_without_gpu_raises_no_cpu_path(tmp_path, wav_dir):
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from nisqa_amd.NISQA_model import nisqaModel
+    m = nisqaModel(_args('predict_dir', _ckpt(tmp_path), data_dir=str(wav_dir)))
+    with pytest.raises(RuntimeError, match='no CPU'):
+        m.predict()
+
+
+def test_cli_argument_errors():
+    sys.path.insert(0, ROOT)
+    import run_predict
+    with pytest.raises(ValueError, match='--deg argument'):
+        run_predict.build_args(['--mode', 'predict_file', '--pretrained_model', 'x.tar'])
+    with pytest.raises(ValueError, match='--data_dir argument'):
+        run_predict.build_args(['--mode', 'predict_dir', '--pretrained_model', 'x.tar'])
+    with pytest.raises(ValueError, match='--csv_deg argument'):
+        run_predict.build_args(['--mode', 'predict_csv', '--pretrained_model', 'x.tar', '--csv_file', 'a.csv'])
+    with pytest.raises(NotImplementedError):
+        run_predict.build_args(['--mode', 'train', '--pretrained_model', 'x.tar'])
+    a = run_predict.build_args(['--mode', 'predict_csv', '--pretrained_model', 'x.tar', '--csv_file', 'a.csv',
+                                '--csv_deg', 'f', '--bs', '7', '--num_workers', '3'])
+    assert a['data_dir'] == '' and a['tr_bs_val'] == 7 and a['tr_num_workers'] == 3
+
+
+def test_unsupported_architecture_is_rejected(tmp_path):
+    from nisqa_amd import NISQA_lib as NL
+    with pytest.raises(NotImplementedError, match='CNN-SA-AP'):
+        NL.NISQA(cnn_model='standard', td='lstm', pool='last_step_bi')
+
+
+# ---- multi-process clip sharding (gloo, world_size 2) ------------------------------------------------------------
+def test_shard_bounds_cover_everything():
+    from nisqa_amd import dist
+    for n in (1, 2, 7, 64, 100000):
+        for w in (1, 2, 3, 8):
+            b = [dist.shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
+
+
+_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import torch, pandas as pd
+import test_host as T
+from nisqa_amd import NISQA_lib as NL, synth
+rank = int(sys.argv[1]); world = int(sys.argv[2])
+torch.distributed.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=rank, world_size=world)
+files = sorted(f for f in os.listdir(%(wavs)r) if f.endswith('.wav'))
+ds = NL.SpeechQualityDataset(pd.DataFrame(files, columns=['deg']), data_dir=%(wavs)r, filename_column='deg',
+                             mos_column='predict_only', dim=True)
+model = NL.NISQA_DIM(**{k: v for k, v in synth.DIM_ARGS.items() if k.startswith(('cnn_', 'td', 'pool', 'ms_seg_length', 'ms_n_mels'))})
+model._engine = T.FakeEngine(5)
+y, _ = NL.predict_dim(model, ds, 2, 'cpu', 0)
+json.dump({'y': y.tolist(), 'cols': list(ds.df.columns)}, open(os.path.join(%(out)r, 'r%%d.json' %% rank), 'w'))
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_predict_loop_sharded_over_two_gloo_ranks(tmp_path, wav_dir):
+    import json
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER % {'root': ROOT, 'port': port, 'wavs': str(wav_dir), 'out': str(tmp_path)})
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), '2'], env=env) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    r0 = json.load(open(tmp_path / 'r0.json'))
+    r1 = json.load(open(tmp_path / 'r1.json'))
+    assert r0['y'] == r1['y']                                 # every rank ends with the full, ordered result
+    # single-process reference
+    from nisqa_amd import NISQA_lib as NL
+    files = sorted(f for f in os.listdir(wav_dir) if f.endswith('.wav'))
+    ds = NL.SpeechQualityDataset(pd.DataFrame(files, columns=['deg']), data_dir=str(wav_dir), filename_column='deg',
+                                 mos_column='predict_only', dim=True)
+    model = NL.NISQA_DIM(**{k: v for k, v in synth.DIM_ARGS.items()
+                            if k.startswith(('cnn_', 'td', 'pool', 'ms_seg_length', 'ms_n_mels'))})
+    model._engine = FakeEngine(5)
+    y, ynan = NL.predict_dim(model, ds, 2, 'cpu', 0)
+    np.testing.assert_allclose(np.array(r0['y']), y, rtol=0, atol=1e-6)
+    assert np.isnan(ynan).all() and ynan.shape == (5, 5)
+    assert r0['cols'] == ['deg', 'mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred']
