@@ -7,6 +7,8 @@ Tolerances (floating point; the bar of BASELINE.json is |dMOS| <= 1e-3 end to en
   td output     2e-4
   final outputs 1e-3      (the north-star bar), measured ~1e-5
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -198,3 +200,44 @@ def test_error_mapping(eng_rand):
         eng_rand.plan([14 * 480 - 1], 48000)
     with pytest.raises(ValueError, match='ms_max_segments'):
         eng_rand.plan([(1301 * 4 + 14) * 480], 48000)
+
+
+def test_predict_dir_drop_in_surface(tmp_path):
+    """nisqaModel(args).predict() on real WAV files (mono PCM16, stereo, float32, 16 kHz) vs the oracle path."""
+    import pandas as pd
+    from nisqa_amd.NISQA_model import nisqaModel
+    path = helpers.find_weights('nisqa.tar')
+    if path is None:                                         # no checkpoint here: same test with random weights
+        args = dict(helpers.DIM_ARGS)
+        args.update({'pretrained_model': False, 'tr_bs_val': 1, 'tr_num_workers': 0})
+        path = str(tmp_path / 'rand.tar')
+        torch.save({'args': args, 'model_state_dict': helpers.random_state_dict(7)}, path)
+    ck_args, sd = helpers.load_checkpoint(path)
+    d = tmp_path / 'wavs'
+    d.mkdir()
+    synth.write_wav(str(d / 'a.wav'), synth.synth_pcm16(50, 2.0), 48000)
+    st = np.stack([synth.synth_pcm16(51, 1.5), synth.synth_pcm16(52, 1.5)], 1)
+    synth.write_wav(str(d / 'b_stereo.wav'), st, 48000)
+    synth.write_wav(str(d / 'c_f32.wav'), (synth.synth_clip(53, 1.2) * 0.5).astype(np.float32), 48000)
+    synth.write_wav(str(d / 'd_16k.wav'), synth.synth_pcm16(54, 2.5, sr=16000), 16000)
+    a = {'mode': 'predict_dir', 'pretrained_model': path, 'deg': None, 'data_dir': str(d), 'output_dir': str(tmp_path),
+         'csv_file': None, 'csv_deg': None, 'num_workers': 2, 'bs': 3, 'ms_channel': None, 'tr_bs_val': 3,
+         'tr_num_workers': 2}
+    m = nisqaModel(a)
+    df = m.predict()
+    assert len(df) == 4 and os.path.isfile(tmp_path / 'NISQA_results.csv')
+    cols = ['mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred']
+    for _, row in df.iterrows():
+        spec = omel.get_melspec(str(d / row['deg']), None, m.args['ms_n_fft'], m.args['ms_hop_length'],
+                                m.args['ms_win_length'], m.args['ms_n_mels'], m.args['ms_fmax'])
+        ref = onet.predict_from_melspec(sd, m.args, spec)
+        got = np.array([row[c] for c in cols], np.float32)
+        err = np.abs(got - ref).max()
+        print(row['deg'], 'max|d|', err)
+        assert err < 1e-3
+    # ms_channel picks one channel of the stereo file
+    a2 = dict(a, mode='predict_file', deg=str(d / 'b_stereo.wav'), ms_channel=1, output_dir=None)
+    df2 = nisqaModel(a2).predict()
+    y = st[:, 1].astype(np.float32) / np.float32(32768.0)
+    ref = onet.predict_from_melspec(sd, m.args, omel.melspec_db_from_audio(y, 48000))
+    assert np.abs(np.array([df2[c].iloc[0] for c in cols], np.float32) - ref).max() < 1e-3
