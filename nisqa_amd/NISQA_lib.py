@@ -139,9 +139,8 @@ class _NisqaBase(nn.Module):
 
     def forward(self, x, n_wins):
         """Reference inner operator model(x[B,L,1,48,15], n_wins[B]) -> [B, heads] (NL:137-142, NL:260-268)."""
-        raise NotImplementedError(
-            'segment-tensor entry point is not wired yet: use predict_dim/predict_mos (PCM in) or '
-            'engine().forward_pcm; see DESIGN.md section "what comes next"')
+        dev = x.device if x.is_cuda else None
+        return self.engine(dev).forward_segments(x, n_wins)
 
 
 class NISQA(_NisqaBase):
@@ -187,6 +186,34 @@ class SpeechQualityDataset(object):
     def load_audio(self, index):
         """(samples, sr) of item ``index``; raises ValueError('Could not load file ...') like NL:2305-2306."""
         return read_wav(self.file_path(index), self.ms_channel)
+
+    def bind_engine(self, factory):
+        """``factory()`` -> HipNisqa; lets __getitem__ produce spectrogram segments like the reference dataset."""
+        self._engine_factory = factory
+        return self
+
+    def __getitem__(self, index):
+        """(x_spec_seg [max_length,1,n_mels,seg_length], y, (index, n_wins)) like NL:2162-2233.  The spectrogram is
+        computed by the HIP front end; the overlapping-window gather (NL:2266-2280) is a host-side view for callers
+        that want the reference's item format -- the predict loop never materialises it."""
+        assert isinstance(index, int), 'index must be integer (no slice)'
+        if getattr(self, '_engine_factory', None) is None:
+            raise RuntimeError('SpeechQualityDataset item access needs bind_engine(...) (spectrograms are computed on the GPU)')
+        eng = self._engine_factory()
+        y, sr = self.load_audio(index)
+        plan = eng.plan([len(y)], sr, names=[self.file_path(index)])
+        t = torch.from_numpy(y).to(eng.device)
+        pcm = eng.pcm16_to_f32(t) if y.dtype == np.int16 else t
+        mel, _ = eng.mel(pcm, plan, sr, clamp=True)
+        spec = mel.cpu().numpy()                                   # [T, n_mels]
+        n_wins = int(plan.n_wins[0])
+        idx = self.seg_hop_length * np.arange(n_wins)[:, None] + np.arange(self.seg_length)[None, :]
+        x = np.transpose(spec[idx], (0, 2, 1))[:, None]           # [n_wins, 1, n_mels, seg_length]
+        if self.max_length is not None:
+            pad = np.zeros((self.max_length,) + x.shape[1:], np.float32)
+            pad[:n_wins] = x
+            x = pad
+        return torch.from_numpy(np.ascontiguousarray(x)), self.labels(1)[0], (index, np.array(n_wins))
 
     def labels(self, n):
         """predict_only labels: NaN rows like NL:2217-2231."""

@@ -80,7 +80,8 @@ class nisqaModel(object):
             to_memory_workers=None, seg_hop_length=a['ms_seg_hop_length'], transform=None,
             ms_n_fft=a['ms_n_fft'], ms_hop_length=a['ms_hop_length'], ms_win_length=a['ms_win_length'],
             ms_n_mels=a['ms_n_mels'], ms_sr=a['ms_sr'], ms_fmax=a['ms_fmax'], ms_channel=a['ms_channel'],
-            double_ended=a['double_ended'], dim=a['dim'], filename_column_ref=a.get('csv_ref'))
+            double_ended=a['double_ended'], dim=a['dim'], filename_column_ref=a.get('csv_ref')).bind_engine(
+                lambda: self.model.engine(self.dev))
 
     def _loadDatasetsFolder(self):
         files = glob(os.path.join(self.args['data_dir'], '*.wav'))

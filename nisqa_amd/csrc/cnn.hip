@@ -31,6 +31,7 @@
 #define BACK_ACT_BYTES 18432             /* 4 segments x 18 px x 64 ch x 4 B */
 #define BACK_ZERO_OFF BACK_ACT_BYTES
 #define BACK_LDS_BYTES (BACK_ACT_BYTES + 256)
+#define NQ_FIRST_ROUND_BLOCKS (256 * 8)   /* single-wave workgroups resident at launch: 256 CUs x 2 waves/SIMD */
 
 // 3x3 conv (padding 1) as implicit GEMM over one wave's MT x NT grid of 32x32 MFMA tiles.
 //   smem : pixel-major activations, CIN floats per pixel, 16-B chunks XOR-swizzled
@@ -40,37 +41,60 @@ template <int CIN, int MT, int NT, int H, int W, int ZERO_OFF>
 NQ_DEV void conv3x3_mfma(f32x16 (&acc)[MT][NT], const char* smem, const f32x4* __restrict__ wf,
                          const int (&py)[MT], const int (&px)[MT], const int (&pbase)[MT],
                          const bool (&pvalid)[MT], int lane) {
-    constexpr int S = CIN / 8;   // K-steps per tap
-    constexpr int C = CIN / 4;   // 16-byte chunks per pixel
+    constexpr int S = CIN / 8;        // K-steps per tap (even: the double-buffer parity of step s is s & 1)
+    constexpr int C = CIN / 4;        // 16-byte chunks per pixel
+    static_assert(S % 2 == 0, "double buffer parity");
     const int h = lane >> 5;
-    for (int dy = -1; dy <= 1; ++dy) {
-        for (int dx = -1; dx <= 1; ++dx) {
-            int rowbyte[MT], swz[MT];
+    const f32x4* wl = wf + lane;
+    // Software pipeline over the K-steps (tap-major): the operands of the NEXT step (B fragments from L2,
+    // A rows from LDS) are requested BEFORE the MFMAs of the current step are issued, into the other half
+    // of a register double buffer, so an L2 round trip (~600 clk) hides under a step of MFMAs (>= 1024 clk).
+    f32x4 bf[2][NT], af[2][MT];
+    int rowbyte[MT], swz[MT];
+    auto tap_addr = [&](int tap) {
+        const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const int y = py[t] + dy, x = px[t] + dx;
-                const bool ok = pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                const int pix = pbase[t] + y * W + x;
-                rowbyte[t] = ok ? pix * (CIN * 4) : ZERO_OFF;
-                swz[t] = ok ? (((pix * C) >> 4) & (C - 1)) : 0;
-            }
-            const f32x4* wtap = wf + ((dy + 1) * 3 + (dx + 1)) * (S * NT * 64) + lane;
+        for (int t = 0; t < MT; ++t) {
+            const int y = py[t] + dy, x = px[t] + dx;
+            const bool ok = pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const int pix = pbase[t] + y * W + x;
+            rowbyte[t] = ok ? pix * (CIN * 4) : ZERO_OFF;
+            swz[t] = ok ? (((pix * C) >> 4) & (C - 1)) : 0;
+        }
+    };
+    tap_addr(0);
 #pragma unroll
-            for (int s = 0; s < S; ++s) {
-                f32x4 bf[NT], af[MT];
+    for (int nt = 0; nt < NT; ++nt) bf[0][nt] = wl[nt * 64];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bf[nt] = wtap[(s * NT + nt) * 64];
+    for (int t = 0; t < MT; ++t) af[0][t] = *(const f32x4*)(smem + rowbyte[t] + ((h ^ swz[t]) << 4));
+    for (int tap = 0; tap < 9; ++tap) {
+        const f32x4* wt = wl + tap * (S * NT * 64);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            constexpr int dummy = 0; (void)dummy;
+            const int nb = (s + 1) & 1;
+            if (s + 1 < S) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bf[nb][nt] = wt[((s + 1) * NT + nt) * 64];
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
-                    af[t] = *(const f32x4*)(smem + rowbyte[t] + (((2 * s + h) ^ swz[t]) << 4));
+                    af[nb][t] = *(const f32x4*)(smem + rowbyte[t] + (((2 * (s + 1) + h) ^ swz[t]) << 4));
+            } else if (tap < 8) {
+                tap_addr(tap + 1);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
+                for (int nt = 0; nt < NT; ++nt) bf[nb][nt] = wt[(S * NT + nt) * 64];
 #pragma unroll
-                    for (int t = 0; t < MT; ++t)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[t][nt] = mfma32(af[t][kk], bf[nt][kk], acc[t][nt]);
+                for (int t = 0; t < MT; ++t) af[nb][t] = *(const f32x4*)(smem + rowbyte[t] + ((h ^ swz[t]) << 4));
             }
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch above ahead of this step's MFMAs
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[t][nt] = mfma32(af[s & 1][t][kk], bf[s & 1][nt][kk], acc[t][nt]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -85,24 +109,35 @@ __device__ constexpr int win53_hi(int b) { return b == 0 ? 2 : b == 1 ? 4 : 5; }
 // ---------------------------------------------------------------------------------------------
 // conv1 (VALU) + pool1 + conv2 + pool2 + conv3 + conv4 + pool3, one wave per segment.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void cnn_front_kernel(
+__global__ __launch_bounds__(64, 2) void cnn_front_kernel(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
     const float* __restrict__ clip_floor, int n_clips, int seg_hop,
-    const float* __restrict__ cw, float* __restrict__ p3) {
+    const float* __restrict__ cw, float* __restrict__ p3,
+    const float* __restrict__ seg_x, int seg_L, int stagger_blocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int p = blockIdx.x;                       // padded token index
     const int b = find_segment(tok_off, n_clips, p);
     const int k = p - tok_off[b];
     if (k >= n_wins[b]) return;                     // padding token of this clip
+    stagger_odd_wave_slot(stagger_blocks, 5);
 
     // ---- stage the 15-frame window (frame-major: 720 contiguous floats), apply the top_db floor
     {
         float* in_lds = (float*)(smem + FRONT_IN_OFF);
-        const float* src = mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
-        const float fl = clip_floor[b];
-        for (int i = lane; i < 720; i += 64) in_lds[i] = fmaxf(src[i], fl);
+        if (seg_x) {
+            // segment-tensor mode: x[b][k][0][48][15] as the reference's model.forward receives it
+            const float* src = seg_x + ((size_t)b * seg_L + k) * 720;
+            for (int i = lane; i < 720; i += 64) {
+                const int m = i / 15;
+                in_lds[(i - 15 * m) * 48 + m] = src[i];
+            }
+        } else {
+            const float* src = mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
+            const float fl = clip_floor[b];
+            for (int i = lane; i < 720; i += 64) in_lds[i] = fmaxf(src[i], fl);
+        }
         ((float*)(smem + FRONT_ZERO_OFF))[lane] = 0.f;
     }
     __syncthreads();
@@ -273,16 +308,17 @@ __global__ __launch_bounds__(64) void cnn_front_kernel(
 // conv6 is evaluated as a padding-1 conv at the centre column x = 1 of the 3-wide image, which is
 // the same sum as the reference's (3 x pool_3[1]) kernel with no width padding (NISQA_lib.py:672-676).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void cnn_back_kernel(
+__global__ __launch_bounds__(64, 2) void cnn_back_kernel(
     const float* __restrict__ p3, const int32_t* __restrict__ tok_off,
     const int32_t* __restrict__ n_wins, int n_clips, const float* __restrict__ cw,
-    float* __restrict__ feat) {
+    float* __restrict__ feat, int stagger_blocks) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int p0 = blockIdx.x * 4;                  // tok_off is a multiple of 32: no clip straddling
     const int b = find_segment(tok_off, n_clips, p0);
     const int nvalid = min(4, n_wins[b] - (p0 - tok_off[b]));
     if (nvalid <= 0) return;
+    stagger_odd_wave_slot(stagger_blocks, 5);
 
     {
         const f32x4* src = (const f32x4*)p3 + (size_t)p0 * (18 * 16);
@@ -372,8 +408,22 @@ extern "C" int nisqa_cnn_front(const float* mel_tm, const int32_t* frame_off, co
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0) return 1;
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(cnn_front_kernel, dim3(total_tok_padded), dim3(64), FRONT_LDS_BYTES, (hipStream_t)stream,
-                       mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, p3_ws);
+                       mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, p3_ws,
+                       (const float*)nullptr, 0, NQ_FIRST_ROUND_BLOCKS);
     return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_cnn_adapt_segments(const float* x, int32_t seg_len_padded, const int32_t* tok_off,
+                                        const int32_t* n_wins, int32_t n_clips, int32_t total_tok_padded,
+                                        const float* cnn_w, float* p3_ws, float* feat, void* stream) {
+    if (!x || seg_len_padded <= 0 || n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31)) return 1;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(cnn_front_kernel, dim3(total_tok_padded), dim3(64), FRONT_LDS_BYTES, (hipStream_t)stream,
+                       (const float*)nullptr, (const int32_t*)nullptr, tok_off, n_wins, (const float*)nullptr, n_clips,
+                       1, cnn_w, p3_ws, x, seg_len_padded, NQ_FIRST_ROUND_BLOCKS);
+    const int rc = NQ_LAUNCH_STATUS();
+    if (rc) return rc;
+    return nisqa_cnn_back(p3_ws, tok_off, n_wins, n_clips, total_tok_padded, cnn_w, feat, stream);
 }
 
 extern "C" int nisqa_cnn_back(const float* p3_ws, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
@@ -381,7 +431,7 @@ extern "C" int nisqa_cnn_back(const float* p3_ws, const int32_t* tok_off, const 
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31)) return 1;
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(cnn_back_kernel, dim3(total_tok_padded / 4), dim3(64), BACK_LDS_BYTES, (hipStream_t)stream,
-                       p3_ws, tok_off, n_wins, n_clips, cnn_w, feat);
+                       p3_ws, tok_off, n_wins, n_clips, cnn_w, feat, NQ_FIRST_ROUND_BLOCKS);
     return NQ_LAUNCH_STATUS();
 }
 

@@ -62,6 +62,19 @@ NQ_DEV float wave_max(float v) {
     return v;
 }
 
+// The two waves that share a SIMD start together and take the same time per work item, so without help
+// they stay phase-locked: both in their VALU/LDS/epilogue phases at once (matrix pipe idle), both in their
+// MFMA phases at once (pipe contended).  Delaying the odd hardware wave slots of the FIRST round of
+// workgroups by ~a phase de-synchronises the pair for the rest of the launch; the sleeping wave costs
+// nothing because its partner then has the matrix pipe to itself.
+NQ_DEV void stagger_odd_wave_slot(int first_round_blocks, int sleeps) {
+    if ((int)blockIdx.x < first_round_blocks) {
+        const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);   // HW_REG_HW_ID[3:0] = wave_id
+        if (wave_slot & 1u)
+            for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);    // 127 * 64 clocks each
+    }
+}
+
 // hipGetLastError() is sticky per thread and PyTorch routinely leaves benign errors behind (e.g.
 // hipPointerGetAttributes on pageable host memory).  Clear it before our launches, read it after.
 #define NQ_LAUNCH_BEGIN() (void)hipGetLastError()

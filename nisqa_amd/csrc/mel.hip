@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
         const int bnd = 4 * ps + row;
         bst[ps] = band_start[bnd] + l16; bwo[ps] = band_woff[bnd] + l16;
     }
-    const int kmax = 4 * mag_stride - 1;
+    const int kmax = min(4 * mag_stride - 1, 2048);   // every plane entry up to here is rewritten each frame (0-weight padding reads stay finite)
 
     const int f_begin = (blockIdx.x * MEL_WAVES + wave) * frames_per_wave;
     const int f_end = min(f_begin + frames_per_wave, total_frames);

@@ -50,6 +50,23 @@ class BatchPlan(object):
         self.total_tok = int(self.tok_off[-1])
         self.dev = None
 
+    @classmethod
+    def from_n_wins(cls, n_wins):
+        """Plan for callers that already hold segments (model.forward): only the token layout is needed."""
+        self = cls.__new__(cls)
+        n = np.asarray(n_wins, dtype=np.int64).reshape(-1)
+        self.n_clips = int(len(n))
+        self.lengths = np.zeros(self.n_clips, np.int64)
+        self.T = np.zeros(self.n_clips, np.int64)
+        self.n_wins = n.astype(np.int32)
+        self.clip_off = np.zeros(self.n_clips + 1, np.int64)
+        self.frame_off = np.zeros(self.n_clips + 1, np.int32)
+        npad = (n + TOK_PAD - 1) // TOK_PAD * TOK_PAD
+        self.tok_off = np.concatenate([[0], np.cumsum(npad)]).astype(np.int32)
+        self.total_samples, self.total_frames, self.total_tok = 0, 0, int(self.tok_off[-1])
+        self.dev = None
+        return self
+
     def to(self, device):
         if self.dev is None or self.dev['device'] != device:
             self.dev = {
@@ -184,6 +201,24 @@ class HipNisqa(object):
                                             _ptr(clip_floor), plan.n_clips, plan.total_tok, self.seg_hop,
                                             _ptr(self.cnn_w), _ptr(p3), _ptr(feat), self._stream()), 'nisqa_cnn_adapt')
         return feat, p3
+
+    def forward_segments(self, x, n_wins):
+        """Reference inner operator model(x[B,L,1,48,15], n_wins[B]) -> [B, heads] (NL:137-142, NL:260-268)."""
+        if x.dim() != 5 or tuple(x.shape[2:]) != (1, 48, SEG_LEN):
+            raise ValueError('expected x of shape [B, L, 1, 48, 15], got {}'.format(tuple(x.shape)))
+        x = x.to(self.device, dtype=torch.float32).contiguous()
+        n = np.asarray(n_wins.detach().cpu().numpy() if torch.is_tensor(n_wins) else n_wins, dtype=np.int64).reshape(-1)
+        B, L = x.shape[0], x.shape[1]
+        if len(n) != B or (n < 1).any() or (n > L).any():
+            raise ValueError('n_wins must hold one count in [1, L] per clip')
+        plan = BatchPlan.from_n_wins(n)
+        d = plan.to(self.device)
+        p3 = torch.empty((plan.total_tok, 18, 64), dtype=torch.float32, device=self.device)
+        feat = torch.empty((plan.total_tok, 384), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nisqa_cnn_adapt_segments(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B, plan.total_tok,
+                                                     _ptr(self.cnn_w), _ptr(p3), _ptr(feat), self._stream()),
+                   'nisqa_cnn_adapt_segments')
+        return self.pool(self.td(feat, plan), plan)
 
     def td(self, feat, plan):
         d = plan.to(self.device)

@@ -241,3 +241,36 @@ def test_predict_dir_drop_in_surface(tmp_path):
     y = st[:, 1].astype(np.float32) / np.float32(32768.0)
     ref = onet.predict_from_melspec(sd, m.args, omel.melspec_db_from_audio(y, 48000))
     assert np.abs(np.array([df2[c].iloc[0] for c in cols], np.float32) - ref).max() < 1e-3
+
+
+def test_inner_operator_forward_on_segment_tensors(eng_rand, batch):
+    """model(x[B,L,1,48,15], n_wins) -- the reference's inner operator (NL:260-268) -- and Dataset.__getitem__."""
+    from nisqa_amd import NISQA_lib as NL
+    args, sd = dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM')
+    ids, pcm = batch
+    specs = [omel.melspec_db_from_audio(p.astype(np.float32) / np.float32(32768.0), 48000) for p in pcm]
+    L = 80
+    xs, nw = [], []
+    for s in specs:
+        x, n = onet.segment_specs(s, 15, 4, L)
+        xs.append(x); nw.append(n)
+    xb = torch.stack(xs, 0)
+    model = NL.NISQA_DIM(**{k: v for k, v in args.items() if k.startswith(('cnn_', 'td', 'pool', 'ms_seg_length', 'ms_n_mels'))})
+    model.load_state_dict(sd, strict=True)
+    model.bind_args(args)
+    out = model(xb.cuda(), torch.tensor(nw)).cpu().numpy()
+    for n, s in enumerate(specs):
+        ref = onet.predict_from_melspec(sd, args, s)
+        assert np.abs(out[n] - ref).max() < 1e-3
+    # dataset item in the reference's format
+    import pandas as pd, tempfile
+    d = tempfile.mkdtemp()
+    synth.write_wav(os.path.join(d, 'a.wav'), pcm[0], 48000)
+    ds = NL.SpeechQualityDataset(pd.DataFrame(['a.wav'], columns=['deg']), data_dir=d, filename_column='deg',
+                                 mos_column='predict_only', seg_length=15, max_length=1300, seg_hop_length=4,
+                                 ms_n_fft=4096, ms_hop_length=0.01, ms_win_length=0.02, ms_n_mels=48, ms_sr=None,
+                                 ms_fmax=20000, dim=True).bind_engine(lambda: eng_rand)
+    x, y, (idx, n_wins) = ds[0]
+    xr, nr = onet.segment_specs(specs[0], 15, 4, 1300)
+    assert tuple(x.shape) == (1300, 1, 48, 15) and int(n_wins) == nr and idx == 0 and np.isnan(y).all() and y.shape == (5,)
+    assert (x - xr).abs().max() < 2e-3
