@@ -1,0 +1,344 @@
+// AdaptCNN conv1..conv4 on split-bf16 MFMA ("bf16x3") -- same role, inputs and outputs as
+// cnn_front_kernel in cnn.hip (reference nisqa/NISQA_lib.py:2239-2282, 487-502, 688-702).
+//
+// Every fp32 operand x is carried as x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 mantissa
+// bits) and each product is formed as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation: 3 MFMAs at 16x the fp32-MFMA rate = 5.3x the exact-fp32 throughput.  Dropped term:
+// lo*lo ~ 2^-18.  conv1 sees dB values up to |80| and uses a 3-term split with the six lowest-order
+// products (K is one MFMA step, so this is nearly free).  Measured effect on the outputs with the
+// real nisqa.tar weights: |dMOS| <= 6e-6 (pure bf16: 4.5e-3, pure f16: 5e-4; bar 1e-3) -- DESIGN.md 4.5.
+//
+// Structure differences from the fp32 kernel, all consequences of the 5x faster matrix pipe:
+//   * weight fragments no longer stream from L2 per wave (that would need ~25 TB/s of L2): a workgroup
+//     is FOUR waves = four segments that walk the K-steps in lockstep, and each 8 KiB chunk of
+//     fragments is brought in once per workgroup with global_load_lds_dwordx4 (direct to LDS, lane-
+//     linear, double-buffered, one barrier per chunk) and read by all four waves;
+//   * conv1 moves from the VALU to the matrix pipe (im2col gather of the 9 taps from three bf16 planes
+//     of the input patch), because at this speed the VALU version would cost as much as conv2-4;
+//   * activations live in LDS as two bf16 planes (hi, lo), pixel-major, same XOR-swizzled 16-byte
+//     chunks and the same row->pixel maps as the fp32 kernel, so pooling stays in-lane.
+#include "common.hpp"
+#include "layout.hpp"
+#include "../../include/nisqa_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+NQ_DEV f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// round-to-nearest-even fp32 -> bf16 (finite inputs)
+NQ_DEV unsigned bf16_bits(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+NQ_DEV float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
+
+#define FB_ACT 15360                       /* per-wave activation region (planes alias as layers retire) */
+#define FB_ZERO FB_ACT                     /* 128 B of zeros per wave */
+#define FB_WAVE (FB_ACT + 128)
+#define FB_BBUF 8192                       /* one weight staging buffer: 2 steps x 2 ntiles x (hi,lo) x 1 KiB */
+#define FB_BOFF (4 * FB_WAVE)
+#define FB_LDS (FB_BOFF + 2 * FB_BBUF)     /* 78336 B -> two workgroups per CU */
+#define FB_PATCH 10752                     /* conv1 input: three bf16 planes [15][48] behind the A1 planes */
+
+// One conv layer (3x3, padding 1) for this wave's segment; the four waves of the workgroup call it in
+// lockstep and share the staged weight fragments.
+//   act_in : this wave's input planes (hi at +0, lo at +PLANE), pixel rows of CIN bf16, swizzled chunks
+//   wb     : layer fragments [TOTAL steps][NT][2][64][8] bf16
+template <int CIN, int MT, int NT, int H, int W>
+NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* zero, char* bbuf,
+                         const unsigned short* __restrict__ wb, const int (&py)[MT], const int (&px)[MT],
+                         const bool (&pvalid)[MT], int lane, int wave) {
+    constexpr int S16 = CIN / 16;             // K=16 steps per tap
+    constexpr int TOTAL = 9 * S16;
+    constexpr int NCH = (TOTAL + 1) / 2;      // chunks of two steps
+    constexpr int Cc = CIN / 8;               // 16-byte chunks per pixel row (per plane)
+    constexpr int PLANE = H * W * CIN * 2;    // bytes per plane
+    constexpr int FRAG_PER_STEP = NT * 2;     // 1 KiB fragments per step
+    const int h = lane >> 5;
+
+    auto stage = [&](int c) {                 // this wave's share of chunk c -> staging buffer c & 1
+        const int first = 2 * c * FRAG_PER_STEP;
+        const int nfrag = min(2, TOTAL - 2 * c) * FRAG_PER_STEP;
+        for (int f = wave; f < nfrag; f += 4)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(wb + (size_t)(first + f) * 512 + lane * 8),
+                (__attribute__((address_space(3))) void*)(bbuf + (c & 1) * FB_BBUF + f * 1024), 16, 0, 0);
+    };
+
+    __syncthreads();                          // everyone is done with the previous layer's staging buffers
+    stage(0);
+    for (int c = 0; c < NCH; ++c) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                      // chunk c landed for all waves; chunk c-1 fully consumed
+        if (c + 1 < NCH) stage(c + 1);
+        const char* bb = bbuf + (c & 1) * FB_BBUF + lane * 16;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const int g = 2 * c + st;
+            if (g < TOTAL) {
+                const int tap = g / S16, s = g - tap * S16;
+                const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+                f32x4 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    bh[nt] = *(const f32x4*)(bb + ((st * NT + nt) * 2 + 0) * 1024);
+                    bl[nt] = *(const f32x4*)(bb + ((st * NT + nt) * 2 + 1) * 1024);
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const int y = py[t] + dy, x = px[t] + dx;
+                    const bool ok = pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+                    const int pix = y * W + x;
+                    const int swz = ((pix * Cc) >> 4) & (Cc - 1);
+                    const char* ph = ok ? act_in + pix * (CIN * 2) + (((2 * s + h) ^ swz) << 4) : zero;
+                    ah[t] = *(const f32x4*)ph;
+                    al[t] = *(const f32x4*)(ok ? ph + PLANE : zero);
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[t][nt] = mfma_bf(ah[t], bl[nt], acc[t][nt]);
+                        acc[t][nt] = mfma_bf(al[t], bh[nt], acc[t][nt]);
+                        acc[t][nt] = mfma_bf(ah[t], bh[nt], acc[t][nt]);
+                    }
+            }
+        }
+    }
+}
+
+__device__ constexpr int bwin75_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 2 : b == 3 ? 4 : 5; }
+__device__ constexpr int bwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b == 2 ? 5 : b == 3 ? 6 : 7; }
+__device__ constexpr int bwin53_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : 3; }
+__device__ constexpr int bwin53_hi(int b) { return b == 0 ? 2 : b == 1 ? 4 : 5; }
+
+// store v = hi + lo into the two bf16 planes at byte offset `off` of the hi plane
+NQ_DEV void store_split(char* plane_hi, int plane_bytes, int off, float v) {
+    const unsigned hi = bf16_bits(v);
+    const unsigned lo = bf16_bits(v - bf16_val(hi));
+    *(unsigned short*)(plane_hi + off) = (unsigned short)hi;
+    *(unsigned short*)(plane_hi + plane_bytes + off) = (unsigned short)lo;
+}
+
+__global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
+    const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
+    const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
+    const float* __restrict__ clip_floor, int n_clips, int seg_hop,
+    const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ p3,
+    const float* __restrict__ seg_x, int seg_L) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p0 = blockIdx.x * 4;                      // tok_off is a multiple of 32: no clip straddling
+    const int b = find_segment(tok_off, n_clips, p0);
+    const int k0 = p0 - tok_off[b];
+    const int nvalid = min(4, n_wins[b] - k0);
+    if (nvalid <= 0) return;                             // whole workgroup is padding
+    const bool valid = wave < nvalid;                    // padding waves still walk the barriers (on zeros)
+    const int p = p0 + wave, k = k0 + wave;
+    char* act = smem + wave * FB_WAVE;
+    char* zero = act + FB_ZERO;
+    char* bbuf = smem + FB_BOFF;
+
+    // ---- stage the 15-frame window as three bf16 planes (hi, mid, lo) [frame j][mel m]
+    {
+        unsigned short* pl = (unsigned short*)(act + FB_PATCH);
+        const float fl = seg_x ? -3.0e38f : clip_floor[b];
+        const float* src = seg_x ? seg_x + ((size_t)b * seg_L + k) * 720
+                                 : mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
+        for (int i = lane; i < 720; i += 64) {
+            float v = 0.f;
+            int dst = i;
+            if (seg_x) { const int m = i / 15; dst = (i - 15 * m) * 48 + m; }
+            if (valid) v = fmaxf(src[i], fl);
+            const unsigned hi = bf16_bits(v);
+            const float r1 = v - bf16_val(hi);
+            const unsigned mid = bf16_bits(r1);
+            const unsigned lo = bf16_bits(r1 - bf16_val(mid));
+            pl[dst] = (unsigned short)hi;
+            pl[720 + dst] = (unsigned short)mid;
+            pl[1440 + dst] = (unsigned short)lo;
+        }
+        if (lane < 32) ((float*)zero)[lane] = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int i = lane & 31, hfi = (i >> 2) & 1, qi = (i & 3) + 4 * (i >> 3);
+    const int n = lane & 31, hf = lane >> 5, h = lane >> 5;
+
+    // ---- conv1 1->16 + pool 48x15 -> 24x7 on the matrix pipe.  K = 16 holds the 9 taps (lane half 0: taps
+    //      0..7, half 1: tap 8); N = 32 holds the 16 channels.  Each lane half owns 12 pooled rows; a pooled
+    //      row = 2 x 15 conv pixels = local index u = 15*yy + x in two 16-row tiles.
+    {
+        const unsigned short* pl = (const unsigned short*)(act + FB_PATCH);
+        f32x4 w1[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) w1[t] = *(const f32x4*)(wb + CNNB_W1 + t * 512 + lane * 8);
+        const float tn = cw[CNN_T1 + (n & 15)];
+        char* a1 = act;                                   // A1 planes: 168 px x 16 ch, plane 5376 B
+        for (int gl = 0; gl < 12; ++gl) {
+            f32x16 acc[2];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int u = 16 * tt + qi;
+                const int yy = u >= 15 ? 1 : 0, x = u - 15 * yy;
+                const int y = 2 * (12 * hfi + gl) + yy;
+                unsigned v[3][8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int tap = 8 * h + e;
+                    const int dy = tap / 3, dx = tap - 3 * dy;
+                    const int m = y + dy - 1, j = x + dx - 1;
+                    const bool ok = u < 30 && tap < 9 && (unsigned)m < 48u && (unsigned)j < 15u;
+                    const int idx = ok ? j * 48 + m : 0;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) v[t][e] = ok ? (unsigned)pl[t * 720 + idx] : 0u;
+                }
+                f32x4 xa[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xa[t][q] = __uint_as_float(v[t][2 * q] | (v[t][2 * q + 1] << 16));
+                f32x16 a = zero16();
+                a = mfma_bf(xa[2], w1[0], a);             // lowest-order terms first
+                a = mfma_bf(xa[1], w1[1], a);
+                a = mfma_bf(xa[0], w1[2], a);
+                a = mfma_bf(xa[1], w1[0], a);
+                a = mfma_bf(xa[0], w1[1], a);
+                a = mfma_bf(xa[0], w1[0], a);
+                acc[tt] = a;
+            }
+#pragma unroll
+            for (int bb = 0; bb < 7; ++bb) {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                    for (int x = 2 * bb; x < 2 * bb + 3; ++x) {
+                        const int u = 15 * yy + x;
+                        mx = fmaxf(mx, acc[u >> 4][u & 15]);
+                    }
+                const int pp = (12 * hf + gl) * 7 + bb;
+                if (n < 16)
+                    store_split(a1, 5376, pp * 32 + (((n >> 3) ^ ((pp >> 3) & 1)) << 4) + (n & 7) * 2, fmaxf(mx + tn, 0.f));
+            }
+        }
+    }
+
+    // ---- conv2 16->32 on 24x7, pool -> 12x5 (row maps as in cnn.hip)
+    {
+        f32x16 acc[6][1];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc[t][0] = zero16();
+        int py[6], px[6];
+        bool pv[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int u = 16 * t + qi;
+            pv[t] = u < 84;
+            const int gl = u / 14, w = u % 14, yy = w / 7;
+            py[t] = 2 * (6 * hfi + gl) + yy;
+            px[t] = w - 7 * yy;
+        }
+        conv3x3_bf16<16, 6, 1, 24, 7>(acc, act, zero, bbuf, wb + CNNB_W2, py, px, pv, lane, wave);
+        const float tn = cw[CNN_T2 + n];
+#pragma unroll
+        for (int gl = 0; gl < 6; ++gl)
+#pragma unroll
+            for (int bb = 0; bb < 5; ++bb) {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                    for (int x = bwin75_lo(bb); x < bwin75_hi(bb); ++x) {
+                        const int u = 14 * gl + 7 * yy + x;
+                        mx = fmaxf(mx, acc[u >> 4][0][u & 15]);
+                    }
+                const int pp = (6 * hf + gl) * 5 + bb;
+                store_split(act, 3840, pp * 64 + (((n >> 3) ^ ((pp >> 2) & 3)) << 4) + (n & 7) * 2, fmaxf(mx + tn, 0.f));
+            }
+    }
+
+    int py[2], px[2];
+    bool pv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int u = 16 * t + qi;
+        pv[t] = u < 30;
+        const int gl = u / 10, w = u % 10, yy = w / 5;
+        py[t] = 2 * (3 * hfi + gl) + yy;
+        px[t] = w - 5 * yy;
+    }
+
+    // ---- conv3 32->64 on 12x5
+    {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
+        conv3x3_bf16<32, 2, 2, 12, 5>(acc, act, zero, bbuf, wb + CNNB_W3, py, px, pv, lane, wave);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = n + 32 * nt;
+            const float tn = cw[CNN_T3 + c];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int u = 16 * t + r;
+                    if (u < 30) {
+                        const int gl = u / 10, w = u % 10, yy = w / 5, x = w - 5 * yy;
+                        const int pp = (2 * (3 * hf + gl) + yy) * 5 + x;
+                        store_split(act, 7680, pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2,
+                                    fmaxf(acc[t][nt][r] + tn, 0.f));
+                    }
+                }
+        }
+    }
+
+    // ---- conv4 64->64 on 12x5, pool -> 6x3, to HBM as p3[token][18][64] (fp32)
+    {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
+        conv3x3_bf16<64, 2, 2, 12, 5>(acc, act, zero, bbuf, wb + CNNB_W4, py, px, pv, lane, wave);
+        if (valid) {
+            float* dst = p3 + (size_t)p * (18 * 64);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int c = n + 32 * nt;
+                const float tn = cw[CNN_T4 + c];
+#pragma unroll
+                for (int gl = 0; gl < 3; ++gl)
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb) {
+                        float mx = -3.0e38f;
+#pragma unroll
+                        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                            for (int x = bwin53_lo(bb); x < bwin53_hi(bb); ++x) {
+                                const int u = 10 * gl + 5 * yy + x;
+                                mx = fmaxf(mx, acc[u >> 4][nt][u & 15]);
+                            }
+                        dst[((3 * hf + gl) * 3 + bb) * 64 + c] = fmaxf(mx + tn, 0.f);
+                    }
+            }
+        }
+    }
+}
+
+extern "C" int nisqa_cnn_front_bf16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                                    const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                                    int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
+                                    const uint16_t* cnn_wb, float* p3_ws, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
+                       mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_ws,
+                       (const float*)nullptr, 0);
+    return NQ_LAUNCH_STATUS();
+}

@@ -20,6 +20,18 @@
 #define CNN_T6 (CNN_WF6 + 9 * 8 * 2 * 256)
 #define CNN_W_FLOATS (CNN_T6 + 64)
 
+// ---- AdaptCNN split-bf16 weight fragments ("cnn_wb", uint16 units; biases stay in cnn_w) -------------
+// conv1: [3 terms hi/mid/lo][64 lanes][8]   B[k = tap (0..15, taps >= 9 are 0)][n (0..31, n >= 16 are 0)]
+// conv2..6: [step g = tap*(CIN/16) + s][ntile][hl (hi, lo)][64 lanes][8]:
+//   value(g, nt, hl, lane, e) = split_hl( W[n = (lane&31)+32*nt][c = 16*s + 8*(lane>>5) + e][tap] * bn_scale[n] )
+#define CNNB_W1 0
+#define CNNB_W2 (CNNB_W1 + 3 * 512)
+#define CNNB_W3 (CNNB_W2 + 9 * 1 * 2 * 512)
+#define CNNB_W4 (CNNB_W3 + 18 * 2 * 2 * 512)
+#define CNNB_W5 (CNNB_W4 + 36 * 2 * 2 * 512)
+#define CNNB_W6 (CNNB_W5 + 36 * 2 * 2 * 512)
+#define CNNB_U16S (CNNB_W6 + 36 * 2 * 2 * 512)
+
 // ---- self-attention blob ("td_w") ----------------------------------------------------------
 // A-fragments af[step][mtile][lane][4]:
 //   value(s, mt, lane, kk) = W[row = (lane&31) + 32*mt][k = 8*s + 4*(lane>>5) + kk]

@@ -7,6 +7,7 @@ the built library raises.
 """
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -90,7 +91,9 @@ def _ptr(t):
 class HipNisqa(object):
     """nisqa.tar / nisqa_mos_only.tar (CNN-SA-AP) on one MI355X."""
 
-    def __init__(self, args, state_dict, device=None):
+    def __init__(self, args, state_dict, device=None, precision=None):
+        """precision: 'f32' (exact fp32 MFMA, default) or 'bf16x3' (split-bf16 conv kernels); the environment
+        variable NISQA_HIP_PRECISION overrides the default."""
         if not torch.cuda.is_available():
             raise RuntimeError('nisqa_amd: no GPU visible (torch.cuda.is_available() is False); '
                                'the HIP engine has no CPU fallback')
@@ -117,11 +120,15 @@ class HipNisqa(object):
         heads = ['pool_layers.%d.model.' % h for h in range(5)] if self.dim else ['pool.model.']
         self.n_heads = len(heads)
         up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        self.precision = precision or os.environ.get('NISQA_HIP_PRECISION', 'f32')
+        if self.precision not in ('f32', 'bf16x3'):
+            raise ValueError('precision must be f32 or bf16x3, got {}'.format(self.precision))
         self.cnn_w = up(_w.pack_adapt_cnn(state_dict))
+        self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict).view(np.int16)) if self.precision == 'bf16x3' else None
         self.td_w = up(_w.pack_self_att(state_dict, self.n_layers))
         self.pool_w = up(_w.pack_pool_att(state_dict, heads))
         self._mel = {}
-        self._ws = None
+        self._ws = {}                      # one workspace per stream (batches may be in flight on several)
 
     # -- tables -----------------------------------------------------------------------------
     def mel_tables(self, sr):
@@ -135,7 +142,9 @@ class HipNisqa(object):
             d['cfg'] = _lib.MelCfg(t.n_fft, t.hop, t.win, t.n_mels, t.n_bins, int(t.band_w.size), 1e-8, 80.0)
             d['model'] = _lib.ModelDev(_ptr(d['window']), _ptr(d['twiddle']), _ptr(d['band_start']), _ptr(d['band_len']),
                                        _ptr(d['band_woff']), _ptr(d['band_w']), _ptr(self.cnn_w), _ptr(self.td_w),
-                                       _ptr(self.pool_w), self.n_layers, self.n_heads, self.seg_hop, None)
+                                       _ptr(self.pool_w), self.n_layers, self.n_heads, self.seg_hop, None,
+                                       _ptr(self.cnn_wb) if self.cnn_wb is not None else None,
+                                       1 if self.precision == 'bf16x3' else 0)
             self._mel[sr] = d
         return self._mel[sr]
 
@@ -155,8 +164,10 @@ class HipNisqa(object):
         mt = self.mel_tables(sr)
         d = plan.to(self.device)
         need = self.lib.nisqa_workspace_bytes(plan.n_clips, plan.total_frames, plan.total_tok)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        skey = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(skey)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[skey] = torch.empty(int(need * 1.25) + 256, dtype=torch.uint8, device=self.device)
         out = torch.empty((plan.n_clips, self.n_heads), dtype=torch.float32, device=self.device)
         model = mt['model']
         if stage_events is not None:
@@ -165,8 +176,8 @@ class HipNisqa(object):
             model.stage_events = ctypes.cast(arr, ctypes.c_void_p)
         rc = self.lib.nisqa_predict_batch(_ptr(pcm), _ptr(d['clip_off']), _ptr(d['frame_off']), _ptr(d['tok_off']),
                                           _ptr(d['n_wins']), plan.n_clips, plan.total_frames, plan.total_tok,
-                                          ctypes.byref(mt['cfg']), ctypes.byref(model), _ptr(self._ws),
-                                          self._ws.numel(), _ptr(out), self._stream())
+                                          ctypes.byref(mt['cfg']), ctypes.byref(model), _ptr(ws),
+                                          ws.numel(), _ptr(out), self._stream())
         _lib.check(rc, 'nisqa_predict_batch')
         return out
 
@@ -197,9 +208,18 @@ class HipNisqa(object):
         d = plan.to(self.device)
         p3 = torch.empty((plan.total_tok, 18, 64), dtype=torch.float32, device=self.device)
         feat = torch.zeros((plan.total_tok, 384), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.nisqa_cnn_adapt(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']),
-                                            _ptr(clip_floor), plan.n_clips, plan.total_tok, self.seg_hop,
-                                            _ptr(self.cnn_w), _ptr(p3), _ptr(feat), self._stream()), 'nisqa_cnn_adapt')
+        if self.precision == 'bf16x3':
+            _lib.check(self.lib.nisqa_cnn_front_bf16(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']),
+                                                     _ptr(d['n_wins']), _ptr(clip_floor), plan.n_clips, plan.total_tok,
+                                                     self.seg_hop, _ptr(self.cnn_w), _ptr(self.cnn_wb), _ptr(p3),
+                                                     self._stream()), 'nisqa_cnn_front_bf16')
+            _lib.check(self.lib.nisqa_cnn_back(_ptr(p3), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
+                                               plan.total_tok, _ptr(self.cnn_w), _ptr(feat), self._stream()),
+                       'nisqa_cnn_back')
+        else:
+            _lib.check(self.lib.nisqa_cnn_adapt(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']),
+                                                _ptr(clip_floor), plan.n_clips, plan.total_tok, self.seg_hop,
+                                                _ptr(self.cnn_w), _ptr(p3), _ptr(feat), self._stream()), 'nisqa_cnn_adapt')
         return feat, p3
 
     def forward_segments(self, x, n_wins):

@@ -28,7 +28,8 @@ class ModelDev(ctypes.Structure):
     """nisqa_model_dev"""
     _fields_ = [('window', c_p), ('twiddle', c_p), ('band_start', c_p), ('band_len', c_p), ('band_woff', c_p),
                 ('band_w', c_p), ('cnn_w', c_p), ('td_w', c_p), ('pool_w', c_p),
-                ('n_layers', c_i32), ('n_heads', c_i32), ('seg_hop', c_i32), ('stage_events', c_p)]
+                ('n_layers', c_i32), ('n_heads', c_i32), ('seg_hop', c_i32), ('stage_events', c_p),
+                ('cnn_wb', c_p), ('cnn_mode', c_i32)]
 
 
 # name -> (restype, argtypes); every symbol include/nisqa_hip.h declares
@@ -39,6 +40,7 @@ SYMBOLS = {
     'nisqa_mel_finalize': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_p, ctypes.c_float, c_p, c_i32, c_p]),
     'nisqa_cnn_adapt': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_cnn_front': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
+    'nisqa_cnn_front_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_cnn_adapt_segments': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_cnn_back': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_td_selfatt': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),

@@ -48,6 +48,14 @@ TDL_LN2_G = TDL_FF2_B + 64
 TDL_LN2_B = TDL_LN2_G + 64
 TDL_FLOATS = TDL_LN2_B + 64
 
+CNNB_W1 = 0
+CNNB_W2 = CNNB_W1 + 3 * 512
+CNNB_W3 = CNNB_W2 + 9 * 1 * 2 * 512
+CNNB_W4 = CNNB_W3 + 18 * 2 * 2 * 512
+CNNB_W5 = CNNB_W4 + 36 * 2 * 2 * 512
+CNNB_W6 = CNNB_W5 + 36 * 2 * 2 * 512
+CNNB_U16S = CNNB_W6 + 36 * 2 * 2 * 512
+
 PL_W1_AF = 0
 PL_B1 = PL_W1_AF + 8 * 4 * 256
 PL_W2 = PL_B1 + 128
@@ -171,4 +179,61 @@ def pack_pool_att(sd, head_prefixes):
         blob[base + PL_W3: base + PL_W3 + 64] = _np(sd, p + 'linear3.weight').reshape(-1)
         blob[base + PL_B2] = _np(sd, p + 'linear2.bias').reshape(-1)[0]
         blob[base + PL_B2 + 1] = _np(sd, p + 'linear3.bias').reshape(-1)[0]
+    return blob
+
+
+# ---- split-bf16 fragments (csrc/cnn_bf16.hip) ---------------------------------------------------
+def bf16_bits(x):
+    """round-to-nearest-even float32 -> bf16 bit patterns (uint16), same formula as the device code"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    return ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def bf16_val(b):
+    return (np.asarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def bf16_split(x, terms=2):
+    """x (float32) -> list of `terms` uint16 arrays with x ~= sum(bf16_val(part))"""
+    r = np.asarray(x, dtype=np.float32)
+    out = []
+    for _ in range(terms):
+        b = bf16_bits(r)
+        out.append(b)
+        r = (r - bf16_val(b)).astype(np.float32)
+    return out
+
+
+def conv_b_fragments_bf16(wf):
+    """wf [cout][cin][3][3] float32 (BN-scaled) -> uint16 [9*cin/16][NT][2][64][8]"""
+    cout, cin = wf.shape[:2]
+    S16, NT = cin // 16, cout // 32
+    w9 = np.asarray(wf, np.float32).reshape(cout, cin, 9)
+    g = np.arange(9 * S16)[:, None, None, None]
+    nt = np.arange(NT)[None, :, None, None]
+    lane = _LANE[None, None, :, None]
+    e = np.arange(8)[None, None, None, :]
+    vals = w9[(lane & 31) + 32 * nt, 16 * (g % S16) + 8 * (lane >> 5) + e, g // S16]      # [G][NT][64][8]
+    hi, lo = bf16_split(vals, 2)
+    return np.stack([hi, lo], 2).reshape(-1)                                               # [G][NT][2][64][8]
+
+
+def pack_adapt_cnn_bf16(sd, pfx='cnn.model.'):
+    """bf16 hi/lo weight fragments for cnn_front_bf16_kernel -> uint16 [CNNB_U16S] (biases: pack_adapt_cnn)."""
+    blob = np.zeros(CNNB_U16S, np.uint16)
+    w, _ = fold_bn(sd, pfx, 1)
+    w1 = w.reshape(16, 9).astype(np.float32)
+    full = np.zeros((64, 8), np.float32)
+    for lane in range(64):
+        j, h = lane & 31, lane >> 5
+        for e in range(8):
+            k = 8 * h + e
+            if j < 16 and k < 9:
+                full[lane, e] = w1[j, k]
+    for t, part in enumerate(bf16_split(full, 3)):
+        blob[CNNB_W1 + t * 512: CNNB_W1 + (t + 1) * 512] = part.reshape(-1)
+    for i, off in zip(range(2, 7), [CNNB_W2, CNNB_W3, CNNB_W4, CNNB_W5, CNNB_W6]):
+        w, _ = fold_bn(sd, pfx, i)
+        fr = conv_b_fragments_bf16(w.astype(np.float32))
+        blob[off:off + fr.size] = fr
     return blob

@@ -110,6 +110,26 @@ def test_pcm16_conversion(eng_rand):
     np.testing.assert_array_equal(d.cpu().numpy(), p.astype(np.float32) / np.float32(32768.0))
 
 
+def test_split_bf16_path_matches_oracle(batch):
+    """precision='bf16x3': conv1-4 on split-bf16 MFMA (3 products per term) -- must stay far inside the 1e-3 bar."""
+    ids, pcm = batch
+    args, sd = dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM')
+    from nisqa_amd.engine import HipNisqa
+    eng = HipNisqa(args, sd, precision='bf16x3')
+    _stages_vs_oracle(eng, args, sd, pcm, tol_feat=1e-3, tol_out=2e-4)
+    path = helpers.find_weights('nisqa.tar')
+    if path is not None:
+        g = helpers.golden('net_dim_real.npz')
+        rargs, rsd = helpers.load_checkpoint(path)
+        eng = HipNisqa(rargs, rsd, precision='bf16x3')
+        allpcm = [clip_pcm(i) for i in range(len(CLIPS))]
+        dev_pcm, plan = _upload(eng, allpcm)
+        out = eng.forward_pcm(dev_pcm, plan, 48000).cpu().numpy()
+        err = np.abs(out - g['out']).max(axis=1)
+        print('bf16x3 real weights per-clip max|d|', err)
+        assert err.max() < 2e-4
+
+
 def _stages_vs_oracle(eng, args, sd, pcm_list, tol_feat=2e-4, tol_out=1e-3):
     dev_pcm, plan = _upload(eng, pcm_list)
     mel, floor = eng.mel(dev_pcm, plan, 48000, clamp=False)      # fused path: CNN applies the floor
