@@ -104,13 +104,17 @@ int nisqa_cnn_front(const float* mel_tm, const int32_t* frame_off, const int32_t
                     const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                     int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
                     float* p3_ws, void* stream);
-/* conv1-4 on split-bf16 MFMA (each fp32 operand = bf16 hi + bf16 lo, three products per term, fp32
- * accumulation; |dMOS| <= 1e-5 vs the fp32 kernel).  Same inputs/outputs as nisqa_cnn_front;
- * cnn_wb = bf16 fragment blob from nisqa_amd.weights.pack_adapt_cnn_bf16, biases are read from cnn_w. */
-int nisqa_cnn_front_bf16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+/* The whole AdaptCNN (conv1-6 + pools) on split-bf16 MFMA in ONE launch: each fp32 operand = bf16 hi + bf16 lo,
+ * three products per term, fp32 accumulation; |dMOS| <= 2e-5 vs the fp32 kernels.  Same inputs
+ * and feat output as nisqa_cnn_adapt; cnn_wb = bf16 fragment blob from nisqa_amd.weights.pack_adapt_cnn_bf16,
+ * biases are read from cnn_w; p3_opt (may be NULL) receives an fp32 copy of the pooled conv4 output. */
+int nisqa_cnn_adapt_bf16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
                          const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                          int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
-                         const uint16_t* cnn_wb, float* p3_ws, void* stream);
+                         const uint16_t* cnn_wb, float* p3_opt, float* feat, void* stream);
+int nisqa_cnn_adapt_segments_bf16(const float* x, int32_t seg_len_padded, const int32_t* tok_off,
+                                  const int32_t* n_wins, int32_t n_clips, int32_t total_tok_padded,
+                                  const float* cnn_w, const uint16_t* cnn_wb, float* feat, void* stream);
 /* Segment-tensor input mode: the reference's inner operator model.forward(x, n_wins)
  * (NISQA_lib.py:137-142, 260-268) hands over x[B][L][1][48][15] (zero-padded to L segments per clip).
  * Same outputs as nisqa_cnn_adapt; no dB floor is applied (x is already clamped). */
@@ -157,7 +161,7 @@ typedef struct {
      * [3] after the conv5-6 kernel, [4] after self-attention, [5] after pooling */
     void* const* stage_events;
     const uint16_t* cnn_wb;  /* split-bf16 conv fragments, or NULL */
-    int32_t cnn_mode;        /* 0 = exact fp32 MFMA kernels, 1 = split-bf16 conv1-4 (needs cnn_wb) */
+    int32_t cnn_mode;        /* 0 = exact fp32 MFMA kernels, 1 = split-bf16 AdaptCNN (needs cnn_wb) */
 } nisqa_model_dev;
 
 size_t nisqa_workspace_bytes(int32_t n_clips, int32_t total_frames, int32_t total_tok_padded);

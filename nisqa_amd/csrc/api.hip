@@ -57,16 +57,19 @@ extern "C" int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, co
     rc = nisqa_mel_finalize(mel, frame_off, n_clips, total_frames, cmax, cfg->top_db, cfloor, 0, stream);
     if (rc) return rc;
     NQ_STAGE(1);
-    if (model->cnn_mode == 1)
-        rc = nisqa_cnn_front_bf16(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
-                                  model->cnn_w, model->cnn_wb, p3, stream);
-    else
+    if (model->cnn_mode == 1) {
+        rc = nisqa_cnn_adapt_bf16(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
+                                  model->cnn_w, model->cnn_wb, nullptr, feat, stream);
+        if (rc) return rc;
+        NQ_STAGE(2);
+    } else {
         rc = nisqa_cnn_front(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
                              model->cnn_w, p3, stream);
-    if (rc) return rc;
-    NQ_STAGE(2);
-    rc = nisqa_cnn_back(p3, tok_off, n_wins, n_clips, total_tok_padded, model->cnn_w, feat, stream);
-    if (rc) return rc;
+        if (rc) return rc;
+        NQ_STAGE(2);
+        rc = nisqa_cnn_back(p3, tok_off, n_wins, n_clips, total_tok_padded, model->cnn_w, feat, stream);
+        if (rc) return rc;
+    }
     NQ_STAGE(3);
     rc = nisqa_td_selfatt(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w, td, x, stream);
     if (rc) return rc;

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
     const float* __restrict__ clip_floor, int n_clips, int seg_hop,
     const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ p3,
-    const float* __restrict__ seg_x, int seg_L) {
+    float* __restrict__ feat, const float* __restrict__ seg_x, int seg_L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         }
     }
 
-    // ---- conv4 64->64 on 12x5, pool -> 6x3, to HBM as p3[token][18][64] (fp32)
+    // ---- conv4 64->64 on 12x5, pool -> 6x3; the pooled output stays in LDS as bf16 planes (18 px x 64 ch)
     {
         f32x16 acc[2][2];
 #pragma unroll
@@ -306,39 +306,103 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
         conv3x3_bf16<64, 2, 2, 12, 5>(acc, act, zero, bbuf, wb + CNNB_W4, py, px, pv, lane, wave);
+        float* dst = p3 ? p3 + (size_t)p * (18 * 64) : nullptr;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = n + 32 * nt;
+            const float tn = cw[CNN_T4 + c];
+#pragma unroll
+            for (int gl = 0; gl < 3; ++gl)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) {
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                        for (int x = bwin53_lo(bb); x < bwin53_hi(bb); ++x) {
+                            const int u = 10 * gl + 5 * yy + x;
+                            mx = fmaxf(mx, acc[u >> 4][nt][u & 15]);
+                        }
+                    const float v = fmaxf(mx + tn, 0.f);
+                    const int pp = (3 * hf + gl) * 3 + bb;
+                    if (dst && valid) dst[pp * 64 + c] = v;                  // optional fp32 copy (debug / parity)
+                    store_split(act, 2304, pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2, v);
+                }
+        }
+    }
+
+    // ---- conv5 64->64 on 6x3 (18 pixels: rows 0..17 of one 32-row tile)
+    {
+        int qy[1], qx[1];
+        bool qv[1];
+        qv[0] = i < 18;
+        qy[0] = i / 3;
+        qx[0] = i - 3 * qy[0];
+        f32x16 acc[1][2];
+        acc[0][0] = zero16();
+        acc[0][1] = zero16();
+        conv3x3_bf16<64, 1, 2, 6, 3>(acc, act, zero, bbuf, wb + CNNB_W5, qy, qx, qv, lane, wave);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = n + 32 * nt;
+            const float tn = cw[CNN_T5 + c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rho = NQ_DROW(r, hf);
+                if (rho < 18)
+                    store_split(act, 2304, rho * 128 + (((c >> 3) ^ ((rho >> 1) & 7)) << 4) + (c & 7) * 2,
+                                fmaxf(acc[0][nt][r] + tn, 0.f));
+            }
+        }
+    }
+
+    // ---- conv6 (3 x 3 kernel, padding (1,0)) = padding-1 conv at the centre column; 6 output rows
+    {
+        int qy[1], qx[1];
+        bool qv[1];
+        qv[0] = i < 6;
+        qy[0] = i;
+        qx[0] = 1;
+        f32x16 acc[1][2];
+        acc[0][0] = zero16();
+        acc[0][1] = zero16();
+        conv3x3_bf16<64, 1, 2, 6, 3>(acc, act, zero, bbuf, wb + CNNB_W6, qy, qx, qv, lane, wave);
         if (valid) {
-            float* dst = p3 + (size_t)p * (18 * 64);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int c = n + 32 * nt;
-                const float tn = cw[CNN_T4 + c];
+                const float tn = cw[CNN_T6 + c];
 #pragma unroll
-                for (int gl = 0; gl < 3; ++gl)
-#pragma unroll
-                    for (int bb = 0; bb < 3; ++bb) {
-                        float mx = -3.0e38f;
-#pragma unroll
-                        for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                            for (int x = bwin53_lo(bb); x < bwin53_hi(bb); ++x) {
-                                const int u = 10 * gl + 5 * yy + x;
-                                mx = fmaxf(mx, acc[u >> 4][nt][u & 15]);
-                            }
-                        dst[((3 * hf + gl) * 3 + bb) * 64 + c] = fmaxf(mx + tn, 0.f);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int rho = NQ_DROW(r, hf);
+                    if (rho < 6) feat[(size_t)p * 384 + c * 6 + rho] = fmaxf(acc[0][nt][r] + tn, 0.f);
+                }
             }
         }
     }
 }
 
-extern "C" int nisqa_cnn_front_bf16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+extern "C" int nisqa_cnn_adapt_bf16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
                                     const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                                     int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
-                                    const uint16_t* cnn_wb, float* p3_ws, void* stream) {
-    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb) return NISQA_ERR_ARG;
+                                    const uint16_t* cnn_wb, float* p3_opt, float* feat, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat)
+        return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
-                       mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_ws,
+                       mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat,
                        (const float*)nullptr, 0);
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_cnn_adapt_segments_bf16(const float* x, int32_t seg_len_padded, const int32_t* tok_off,
+                                             const int32_t* n_wins, int32_t n_clips, int32_t total_tok_padded,
+                                             const float* cnn_w, const uint16_t* cnn_wb, float* feat, void* stream) {
+    if (!x || seg_len_padded <= 0 || n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || !cnn_wb || !feat)
+        return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
+                       (const float*)nullptr, (const int32_t*)nullptr, tok_off, n_wins, (const float*)nullptr, n_clips, 1,
+                       cnn_w, cnn_wb, (float*)nullptr, feat, x, seg_len_padded);
     return NQ_LAUNCH_STATUS();
 }

@@ -209,13 +209,10 @@ class HipNisqa(object):
         p3 = torch.empty((plan.total_tok, 18, 64), dtype=torch.float32, device=self.device)
         feat = torch.zeros((plan.total_tok, 384), dtype=torch.float32, device=self.device)
         if self.precision == 'bf16x3':
-            _lib.check(self.lib.nisqa_cnn_front_bf16(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']),
+            _lib.check(self.lib.nisqa_cnn_adapt_bf16(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']),
                                                      _ptr(d['n_wins']), _ptr(clip_floor), plan.n_clips, plan.total_tok,
                                                      self.seg_hop, _ptr(self.cnn_w), _ptr(self.cnn_wb), _ptr(p3),
-                                                     self._stream()), 'nisqa_cnn_front_bf16')
-            _lib.check(self.lib.nisqa_cnn_back(_ptr(p3), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
-                                               plan.total_tok, _ptr(self.cnn_w), _ptr(feat), self._stream()),
-                       'nisqa_cnn_back')
+                                                     _ptr(feat), self._stream()), 'nisqa_cnn_adapt_bf16')
         else:
             _lib.check(self.lib.nisqa_cnn_adapt(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']),
                                                 _ptr(clip_floor), plan.n_clips, plan.total_tok, self.seg_hop,
@@ -235,9 +232,14 @@ class HipNisqa(object):
         d = plan.to(self.device)
         p3 = torch.empty((plan.total_tok, 18, 64), dtype=torch.float32, device=self.device)
         feat = torch.empty((plan.total_tok, 384), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.nisqa_cnn_adapt_segments(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B, plan.total_tok,
-                                                     _ptr(self.cnn_w), _ptr(p3), _ptr(feat), self._stream()),
-                   'nisqa_cnn_adapt_segments')
+        if self.precision == 'bf16x3':
+            _lib.check(self.lib.nisqa_cnn_adapt_segments_bf16(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B,
+                                                              plan.total_tok, _ptr(self.cnn_w), _ptr(self.cnn_wb),
+                                                              _ptr(feat), self._stream()), 'nisqa_cnn_adapt_segments_bf16')
+        else:
+            _lib.check(self.lib.nisqa_cnn_adapt_segments(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B,
+                                                         plan.total_tok, _ptr(self.cnn_w), _ptr(p3), _ptr(feat),
+                                                         self._stream()), 'nisqa_cnn_adapt_segments')
         return self.pool(self.td(feat, plan), plan)
 
     def td(self, feat, plan):

@@ -40,7 +40,8 @@ SYMBOLS = {
     'nisqa_mel_finalize': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_p, ctypes.c_float, c_p, c_i32, c_p]),
     'nisqa_cnn_adapt': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_cnn_front': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
-    'nisqa_cnn_front_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'nisqa_cnn_adapt_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p]),
+    'nisqa_cnn_adapt_segments_bf16': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_cnn_adapt_segments': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_cnn_back': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_td_selfatt': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
