@@ -26,6 +26,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 NQ_DEV f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+NQ_DEV f32x4 mfma_bf16x16(f32x4 a, f32x4 b, f32x4 c) {     // 16x16x32: A[i = l&15][k = 8*(l>>4)+e], D row 4*(l>>4)+r
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 // round-to-nearest-even fp32 -> bf16 (finite inputs)
 NQ_DEV unsigned bf16_bits(float v) {
     const unsigned u = __float_as_uint(v);
@@ -33,13 +36,14 @@ NQ_DEV unsigned bf16_bits(float v) {
 }
 NQ_DEV float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
 
-#define FB_ACT 15360                       /* per-wave activation region (planes alias as layers retire) */
+#define FB_ACT 15872                       /* per-wave activation region (planes alias as layers retire) */
 #define FB_ZERO FB_ACT                     /* 128 B of zeros per wave */
 #define FB_WAVE (FB_ACT + 128)
 #define FB_BBUF 8192                       /* one weight staging buffer: 2 steps x 2 ntiles x (hi,lo) x 1 KiB */
 #define FB_BOFF (4 * FB_WAVE)
-#define FB_LDS (FB_BOFF + 2 * FB_BBUF)     /* 78336 B -> two workgroups per CU */
-#define FB_PATCH 10752                     /* conv1 input: three bf16 planes [15][48] behind the A1 planes */
+#define FB_LDS (FB_BOFF + 2 * FB_BBUF)     /* 80384 B -> two workgroups per CU */
+#define FB_PATCH 10752                     /* conv1 input: three zero-bordered bf16 planes [17][50] behind the A1 planes */
+#define FB_PPLANE 1700                     /* bytes per patch plane (850 bf16) */
 
 // One conv layer (3x3, padding 1) for this wave's segment; the four waves of the workgroup call it in
 // lockstep and share the staged weight fragments.
@@ -68,6 +72,7 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
 
     __syncthreads();                          // everyone is done with the previous layer's staging buffers
     stage(0);
+#pragma unroll
     for (int c = 0; c < NCH; ++c) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                      // chunk c landed for all waves; chunk c-1 fully consumed
@@ -113,10 +118,16 @@ __device__ constexpr int bwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b =
 __device__ constexpr int bwin53_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : 3; }
 __device__ constexpr int bwin53_hi(int b) { return b == 0 ? 2 : b == 1 ? 4 : 5; }
 
+// hardware fp32 -> bf16 (round to nearest even), two values per instruction
+NQ_DEV unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // store v = hi + lo into the two bf16 planes at byte offset `off` of the hi plane
 NQ_DEV void store_split(char* plane_hi, int plane_bytes, int off, float v) {
-    const unsigned hi = bf16_bits(v);
-    const unsigned lo = bf16_bits(v - bf16_val(hi));
+    const unsigned hi = cvt_pk_bf16(v, 0.f);
+    const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
     *(unsigned short*)(plane_hi + off) = (unsigned short)hi;
     *(unsigned short*)(plane_hi + plane_bytes + off) = (unsigned short)lo;
 }
@@ -141,26 +152,29 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     char* zero = act + FB_ZERO;
     char* bbuf = smem + FB_BOFF;
 
-    // ---- stage the 15-frame window as three bf16 planes (hi, mid, lo) [frame j][mel m]
+    // ---- stage the 15-frame window as three zero-bordered bf16 planes (hi, mid, lo) [frame j + 1][mel m + 1]:
+    //      the 3x3 taps of any output pixel are then at constant offsets from it, no bounds checks
     {
-        unsigned short* pl = (unsigned short*)(act + FB_PATCH);
+        char* pb = act + FB_PATCH;
+        for (int q = lane; q < (3 * FB_PPLANE + 15) / 16; q += 64) *(f32x4*)(pb + q * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane < 32) ((float*)zero)[lane] = 0.f;
+        __builtin_amdgcn_wave_barrier();
         const float fl = seg_x ? -3.0e38f : clip_floor[b];
         const float* src = seg_x ? seg_x + ((size_t)b * seg_L + k) * 720
                                  : mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
-        for (int i = lane; i < 720; i += 64) {
-            float v = 0.f;
-            int dst = i;
-            if (seg_x) { const int m = i / 15; dst = (i - 15 * m) * 48 + m; }
-            if (valid) v = fmaxf(src[i], fl);
-            const unsigned hi = bf16_bits(v);
-            const float r1 = v - bf16_val(hi);
-            const unsigned mid = bf16_bits(r1);
-            const unsigned lo = bf16_bits(r1 - bf16_val(mid));
-            pl[dst] = (unsigned short)hi;
-            pl[720 + dst] = (unsigned short)mid;
-            pl[1440 + dst] = (unsigned short)lo;
+        for (int i0 = lane; i0 < 720; i0 += 64) {
+            int j, m;
+            if (seg_x) { m = i0 / 15; j = i0 - 15 * m; } else { j = i0 / 48; m = i0 - 48 * j; }
+            const float v = valid ? fmaxf(src[i0], fl) : 0.f;
+            const unsigned hi = cvt_pk_bf16(v, 0.f);
+            const float r1 = v - __uint_as_float(hi << 16);
+            const unsigned mid = cvt_pk_bf16(r1, 0.f);
+            const unsigned lo = cvt_pk_bf16(r1 - __uint_as_float(mid << 16), 0.f);
+            const int o = ((j + 1) * 50 + (m + 1)) * 2;
+            *(unsigned short*)(pb + o) = (unsigned short)hi;
+            *(unsigned short*)(pb + FB_PPLANE + o) = (unsigned short)mid;
+            *(unsigned short*)(pb + 2 * FB_PPLANE + o) = (unsigned short)lo;
         }
-        if (lane < 32) ((float*)zero)[lane] = 0.f;
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -171,35 +185,34 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     //      0..7, half 1: tap 8); N = 32 holds the 16 channels.  Each lane half owns 12 pooled rows; a pooled
     //      row = 2 x 15 conv pixels = local index u = 15*yy + x in two 16-row tiles.
     {
-        const unsigned short* pl = (const unsigned short*)(act + FB_PATCH);
+        const char* pb = act + FB_PATCH;
         f32x4 w1[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) w1[t] = *(const f32x4*)(wb + CNNB_W1 + t * 512 + lane * 8);
         const float tn = cw[CNN_T1 + (n & 15)];
         char* a1 = act;                                   // A1 planes: 168 px x 16 ch, plane 5376 B
+        // byte offset of tap 8h + e relative to the pixel's (dy, dx) = (0, 0) corner in the bordered patch; lane half
+        // 1 only needs tap 8 (its taps 9..15 meet zero weights, any finite value will do)
+        int toff[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) toff[e] = h ? 2 * (2 * 50 + 2) : 2 * ((e % 3) * 50 + e / 3);
         for (int gl = 0; gl < 12; ++gl) {
             f32x16 acc[2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const int u = 16 * tt + qi;
+                const int u = min(16 * tt + qi, 29);      // rows 30, 31 of the pair are padding (results unused)
                 const int yy = u >= 15 ? 1 : 0, x = u - 15 * yy;
                 const int y = 2 * (12 * hfi + gl) + yy;
-                unsigned v[3][8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int tap = 8 * h + e;
-                    const int dy = tap / 3, dx = tap - 3 * dy;
-                    const int m = y + dy - 1, j = x + dx - 1;
-                    const bool ok = u < 30 && tap < 9 && (unsigned)m < 48u && (unsigned)j < 15u;
-                    const int idx = ok ? j * 48 + m : 0;
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) v[t][e] = ok ? (unsigned)pl[t * 720 + idx] : 0u;
-                }
+                const char* base = pb + (x * 50 + y) * 2;
                 f32x4 xa[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) xa[t][q] = __uint_as_float(v[t][2 * q] | (v[t][2 * q + 1] << 16));
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned lo16 = *(const unsigned short*)(base + t * FB_PPLANE + toff[2 * q]);
+                        const unsigned hi16 = *(const unsigned short*)(base + t * FB_PPLANE + toff[2 * q + 1]);
+                        xa[t][q] = __uint_as_float(lo16 | (hi16 << 16));
+                    }
                 f32x16 a = zero16();
                 a = mfma_bf(xa[2], w1[0], a);             // lowest-order terms first
                 a = mfma_bf(xa[1], w1[1], a);
@@ -298,7 +311,10 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         }
     }
 
-    // ---- conv4 64->64 on 12x5, pool -> 6x3; the pooled output stays in LDS as bf16 planes (18 px x 64 ch)
+    // ---- conv4 64->64 on 12x5, pool -> 6x3.  The pooled outputs of the workgroup's four segments go to a
+    //      SHARED pair of bf16 planes S4[72 px][64 ch] (row = 18 * wave + pixel) for the N-split conv5/conv6.
+    char* s4 = smem;                       // 2 planes x 9216 B (wave 0/1 regions; their A3 is dead by then)
+    char* s5 = smem + 2 * FB_WAVE;         // conv5 output, same shape (wave 2/3 regions)
     {
         f32x16 acc[2][2];
 #pragma unroll
@@ -306,6 +322,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
         conv3x3_bf16<64, 2, 2, 12, 5>(acc, act, zero, bbuf, wb + CNNB_W4, py, px, pv, lane, wave);
+        __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
         float* dst = p3 ? p3 + (size_t)p * (18 * 64) : nullptr;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -324,61 +341,124 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                             mx = fmaxf(mx, acc[u >> 4][nt][u & 15]);
                         }
                     const float v = fmaxf(mx + tn, 0.f);
-                    const int pp = (3 * hf + gl) * 3 + bb;
-                    if (dst && valid) dst[pp * 64 + c] = v;                  // optional fp32 copy (debug / parity)
-                    store_split(act, 2304, pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2, v);
+                    const int pl = (3 * hf + gl) * 3 + bb;
+                    if (dst && valid) dst[pl * 64 + c] = v;                  // optional fp32 copy (debug / parity)
+                    const int pp = 18 * wave + pl;
+                    store_split(s4, 9216, pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2, v);
                 }
         }
     }
+    __syncthreads();
 
-    // ---- conv5 64->64 on 6x3 (18 pixels: rows 0..17 of one 32-row tile)
+    // ---- conv5 / conv6 with N split over the waves: wave w owns output channels 16w..16w+15 of ALL four
+    //      segments (72 / 24 output rows in 16-row tiles of v_mfma_f32_16x16x32_bf16) and streams its private
+    //      quarter of the weights from L2 (no staging, no barriers); fragments [wave][step][hi,lo][lane][8].
     {
-        int qy[1], qx[1];
-        bool qv[1];
-        qv[0] = i < 18;
-        qy[0] = i / 3;
-        qx[0] = i - 3 * qy[0];
-        f32x16 acc[1][2];
-        acc[0][0] = zero16();
-        acc[0][1] = zero16();
-        conv3x3_bf16<64, 1, 2, 6, 3>(acc, act, zero, bbuf, wb + CNNB_W5, qy, qx, qv, lane, wave);
+        const int i16 = lane & 15, kg = lane >> 4;
+        const int ch = 16 * wave + i16;                    // D-fragment column = output channel
+        const char* zero = smem + 3 * FB_WAVE + FB_ZERO;   // wave 3's zero block: the only one S4 / S5 do not cover
+        // conv5: rows rho = 16 t + i16 <-> (slot = rho / 18, pixel = rho % 18), 6 x 3 image per slot
+        f32x4 acc5[5];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int c = n + 32 * nt;
-            const float tn = cw[CNN_T5 + c];
+        for (int t = 0; t < 5; ++t) acc5[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int ry[5], rx[5], rb[5];
+        bool rv[5];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rho = NQ_DROW(r, hf);
-                if (rho < 18)
-                    store_split(act, 2304, rho * 128 + (((c >> 3) ^ ((rho >> 1) & 7)) << 4) + (c & 7) * 2,
-                                fmaxf(acc[0][nt][r] + tn, 0.f));
+        for (int t = 0; t < 5; ++t) {
+            const int rho = 16 * t + i16;
+            rv[t] = rho < 72;
+            const int slot = rho / 18, pix = rho - 18 * slot;
+            ry[t] = pix / 3;
+            rx[t] = pix - 3 * ry[t];
+            rb[t] = slot * 18;
+        }
+        const f32x4* w5 = (const f32x4*)(wb + CNNB_W5) + (size_t)wave * (18 * 2 * 64) + lane;
+        f32x4 bq[2][2];
+        bq[0][0] = w5[0]; bq[0][1] = w5[64];
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+            if (g + 1 < 18) { bq[(g + 1) & 1][0] = w5[(g + 1) * 128]; bq[(g + 1) & 1][1] = w5[(g + 1) * 128 + 64]; }
+            const int tap = g >> 1, s = g & 1;
+            const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+            f32x4 ah[5], al[5];
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                const int y = ry[t] + dy, x = rx[t] + dx;
+                const bool ok = rv[t] && (unsigned)y < 6u && (unsigned)x < 3u;
+                const int pix = rb[t] + y * 3 + x;
+                const char* ph = ok ? s4 + pix * 128 + (((4 * s + kg) ^ ((pix >> 1) & 7)) << 4) : zero;
+                ah[t] = *(const f32x4*)ph;
+                al[t] = *(const f32x4*)(ok ? ph + 9216 : zero);
+            }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][1], acc5[t]);
+                acc5[t] = mfma_bf16x16(al[t], bq[g & 1][0], acc5[t]);
+                acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][0], acc5[t]);
             }
         }
-    }
-
-    // ---- conv6 (3 x 3 kernel, padding (1,0)) = padding-1 conv at the centre column; 6 output rows
-    {
-        int qy[1], qx[1];
-        bool qv[1];
-        qv[0] = i < 6;
-        qy[0] = i;
-        qx[0] = 1;
-        f32x16 acc[1][2];
-        acc[0][0] = zero16();
-        acc[0][1] = zero16();
-        conv3x3_bf16<64, 1, 2, 6, 3>(acc, act, zero, bbuf, wb + CNNB_W6, qy, qx, qv, lane, wave);
-        if (valid) {
+        {
+            const float tn = cw[CNN_T5 + ch];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int c = n + 32 * nt;
-                const float tn = cw[CNN_T6 + c];
+            for (int t = 0; t < 5; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rho = NQ_DROW(r, hf);
-                    if (rho < 6) feat[(size_t)p * 384 + c * 6 + rho] = fmaxf(acc[0][nt][r] + tn, 0.f);
+                for (int r = 0; r < 4; ++r) {
+                    const int rho = 16 * t + 4 * kg + r;
+                    if (rho < 72)
+                        store_split(s5, 9216, rho * 128 + (((ch >> 3) ^ ((rho >> 1) & 7)) << 4) + (ch & 7) * 2,
+                                    fmaxf(acc5[t][r] + tn, 0.f));
                 }
+        }
+        __syncthreads();
+
+        // conv6 (3 x 3 kernel, padding (1,0)) = padding-1 conv at the centre column: rows (slot, y), 24 of 32
+        f32x4 acc6[2];
+        acc6[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc6[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int sy[2], sb[2];
+        bool sv[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int rho = 16 * t + i16;
+            sv[t] = rho < 24;
+            const int slot = rho / 6;
+            sy[t] = rho - 6 * slot;
+            sb[t] = slot * 18;
+        }
+        const f32x4* w6 = (const f32x4*)(wb + CNNB_W6) + (size_t)wave * (18 * 2 * 64) + lane;
+        bq[0][0] = w6[0]; bq[0][1] = w6[64];
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+            if (g + 1 < 18) { bq[(g + 1) & 1][0] = w6[(g + 1) * 128]; bq[(g + 1) & 1][1] = w6[(g + 1) * 128 + 64]; }
+            const int tap = g >> 1, s = g & 1;
+            const int dy = tap / 3 - 1, xin = tap - 3 * (tap / 3);       // input column = dx (output at x = 1)
+            f32x4 ah[2], al[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int y = sy[t] + dy;
+                const bool ok = sv[t] && (unsigned)y < 6u;
+                const int pix = sb[t] + y * 3 + xin;
+                const char* ph = ok ? s5 + pix * 128 + (((4 * s + kg) ^ ((pix >> 1) & 7)) << 4) : zero;
+                ah[t] = *(const f32x4*)ph;
+                al[t] = *(const f32x4*)(ok ? ph + 9216 : zero);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                acc6[t] = mfma_bf16x16(ah[t], bq[g & 1][1], acc6[t]);
+                acc6[t] = mfma_bf16x16(al[t], bq[g & 1][0], acc6[t]);
+                acc6[t] = mfma_bf16x16(ah[t], bq[g & 1][0], acc6[t]);
             }
         }
+        const float tn = cw[CNN_T6 + ch];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rho = 16 * t + 4 * kg + r;
+                const int slot = rho / 6, y = rho - 6 * slot;
+                if (rho < 24 && slot < nvalid)
+                    feat[(size_t)(p0 + slot) * 384 + ch * 6 + y] = fmaxf(acc6[t][r] + tn, 0.f);
+            }
     }
 }
 

@@ -218,6 +218,19 @@ def conv_b_fragments_bf16(wf):
     return np.stack([hi, lo], 2).reshape(-1)                                               # [G][NT][2][64][8]
 
 
+def conv_b_fragments_bf16_nsplit(wf):
+    """conv5/conv6 fragments for the N-split 16x16x32 form: uint16 [4 waves][18 steps][2][64][8],
+    value = W[n = 16*w + (lane&15)][c = 32*(g&1) + 8*(lane>>4) + e][tap = g>>1]"""
+    w9 = np.asarray(wf, np.float32).reshape(64, 64, 9)
+    w = np.arange(4)[:, None, None, None]
+    g = np.arange(18)[None, :, None, None]
+    lane = _LANE[None, None, :, None]
+    e = np.arange(8)[None, None, None, :]
+    vals = w9[16 * w + (lane & 15), 32 * (g & 1) + 8 * (lane >> 4) + e, g >> 1]             # [4][18][64][8]
+    hi, lo = bf16_split(vals, 2)
+    return np.stack([hi, lo], 2).reshape(-1)
+
+
 def pack_adapt_cnn_bf16(sd, pfx='cnn.model.'):
     """bf16 hi/lo weight fragments for cnn_front_bf16_kernel -> uint16 [CNNB_U16S] (biases: pack_adapt_cnn)."""
     blob = np.zeros(CNNB_U16S, np.uint16)
@@ -234,6 +247,6 @@ def pack_adapt_cnn_bf16(sd, pfx='cnn.model.'):
         blob[CNNB_W1 + t * 512: CNNB_W1 + (t + 1) * 512] = part.reshape(-1)
     for i, off in zip(range(2, 7), [CNNB_W2, CNNB_W3, CNNB_W4, CNNB_W5, CNNB_W6]):
         w, _ = fold_bn(sd, pfx, i)
-        fr = conv_b_fragments_bf16(w.astype(np.float32))
+        fr = conv_b_fragments_bf16_nsplit(w.astype(np.float32)) if i >= 5 else conv_b_fragments_bf16(w.astype(np.float32))
         blob[off:off + fr.size] = fr
     return blob
