@@ -14,9 +14,12 @@ data-path collective); the only exchange is the final all_gather of result rows,
 region.  value = clips all ranks processed / max-over-ranks wall time.
 
 Extra objects on the JSON line (see DESIGN.md "Measurement"):
-  roofline     dominant kernel (cnn_front_kernel, conv1-4 + pools): algorithmic FLOPs per launch /
-               its mean launch duration measured with HIP events recorded inside the timed region
-               on the launch stream, against the dense fp32 MFMA peak (157.3 TFLOP/s).
+  roofline     dominant kernel: algorithmic FLOPs per launch / its mean launch duration measured with HIP
+               events recorded inside the timed region on the launch stream.  precision bf16x3 (default):
+               cnn_front_bf16_kernel (whole AdaptCNN, 160.6 GFLOP/launch) against the dense bf16 MFMA peak
+               (2500 TFLOP/s; the kernel issues 3 bf16 products per algorithmic product, so 1/3 is its
+               ceiling); precision f32: cnn_front_kernel (conv1-4, 132.6 GFLOP) against 157.3 TFLOP/s.
+  alt_precision the same workload on the other precision path, measured after the timed region.
   cpu_baseline the CPU oracle (a port of the reference path: numpy mel restatement + torch-CPU
                network) timed on this box's host cores over a bounded sample, rank 0, N = 1 only.
 """
@@ -42,29 +45,33 @@ N_DISTINCT = 16          # distinct synthetic clips per rank (tiled to BATCH); g
 
 # Algorithmic FLOPs per 10 s clip (247 segments), SURVEY.md section 8a / BASELINE.md:
 FLOP_CONV1_4 = (51.2 + 382.4 + 546.3 + 1092.6) * 1e6      # what one cnn_front_kernel launch does, per clip
+FLOP_CONV5_6 = (327.8 + 109.3) * 1e6
 FLOP_TOTAL = 2.93e9                                          # whole path incl. mel in FFT form
 PEAK_F32_MFMA = 157.3                                        # TFLOP/s, MI355X_MICROARCH.md
+PEAK_BF16_MFMA = 2500.0                                      # TFLOP/s dense, MI355X_MICROARCH.md
 
 
-def cpu_baseline(n_clips=6):
-    """Oracle (CPU port of the reference path) on a bounded sample; returns the JSON object."""
+def cpu_baseline(n_distinct=6, min_seconds=12.0):
+    """Oracle (CPU port of the reference path) on a bounded sample (~12 s of CPU work); returns the JSON object."""
     from oracle import mel as omel, net as onet
     args, sd = dict(synth.DIM_ARGS), synth.random_state_dict(7, 'NISQA_DIM')
-    clips = [synth.synth_pcm16(2000 + i, SECONDS).astype(np.float32) / np.float32(32768.0) for i in range(n_clips)]
+    clips = [synth.synth_pcm16(2000 + i, SECONDS).astype(np.float32) / np.float32(32768.0) for i in range(n_distinct)]
     onet.predict_from_melspec(sd, args, omel.melspec_db_from_audio(clips[0][:SR], SR))   # warm-up
     t0 = time.perf_counter()
-    t_mel = 0.0
-    for y in clips:
+    t_mel, n = 0.0, 0
+    while n < n_distinct or time.perf_counter() - t0 < min_seconds:
+        y = clips[n % n_distinct]
         t1 = time.perf_counter()
         spec = omel.melspec_db_from_audio(y, SR)
         t_mel += time.perf_counter() - t1
         onet.predict_from_melspec(sd, args, spec)
+        n += 1
     dt = time.perf_counter() - t0
-    return {'value': round(n_clips / dt, 3), 'unit': 'clips/s', 'cores': int(torch.get_num_threads()),
+    return {'value': round(n / dt, 3), 'unit': 'clips/s', 'cores': int(torch.get_num_threads()),
             'kind': 'port',
-            'sample': '%d x 10 s clips, oracle.mel (numpy restatement of librosa 0.8.1) + oracle.net (torch CPU fp32), '
-                      'one clip at a time; %.2f s total, mel share %.0f%%; host has %d cores'
-                      % (n_clips, dt, 100.0 * t_mel / dt, os.cpu_count())}
+            'sample': '%d x 10 s clips (%d distinct), oracle.mel (numpy restatement of librosa 0.8.1) + oracle.net '
+                      '(torch CPU fp32), one clip at a time; %.1f s total, mel share %.0f%%; host has %d cores'
+                      % (n, n_distinct, dt, 100.0 * t_mel / dt, os.cpu_count())}
 
 
 def main():
@@ -73,7 +80,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--streams', type=int, default=2, help='HIP streams the steps alternate over (kernel tails of one '
+    ap.add_argument('--precision', default=None, choices=['bf16x3', 'f32'])
+    ap.add_argument('--streams', type=int, default=1, help='HIP streams the steps alternate over (kernel tails of one '
                     'batch overlap the next batch)')
     a = ap.parse_args()
 
@@ -93,7 +101,7 @@ def main():
         torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from nisqa_amd.engine import HipNisqa
-    eng = HipNisqa(dict(synth.DIM_ARGS), synth.random_state_dict(7, 'NISQA_DIM'), dev)
+    eng = HipNisqa(dict(synth.DIM_ARGS), synth.random_state_dict(7, 'NISQA_DIM'), dev, precision=a.precision)
 
     # synthetic batch, resident in HBM before the timed region
     base = [synth.synth_pcm16(1000 * rank + i, SECONDS) for i in range(N_DISTINCT)]
@@ -148,25 +156,61 @@ def main():
         names = ['mel', 'cnn_front', 'cnn_back', 'selfatt', 'pool']
         stage_ms = {n: float(np.mean([evs[s][i].elapsed_time(evs[s][i + 1]) for s in range(a.steps)]))
                     for i, n in enumerate(names)}
-        front_s = stage_ms['cnn_front'] * 1e-3
-        achieved = FLOP_CONV1_4 * BATCH / front_s / 1e12
+        def roofline_of(prec, ms_front):
+            if prec == 'bf16x3':
+                flop, peak, kern = (FLOP_CONV1_4 + FLOP_CONV5_6) * BATCH, PEAK_BF16_MFMA, \
+                    'cnn_front_bf16_kernel (AdaptCNN conv1-6 + pools, split-bf16 MFMA: 3 products per term)'
+            else:
+                flop, peak, kern = FLOP_CONV1_4 * BATCH, PEAK_F32_MFMA, 'cnn_front_kernel (conv1-4 + pools, fp32 MFMA)'
+            ach = flop / (ms_front * 1e-3) / 1e12
+            return {'kernel': kern, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                    'frac': round(ach / peak, 4), 'traffic': None, 'flop_per_launch': flop,
+                    'avg_launch_ms': round(ms_front, 4)}
+
         clips = BATCH * a.steps * world
+        roof = roofline_of(eng.precision, stage_ms['cnn_front'])
+        roof['whole_path_tflops'] = round(FLOP_TOTAL * clips / dt / 1e12 / world, 2)
         res = {
             'metric': 'clips/sec (10 s, 48 kHz)', 'value': round(clips / dt, 2), 'unit': 'clips/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16x3 (bf16 hi+lo operands, 3 MFMA products per term, f32 accumulate; mel/attention/pooling f32)'
+                     if eng.precision == 'bf16x3' else 'f32',
             'data': 'synthetic 48 kHz / 10 s PCM16 clips (SURVEY 8d generator), random-init nisqa.tar architecture',
             'config': {'workload': 'predict_dir nisqa.tar (NISQA_DIM CNN-SA-AP) bs=64 per GPU, 10 s synthetic 48 kHz '
                                    'clips, PCM resident in HBM', 'batch_clips_per_gpu': BATCH, 'streams': len(streams),
+                       'precision': eng.precision,
                        'segments_per_batch': int(plan.n_wins.sum()), 'frames_per_batch': plan.total_frames,
                        'parallelism': 'clip-sharded x%d, final all_gather of MOS rows' % world},
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
-            'roofline': {'kernel': 'cnn_front_kernel (conv1-4 + pools, fp32 MFMA)', 'bound': 'mfma',
-                         'achieved': round(achieved, 2), 'peak': PEAK_F32_MFMA, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / PEAK_F32_MFMA, 4), 'traffic': None,
-                         'flop_per_launch': FLOP_CONV1_4 * BATCH, 'avg_launch_ms': round(stage_ms['cnn_front'], 4),
-                         'whole_path_tflops': round(FLOP_TOTAL * clips / dt / 1e12 / world, 2)},
+            'roofline': roof,
         }
+        if world == 1:
+            # the other precision path on the same workload (secondary measurement, outside the timed region)
+            other = 'f32' if eng.precision == 'bf16x3' else 'bf16x3'
+            eng2 = HipNisqa(dict(synth.DIM_ARGS), synth.random_state_dict(7, 'NISQA_DIM'), dev, precision=other)
+            for _ in range(2):
+                o2 = eng2.forward_pcm(pcm, plan, SR)
+            torch.cuda.synchronize()
+            n2 = max(5, a.steps // 2)
+            ev2 = []
+            for _ in range(n2):
+                e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+                for x in e:
+                    x.record()
+                ev2.append(e)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s in range(n2):
+                o2 = eng2.forward_pcm(pcm, plan, SR, stage_events=ev2[s])
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            ms2 = float(np.mean([ev2[s][1].elapsed_time(ev2[s][2]) for s in range(n2)]))
+            r2 = roofline_of(other, ms2)
+            res['alt_precision'] = {'precision': other, 'value': round(BATCH * n2 / dt2, 2), 'unit': 'clips/s',
+                                    'steps': n2, 'roofline_frac': r2['frac'], 'roofline_achieved': r2['achieved'],
+                                    'roofline_peak': r2['peak'],
+                                    'max_abs_diff_vs_primary': float((o2 - outs[-1]).abs().max())}
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline()
         print(json.dumps(res))

@@ -92,8 +92,8 @@ class HipNisqa(object):
     """nisqa.tar / nisqa_mos_only.tar (CNN-SA-AP) on one MI355X."""
 
     def __init__(self, args, state_dict, device=None, precision=None):
-        """precision: 'f32' (exact fp32 MFMA, default) or 'bf16x3' (split-bf16 conv kernels); the environment
-        variable NISQA_HIP_PRECISION overrides the default."""
+        """precision: 'bf16x3' (default: AdaptCNN on split-bf16 MFMA, fp32-class accuracy, |dMOS| <= 3e-5) or
+        'f32' (every GEMM on exact fp32 MFMA); the environment variable NISQA_HIP_PRECISION sets the default."""
         if not torch.cuda.is_available():
             raise RuntimeError('nisqa_amd: no GPU visible (torch.cuda.is_available() is False); '
                                'the HIP engine has no CPU fallback')
@@ -120,7 +120,7 @@ class HipNisqa(object):
         heads = ['pool_layers.%d.model.' % h for h in range(5)] if self.dim else ['pool.model.']
         self.n_heads = len(heads)
         up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
-        self.precision = precision or os.environ.get('NISQA_HIP_PRECISION', 'f32')
+        self.precision = precision or os.environ.get('NISQA_HIP_PRECISION', 'bf16x3')
         if self.precision not in ('f32', 'bf16x3'):
             raise ValueError('precision must be f32 or bf16x3, got {}'.format(self.precision))
         self.cnn_w = up(_w.pack_adapt_cnn(state_dict))

@@ -1,11 +1,12 @@
 """GPU parity tests (run with -m gpu on an MI355X): HIP path vs the CPU oracle and the committed
 golden fixtures, stage by stage and end to end, through the C ABI (ctypes -> libnisqa_hip.so).
 
-Tolerances (floating point; the bar of BASELINE.json is |dMOS| <= 1e-3 end to end):
-  mel dB        2e-3 dB   (f32 FFT vs librosa's f64 FFT; worst near the amin floor)
-  CNN features  2e-4      (SURVEY.md section 7 asks <= 1e-4 on features; measured ~1e-5)
-  td output     2e-4
-  final outputs 1e-3      (the north-star bar), measured ~1e-5
+Both precision paths of the engine are run: 'f32' (every GEMM on exact fp32 MFMA) and 'bf16x3' (default: AdaptCNN
+on split-bf16 MFMA).  Tolerances (floating point; the bar of BASELINE.json is |dMOS| <= 1e-3 end to end):
+  mel dB        2e-3 dB   (f32 FFT vs librosa's f64 FFT; worst near the amin floor; measured <= 2.6e-4)
+  CNN features  f32 2e-4 (measured 1.3e-5)   bf16x3 1e-3 (measured 1.5e-4, features reach |8|)
+  td output     same bounds (measured 2e-6 / 1.6e-5)
+  final outputs f32 1e-4 (measured 2.2e-6)   bf16x3 2e-4 (measured 2.7e-5)   -- north-star bar 1e-3
 """
 import os
 
@@ -28,14 +29,19 @@ def clip_pcm(i):
     return synth.synth_pcm16(c[1], c[2]) if c[0] == 'seed' else synth.edge_clip(c[1])
 
 
-def _engine(args, sd):
+PRECISIONS = ['f32', 'bf16x3']
+# stage tolerances per precision path: (CNN features / td output, final outputs)
+TOL = {'f32': (2e-4, 1e-4), 'bf16x3': (1e-3, 2e-4)}
+
+
+def _engine(args, sd, precision=None):
     from nisqa_amd.engine import HipNisqa
-    return HipNisqa(args, sd)
+    return HipNisqa(args, sd, precision=precision)
 
 
-@pytest.fixture(scope='module')
-def eng_rand():
-    return _engine(dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM'))
+@pytest.fixture(scope='module', params=PRECISIONS)
+def eng_rand(request):
+    return _engine(dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM'), request.param)
 
 
 @pytest.fixture(scope='module')
@@ -110,26 +116,6 @@ def test_pcm16_conversion(eng_rand):
     np.testing.assert_array_equal(d.cpu().numpy(), p.astype(np.float32) / np.float32(32768.0))
 
 
-def test_split_bf16_path_matches_oracle(batch):
-    """precision='bf16x3': conv1-4 on split-bf16 MFMA (3 products per term) -- must stay far inside the 1e-3 bar."""
-    ids, pcm = batch
-    args, sd = dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM')
-    from nisqa_amd.engine import HipNisqa
-    eng = HipNisqa(args, sd, precision='bf16x3')
-    _stages_vs_oracle(eng, args, sd, pcm, tol_feat=1e-3, tol_out=2e-4)
-    path = helpers.find_weights('nisqa.tar')
-    if path is not None:
-        g = helpers.golden('net_dim_real.npz')
-        rargs, rsd = helpers.load_checkpoint(path)
-        eng = HipNisqa(rargs, rsd, precision='bf16x3')
-        allpcm = [clip_pcm(i) for i in range(len(CLIPS))]
-        dev_pcm, plan = _upload(eng, allpcm)
-        out = eng.forward_pcm(dev_pcm, plan, 48000).cpu().numpy()
-        err = np.abs(out - g['out']).max(axis=1)
-        print('bf16x3 real weights per-clip max|d|', err)
-        assert err.max() < 2e-4
-
-
 def _stages_vs_oracle(eng, args, sd, pcm_list, tol_feat=2e-4, tol_out=1e-3):
     dev_pcm, plan = _upload(eng, pcm_list)
     mel, floor = eng.mel(dev_pcm, plan, 48000, clamp=False)      # fused path: CNN applies the floor
@@ -161,11 +147,13 @@ def _stages_vs_oracle(eng, args, sd, pcm_list, tol_feat=2e-4, tol_out=1e-3):
 
 def test_network_stages_match_oracle_random_weights(eng_rand, batch):
     ids, pcm = batch
-    _stages_vs_oracle(eng_rand, dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM'), pcm)
+    tf, to = TOL[eng_rand.precision]
+    _stages_vs_oracle(eng_rand, dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM'), pcm, tf, to)
 
 
+@pytest.mark.parametrize('precision', PRECISIONS)
 @pytest.mark.parametrize('name', ['dim_rand', 'mos_rand', 'dim_real', 'mos_real'])
-def test_end_to_end_matches_reference_fixture(name):
+def test_end_to_end_matches_reference_fixture(name, precision):
     """PCM -> outputs on the GPU vs fixtures produced by the reference's torch modules."""
     g = helpers.golden('net_%s.npz' % name)
     if name.endswith('real'):
@@ -177,7 +165,7 @@ def test_end_to_end_matches_reference_fixture(name):
         args, sd = dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM')
     else:
         args, sd = dict(helpers.MOS_ARGS), helpers.random_state_dict(8, 'NISQA')
-    eng = _engine(args, sd)
+    eng = _engine(args, sd, precision)
     ids = list(range(len(CLIPS)))                      # includes the 10 s clip and the 52 s / 1300-segment cap
     pcm = [clip_pcm(i) for i in ids]
     dev_pcm, plan = _upload(eng, pcm)
@@ -185,8 +173,8 @@ def test_end_to_end_matches_reference_fixture(name):
     out = eng.forward_pcm(dev_pcm, plan, 48000)
     torch.cuda.synchronize()
     err = np.abs(out.cpu().numpy() - g['out']).max(axis=1)
-    print(name, 'per-clip max|d|', err)
-    assert err.max() < 1e-3
+    print(name, precision, 'per-clip max|d|', err)
+    assert err.max() < TOL[precision][1]
 
 
 def test_batch_composition_independence(eng_rand):
