@@ -39,77 +39,69 @@ NQ_DEV float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
 #define FB_ACT 15872                       /* per-wave activation region (planes alias as layers retire) */
 #define FB_ZERO FB_ACT                     /* 128 B of zeros per wave */
 #define FB_WAVE (FB_ACT + 128)
-#define FB_BBUF 8192                       /* one weight staging buffer: 2 steps x 2 ntiles x (hi,lo) x 1 KiB */
-#define FB_BOFF (4 * FB_WAVE)
-#define FB_LDS (FB_BOFF + 2 * FB_BBUF)     /* 80384 B -> two workgroups per CU */
+#define FB_LDS (4 * FB_WAVE)               /* 64000 B -> two workgroups (8 waves) per CU */
 #define FB_PATCH 10752                     /* conv1 input: three zero-bordered bf16 planes [17][50] behind the A1 planes */
 #define FB_PPLANE 1700                     /* bytes per patch plane (850 bf16) */
 
-// One conv layer (3x3, padding 1) for this wave's segment; the four waves of the workgroup call it in
-// lockstep and share the staged weight fragments.
+// One conv layer (3x3, padding 1) for this wave's segment, barrier-free.
 //   act_in : this wave's input planes (hi at +0, lo at +PLANE), pixel rows of CIN bf16, swizzled chunks
-//   wb     : layer fragments [TOTAL steps][NT][2][64][8] bf16
-template <int CIN, int MT, int NT, int H, int W>
-NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* zero, char* bbuf,
+//   wb     : layer fragments [TOTAL steps][NT][2][64][8] bf16, streamed from L2: one contiguous 1 KiB
+//            global_load_dwordx4 per fragment, requested TWO K-steps ahead into a 3-deep register ring
+//            (an L2 round trip is ~600 clk, a step of MFMAs 200-800 clk); ~10 TB/s of L2 reads chip-wide
+//   APF    : also double-buffer the A rows from LDS one step ahead (off for conv2: 6 M-tiles of registers)
+template <int CIN, int MT, int NT, int H, int W, bool APF>
+NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* zero,
                          const unsigned short* __restrict__ wb, const int (&py)[MT], const int (&px)[MT],
-                         const bool (&pvalid)[MT], int lane, int wave) {
+                         const bool (&pvalid)[MT], int lane) {
     constexpr int S16 = CIN / 16;             // K=16 steps per tap
     constexpr int TOTAL = 9 * S16;
-    constexpr int NCH = (TOTAL + 1) / 2;      // chunks of two steps
     constexpr int Cc = CIN / 8;               // 16-byte chunks per pixel row (per plane)
     constexpr int PLANE = H * W * CIN * 2;    // bytes per plane
-    constexpr int FRAG_PER_STEP = NT * 2;     // 1 KiB fragments per step
+    constexpr int AB = APF ? 2 : 1;
     const int h = lane >> 5;
+    const f32x4* wl = (const f32x4*)wb + lane;
+    f32x4 bh[3][NT], bl[3][NT], ah[AB][MT], al[AB][MT];
 
-    auto stage = [&](int c) {                 // this wave's share of chunk c -> staging buffer c & 1
-        const int first = 2 * c * FRAG_PER_STEP;
-        const int nfrag = min(2, TOTAL - 2 * c) * FRAG_PER_STEP;
-        for (int f = wave; f < nfrag; f += 4)
-            __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(wb + (size_t)(first + f) * 512 + lane * 8),
-                (__attribute__((address_space(3))) void*)(bbuf + (c & 1) * FB_BBUF + f * 1024), 16, 0, 0);
+    auto load_b = [&](int g, int slot) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bh[slot][nt] = wl[((g * NT + nt) * 2 + 0) * 64];
+            bl[slot][nt] = wl[((g * NT + nt) * 2 + 1) * 64];
+        }
+    };
+    auto load_a = [&](int g, int slot) {
+        const int tap = g / S16, s = g - tap * S16;
+        const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int y = py[t] + dy, x = px[t] + dx;
+            const bool ok = pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const int pix = y * W + x;
+            const int swz = ((pix * Cc) >> 4) & (Cc - 1);
+            const char* ph = ok ? act_in + pix * (CIN * 2) + (((2 * s + h) ^ swz) << 4) : zero;
+            ah[slot][t] = *(const f32x4*)ph;
+            al[slot][t] = *(const f32x4*)(ok ? ph + PLANE : zero);
+        }
     };
 
-    __syncthreads();                          // everyone is done with the previous layer's staging buffers
-    stage(0);
+    load_b(0, 0);
+    load_b(1, 1);
+    if (APF) load_a(0, 0);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                      // chunk c landed for all waves; chunk c-1 fully consumed
-        if (c + 1 < NCH) stage(c + 1);
-        const char* bb = bbuf + (c & 1) * FB_BBUF + lane * 16;
+    for (int g = 0; g < TOTAL; ++g) {
+        if (g + 2 < TOTAL) load_b(g + 2, (g + 2) % 3);
+        if (APF) { if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1); } else load_a(g, 0);
+        __builtin_amdgcn_sched_barrier(0);        // keep the requests above ahead of this step's MFMAs
+        const int sa = APF ? (g & 1) : 0, sb = g % 3;
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const int g = 2 * c + st;
-            if (g < TOTAL) {
-                const int tap = g / S16, s = g - tap * S16;
-                const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
-                f32x4 ah[MT], al[MT], bh[NT], bl[NT];
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    bh[nt] = *(const f32x4*)(bb + ((st * NT + nt) * 2 + 0) * 1024);
-                    bl[nt] = *(const f32x4*)(bb + ((st * NT + nt) * 2 + 1) * 1024);
-                }
-#pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    const int y = py[t] + dy, x = px[t] + dx;
-                    const bool ok = pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-                    const int pix = y * W + x;
-                    const int swz = ((pix * Cc) >> 4) & (Cc - 1);
-                    const char* ph = ok ? act_in + pix * (CIN * 2) + (((2 * s + h) ^ swz) << 4) : zero;
-                    ah[t] = *(const f32x4*)ph;
-                    al[t] = *(const f32x4*)(ok ? ph + PLANE : zero);
-                }
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[t][nt] = mfma_bf(ah[t], bl[nt], acc[t][nt]);
-                        acc[t][nt] = mfma_bf(al[t], bh[nt], acc[t][nt]);
-                        acc[t][nt] = mfma_bf(ah[t], bh[nt], acc[t][nt]);
-                    }
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[t][nt] = mfma_bf(ah[sa][t], bl[sb][nt], acc[t][nt]);
+                acc[t][nt] = mfma_bf(al[sa][t], bh[sb][nt], acc[t][nt]);
+                acc[t][nt] = mfma_bf(ah[sa][t], bh[sb][nt], acc[t][nt]);
             }
-        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -150,7 +142,6 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const int p = p0 + wave, k = k0 + wave;
     char* act = smem + wave * FB_WAVE;
     char* zero = act + FB_ZERO;
-    char* bbuf = smem + FB_BOFF;
 
     // ---- stage the 15-frame window as three zero-bordered bf16 planes (hi, mid, lo) [frame j + 1][mel m + 1]:
     //      the 3x3 taps of any output pixel are then at constant offsets from it, no bounds checks
@@ -254,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             py[t] = 2 * (6 * hfi + gl) + yy;
             px[t] = w - 7 * yy;
         }
-        conv3x3_bf16<16, 6, 1, 24, 7>(acc, act, zero, bbuf, wb + CNNB_W2, py, px, pv, lane, wave);
+        conv3x3_bf16<16, 6, 1, 24, 7, false>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane);
         const float tn = cw[CNN_T2 + n];
 #pragma unroll
         for (int gl = 0; gl < 6; ++gl)
@@ -291,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<32, 2, 2, 12, 5>(acc, act, zero, bbuf, wb + CNNB_W3, py, px, pv, lane, wave);
+        conv3x3_bf16<32, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W3, py, px, pv, lane);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int c = n + 32 * nt;
@@ -321,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<64, 2, 2, 12, 5>(acc, act, zero, bbuf, wb + CNNB_W4, py, px, pv, lane, wave);
+        conv3x3_bf16<64, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W4, py, px, pv, lane);
         __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
         float* dst = p3 ? p3 + (size_t)p * (18 * 64) : nullptr;
 #pragma unroll
