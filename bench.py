@@ -81,6 +81,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', default=None, choices=['bf16x3', 'f32'])
+    ap.add_argument('--no-extras', action='store_true', help='skip the alt-precision and 3-stream passes (profiling runs)')
     ap.add_argument('--streams', type=int, default=1, help='HIP streams the steps alternate over (kernel tails of one '
                     'batch overlap the next batch)')
     a = ap.parse_args()
@@ -185,7 +186,7 @@ def main():
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
             'roofline': roof,
         }
-        if world == 1:
+        if world == 1 and not a.no_extras:
             # the other precision path on the same workload (secondary measurement, outside the timed region)
             other = 'f32' if eng.precision == 'bf16x3' else 'bf16x3'
             eng2 = HipNisqa(dict(synth.DIM_ARGS), synth.random_state_dict(7, 'NISQA_DIM'), dev, precision=other)
@@ -211,7 +212,7 @@ def main():
                                     'steps': n2, 'roofline_frac': r2['frac'], 'roofline_achieved': r2['achieved'],
                                     'roofline_peak': r2['peak'],
                                     'max_abs_diff_vs_primary': float((o2 - outs[-1]).abs().max())}
-        if world == 1 and len(streams) == 1:
+        if world == 1 and len(streams) == 1 and not a.no_extras:
             # same steps alternated over 3 streams: kernel tails / the latency-bound attention kernels of one batch
             # overlap the next batch (what the predict loop does); per-kernel times are not comparable in this mode
             st3 = [torch.cuda.Stream(device=dev) for _ in range(3)]
