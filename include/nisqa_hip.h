@@ -147,6 +147,23 @@ int nisqa_pool_att(const float* x, const int32_t* tok_off, const int32_t* n_wins
                    const float* pool_w, float* ws, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * nisqa_tts.tar architecture.
+ * nisqa_cnn_standard replaces segment_specs + Framewise.forward + StandardCNN.forward incl. fc_out
+ * (NISQA_lib.py:2239-2282, 487-502, 811-836): feat20[NP][20]; p3_ws scratch [NP][12][64] floats; cnn_std_w from
+ * nisqa_amd.weights.pack_standard_cnn.
+ * nisqa_lstm_laststep replaces LSTM.forward (bidirectional, hidden 128; NISQA_lib.py:925-943) and
+ * PoolLastStepBi.forward (NISQA_lib.py:1107-1115): out[B][1]; hfin_ws scratch [B][256] floats; seq_opt (may be
+ * NULL) receives the full [NP][256] LSTM output; lstm_w from nisqa_amd.weights.pack_lstm_laststep.
+ * ------------------------------------------------------------------------------------------ */
+int nisqa_cnn_standard(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                       const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                       int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
+                       float* p3_ws, float* feat20, void* stream);
+int nisqa_lstm_laststep(const float* feat20, const int32_t* tok_off, const int32_t* n_wins,
+                        int32_t n_clips, const float* lstm_w, float* hfin_ws, float* seq_opt,
+                        float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Whole forward for one batch: replaces the body of the per-batch step of predict_dim /
  * predict_mos (NISQA_lib.py:1420-1467): PCM in, [B][n_heads] out.  Internally the calls above,
  * carving scratch out of `ws` (size from nisqa_workspace_bytes).
@@ -162,6 +179,8 @@ typedef struct {
     void* const* stage_events;
     const uint16_t* cnn_wb;  /* split-bf16 conv fragments, or NULL */
     int32_t cnn_mode;        /* 0 = exact fp32 MFMA kernels, 1 = split-bf16 AdaptCNN (needs cnn_wb) */
+    int32_t arch;            /* 0 = CNN-SA-AP (nisqa.tar, nisqa_mos_only.tar); 1 = StandardCNN + BiLSTM + last-step
+                              * pooling (nisqa_tts.tar): cnn_w = cnn_std_w blob, td_w = lstm_w blob, pool_w unused */
 } nisqa_model_dev;
 
 size_t nisqa_workspace_bytes(int32_t n_clips, int32_t total_frames, int32_t total_tok_padded);

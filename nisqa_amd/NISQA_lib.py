@@ -92,6 +92,32 @@ class _PoolAttFFParams(nn.Module):
         self.linear3 = _lin(1, d)
 
 
+class _StandardCNNParams(nn.Module):
+    def __init__(self, c1, c2, c3, fc_out_h):
+        super().__init__()
+        chans = [1, c1, c2, c3, c3, c3, c3]
+        for i in range(1, 7):
+            setattr(self, 'conv%d' % i, _conv(chans[i], chans[i - 1], 3, 3))
+            setattr(self, 'bn%d' % i, _bn(chans[i]))
+        self.fc_out = _lin(fc_out_h, c3 * 6 * 2)                   # NL:803-807
+        self.fan_out = fc_out_h
+
+
+class _LSTMParams(nn.Module):
+    def __init__(self, input_size, lstm_h):
+        super().__init__()
+        # parameter holder with nn.LSTM's own key names (weight_ih_l0, ..., *_reverse); never called
+        self.lstm = nn.LSTM(input_size=input_size, hidden_size=lstm_h, num_layers=1, batch_first=True, bidirectional=True)
+        for p_ in self.lstm.parameters():
+            p_.requires_grad_(False)
+
+
+class _PoolLastStepBiParams(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.linear = _lin(1, d)
+
+
 class _Wrap(nn.Module):
     def __init__(self, model):
         super().__init__()
@@ -104,13 +130,23 @@ class _NisqaBase(nn.Module):
     def __init__(self, n_heads, **kw):
         super().__init__()
         g = lambda k, d=None: kw.get(k, d)
+        self._hp = dict(kw)
+        self._engine = None
+        self._engine_args = None
+        if g('cnn_model') == 'standard' and g('td') == 'lstm' and g('pool') == 'last_step_bi' \
+                and g('td_2', 'skip') in (None, 'skip') and n_heads == 1:
+            # nisqa_tts.tar architecture (NL:712-836, NL:897-943, NL:1099-1115)
+            self.cnn = _Wrap(_StandardCNNParams(g('cnn_c_out_1', 16), g('cnn_c_out_2', 32), g('cnn_c_out_3', 64),
+                                                g('cnn_fc_out_h', 20)))
+            self.time_dependency = _Wrap(_LSTMParams(self.cnn.model.fan_out, g('td_lstm_h', 128)))
+            self.pool = _Wrap(_PoolLastStepBiParams(2 * g('td_lstm_h', 128)))
+            return
         if g('cnn_model', 'adapt') != 'adapt' or g('td', 'self_att') != 'self_att' or g('pool', 'att') != 'att' \
                 or g('td_2', 'skip') not in (None, 'skip') or not g('pool_att_h', 128):
             raise NotImplementedError(
                 'nisqa_amd accelerates the CNN-SA-AP path (cnn_model=adapt, td=self_att, td_2=skip, pool=att with '
-                'pool_att_h); got cnn_model={} td={} td_2={} pool={}'.format(
-                    g('cnn_model'), g('td'), g('td_2'), g('pool')))
-        self._hp = dict(kw)
+                'pool_att_h) and the nisqa_tts path (cnn_model=standard, td=lstm, pool=last_step_bi); got '
+                'cnn_model={} td={} td_2={} pool={}'.format(g('cnn_model'), g('td'), g('td_2'), g('pool')))
         self.cnn = _Wrap(_AdaptCNNParams(g('cnn_c_out_1', 16), g('cnn_c_out_2', 32), g('cnn_c_out_3', 64),
                                          g('cnn_kernel_size', 3), g('cnn_pool_3', [6, 3])))
         d = g('td_sa_d_model', 64)
@@ -120,8 +156,6 @@ class _NisqaBase(nn.Module):
             self.pool_layers = nn.ModuleList([_Wrap(_PoolAttFFParams(d, g('pool_att_h', 128))) for _ in range(5)])
         else:
             self.pool = _Wrap(_PoolAttFFParams(d, g('pool_att_h', 128)))
-        self._engine = None
-        self._engine_args = None
 
     def bind_args(self, args):
         """Give the module the checkpoint's args (ms_* front-end parameters live there, NISQA_model.py:941-942)."""

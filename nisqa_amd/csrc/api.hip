@@ -57,6 +57,20 @@ extern "C" int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, co
     rc = nisqa_mel_finalize(mel, frame_off, n_clips, total_frames, cmax, cfg->top_db, cfloor, 0, stream);
     if (rc) return rc;
     NQ_STAGE(1);
+    if (model->arch == 1) {
+        // StandardCNN + BiLSTM + last-step pooling; scratch: p3 region holds [NP][12][64], feat region [NP][20],
+        // td region the [B][256] final LSTM states
+        rc = nisqa_cnn_standard(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
+                                model->cnn_w, p3, feat, stream);
+        if (rc) return rc;
+        NQ_STAGE(2);
+        NQ_STAGE(3);
+        rc = nisqa_lstm_laststep(feat, tok_off, n_wins, n_clips, model->td_w, td, nullptr, out, stream);
+        if (rc) return rc;
+        NQ_STAGE(4);
+        NQ_STAGE(5);
+        return NISQA_OK;
+    }
     if (model->cnn_mode == 1) {
         rc = nisqa_cnn_adapt_bf16(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
                                   model->cnn_w, model->cnn_wb, nullptr, feat, stream);

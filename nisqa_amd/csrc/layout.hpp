@@ -20,6 +20,22 @@
 #define CNN_T6 (CNN_WF6 + 9 * 8 * 2 * 256)
 #define CNN_W_FLOATS (CNN_T6 + 64)
 
+// ---- StandardCNN blob ("cnn_std_w"): the AdaptCNN offsets above (identical conv shapes; conv6 is a full
+// padding-1 3x3 here) followed by fc_out 768 -> 20 in kernel order:
+//   CNNS_FC_W[k' = pixel*64 + c][j]  = fc_out.weight[j][c*12 + pixel]   (pixel = y*2 + x of the 6x2 map)
+#define CNNS_FC_W CNN_W_FLOATS
+#define CNNS_FC_B (CNNS_FC_W + 768 * 20)
+#define CNNS_W_FLOATS (CNNS_FC_B + 32)
+
+// ---- BiLSTM blob ("lstm_w"), per direction d: W_ih [512][20], W_hh [512][128], b_ih + b_hh [512] (gate order i,f,g,o)
+#define LSTM_WIH 0
+#define LSTM_WHH (LSTM_WIH + 512 * 20)
+#define LSTM_B (LSTM_WHH + 512 * 128)
+#define LSTM_DIR_FLOATS (LSTM_B + 512)
+// then last-step pooling: linear.weight [256], bias, pad
+#define LSTM_POOL_W (2 * LSTM_DIR_FLOATS)
+#define LSTM_W_FLOATS (LSTM_POOL_W + 256 + 4)
+
 // ---- AdaptCNN split-bf16 weight fragments ("cnn_wb", uint16 units; biases stay in cnn_w) -------------
 // conv1: [3 terms hi/mid/lo][64 lanes][8]   B[k = tap (0..15, taps >= 9 are 0)][n (0..31, n >= 16 are 0)]
 // conv5, conv6 (N split over 4 waves, 16x16x32 MFMA): [wave][step g = 2*tap + s][hl][64 lanes][8]:

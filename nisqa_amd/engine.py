@@ -101,25 +101,42 @@ class HipNisqa(object):
         self.device = torch.device(device if device is not None else 'cuda:%d' % torch.cuda.current_device())
         self.args = args
         a = args
-        if a.get('cnn_model') != 'adapt' or a.get('td') != 'self_att' or a.get('pool') != 'att' \
-                or a.get('td_2') not in (None, 'skip') or a.get('td_sa_pos_enc'):
+        sa = a.get('cnn_model') == 'adapt' and a.get('td') == 'self_att' and a.get('pool') == 'att'
+        tts = a.get('cnn_model') == 'standard' and a.get('td') == 'lstm' and a.get('pool') == 'last_step_bi'
+        if not (sa or tts) or a.get('td_2') not in (None, 'skip') or a.get('td_sa_pos_enc'):
             raise NotImplementedError(
-                'HIP engine covers cnn_model=adapt / td=self_att / pool=att (nisqa.tar, nisqa_mos_only.tar); got '
-                'cnn_model={} td={} td_2={} pool={}'.format(a.get('cnn_model'), a.get('td'), a.get('td_2'), a.get('pool')))
-        if a['ms_seg_length'] != SEG_LEN or a['ms_n_mels'] != 48 or list(a['cnn_pool_1']) != [24, 7] \
-                or list(a['cnn_pool_2']) != [12, 5] or list(a['cnn_pool_3']) != [6, 3] \
-                or a['td_sa_nhead'] != 1 or a['td_sa_d_model'] != 64 or not a.get('pool_att_h'):
-            raise NotImplementedError('HIP engine is built for the nisqa.tar geometry (15-frame segments, 48 mels, '
-                                      'pools 24x7/12x5/6x3, 1 head, d_model 64)')
+                'HIP engine covers cnn_model=adapt / td=self_att / pool=att (nisqa.tar, nisqa_mos_only.tar) and '
+                'cnn_model=standard / td=lstm / pool=last_step_bi (nisqa_tts.tar); got cnn_model={} td={} td_2={} pool={}'
+                .format(a.get('cnn_model'), a.get('td'), a.get('td_2'), a.get('pool')))
+        if a['ms_seg_length'] != SEG_LEN or a['ms_n_mels'] != 48:
+            raise NotImplementedError('HIP engine is built for 15-frame segments of 48 mel bands')
+        if sa and (list(a['cnn_pool_1']) != [24, 7] or list(a['cnn_pool_2']) != [12, 5] or list(a['cnn_pool_3']) != [6, 3]
+                   or a['td_sa_nhead'] != 1 or a['td_sa_d_model'] != 64 or not a.get('pool_att_h')):
+            raise NotImplementedError('HIP engine is built for the nisqa.tar geometry (pools 24x7/12x5/6x3, 1 head, '
+                                      'd_model 64, pool_att_h)')
+        if tts and (a.get('cnn_fc_out_h') != 20 or a.get('td_lstm_h') != 128 or a.get('td_lstm_num_layers') != 1
+                    or not a.get('td_lstm_bidirectional') or a['model'] != 'NISQA'):
+            raise NotImplementedError('HIP engine is built for the nisqa_tts.tar geometry (fc 20, BiLSTM 128 x 1 layer)')
+        self.arch = 1 if tts else 0
         if a.get('ms_sr') is not None:
             raise NotImplementedError('ms_sr resampling is not implemented (all shipped checkpoints use ms_sr=None)')
         self.seg_hop = int(a['ms_seg_hop_length'])
         self.max_segments = a['ms_max_segments']
-        self.n_layers = int(a['td_sa_num_layers'])
         self.dim = a['model'] == 'NISQA_DIM'
+        up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        if self.arch == 1:
+            # StandardCNN + BiLSTM + last-step pooling: exact fp32 kernels only
+            self.precision, self.n_layers, self.n_heads = 'f32', 0, 1
+            self.cnn_w = up(_w.pack_standard_cnn(state_dict))
+            self.td_w = up(_w.pack_lstm_laststep(state_dict))
+            self.pool_w = torch.zeros(4, dtype=torch.float32, device=self.device)
+            self.cnn_wb = None
+            self._mel = {}
+            self._ws = {}
+            return
+        self.n_layers = int(a['td_sa_num_layers'])
         heads = ['pool_layers.%d.model.' % h for h in range(5)] if self.dim else ['pool.model.']
         self.n_heads = len(heads)
-        up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
         self.precision = precision or os.environ.get('NISQA_HIP_PRECISION', 'bf16x3')
         if self.precision not in ('f32', 'bf16x3'):
             raise ValueError('precision must be f32 or bf16x3, got {}'.format(self.precision))
@@ -144,7 +161,7 @@ class HipNisqa(object):
                                        _ptr(d['band_woff']), _ptr(d['band_w']), _ptr(self.cnn_w), _ptr(self.td_w),
                                        _ptr(self.pool_w), self.n_layers, self.n_heads, self.seg_hop, None,
                                        _ptr(self.cnn_wb) if self.cnn_wb is not None else None,
-                                       1 if self.precision == 'bf16x3' else 0)
+                                       1 if self.precision == 'bf16x3' else 0, self.arch)
             self._mel[sr] = d
         return self._mel[sr]
 
@@ -221,6 +238,8 @@ class HipNisqa(object):
 
     def forward_segments(self, x, n_wins):
         """Reference inner operator model(x[B,L,1,48,15], n_wins[B]) -> [B, heads] (NL:137-142, NL:260-268)."""
+        if self.arch != 0:
+            raise NotImplementedError('segment-tensor forward is implemented for the CNN-SA-AP architecture only')
         if x.dim() != 5 or tuple(x.shape[2:]) != (1, 48, SEG_LEN):
             raise ValueError('expected x of shape [B, L, 1, 48, 15], got {}'.format(tuple(x.shape)))
         x = x.to(self.device, dtype=torch.float32).contiguous()
@@ -241,6 +260,28 @@ class HipNisqa(object):
                                                          plan.total_tok, _ptr(self.cnn_w), _ptr(p3), _ptr(feat),
                                                          self._stream()), 'nisqa_cnn_adapt_segments')
         return self.pool(self.td(feat, plan), plan)
+
+    # -- nisqa_tts.tar stages ------------------------------------------------------------------------
+    def cnn_std(self, mel_tm, clip_floor, plan):
+        """StandardCNN + fc_out -> feat20 [NP, 20]"""
+        d = plan.to(self.device)
+        p3 = torch.empty((plan.total_tok, 12, 64), dtype=torch.float32, device=self.device)
+        feat = torch.zeros((plan.total_tok, 20), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nisqa_cnn_standard(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']),
+                                               _ptr(clip_floor), plan.n_clips, plan.total_tok, self.seg_hop,
+                                               _ptr(self.cnn_w), _ptr(p3), _ptr(feat), self._stream()), 'nisqa_cnn_standard')
+        return feat
+
+    def lstm(self, feat20, plan, want_seq=False):
+        """BiLSTM + PoolLastStepBi -> (out [B,1], seq [NP,256] or None)"""
+        d = plan.to(self.device)
+        hfin = torch.empty((plan.n_clips, 256), dtype=torch.float32, device=self.device)
+        seq = torch.zeros((plan.total_tok, 256), dtype=torch.float32, device=self.device) if want_seq else None
+        out = torch.empty((plan.n_clips, 1), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nisqa_lstm_laststep(_ptr(feat20), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
+                                                _ptr(self.td_w), _ptr(hfin), _ptr(seq) if want_seq else None, _ptr(out),
+                                                self._stream()), 'nisqa_lstm_laststep')
+        return out, seq
 
     def td(self, feat, plan):
         d = plan.to(self.device)

@@ -97,6 +97,13 @@ DIM_ARGS = {
     'dim': True, 'double_ended': False,
 }
 MOS_ARGS = dict(DIM_ARGS, model='NISQA', name='rand_mos', dim=False)
+# args of weights/nisqa_tts.tar (StandardCNN + fc 768->20 + BiLSTM(128) + last-step pooling; hop 1, fmax 8000)
+TTS_ARGS = dict(DIM_ARGS, model='NISQA', name='rand_tts', dim=False, ms_fmax=8000, ms_seg_hop_length=1,
+                ms_max_segments=6000, cnn_model='standard', cnn_fc_out_h=20, cnn_pool_1=None, cnn_pool_2=None,
+                cnn_pool_3=None, td='lstm', td_sa_d_model=None, td_sa_nhead=None, td_sa_pos_enc=None,
+                td_sa_num_layers=None, td_sa_h=None, td_sa_dropout=None, td_lstm_h=128, td_lstm_num_layers=1,
+                td_lstm_dropout=0, td_lstm_bidirectional=True, pool='last_step_bi', pool_att_h=None,
+                pool_att_dropout=None)
 
 
 
@@ -128,6 +135,18 @@ def random_state_dict(seed, model='NISQA_DIM'):
         sd['cnn.model.bn%d.num_batches_tracked' % i] = torch.tensor(100, dtype=torch.int64)
     # conv1 sees dB values of magnitude ~40: keep its output O(1)
     sd['cnn.model.conv1.weight'] = sd['cnn.model.conv1.weight'] * 0.05
+    if model == 'NISQA_TTS':
+        sd['cnn.model.fc_out.weight'] = rn(20, 768, std=768 ** -0.5)
+        sd['cnn.model.fc_out.bias'] = rn(20, std=0.1)
+        lp = 'time_dependency.model.lstm.'
+        for sfx in ('', '_reverse'):
+            sd[lp + 'weight_ih_l0' + sfx] = rn(512, 20, std=0.3)
+            sd[lp + 'weight_hh_l0' + sfx] = rn(512, 128, std=0.15)
+            sd[lp + 'bias_ih_l0' + sfx] = rn(512, std=0.1)
+            sd[lp + 'bias_hh_l0' + sfx] = rn(512, std=0.1)
+        sd['pool.model.linear.weight'] = rn(1, 256, std=0.2)
+        sd['pool.model.linear.bias'] = 3.0 + rn(1, std=0.1)
+        return sd
     td = 'time_dependency.model.'
     sd[td + 'norm1.weight'] = 1.0 + rn(64, std=0.1)
     sd[td + 'norm1.bias'] = rn(64, std=0.1)

@@ -48,6 +48,17 @@ TDL_LN2_G = TDL_FF2_B + 64
 TDL_LN2_B = TDL_LN2_G + 64
 TDL_FLOATS = TDL_LN2_B + 64
 
+CNNS_FC_W = CNN_W_FLOATS
+CNNS_FC_B = CNNS_FC_W + 768 * 20
+CNNS_W_FLOATS = CNNS_FC_B + 32
+
+LSTM_WIH = 0
+LSTM_WHH = LSTM_WIH + 512 * 20
+LSTM_B = LSTM_WHH + 512 * 128
+LSTM_DIR_FLOATS = LSTM_B + 512
+LSTM_POOL_W = 2 * LSTM_DIR_FLOATS
+LSTM_W_FLOATS = LSTM_POOL_W + 256 + 4
+
 CNNB_W1 = 0
 CNNB_W2 = CNNB_W1 + 3 * 512
 CNNB_W3 = CNNB_W2 + 9 * 1 * 2 * 512
@@ -249,4 +260,45 @@ def pack_adapt_cnn_bf16(sd, pfx='cnn.model.'):
         w, _ = fold_bn(sd, pfx, i)
         fr = conv_b_fragments_bf16_nsplit(w.astype(np.float32)) if i >= 5 else conv_b_fragments_bf16(w.astype(np.float32))
         blob[off:off + fr.size] = fr
+    return blob
+
+
+# ---- nisqa_tts.tar architecture ----------------------------------------------------------------------
+def pack_standard_cnn(sd, pfx='cnn.model.'):
+    """StandardCNN (16/32/64 channels, 3x3 kernels, fc_out 768 -> 20) -> float32 [CNNS_W_FLOATS]."""
+    shapes = [(16, 1), (32, 16), (64, 32), (64, 64), (64, 64), (64, 64)]
+    for i, (co, ci) in enumerate(shapes, 1):
+        if tuple(sd[pfx + 'conv%d.weight' % i].shape) != (co, ci, 3, 3):
+            raise NotImplementedError('HIP StandardCNN kernel is built for the nisqa_tts.tar geometry')
+    if pfx + 'fc_out.weight' not in sd or tuple(sd[pfx + 'fc_out.weight'].shape) != (20, 768):
+        raise NotImplementedError('HIP StandardCNN kernel needs cnn_fc_out_h=20')
+    blob = np.zeros(CNNS_W_FLOATS, np.float32)
+    w, t = fold_bn(sd, pfx, 1)
+    blob[CNN_W1:CNN_W1 + 144] = w.reshape(16, 9).astype(np.float32).reshape(-1)
+    blob[CNN_T1:CNN_T1 + 16] = t
+    for i, (wo, to) in zip(range(2, 7), [(CNN_WF2, CNN_T2), (CNN_WF3, CNN_T3), (CNN_WF4, CNN_T4),
+                                          (CNN_WF5, CNN_T5), (CNN_WF6, CNN_T6)]):
+        w, t = fold_bn(sd, pfx, i)
+        fr = conv_b_fragments(w)
+        blob[wo:wo + fr.size] = fr
+        blob[to:to + t.size] = t
+    fc = _np(sd, pfx + 'fc_out.weight').reshape(20, 64, 12)            # [j][c][pixel]  (flatten c*12 + y*2 + x, NL:830)
+    blob[CNNS_FC_W:CNNS_FC_W + 768 * 20] = np.transpose(fc, (2, 1, 0)).reshape(-1)    # [pixel*64 + c][j]
+    blob[CNNS_FC_B:CNNS_FC_B + 20] = _np(sd, pfx + 'fc_out.bias')
+    return blob
+
+
+def pack_lstm_laststep(sd, lpfx='time_dependency.model.lstm.', ppfx='pool.model.'):
+    """nn.LSTM(20, 128, bidirectional) + PoolLastStepBi linear 256 -> 1 -> float32 [LSTM_W_FLOATS]."""
+    if tuple(sd[lpfx + 'weight_ih_l0'].shape) != (512, 20) or tuple(sd[lpfx + 'weight_hh_l0'].shape) != (512, 128) \
+            or lpfx + 'weight_ih_l0_reverse' not in sd or lpfx + 'weight_ih_l1' in sd:
+        raise NotImplementedError('HIP LSTM kernel needs one bidirectional layer, input 20, hidden 128')
+    blob = np.zeros(LSTM_W_FLOATS, np.float32)
+    for d, sfx in enumerate(('', '_reverse')):
+        base = d * LSTM_DIR_FLOATS
+        blob[base + LSTM_WIH: base + LSTM_WIH + 512 * 20] = _np(sd, lpfx + 'weight_ih_l0' + sfx).reshape(-1)
+        blob[base + LSTM_WHH: base + LSTM_WHH + 512 * 128] = _np(sd, lpfx + 'weight_hh_l0' + sfx).reshape(-1)
+        blob[base + LSTM_B: base + LSTM_B + 512] = (_np(sd, lpfx + 'bias_ih_l0' + sfx) + _np(sd, lpfx + 'bias_hh_l0' + sfx))
+    blob[LSTM_POOL_W: LSTM_POOL_W + 256] = _np(sd, ppfx + 'linear.weight').reshape(-1)
+    blob[LSTM_POOL_W + 256] = _np(sd, ppfx + 'linear.bias').reshape(-1)[0]
     return blob

@@ -37,7 +37,7 @@ def clip_pcm(c):
     return synth.synth_pcm16(c[1], c[2]) if c[0] == 'seed' else synth.edge_clip(c[1])
 
 
-def run_reference(args, sd, specs):
+def run_reference(args, sd, specs, stage_idx=None):
     """Reference forward on a padded batch (segment_specs + model), returns outputs and stages."""
     model, NL = ref_shim.build_reference_model(args, sd)
     xs, nw = [], []
@@ -57,7 +57,7 @@ def run_reference(args, sd, specs):
             xb = torch.stack([xs[i] for i in grp], 0)
             nb = torch.tensor([nw[i] for i in grp])
             outs[grp] = model(xb, nb).numpy()
-        for i in STAGE_CLIPS:
+        for i in (STAGE_CLIPS if stage_idx is None else stage_idx):
             seg = xs[i][:nw[i]]
             feat = model.cnn.model(seg)
             td, _ = model.time_dependency(feat.unsqueeze(0), torch.tensor([nw[i]]))
@@ -91,6 +91,24 @@ def main():
     a, sd = helpers.load_checkpoint(real_mos); sets.append(('mos_real', a, sd))
     sets.append(('dim_rand', dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM')))
     sets.append(('mos_rand', dict(helpers.MOS_ARGS), helpers.random_state_dict(8, 'NISQA')))
+    # nisqa_tts.tar architecture (StandardCNN + BiLSTM + last-step pooling): fmax 8000, segment hop 1
+    tts_ids = [0, 3, 4, 5, 6, 1]
+    tts_specs_all = {i: omel.melspec_db_from_audio(pcm[i].astype(np.float32) / np.float32(32768.0), 48000, fmax=8000.0)
+                     for i in tts_ids}
+    a, sd = helpers.load_checkpoint(helpers.find_weights('nisqa_tts.tar'))
+    tts_sets = [('tts_real', a, sd), ('tts_rand', dict(helpers.TTS_ARGS), helpers.random_state_dict(9, 'NISQA_TTS'))]
+    for name, args, sd in tts_sets:
+        outs, nw, stages = run_reference(args, sd, [tts_specs_all[i] for i in tts_ids], stage_idx=[0, 1, 4])
+        fix = dict(common)
+        fix['provenance'] = np.array('network: reference torch modules (StandardCNN, LSTM, PoolLastStepBi) via '
+                                     'oracle.ref_shim, CPU fp32, padded batch; input mel: oracle.mel restatement, '
+                                     'fmax 8000; weights: ' + name)
+        fix['clip_index'] = np.array(tts_ids)
+        fix['out'] = outs
+        fix['n_wins'] = nw
+        fix.update(stages)
+        np.savez_compressed(os.path.join(HERE, 'net_%s.npz' % name), **fix)
+        print(name, '\n', outs)
     for name, args, sd in sets:
         outs, nw, stages = run_reference(args, sd, specs)
         fix = dict(common)

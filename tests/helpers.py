@@ -10,7 +10,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
-from nisqa_amd.synth import DIM_ARGS, MOS_ARGS, random_state_dict  # noqa: E402,F401
+from nisqa_amd.synth import DIM_ARGS, MOS_ARGS, TTS_ARGS, random_state_dict  # noqa: E402,F401
 
 
 def find_weights(name='nisqa.tar'):

@@ -282,3 +282,71 @@ def test_inner_operator_forward_on_segment_tensors(eng_rand, batch):
     xr, nr = onet.segment_specs(specs[0], 15, 4, 1300)
     assert tuple(x.shape) == (1300, 1, 48, 15) and int(n_wins) == nr and idx == 0 and np.isnan(y).all() and y.shape == (5,)
     assert (x - xr).abs().max() < 2e-3
+
+
+# ---- nisqa_tts.tar architecture: StandardCNN + fc_out + BiLSTM + last-step pooling -------
+TTS_CLIPS = [0, 3, 4, 5, 6, 1]            # indices into CLIPS, same set as tests/golden/net_tts_*.npz
+
+
+@pytest.mark.parametrize('name', ['tts_rand', 'tts_real'])
+def test_tts_architecture_stages_and_fixture(name):
+    g = helpers.golden('net_%s.npz' % name)
+    if name == 'tts_real':
+        path = helpers.find_weights('nisqa_tts.tar')
+        if path is None:
+            pytest.skip('real checkpoint not on this machine')
+        args, sd = helpers.load_checkpoint(path)
+    else:
+        args, sd = dict(helpers.TTS_ARGS), helpers.random_state_dict(9, 'NISQA_TTS')
+    eng = _engine(args, sd)
+    assert eng.arch == 1 and eng.seg_hop == 1
+    pcm = [clip_pcm(i) for i in TTS_CLIPS]
+    dev_pcm, plan = _upload(eng, pcm)
+    assert list(plan.n_wins) == list(g['n_wins'])
+    mel, floor = eng.mel(dev_pcm, plan, 48000, clamp=False)
+    feat = eng.cnn_std(mel, floor, plan)
+    out_st, seq = eng.lstm(feat, plan, want_seq=True)
+    out = eng.forward_pcm(dev_pcm, plan, 48000)
+    torch.cuda.synchronize()
+    mel_h = torch.maximum(mel, floor[torch.from_numpy(np.repeat(np.arange(plan.n_clips), plan.T)).to(mel.device)][:, None]).cpu().numpy()
+    feat_h, seq_h, out_h, outs_h = feat.cpu().numpy(), seq.cpu().numpy(), out.cpu().numpy(), out_st.cpu().numpy()
+    worst = {'mel': 0.0, 'feat': 0.0, 'td': 0.0, 'out': 0.0}
+    for n, i in enumerate(TTS_CLIPS):
+        y = pcm[n].astype(np.float32) / np.float32(32768.0)
+        spec_ref = omel.melspec_db_from_audio(y, 48000, fmax=8000.0)
+        spec = mel_h[plan.frame_off[n]:plan.frame_off[n + 1]].T
+        worst['mel'] = max(worst['mel'], np.abs(spec - spec_ref).max())
+        ref_out, st = onet.predict_from_melspec(sd, args, spec, return_stages=True)     # GPU mel -> oracle network
+        nw, t0 = int(plan.n_wins[n]), int(plan.tok_off[n])
+        worst['feat'] = max(worst['feat'], np.abs(feat_h[t0:t0 + nw] - st['feat']).max())
+        worst['td'] = max(worst['td'], np.abs(seq_h[t0:t0 + nw] - st['td']).max())
+        worst['out'] = max(worst['out'], np.abs(out_h[n] - ref_out).max(), np.abs(outs_h[n] - ref_out).max())
+    err_fix = np.abs(out_h - g['out']).max()
+    print(name, 'stage max|d|', worst, 'vs reference fixture', err_fix)
+    assert worst['mel'] < 2e-3 and worst['feat'] < 2e-4 and worst['td'] < 2e-4
+    assert worst['out'] < 1e-3 and err_fix < 1e-3
+
+
+def test_tts_drop_in_surface(tmp_path):
+    """predict_dir with a StandardCNN/LSTM checkpoint through nisqaModel (mixed lengths 0.4 .. 3 s)."""
+    from nisqa_amd.NISQA_model import nisqaModel
+    args = dict(helpers.TTS_ARGS)
+    args.update({'pretrained_model': False, 'tr_bs_val': 1, 'tr_num_workers': 0})
+    path = str(tmp_path / 'tts_rand.tar')
+    sd = helpers.random_state_dict(9, 'NISQA_TTS')
+    torch.save({'args': args, 'model_state_dict': sd}, path)
+    d = tmp_path / 'wavs'
+    d.mkdir()
+    durs = np.random.default_rng(7).uniform(0.4, 3.0, 5)
+    for i, du in enumerate(durs):
+        synth.write_wav(str(d / ('t%d.wav' % i)), synth.synth_pcm16(70 + i, float(du)), 48000)
+    a = {'mode': 'predict_dir', 'pretrained_model': path, 'deg': None, 'data_dir': str(d), 'output_dir': None,
+         'csv_file': None, 'csv_deg': None, 'num_workers': 0, 'bs': 4, 'ms_channel': None, 'tr_bs_val': 4,
+         'tr_num_workers': 0}
+    m = nisqaModel(a)
+    df = m.predict()
+    assert list(df.columns) == ['deg', 'mos_pred'] and len(df) == 5
+    for _, row in df.iterrows():
+        spec = omel.get_melspec(str(d / row['deg']), None, 4096, 0.01, 0.02, 48, 8000)
+        ref = onet.predict_from_melspec(sd, m.args, spec)
+        assert abs(row['mos_pred'] - ref[0]) < 1e-3

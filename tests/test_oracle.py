@@ -135,3 +135,24 @@ def test_net_oracle_against_live_reference():
         ref = model(x.unsqueeze(0), torch.tensor([int(n)])).numpy()[0]
     out = onet.predict_from_melspec(sd, args, spec)
     np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', ['tts_real', 'tts_rand'])
+def test_net_oracle_tts_architecture_matches_reference_fixture(name):
+    """nisqa_tts.tar architecture: StandardCNN (NL:811-836), BiLSTM (NL:925-943), PoolLastStepBi (NL:1107-1115)."""
+    g = helpers.golden('net_%s.npz' % name)
+    if name.endswith('real'):
+        path = helpers.find_weights('nisqa_tts.tar')
+        if path is None:
+            pytest.skip('real checkpoint not on this machine')
+        args, sd = helpers.load_checkpoint(path)
+    else:
+        args, sd = dict(helpers.TTS_ARGS), helpers.random_state_dict(9, 'NISQA_TTS')
+    for n, i in enumerate(g['clip_index']):
+        spec = omel.melspec_db_from_audio(clip_pcm(int(i)).astype(np.float32) / np.float32(32768.0), 48000, fmax=8000.0)
+        out, st = onet.predict_from_melspec(sd, args, spec, return_stages=True)
+        assert st['n_wins'] == int(g['n_wins'][n]) == spec.shape[1] - 14          # segment hop 1
+        np.testing.assert_allclose(out, g['out'][n], rtol=0, atol=3e-5)
+        if 'feat_%d' % n in g.files:
+            np.testing.assert_allclose(st['feat'], g['feat_%d' % n], rtol=0, atol=3e-5)
+            np.testing.assert_allclose(st['td'], g['td_%d' % n], rtol=0, atol=3e-5)
