@@ -35,7 +35,7 @@ def _header_defines(path):
 
 def test_layout_header_matches_python():
     env = _header_defines(os.path.join(ROOT, 'nisqa_amd', 'csrc', 'layout.hpp'))
-    names = [n for n in dir(W) if re.match(r'(CNN|CNNB|TD|TDL|PL)_', n)]
+    names = [n for n in dir(W) if re.match(r'(CNN|CNNB|CNNS|LSTM|TD|TDL|PL)_', n)]
     assert len(names) > 30
     for n in names:
         assert env[n] == getattr(W, n), n
@@ -337,7 +337,27 @@ def test_cli_argument_errors():
 def test_unsupported_architecture_is_rejected(tmp_path):
     from nisqa_amd import NISQA_lib as NL
     with pytest.raises(NotImplementedError, match='CNN-SA-AP'):
-        NL.NISQA(cnn_model='standard', td='lstm', pool='last_step_bi')
+        NL.NISQA(cnn_model='adapt', td='lstm', pool='avg')                     # config/train_nisqa_cnn_lstm_avg.yaml
+    with pytest.raises(NotImplementedError):
+        NL.NISQA_DIM(cnn_model='standard', td='lstm', pool='last_step_bi')     # tts architecture is MOS-only
+    m = NL.NISQA(cnn_model='standard', td='lstm', pool='last_step_bi', cnn_fc_out_h=20, td_lstm_h=128)
+    assert 'time_dependency.model.lstm.weight_hh_l0_reverse' in m.state_dict()
+
+
+def test_tts_packing_layouts():
+    sd = synth.random_state_dict(9, 'NISQA_TTS')
+    blob = W.pack_standard_cnn(sd)
+    assert blob.shape == (W.CNNS_W_FLOATS,)
+    fc = sd['cnn.model.fc_out.weight'].numpy()
+    for (j, c, pix) in [(0, 0, 0), (19, 63, 11), (7, 13, 5)]:
+        assert blob[W.CNNS_FC_W + (pix * 64 + c) * 20 + j] == fc[j, c * 12 + pix]
+    lw = W.pack_lstm_laststep(sd)
+    assert lw.shape == (W.LSTM_W_FLOATS,)
+    whh_r = sd['time_dependency.model.lstm.weight_hh_l0_reverse'].numpy()
+    assert lw[W.LSTM_DIR_FLOATS + W.LSTM_WHH + 300 * 128 + 17] == whh_r[300, 17]
+    b = (sd['time_dependency.model.lstm.bias_ih_l0'] + sd['time_dependency.model.lstm.bias_hh_l0']).numpy()
+    np.testing.assert_allclose(lw[W.LSTM_B:W.LSTM_B + 512], b, rtol=1e-6)
+    assert lw[W.LSTM_POOL_W + 256] == sd['pool.model.linear.bias'].numpy()[0]
 
 
 # ---- multi-process clip sharding (gloo, world_size 2) ------------------------------------------------------------
