@@ -12,6 +12,7 @@ alternative blocks no shipped checkpoint uses.
 """
 import os
 from concurrent.futures import ThreadPoolExecutor
+from contextlib import nullcontext as _nullcontext
 
 import numpy as np
 import pandas as pd; pd.options.mode.chained_assignment = None
@@ -282,6 +283,19 @@ def _predict(model, ds, bs, dev, num_workers):
 
         starts = list(range(lo, hi, bs))
         nxt = load_batch(starts[0]) if starts else None
+        # two HIP streams: the H2D copy + forward of batch i+1 are enqueued while batch i is still running, and the
+        # D2H of batch i's [B, heads] rows is waited for one batch late (no device-wide sync in the loop)
+        use_streams = eng.device.type == 'cuda'
+        streams = [torch.cuda.Stream(device=eng.device) for _ in range(2)] if use_streams else [None, None]
+        inflight = []                                               # (ids, out tensor, stream)
+
+        def drain(keep):
+            while len(inflight) > keep:
+                ids, out, st = inflight.pop(0)
+                if st is not None:
+                    st.synchronize()
+                y_local[np.asarray(ids) - lo] = out.cpu().numpy()
+
         for bi, s in enumerate(starts):
             idx, items = nxt
             fut = None
@@ -290,21 +304,23 @@ def _predict(model, ds, bs, dev, num_workers):
             by_sr = {}
             for i, (y, sr) in zip(idx, items):
                 by_sr.setdefault(sr, []).append((i, y))
-            pending = []
-            for sr, grp in by_sr.items():                          # files of one rate share the mel tables
-                plan = eng.plan([len(y) for _, y in grp], sr, names=[ds.file_path(i) for i, _ in grp])
-                if all(y.dtype == np.int16 for _, y in grp):
-                    host = torch.from_numpy(np.concatenate([y for _, y in grp]))
-                    pcm = eng.pcm16_to_f32((host.pin_memory() if pin else host).to(eng.device, non_blocking=True))
-                else:
-                    host = torch.from_numpy(np.concatenate(
-                        [y.astype(np.float32) / np.float32(32768.0) if y.dtype == np.int16 else y for _, y in grp]))
-                    pcm = (host.pin_memory() if pin else host).to(eng.device, non_blocking=True)
-                pending.append(([i for i, _ in grp], eng.forward_pcm(pcm, plan, sr)))
-            for ids, out in pending:
-                y_local[np.asarray(ids) - lo] = out.cpu().numpy()
+            st = streams[bi % 2]
+            ctx = torch.cuda.stream(st) if st is not None else _nullcontext()
+            with ctx:
+                for sr, grp in by_sr.items():                      # files of one rate share the mel tables
+                    plan = eng.plan([len(y) for _, y in grp], sr, names=[ds.file_path(i) for i, _ in grp])
+                    if all(y.dtype == np.int16 for _, y in grp):
+                        host = torch.from_numpy(np.concatenate([y for _, y in grp]))
+                        pcm = eng.pcm16_to_f32((host.pin_memory() if pin else host).to(eng.device, non_blocking=True))
+                    else:
+                        host = torch.from_numpy(np.concatenate(
+                            [y.astype(np.float32) / np.float32(32768.0) if y.dtype == np.int16 else y for _, y in grp]))
+                        pcm = (host.pin_memory() if pin else host).to(eng.device, non_blocking=True)
+                    inflight.append(([i for i, _ in grp], eng.forward_pcm(pcm, plan, sr), st))
+            drain(keep=len(by_sr))                                  # results of the previous batch
             if bi + 1 < len(starts):
                 nxt = fut.result() if fut is not None else load_batch(starts[bi + 1])
+        drain(keep=0)
     finally:
         if pool is not None:
             pool.shutdown(wait=True)
