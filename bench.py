@@ -95,11 +95,19 @@ def main():
                              % (a.gpus, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path)')
+    # NISQA_BENCH_SHARED_GPU=1 is a test knob: all ranks share cuda:0 over gloo, to exercise the N > 1 code path on a
+    # one-GPU box; the real multi-GPU run is one rank per GPU over RCCL ("nccl")
+    shared = os.environ.get('NISQA_BENCH_SHARED_GPU') == '1'
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if shared:
+            torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from nisqa_amd.engine import HipNisqa
     eng = HipNisqa(dict(synth.DIM_ARGS), synth.random_state_dict(7, 'NISQA_DIM'), dev, precision=a.precision)

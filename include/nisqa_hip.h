@@ -146,6 +146,22 @@ int nisqa_pool_att(const float* x, const int32_t* tok_off, const int32_t* n_wins
                    int32_t n_clips, int32_t total_tok_padded, int32_t n_heads,
                    const float* pool_w, float* ws, float* out, void* stream);
 
+/* Split-bf16 variants of the two calls above (same results to ~1e-5): td_wb / pool_wb are the bf16
+ * hi/lo weight fragments from nisqa_amd.weights.pack_self_att_bf16 / pack_pool_att_bf16; biases and LayerNorm
+ * parameters are still read from td_w / pool_w.  ws sizes as for the fp32 calls. */
+int nisqa_td_selfatt_bf16(const float* feat, const int32_t* tok_off, const int32_t* n_wins,
+                          int32_t n_clips, int32_t total_tok_padded, int32_t n_layers,
+                          const float* td_w, const uint16_t* td_wb, float* ws, float* x_out, void* stream);
+int nisqa_pool_att_bf16(const float* x, const int32_t* tok_off, const int32_t* n_wins,
+                        int32_t n_clips, int32_t total_tok_padded, int32_t n_heads,
+                        const float* pool_w, const uint16_t* pool_wb, float* ws, float* out, void* stream);
+int nisqa_pool_score_bf16(const float* x, const int32_t* tok_off, const int32_t* n_wins,
+                          int32_t n_clips, int32_t total_tok_padded, int32_t n_heads,
+                          const float* pool_w, const uint16_t* pool_wb, float* ws, void* stream);
+/* second pass of the pooling (masked softmax over tokens + weighted sum) on scores left in ws */
+int nisqa_pool_final(const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                     int32_t total_tok_padded, int32_t n_heads, const float* ws, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * nisqa_tts.tar architecture.
  * nisqa_cnn_standard replaces segment_specs + Framewise.forward + StandardCNN.forward incl. fc_out
@@ -178,7 +194,9 @@ typedef struct {
      * [3] after the conv5-6 kernel, [4] after self-attention, [5] after pooling */
     void* const* stage_events;
     const uint16_t* cnn_wb;  /* split-bf16 conv fragments, or NULL */
-    int32_t cnn_mode;        /* 0 = exact fp32 MFMA kernels, 1 = split-bf16 AdaptCNN (needs cnn_wb) */
+    int32_t cnn_mode;        /* 0 = exact fp32 MFMA kernels, 1 = split-bf16 kernels (needs cnn_wb, td_wb, pool_wb) */
+    const uint16_t* td_wb;   /* split-bf16 self-attention fragments, or NULL */
+    const uint16_t* pool_wb; /* split-bf16 pooling fragments, or NULL */
     int32_t arch;            /* 0 = CNN-SA-AP (nisqa.tar, nisqa_mos_only.tar); 1 = StandardCNN + BiLSTM + last-step
                               * pooling (nisqa_tts.tar): cnn_w = cnn_std_w blob, td_w = lstm_w blob, pool_w unused */
 } nisqa_model_dev;

@@ -85,10 +85,15 @@ extern "C" int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, co
         if (rc) return rc;
     }
     NQ_STAGE(3);
-    rc = nisqa_td_selfatt(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w, td, x, stream);
+    const bool bf = model->cnn_mode == 1 && model->td_wb && model->pool_wb;
+    rc = bf ? nisqa_td_selfatt_bf16(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w,
+                                    model->td_wb, td, x, stream)
+            : nisqa_td_selfatt(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w, td, x, stream);
     if (rc) return rc;
     NQ_STAGE(4);
-    rc = nisqa_pool_att(x, tok_off, n_wins, n_clips, total_tok_padded, model->n_heads, model->pool_w, pool, out, stream);
+    rc = bf ? nisqa_pool_att_bf16(x, tok_off, n_wins, n_clips, total_tok_padded, model->n_heads, model->pool_w,
+                                  model->pool_wb, pool, out, stream)
+            : nisqa_pool_att(x, tok_off, n_wins, n_clips, total_tok_padded, model->n_heads, model->pool_w, pool, out, stream);
     if (rc) return rc;
     NQ_STAGE(5);
     return NISQA_OK;

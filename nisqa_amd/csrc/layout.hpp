@@ -50,6 +50,19 @@
 #define CNNB_W6 (CNNB_W5 + 36 * 2 * 2 * 512)
 #define CNNB_U16S (CNNB_W6 + 36 * 2 * 2 * 512)
 
+// ---- split-bf16 fragments of the self-attention / pooling weights ("td_wb", "pool_wb"; uint16 units) --------
+// A-fragment [step][mtile][hl][64 lanes][8]; lane (i = l&31, h = l>>5), element e:
+//   natural order (first GEMM, B operand comes from memory):   W[32*mt + i][16*s + 8*h + e]
+//   chain order (B operand = previous D fragment):             W[32*mt + i][16*s + (e&3) + 8*(e>>2) + 4*h]
+#define TDB_PROJ 0                                   /* natural, 24 steps x 2 mtiles */
+#define TDB_LAYER0 (TDB_PROJ + 24 * 2 * 2 * 512)
+#define TDBL_QKV 0                                   /* chain, 4 steps x 6 mtiles */
+#define TDBL_OUT (TDBL_QKV + 4 * 6 * 2 * 512)
+#define TDBL_FF1 (TDBL_OUT + 4 * 2 * 2 * 512)
+#define TDBL_FF2 (TDBL_FF1 + 4 * 2 * 2 * 512)
+#define TDBL_U16S (TDBL_FF2 + 4 * 2 * 2 * 512)
+#define PLB_U16S (4 * 4 * 2 * 512)                   /* per head: linear1 [128][64], chain, 4 steps x 4 mtiles */
+
 // ---- self-attention blob ("td_w") ----------------------------------------------------------
 // A-fragments af[step][mtile][lane][4]:
 //   value(s, mt, lane, kk) = W[row = (lane&31) + 32*mt][k = 8*s + 4*(lane>>5) + kk]

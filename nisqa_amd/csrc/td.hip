@@ -51,16 +51,23 @@ NQ_DEV void store_dtok(float* __restrict__ rowp, const f32x16 (&v)[2], int hf, f
 // out[mt] += W[64*... rows][64] * in   (in = D layout of a 64-feature x 32-token tile)
 template <int MT>
 NQ_DEV void chain_gemm64(const f32x4* __restrict__ af, const f32x16 (&in)[2], f32x16 (&out)[MT], int lane) {
+    // weight fragments stream from L2: request step s+1 before issuing the MFMAs of step s
+    f32x4 a[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a[0][mt] = af[mt * 64 + lane];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        f32x4 a[MT];
+        if (s + 1 < 8) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt] = af[(s * MT + mt) * 64 + lane];
+            for (int mt = 0; mt < MT; ++mt) a[(s + 1) & 1][mt] = af[((s + 1) * MT + mt) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                out[mt] = mfma32(a[mt][kk], in[s >> 2][4 * (s & 3) + kk], out[mt]);
+                out[mt] = mfma32(a[s & 1][mt][kk], in[s >> 2][4 * (s & 3) + kk], out[mt]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -169,17 +176,34 @@ __global__ __launch_bounds__(64) void td_layer_kernel(const int32_t* __restrict_
     o[0] = zero16(); o[1] = zero16();
     float m = -INFINITY, l = 0.f;
     const int nkt = (n + 31) >> 5;
-    for (int kt = 0; kt < nkt; ++kt) {
+    // K rows (A operand of S^T = K Q^T) and V^T rows (A operand of O^T = V^T P^T) are register-prefetched:
+    // the next tile's K and this tile's V are requested before this tile's QK^T MFMAs are issued
+    f32x4 kA[8], kB[8];
+    {
+        const float* krow = k + (size_t)(c0 + j) * 64 + 4 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) kA[s] = *(const f32x4*)(krow + 8 * s);
+    }
+    auto tile = [&](int kt, const f32x4 (&kcur)[8], f32x4 (&knext)[8]) {
         const int key0 = c0 + 32 * kt;
+        f32x4 vf[2][4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            vf[0][g] = *(const f32x4*)(vT + (size_t)j * np + key0 + 8 * g + 4 * h);
+            vf[1][g] = *(const f32x4*)(vT + (size_t)(j + 32) * np + key0 + 8 * g + 4 * h);
+        }
+        if (kt + 1 < nkt) {
+            const float* krow = k + (size_t)(key0 + 32 + j) * 64 + 4 * h;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) knext[s] = *(const f32x4*)(krow + 8 * s);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // S^T tile: rows = keys, cols = queries
         f32x16 sacc = zero16();
-        const float* krow = k + (size_t)(key0 + j) * 64 + 4 * h;   // A row i = lane & 31
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const f32x4 a = *(const f32x4*)(krow + 8 * s);
+        for (int s = 0; s < 8; ++s)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) sacc = mfma32(a[kk], qf[s][kk], sacc);
-        }
+            for (int kk = 0; kk < 4; ++kk) sacc = mfma32(kcur[s][kk], qf[s][kk], sacc);
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -202,15 +226,16 @@ __global__ __launch_bounds__(64) void td_layer_kernel(const int32_t* __restrict_
         for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
         // O^T += V^T P^T : A = vT[feature][keys], B = P^T straight from the accumulator
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 a0 = *(const f32x4*)(vT + (size_t)j * np + key0 + 8 * g + 4 * h);
-            const f32x4 a1 = *(const f32x4*)(vT + (size_t)(j + 32) * np + key0 + 8 * g + 4 * h);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                o[0] = mfma32(a0[kk], sacc[4 * g + kk], o[0]);
-                o[1] = mfma32(a1[kk], sacc[4 * g + kk], o[1]);
+                o[0] = mfma32(vf[0][g][kk], sacc[4 * g + kk], o[0]);
+                o[1] = mfma32(vf[1][g][kk], sacc[4 * g + kk], o[1]);
             }
-        }
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile(kt, kA, kB);
+        if (kt + 1 < nkt) tile(kt + 1, kB, kA);
     }
     const float inv_l = 1.0f / l;
 #pragma unroll
@@ -324,6 +349,15 @@ extern "C" int nisqa_td_selfatt(const float* feat, const int32_t* tok_off, const
                            (const float*)x_out, (const float*)qb[c], (const float*)kb[c], (const float*)vb[c], x_out,
                            qb[nx], kb[nx], vb[nx]);
     }
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_pool_final(const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips, int32_t total_tok_padded,
+                                int32_t n_heads, const float* ws, float* out, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || n_heads < 1 || n_heads > 8) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(pool_final_kernel, dim3(n_clips), dim3(64), 0, (hipStream_t)stream, tok_off, n_wins, n_heads, ws,
+                       ws + (size_t)total_tok_padded * 8, out);
     return NQ_LAUNCH_STATUS();
 }
 

@@ -1,0 +1,403 @@
+// Self-attention and attention-pooling on split-bf16 MFMA -- same kernels, layouts and maths as td.hip
+// (reference nisqa/NISQA_lib.py:988-996, 1025-1040, 1171-1183) with every GEMM as three
+// v_mfma_f32_32x32x16_bf16 products of bf16 hi/lo operands (fp32 accumulate; |dMOS| ~ 1e-5).
+//
+// What changes against the fp32 version:
+//   * a K-step is 16 wide; lane half h supplies 8 k-slots.  For operands that come from MEMORY the slots are
+//     8 consecutive indices (16 B of bf16).  For the register-chained GEMMs the slots of lane half h are the
+//     rows this half already owns in the previous D fragment, 16s + (e&3) + 8(e>>2) + 4h, so the accumulator is
+//     split into (hi, lo) in place with v_cvt_pk_bf16_f32 and fed back as the B operand -- no data movement;
+//     the weight fragments are packed in the matching order on the host;
+//   * q, k are stored as bf16 hi/lo planes [tok][64], v as hi/lo planes [64][tok] (same bytes as fp32);
+//   * softmax, LayerNorm, residuals, biases stay fp32 in registers.
+#include "common.hpp"
+#include "layout.hpp"
+#include "../../include/nisqa_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define LN_EPS 1e-5f
+
+NQ_DEV f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+NQ_DEV unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (v0, v1) -> packed bf16 hi pair and packed bf16 lo pair
+NQ_DEV void split2(float v0, float v1, unsigned& hi, unsigned& lo) {
+    hi = cvt_pk_bf16(v0, v1);
+    lo = cvt_pk_bf16(v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xffff0000u));
+}
+// 8 consecutive registers of a D fragment -> B-operand (hi, lo) of one K=16 step
+NQ_DEV void split8(const f32x16& a, int base, f32x4& hi, f32x4& lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned h_, l_;
+        split2(a[base + 2 * q], a[base + 2 * q + 1], h_, l_);
+        hi[q] = __uint_as_float(h_);
+        lo[q] = __uint_as_float(l_);
+    }
+}
+
+template <int MT>
+NQ_DEV void load_dvec(const float* __restrict__ base, f32x16 (&out)[MT], int hf) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 v = *(const f32x4*)(base + 32 * mt + 8 * g + 4 * hf);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[mt][4 * g + e] = v[e];
+        }
+}
+NQ_DEV void store_dtok(float* __restrict__ rowp, const f32x16 (&v)[2], int hf) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = v[mt][4 * g + e];
+            *(f32x4*)(rowp + 32 * mt + 8 * g + 4 * hf) = o;
+        }
+}
+// a 64-feature D tile as bf16 hi / lo rows [64] (token-major planes)
+NQ_DEV void store_dtok_split(u16* __restrict__ hi_row, u16* __restrict__ lo_row, const f32x16 (&v)[2], int hf, float scale) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            unsigned h0, l0, h1, l1;
+            split2(v[mt][4 * g] * scale, v[mt][4 * g + 1] * scale, h0, l0);
+            split2(v[mt][4 * g + 2] * scale, v[mt][4 * g + 3] * scale, h1, l1);
+            *(u32x2*)(hi_row + 32 * mt + 8 * g + 4 * hf) = u32x2{h0, h1};
+            *(u32x2*)(lo_row + 32 * mt + 8 * g + 4 * hf) = u32x2{l0, l1};
+        }
+}
+
+// out[mt] += W * in  (W: chain-order bf16 fragments [4 steps][MT][hl][64][8], in: D layout of a 64 x 32 tile)
+template <int MT>
+NQ_DEV void chain_gemm_bf(const u16* __restrict__ wb, const f32x16 (&in)[2], f32x16 (&out)[MT], int lane) {
+    const f32x4* af = (const f32x4*)wb + lane;
+    f32x4 ah[2][MT], al[2][MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { ah[0][mt] = af[(mt * 2 + 0) * 64]; al[0][mt] = af[(mt * 2 + 1) * 64]; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s + 1 < 4) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                ah[(s + 1) & 1][mt] = af[(((s + 1) * MT + mt) * 2 + 0) * 64];
+                al[(s + 1) & 1][mt] = af[(((s + 1) * MT + mt) * 2 + 1) * 64];
+            }
+        }
+        f32x4 bh, bl;
+        split8(in[s >> 1], 8 * (s & 1), bh, bl);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            out[mt] = mfma_bf(ah[s & 1][mt], bl, out[mt]);
+            out[mt] = mfma_bf(al[s & 1][mt], bh, out[mt]);
+            out[mt] = mfma_bf(ah[s & 1][mt], bh, out[mt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+NQ_DEV void layernorm64(f32x16 (&x)[2], const float* __restrict__ gamma, const float* __restrict__ beta, int hf) {
+    float s = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += x[mt][r];
+    s += __shfl_xor(s, 32);
+    const float mean = s * (1.0f / 64.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = x[mt][r] - mean;
+            q = fmaf(d, d, q);
+        }
+    q += __shfl_xor(q, 32);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + LN_EPS);
+    f32x16 g[2], bt[2];
+    load_dvec<2>(gamma, g, hf);
+    load_dvec<2>(beta, bt, hf);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[mt][r] = (x[mt][r] - mean) * rstd * g[mt][r] + bt[mt][r];
+}
+
+struct qkv_planes { u16 *qh, *ql, *kh, *kl, *vh, *vl; };   // q,k: [NP][64]; v: [64][NP]
+NQ_DEV qkv_planes planes_of(float* base, size_t np64) {
+    u16* p = (u16*)base;                                    // 6 planes of np*64 bf16 = 3 * np64 floats
+    qkv_planes r;
+    r.qh = p; r.ql = p + np64; r.kh = p + 2 * np64; r.kl = p + 3 * np64; r.vh = p + 4 * np64; r.vl = p + 5 * np64;
+    return r;
+}
+
+NQ_DEV void qkv_store_bf(const float* __restrict__ lw, const u16* __restrict__ lwb, const f32x16 (&x)[2],
+                         const qkv_planes& P, int tok, int np, int lane) {
+    const int hf = lane >> 5;
+    f32x16 acc[6];
+    load_dvec<6>(lw + TDL_QKV_B, acc, hf);
+    chain_gemm_bf<6>(lwb + TDBL_QKV, x, acc, lane);
+    f32x16 t2[2];
+    t2[0] = acc[0]; t2[1] = acc[1];
+    store_dtok_split(P.qh + (size_t)tok * 64, P.ql + (size_t)tok * 64, t2, hf, 0.125f);
+    t2[0] = acc[2]; t2[1] = acc[3];
+    store_dtok_split(P.kh + (size_t)tok * 64, P.kl + (size_t)tok * 64, t2, hf, 1.0f);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            unsigned h_, l_;
+            split2(acc[4 + mt][r], acc[4 + mt][r + 1], h_, l_);
+            const size_t f0 = (size_t)(32 * mt + NQ_DROW(r, hf)) * np + tok, f1 = f0 + np;   // rows r, r+1 are adjacent features
+            P.vh[f0] = (u16)h_; P.vh[f1] = (u16)(h_ >> 16);
+            P.vl[f0] = (u16)l_; P.vl[f1] = (u16)(l_ >> 16);
+        }
+}
+
+// Linear 384 -> 64 + LayerNorm + layer-0 QKV, one wave per 32-token tile
+__global__ __launch_bounds__(64) void td_proj_bf16_kernel(const float* __restrict__ feat, const int32_t* __restrict__ tok_off,
+                                                          const int32_t* __restrict__ n_wins, int n_clips, int np,
+                                                          const float* __restrict__ tw, const u16* __restrict__ twb,
+                                                          float* __restrict__ x, float* __restrict__ qkv) {
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int tile0 = blockIdx.x * 32;
+    const int b = find_segment(tok_off, n_clips, tile0);
+    const int n = n_wins[b], k0 = tile0 - tok_off[b];
+    if (k0 >= n) return;
+    const int tok = tile0 + j;
+    const bool valid = k0 + j < n;
+    const f32x4* frow = (const f32x4*)(feat + (size_t)tok * 384);
+    const f32x4* af = (const f32x4*)(twb + TDB_PROJ) + lane;
+    f32x16 acc[2];
+    load_dvec<2>(tw + TD_PROJ_B, acc, h);
+    f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 f0 = valid ? frow[2 * h] : z4, f1 = valid ? frow[2 * h + 1] : z4;
+#pragma unroll 2
+    for (int s = 0; s < 24; ++s) {
+        f32x4 n0 = z4, n1 = z4;
+        if (s + 1 < 24 && valid) { n0 = frow[4 * (s + 1) + 2 * h]; n1 = frow[4 * (s + 1) + 2 * h + 1]; }
+        const f32x4 ah0 = af[((s * 2 + 0) * 2 + 0) * 64], al0 = af[((s * 2 + 0) * 2 + 1) * 64];
+        const f32x4 ah1 = af[((s * 2 + 1) * 2 + 0) * 64], al1 = af[((s * 2 + 1) * 2 + 1) * 64];
+        f32x4 bh, bl;
+        unsigned hh, ll;
+        split2(f0[0], f0[1], hh, ll); bh[0] = __uint_as_float(hh); bl[0] = __uint_as_float(ll);
+        split2(f0[2], f0[3], hh, ll); bh[1] = __uint_as_float(hh); bl[1] = __uint_as_float(ll);
+        split2(f1[0], f1[1], hh, ll); bh[2] = __uint_as_float(hh); bl[2] = __uint_as_float(ll);
+        split2(f1[2], f1[3], hh, ll); bh[3] = __uint_as_float(hh); bl[3] = __uint_as_float(ll);
+        acc[0] = mfma_bf(ah0, bl, acc[0]); acc[0] = mfma_bf(al0, bh, acc[0]); acc[0] = mfma_bf(ah0, bh, acc[0]);
+        acc[1] = mfma_bf(ah1, bl, acc[1]); acc[1] = mfma_bf(al1, bh, acc[1]); acc[1] = mfma_bf(ah1, bh, acc[1]);
+        f0 = n0; f1 = n1;
+    }
+    layernorm64(acc, tw + TD_LN0_G, tw + TD_LN0_B, h);
+    store_dtok(x + (size_t)tok * 64, acc, h);
+    qkv_store_bf(tw + TD_LAYER0, twb + TDB_LAYER0, acc, planes_of(qkv, (size_t)np * 64), tok, np, lane);
+}
+
+__global__ __launch_bounds__(64) void td_layer_bf16_kernel(const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
+                                                           int n_clips, int np, const float* __restrict__ lw,
+                                                           const u16* __restrict__ lwb, const float* __restrict__ lw_next,
+                                                           const u16* __restrict__ lwb_next, const float* x_in, float* qkv_cur,
+                                                           float* x_out, float* qkv_next) {
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int tile0 = blockIdx.x * 32;
+    const int b = find_segment(tok_off, n_clips, tile0);
+    const int n = n_wins[b], c0 = tok_off[b];
+    if (tile0 - c0 >= n) return;
+    const int tok = tile0 + j;
+    const qkv_planes P = planes_of(qkv_cur, (size_t)np * 64);
+
+    f32x4 qh[4], ql[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        qh[s] = *(const f32x4*)(P.qh + (size_t)tok * 64 + 16 * s + 8 * h);
+        ql[s] = *(const f32x4*)(P.ql + (size_t)tok * 64 + 16 * s + 8 * h);
+    }
+    f32x16 o[2];
+    o[0] = zero16(); o[1] = zero16();
+    float m = -INFINITY, l = 0.f;
+    const int nkt = (n + 31) >> 5;
+    f32x4 kAh[4], kAl[4], kBh[4], kBl[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        kAh[s] = *(const f32x4*)(P.kh + (size_t)(c0 + j) * 64 + 16 * s + 8 * h);
+        kAl[s] = *(const f32x4*)(P.kl + (size_t)(c0 + j) * 64 + 16 * s + 8 * h);
+    }
+    auto tile = [&](int kt, const f32x4 (&kh_)[4], const f32x4 (&kl_)[4], f32x4 (&nh_)[4], f32x4 (&nl_)[4]) {
+        const int key0 = c0 + 32 * kt;
+        // V^T fragments: element e of lane half h <-> key 16 s + (e&3) + 8 (e>>2) + 4 h (the rows of P this half owns)
+        f32x4 vh_[2][2], vl_[2][2];
+#pragma unroll
+        for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const size_t base = (size_t)(j + 32 * ft) * np + key0 + 16 * s + 4 * h;
+                const u32x2 a0 = *(const u32x2*)(P.vh + base), a1 = *(const u32x2*)(P.vh + base + 8);
+                const u32x2 b0 = *(const u32x2*)(P.vl + base), b1 = *(const u32x2*)(P.vl + base + 8);
+                vh_[ft][s] = f32x4{__uint_as_float(a0[0]), __uint_as_float(a0[1]), __uint_as_float(a1[0]), __uint_as_float(a1[1])};
+                vl_[ft][s] = f32x4{__uint_as_float(b0[0]), __uint_as_float(b0[1]), __uint_as_float(b1[0]), __uint_as_float(b1[1])};
+            }
+        if (kt + 1 < nkt) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                nh_[s] = *(const f32x4*)(P.kh + (size_t)(key0 + 32 + j) * 64 + 16 * s + 8 * h);
+                nl_[s] = *(const f32x4*)(P.kl + (size_t)(key0 + 32 + j) * 64 + 16 * s + 8 * h);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 sacc = zero16();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            sacc = mfma_bf(kh_[s], ql[s], sacc);
+            sacc = mfma_bf(kl_[s], qh[s], sacc);
+            sacc = mfma_bf(kh_[s], qh[s], sacc);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (32 * kt + NQ_DROW(r, h) >= n) sacc[r] = -INFINITY;
+            mx = fmaxf(mx, sacc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m, mx);
+        const float alpha = expf(m - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sacc[r] = expf(sacc[r] - m_new);
+            rs += sacc[r];
+        }
+        rs += __shfl_xor(rs, 32);
+        l = l * alpha + rs;
+        m = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f32x4 ph, pl;
+            split8(sacc, 8 * s, ph, pl);
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                o[ft] = mfma_bf(vh_[ft][s], pl, o[ft]);
+                o[ft] = mfma_bf(vl_[ft][s], ph, o[ft]);
+                o[ft] = mfma_bf(vh_[ft][s], ph, o[ft]);
+            }
+        }
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile(kt, kAh, kAl, kBh, kBl);
+        if (kt + 1 < nkt) tile(kt + 1, kBh, kBl, kAh, kAl);
+    }
+    const float inv_l = 1.0f / l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= inv_l; o[1][r] *= inv_l; }
+
+    f32x16 y[2], xr[2];
+    load_dvec<2>(lw + TDL_OUT_B, y, h);
+    chain_gemm_bf<2>(lwb + TDBL_OUT, o, y, lane);
+    load_dvec<2>(x_in + (size_t)tok * 64, xr, h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { y[0][r] += xr[0][r]; y[1][r] += xr[1][r]; }
+    layernorm64(y, lw + TDL_LN1_G, lw + TDL_LN1_B, h);
+    f32x16 h1[2], h2[2];
+    load_dvec<2>(lw + TDL_FF1_B, h1, h);
+    chain_gemm_bf<2>(lwb + TDBL_FF1, y, h1, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { h1[0][r] = fmaxf(h1[0][r], 0.f); h1[1][r] = fmaxf(h1[1][r], 0.f); }
+    load_dvec<2>(lw + TDL_FF2_B, h2, h);
+    chain_gemm_bf<2>(lwb + TDBL_FF2, h1, h2, lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { y[0][r] += h2[0][r]; y[1][r] += h2[1][r]; }
+    layernorm64(y, lw + TDL_LN2_G, lw + TDL_LN2_B, h);
+    store_dtok(x_out + (size_t)tok * 64, y, h);
+    if (lw_next) qkv_store_bf(lw_next, lwb_next, y, planes_of(qkv_next, (size_t)np * 64), tok, np, lane);
+}
+
+__global__ __launch_bounds__(64) void pool_score_bf16_kernel(const float* __restrict__ x, const int32_t* __restrict__ tok_off,
+                                                             const int32_t* __restrict__ n_wins, int n_clips, int n_heads,
+                                                             const float* __restrict__ pw, const u16* __restrict__ pwb,
+                                                             float* __restrict__ sc, float* __restrict__ yv) {
+    const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
+    const int tile0 = blockIdx.x * 32;
+    const int b = find_segment(tok_off, n_clips, tile0);
+    if (tile0 - tok_off[b] >= n_wins[b]) return;
+    const int tok = tile0 + j;
+    f32x16 xr[2];
+    load_dvec<2>(x + (size_t)tok * 64, xr, h);
+    for (int hd = 0; hd < n_heads; ++hd) {
+        const float* w = pw + (size_t)hd * PL_FLOATS;
+        f32x16 hid[4], w2[4], w3[2];
+        load_dvec<4>(w + PL_B1, hid, h);
+        chain_gemm_bf<4>(pwb + (size_t)hd * PLB_U16S, xr, hid, lane);
+        load_dvec<4>(w + PL_W2, w2, h);
+        load_dvec<2>(w + PL_W3, w3, h);
+        float s = 0.f, v = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s = fmaf(w2[mt][r], fmaxf(hid[mt][r], 0.f), s);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v = fmaf(w3[mt][r], xr[mt][r], v);
+        s += __shfl_xor(s, 32);
+        v += __shfl_xor(v, 32);
+        if (h == 0) {
+            sc[(size_t)tok * 8 + hd] = s + w[PL_B2];
+            yv[(size_t)tok * 8 + hd] = v + w[PL_B2 + 1];
+        }
+    }
+}
+
+extern "C" int nisqa_td_selfatt_bf16(const float* feat, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                                     int32_t total_tok_padded, int32_t n_layers, const float* td_w, const uint16_t* td_wb,
+                                     float* ws, float* x_out, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || n_layers < 1 || !td_wb) return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int np = total_tok_padded;
+    const size_t sz = (size_t)np * 64;
+    float* qkv[2] = {ws, ws + 3 * sz};                  // each: six bf16 planes of np*64 = 3*sz floats
+    const int tiles = np / 32;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(td_proj_bf16_kernel, dim3(tiles), dim3(64), 0, st, feat, tok_off, n_wins, n_clips, np, td_w, td_wb,
+                       x_out, qkv[0]);
+    for (int l = 0; l < n_layers; ++l) {
+        const float* lw = td_w + TD_LAYER0 + (size_t)l * TDL_FLOATS;
+        const uint16_t* lwb = td_wb + TDB_LAYER0 + (size_t)l * TDBL_U16S;
+        const bool more = l + 1 < n_layers;
+        hipLaunchKernelGGL(td_layer_bf16_kernel, dim3(tiles), dim3(64), 0, st, tok_off, n_wins, n_clips, np, lw, lwb,
+                           more ? lw + TDL_FLOATS : (const float*)nullptr, more ? lwb + TDBL_U16S : (const uint16_t*)nullptr,
+                           (const float*)x_out, qkv[l & 1], x_out, qkv[(l & 1) ^ 1]);
+    }
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_pool_score_bf16(const float* x, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                                     int32_t total_tok_padded, int32_t n_heads, const float* pool_w, const uint16_t* pool_wb,
+                                     float* ws, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || n_heads < 1 || n_heads > 8 || !pool_wb)
+        return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(pool_score_bf16_kernel, dim3(total_tok_padded / 32), dim3(64), 0, (hipStream_t)stream, x, tok_off,
+                       n_wins, n_clips, n_heads, pool_w, pool_wb, ws, ws + (size_t)total_tok_padded * 8);
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_pool_att_bf16(const float* x, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                                   int32_t total_tok_padded, int32_t n_heads, const float* pool_w, const uint16_t* pool_wb,
+                                   float* ws, float* out, void* stream) {
+    const int rc = nisqa_pool_score_bf16(x, tok_off, n_wins, n_clips, total_tok_padded, n_heads, pool_w, pool_wb, ws, stream);
+    if (rc) return rc;
+    return nisqa_pool_final(tok_off, n_wins, n_clips, total_tok_padded, n_heads, ws, out, stream);
+}

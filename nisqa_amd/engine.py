@@ -130,7 +130,7 @@ class HipNisqa(object):
             self.cnn_w = up(_w.pack_standard_cnn(state_dict))
             self.td_w = up(_w.pack_lstm_laststep(state_dict))
             self.pool_w = torch.zeros(4, dtype=torch.float32, device=self.device)
-            self.cnn_wb = None
+            self.cnn_wb = self.td_wb = self.pool_wb = None
             self._mel = {}
             self._ws = {}
             return
@@ -141,9 +141,12 @@ class HipNisqa(object):
         if self.precision not in ('f32', 'bf16x3'):
             raise ValueError('precision must be f32 or bf16x3, got {}'.format(self.precision))
         self.cnn_w = up(_w.pack_adapt_cnn(state_dict))
-        self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict).view(np.int16)) if self.precision == 'bf16x3' else None
+        bf = self.precision == 'bf16x3'
+        self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict).view(np.int16)) if bf else None
         self.td_w = up(_w.pack_self_att(state_dict, self.n_layers))
         self.pool_w = up(_w.pack_pool_att(state_dict, heads))
+        self.td_wb = up(_w.pack_self_att_bf16(state_dict, self.n_layers).view(np.int16)) if bf else None
+        self.pool_wb = up(_w.pack_pool_att_bf16(state_dict, heads).view(np.int16)) if bf else None
         self._mel = {}
         self._ws = {}                      # one workspace per stream (batches may be in flight on several)
 
@@ -161,7 +164,9 @@ class HipNisqa(object):
                                        _ptr(d['band_woff']), _ptr(d['band_w']), _ptr(self.cnn_w), _ptr(self.td_w),
                                        _ptr(self.pool_w), self.n_layers, self.n_heads, self.seg_hop, None,
                                        _ptr(self.cnn_wb) if self.cnn_wb is not None else None,
-                                       1 if self.precision == 'bf16x3' else 0, self.arch)
+                                       1 if self.precision == 'bf16x3' else 0,
+                                       _ptr(self.td_wb) if self.td_wb is not None else None,
+                                       _ptr(self.pool_wb) if self.pool_wb is not None else None, self.arch)
             self._mel[sr] = d
         return self._mel[sr]
 
@@ -287,16 +292,26 @@ class HipNisqa(object):
         d = plan.to(self.device)
         ws = torch.empty(plan.total_tok * 64 * 6, dtype=torch.float32, device=self.device)
         x = torch.zeros((plan.total_tok, 64), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.nisqa_td_selfatt(_ptr(feat), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
-                                             plan.total_tok, self.n_layers, _ptr(self.td_w), _ptr(ws), _ptr(x),
-                                             self._stream()), 'nisqa_td_selfatt')
+        if self.precision == 'bf16x3':
+            _lib.check(self.lib.nisqa_td_selfatt_bf16(_ptr(feat), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
+                                                      plan.total_tok, self.n_layers, _ptr(self.td_w), _ptr(self.td_wb),
+                                                      _ptr(ws), _ptr(x), self._stream()), 'nisqa_td_selfatt_bf16')
+        else:
+            _lib.check(self.lib.nisqa_td_selfatt(_ptr(feat), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
+                                                 plan.total_tok, self.n_layers, _ptr(self.td_w), _ptr(ws), _ptr(x),
+                                                 self._stream()), 'nisqa_td_selfatt')
         return x
 
     def pool(self, x, plan):
         d = plan.to(self.device)
         ws = torch.empty(plan.total_tok * 16, dtype=torch.float32, device=self.device)
         out = torch.empty((plan.n_clips, self.n_heads), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.nisqa_pool_att(_ptr(x), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips, plan.total_tok,
-                                           self.n_heads, _ptr(self.pool_w), _ptr(ws), _ptr(out), self._stream()),
-                   'nisqa_pool_att')
+        if self.precision == 'bf16x3':
+            _lib.check(self.lib.nisqa_pool_att_bf16(_ptr(x), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
+                                                    plan.total_tok, self.n_heads, _ptr(self.pool_w), _ptr(self.pool_wb),
+                                                    _ptr(ws), _ptr(out), self._stream()), 'nisqa_pool_att_bf16')
+        else:
+            _lib.check(self.lib.nisqa_pool_att(_ptr(x), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips, plan.total_tok,
+                                               self.n_heads, _ptr(self.pool_w), _ptr(ws), _ptr(out), self._stream()),
+                       'nisqa_pool_att')
         return out

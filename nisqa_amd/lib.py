@@ -29,7 +29,7 @@ class ModelDev(ctypes.Structure):
     _fields_ = [('window', c_p), ('twiddle', c_p), ('band_start', c_p), ('band_len', c_p), ('band_woff', c_p),
                 ('band_w', c_p), ('cnn_w', c_p), ('td_w', c_p), ('pool_w', c_p),
                 ('n_layers', c_i32), ('n_heads', c_i32), ('seg_hop', c_i32), ('stage_events', c_p),
-                ('cnn_wb', c_p), ('cnn_mode', c_i32), ('arch', c_i32)]
+                ('cnn_wb', c_p), ('cnn_mode', c_i32), ('td_wb', c_p), ('pool_wb', c_p), ('arch', c_i32)]
 
 
 # name -> (restype, argtypes); every symbol include/nisqa_hip.h declares
@@ -47,6 +47,10 @@ SYMBOLS = {
     'nisqa_cnn_standard': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_lstm_laststep': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p]),
     'nisqa_td_selfatt': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'nisqa_td_selfatt_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p]),
+    'nisqa_pool_att_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p]),
+    'nisqa_pool_score_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'nisqa_pool_final': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_pool_att': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_workspace_bytes': (ctypes.c_size_t, [c_i32, c_i32, c_i32]),
     'nisqa_predict_batch': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, ctypes.POINTER(MelCfg),

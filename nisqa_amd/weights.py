@@ -67,6 +67,15 @@ CNNB_W5 = CNNB_W4 + 36 * 2 * 2 * 512
 CNNB_W6 = CNNB_W5 + 36 * 2 * 2 * 512
 CNNB_U16S = CNNB_W6 + 36 * 2 * 2 * 512
 
+TDB_PROJ = 0
+TDB_LAYER0 = TDB_PROJ + 24 * 2 * 2 * 512
+TDBL_QKV = 0
+TDBL_OUT = TDBL_QKV + 4 * 6 * 2 * 512
+TDBL_FF1 = TDBL_OUT + 4 * 2 * 2 * 512
+TDBL_FF2 = TDBL_FF1 + 4 * 2 * 2 * 512
+TDBL_U16S = TDBL_FF2 + 4 * 2 * 2 * 512
+PLB_U16S = 4 * 4 * 2 * 512
+
 PL_W1_AF = 0
 PL_B1 = PL_W1_AF + 8 * 4 * 256
 PL_W2 = PL_B1 + 128
@@ -301,4 +310,45 @@ def pack_lstm_laststep(sd, lpfx='time_dependency.model.lstm.', ppfx='pool.model.
         blob[base + LSTM_B: base + LSTM_B + 512] = (_np(sd, lpfx + 'bias_ih_l0' + sfx) + _np(sd, lpfx + 'bias_hh_l0' + sfx))
     blob[LSTM_POOL_W: LSTM_POOL_W + 256] = _np(sd, ppfx + 'linear.weight').reshape(-1)
     blob[LSTM_POOL_W + 256] = _np(sd, ppfx + 'linear.bias').reshape(-1)[0]
+    return blob
+
+
+# ---- split-bf16 fragments of the linear layers (csrc/td_bf16.hip) ---------------------------------------------
+def linear_a_fragments_bf16(w, chain):
+    """w [rows][K] -> uint16 [K/16][rows/32][2][64][8].  k-slot e of lane half h = column 16s + 8h + e (natural: the B
+    operand is read from memory) or 16s + (e&3) + 8(e>>2) + 4h (chain: the B operand is the previous D fragment)."""
+    w = np.asarray(w, np.float32)
+    rows, K = w.shape
+    s = np.arange(K // 16)[:, None, None, None]
+    mt = np.arange(rows // 32)[None, :, None, None]
+    lane = _LANE[None, None, :, None]
+    e = np.arange(8)[None, None, None, :]
+    col = 16 * s + ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) if chain else 8 * (lane >> 5) + e)
+    vals = w[(lane & 31) + 32 * mt, col]
+    hi, lo = bf16_split(vals, 2)
+    return np.stack([hi, lo], 2).reshape(-1)
+
+
+def pack_self_att_bf16(sd, n_layers, pfx='time_dependency.model.'):
+    blob = np.zeros(TDB_LAYER0 + n_layers * TDBL_U16S, np.uint16)
+
+    def put(off, fr):
+        blob[off:off + fr.size] = fr
+
+    put(TDB_PROJ, linear_a_fragments_bf16(_np(sd, pfx + 'linear.weight'), chain=False))
+    for l in range(n_layers):
+        p = pfx + 'layers.%d.' % l
+        base = TDB_LAYER0 + l * TDBL_U16S
+        put(base + TDBL_QKV, linear_a_fragments_bf16(_np(sd, p + 'self_attn.in_proj_weight'), chain=True))
+        put(base + TDBL_OUT, linear_a_fragments_bf16(_np(sd, p + 'self_attn.out_proj.weight'), chain=True))
+        put(base + TDBL_FF1, linear_a_fragments_bf16(_np(sd, p + 'linear1.weight'), chain=True))
+        put(base + TDBL_FF2, linear_a_fragments_bf16(_np(sd, p + 'linear2.weight'), chain=True))
+    return blob
+
+
+def pack_pool_att_bf16(sd, head_prefixes):
+    blob = np.zeros(len(head_prefixes) * PLB_U16S, np.uint16)
+    for h, p in enumerate(head_prefixes):
+        fr = linear_a_fragments_bf16(_np(sd, p + 'linear1.weight'), chain=True)
+        blob[h * PLB_U16S: h * PLB_U16S + fr.size] = fr
     return blob
