@@ -17,6 +17,7 @@
 //     of the input patch), because at this speed the VALU version would cost as much as conv2-4;
 //   * activations live in LDS as two bf16 planes (hi, lo), pixel-major, same XOR-swizzled 16-byte
 //     chunks and the same row->pixel maps as the fp32 kernel, so pooling stays in-lane.
+#include <stdlib.h>
 #include "common.hpp"
 #include "layout.hpp"
 #include "../../include/nisqa_hip.h"
@@ -52,7 +53,7 @@ NQ_DEV float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
 template <int CIN, int MT, int NT, int H, int W, bool APF>
 NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* zero,
                          const unsigned short* __restrict__ wb, const int (&py)[MT], const int (&px)[MT],
-                         const bool (&pvalid)[MT], int lane) {
+                         const bool (&pvalid)[MT], int lane, int dbg = 0) {
     constexpr int S16 = CIN / 16;             // K=16 steps per tap
     constexpr int TOTAL = 9 * S16;
     constexpr int Cc = CIN / 8;               // 16-byte chunks per pixel row (per plane)
@@ -65,8 +66,9 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
     auto load_b = [&](int g, int slot) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            bh[slot][nt] = wl[((g * NT + nt) * 2 + 0) * 64];
-            bl[slot][nt] = wl[((g * NT + nt) * 2 + 1) * 64];
+            const int gg = (dbg & 4) ? 0 : g;
+            bh[slot][nt] = wl[((gg * NT + nt) * 2 + 0) * 64];
+            bl[slot][nt] = wl[((gg * NT + nt) * 2 + 1) * 64];
         }
     };
     auto load_a = [&](int g, int slot) {
@@ -75,7 +77,7 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int y = py[t] + dy, x = px[t] + dx;
-            const bool ok = pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const bool ok = !(dbg & 8) && pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
             const int pix = y * W + x;
             const int swz = ((pix * Cc) >> 4) & (Cc - 1);
             const char* ph = ok ? act_in + pix * (CIN * 2) + (((2 * s + h) ^ swz) << 4) : zero;
@@ -91,17 +93,21 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
     for (int g = 0; g < TOTAL; ++g) {
         if (g + 2 < TOTAL) load_b(g + 2, (g + 2) % 3);
         if (APF) { if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1); } else load_a(g, 0);
-        __builtin_amdgcn_sched_barrier(0);        // keep the requests above ahead of this step's MFMAs
         const int sa = APF ? (g & 1) : 0, sb = g % 3;
+        // product-major: consecutive MFMAs go to DIFFERENT accumulators (no dependent-accumulate bubbles)
 #pragma unroll
         for (int t = 0; t < MT; ++t)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                acc[t][nt] = mfma_bf(ah[sa][t], bl[sb][nt], acc[t][nt]);
-                acc[t][nt] = mfma_bf(al[sa][t], bh[sb][nt], acc[t][nt]);
-                acc[t][nt] = mfma_bf(ah[sa][t], bh[sb][nt], acc[t][nt]);
-            }
-        __builtin_amdgcn_sched_barrier(0);
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bl[sb][nt], acc[t][nt]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(al[sa][t], bh[sb][nt], acc[t][nt]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bh[sb][nt], acc[t][nt]);
+
     }
 }
 
@@ -110,11 +116,13 @@ __device__ constexpr int bwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b =
 __device__ constexpr int bwin53_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : 3; }
 __device__ constexpr int bwin53_hi(int b) { return b == 0 ? 2 : b == 1 ? 4 : 5; }
 
-// hardware fp32 -> bf16 (round to nearest even), two values per instruction
+// fp32 -> bf16 (round to nearest even), two values per instruction: the compiler selects v_cvt_pk_bf16_f32 for
+// this conversion, and -- unlike an inline-asm statement -- tracks its hazards and schedules around it
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 NQ_DEV unsigned cvt_pk_bf16(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 // store v = hi + lo into the two bf16 planes at byte offset `off` of the hi plane
 NQ_DEV void store_split(char* plane_hi, int plane_bytes, int off, float v) {
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
     const float* __restrict__ clip_floor, int n_clips, int seg_hop,
     const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ p3,
-    float* __restrict__ feat, const float* __restrict__ seg_x, int seg_L) {
+    float* __restrict__ feat, const float* __restrict__ seg_x, int seg_L, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -189,30 +197,31 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         for (int e = 0; e < 8; ++e) toff[e] = h ? 2 * (2 * 50 + 2) : 2 * ((e % 3) * 50 + e / 3);
         for (int gl = 0; gl < 12; ++gl) {
             f32x16 acc[2];
+            f32x4 xa[2][3];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int u = min(16 * tt + qi, 29);      // rows 30, 31 of the pair are padding (results unused)
                 const int yy = u >= 15 ? 1 : 0, x = u - 15 * yy;
                 const int y = 2 * (12 * hfi + gl) + yy;
                 const char* base = pb + (x * 50 + y) * 2;
-                f32x4 xa[3];
 #pragma unroll
                 for (int t = 0; t < 3; ++t)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const unsigned lo16 = *(const unsigned short*)(base + t * FB_PPLANE + toff[2 * q]);
                         const unsigned hi16 = *(const unsigned short*)(base + t * FB_PPLANE + toff[2 * q + 1]);
-                        xa[t][q] = __uint_as_float(lo16 | (hi16 << 16));
+                        xa[tt][t][q] = __uint_as_float(lo16 | (hi16 << 16));
                     }
-                f32x16 a = zero16();
-                a = mfma_bf(xa[2], w1[0], a);             // lowest-order terms first
-                a = mfma_bf(xa[1], w1[1], a);
-                a = mfma_bf(xa[0], w1[2], a);
-                a = mfma_bf(xa[1], w1[0], a);
-                a = mfma_bf(xa[0], w1[1], a);
-                a = mfma_bf(xa[0], w1[0], a);
-                acc[tt] = a;
             }
+            acc[0] = zero16();
+            acc[1] = zero16();
+            // six lowest-order products of the 3-term splits, smallest first, alternating between the two tiles
+            acc[0] = mfma_bf(xa[0][2], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][2], w1[0], acc[1]);
+            acc[0] = mfma_bf(xa[0][1], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[1], acc[1]);
+            acc[0] = mfma_bf(xa[0][0], w1[2], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[2], acc[1]);
+            acc[0] = mfma_bf(xa[0][1], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[0], acc[1]);
+            acc[0] = mfma_bf(xa[0][0], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[1], acc[1]);
+            acc[0] = mfma_bf(xa[0][0], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[0], acc[1]);
 #pragma unroll
             for (int bb = 0; bb < 7; ++bb) {
                 float mx = -3.0e38f;
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             py[t] = 2 * (6 * hfi + gl) + yy;
             px[t] = w - 7 * yy;
         }
-        conv3x3_bf16<16, 6, 1, 24, 7, false>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane);
+        conv3x3_bf16<16, 6, 1, 24, 7, false>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane, dbg);
         const float tn = cw[CNN_T2 + n];
 #pragma unroll
         for (int gl = 0; gl < 6; ++gl)
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<32, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W3, py, px, pv, lane);
+        conv3x3_bf16<32, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W3, py, px, pv, lane, dbg);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int c = n + 32 * nt;
@@ -312,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<64, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W4, py, px, pv, lane);
+        conv3x3_bf16<64, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W4, py, px, pv, lane, dbg);
         __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
         float* dst = p3 ? p3 + (size_t)p * (18 * 64) : nullptr;
 #pragma unroll
@@ -382,11 +391,11 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                 al[t] = *(const f32x4*)(ok ? ph + 9216 : zero);
             }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][1], acc5[t]);
-                acc5[t] = mfma_bf16x16(al[t], bq[g & 1][0], acc5[t]);
-                acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][0], acc5[t]);
-            }
+            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][1], acc5[t]);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(al[t], bq[g & 1][0], acc5[t]);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][0], acc5[t]);
         }
         {
             const float tn = cw[CNN_T5 + ch];
@@ -403,9 +412,11 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         __syncthreads();
 
         // conv6 (3 x 3 kernel, padding (1,0)) = padding-1 conv at the centre column: rows (slot, y), 24 of 32
-        f32x4 acc6[2];
+        f32x4 acc6[2], acc6b[2];            // even / odd K-steps accumulate separately: four independent chains
         acc6[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc6[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc6b[0] = acc6[0];
+        acc6b[1] = acc6[0];
         int sy[2], sb[2];
         bool sv[2];
 #pragma unroll
@@ -433,13 +444,26 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                 ah[t] = *(const f32x4*)ph;
                 al[t] = *(const f32x4*)(ok ? ph + 9216 : zero);
             }
+            if (g & 1) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                acc6[t] = mfma_bf16x16(ah[t], bq[g & 1][1], acc6[t]);
-                acc6[t] = mfma_bf16x16(al[t], bq[g & 1][0], acc6[t]);
-                acc6[t] = mfma_bf16x16(ah[t], bq[g & 1][0], acc6[t]);
+                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(ah[t], bq[1][1], acc6b[t]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(al[t], bq[1][0], acc6b[t]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(ah[t], bq[1][0], acc6b[t]);
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(ah[t], bq[0][1], acc6[t]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(al[t], bq[0][0], acc6[t]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(ah[t], bq[0][0], acc6[t]);
             }
         }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc6[t][r] += acc6b[t][r];
         const float tn = cw[CNN_T6 + ch];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -462,7 +486,7 @@ extern "C" int nisqa_cnn_adapt_bf16(const float* mel_tm, const int32_t* frame_of
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
                        mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat,
-                       (const float*)nullptr, 0);
+                       (const float*)nullptr, 0, getenv("NQ_DBG") ? atoi(getenv("NQ_DBG")) : 0);
     return NQ_LAUNCH_STATUS();
 }
 
@@ -474,6 +498,6 @@ extern "C" int nisqa_cnn_adapt_segments_bf16(const float* x, int32_t seg_len_pad
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
                        (const float*)nullptr, (const int32_t*)nullptr, tok_off, n_wins, (const float*)nullptr, n_clips, 1,
-                       cnn_w, cnn_wb, (float*)nullptr, feat, x, seg_len_padded);
+                       cnn_w, cnn_wb, (float*)nullptr, feat, x, seg_len_padded, 0);
     return NQ_LAUNCH_STATUS();
 }

@@ -22,10 +22,13 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 NQ_DEV f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// fp32 -> bf16 (round to nearest even), two values per instruction: the compiler selects v_cvt_pk_bf16_f32 for
+// this conversion, and -- unlike an inline-asm statement -- tracks its hazards and schedules around it
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 NQ_DEV unsigned cvt_pk_bf16(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 // (v0, v1) -> packed bf16 hi pair and packed bf16 lo pair
 NQ_DEV void split2(float v0, float v1, unsigned& hi, unsigned& lo) {
@@ -97,13 +100,13 @@ NQ_DEV void chain_gemm_bf(const u16* __restrict__ wb, const f32x16 (&in)[2], f32
         }
         f32x4 bh, bl;
         split8(in[s >> 1], 8 * (s & 1), bh, bl);
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);     // keep next step's fragment requests ahead of this step's MFMAs
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            out[mt] = mfma_bf(ah[s & 1][mt], bl, out[mt]);
-            out[mt] = mfma_bf(al[s & 1][mt], bh, out[mt]);
-            out[mt] = mfma_bf(ah[s & 1][mt], bh, out[mt]);
-        }
+        for (int mt = 0; mt < MT; ++mt) out[mt] = mfma_bf(ah[s & 1][mt], bl, out[mt]);   // product-major: consecutive
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) out[mt] = mfma_bf(al[s & 1][mt], bh, out[mt]);   // MFMAs on different
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) out[mt] = mfma_bf(ah[s & 1][mt], bh, out[mt]);   // accumulators
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -255,14 +258,16 @@ __global__ __launch_bounds__(64) void td_layer_bf16_kernel(const int32_t* __rest
                 nl_[s] = *(const f32x4*)(P.kl + (size_t)(key0 + 32 + j) * 64 + 16 * s + 8 * h);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 sacc = zero16();
+        __builtin_amdgcn_sched_barrier(0);     // K / V requests of the next tile stay ahead of this tile's MFMAs
+        f32x16 sacc = zero16(), sacc1 = zero16(), sacc2 = zero16();    // one accumulator per product: independent chains
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            sacc = mfma_bf(kh_[s], ql[s], sacc);
-            sacc = mfma_bf(kl_[s], qh[s], sacc);
+            sacc1 = mfma_bf(kh_[s], ql[s], sacc1);
+            sacc2 = mfma_bf(kl_[s], qh[s], sacc2);
             sacc = mfma_bf(kh_[s], qh[s], sacc);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] += sacc1[r] + sacc2[r];
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -287,12 +292,9 @@ __global__ __launch_bounds__(64) void td_layer_bf16_kernel(const int32_t* __rest
         for (int s = 0; s < 2; ++s) {
             f32x4 ph, pl;
             split8(sacc, 8 * s, ph, pl);
-#pragma unroll
-            for (int ft = 0; ft < 2; ++ft) {
-                o[ft] = mfma_bf(vh_[ft][s], pl, o[ft]);
-                o[ft] = mfma_bf(vl_[ft][s], ph, o[ft]);
-                o[ft] = mfma_bf(vh_[ft][s], ph, o[ft]);
-            }
+            o[0] = mfma_bf(vh_[0][s], pl, o[0]); o[1] = mfma_bf(vh_[1][s], pl, o[1]);
+            o[0] = mfma_bf(vl_[0][s], ph, o[0]); o[1] = mfma_bf(vl_[1][s], ph, o[1]);
+            o[0] = mfma_bf(vh_[0][s], ph, o[0]); o[1] = mfma_bf(vh_[1][s], ph, o[1]);
         }
     };
     for (int kt = 0; kt < nkt; kt += 2) {

@@ -203,6 +203,19 @@ def test_full_size_batch_properties(eng_rand):
     assert np.abs(out2 - out[perm]).max() < 1e-5
 
 
+def test_config3_batch_size_256(eng_rand):
+    """BASELINE config 3 uses bs = 256 per GPU: 256 x 10 s in one call must reproduce the bs = 64 rows."""
+    base = [synth.synth_pcm16(300 + i, 10.0) for i in range(4)]
+    d64, p64 = _upload(eng_rand, [base[i % 4] for i in range(64)])
+    o64 = eng_rand.forward_pcm(d64, p64, 48000).cpu().numpy()
+    d256, p256 = _upload(eng_rand, [base[i % 4] for i in range(256)])
+    assert p256.total_tok == 256 * 256 and p256.total_frames == 256 * 1001
+    o256 = eng_rand.forward_pcm(d256, p256, 48000).cpu().numpy()
+    assert np.isfinite(o256).all()
+    for i in range(256):
+        assert np.abs(o256[i] - o64[i % 4]).max() < 1e-5
+
+
 def test_error_mapping(eng_rand):
     with pytest.raises(ValueError, match='Sample too short'):
         eng_rand.plan([14 * 480 - 1], 48000)
