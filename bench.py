@@ -49,6 +49,9 @@ FLOP_CONV5_6 = (327.8 + 109.3) * 1e6
 FLOP_TOTAL = 2.93e9                                          # whole path incl. mel in FFT form
 PEAK_F32_MFMA = 157.3                                        # TFLOP/s, MI355X_MICROARCH.md
 PEAK_BF16_MFMA = 2500.0                                      # TFLOP/s dense, MI355X_MICROARCH.md
+# HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, KB units, the
+# gfx950 x2 correction for wide reads): profiles/r01_pmc_bench_bf16x3.txt, profiles/r01_pmc_f32_cnn.txt
+PMC_TRAFFIC_BYTES = {'bf16x3': 2 * 13055.9e3 * 1.024 + 23724.1e3 * 1.024, 'f32': 2 * 23916.2e3 * 1.024 + 71136.0e3 * 1.024}
 
 
 def cpu_baseline(n_distinct=6, min_seconds=12.0):
@@ -173,7 +176,8 @@ def main():
                 flop, peak, kern = FLOP_CONV1_4 * BATCH, PEAK_F32_MFMA, 'cnn_front_kernel (conv1-4 + pools, fp32 MFMA)'
             ach = flop / (ms_front * 1e-3) / 1e12
             return {'kernel': kern, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                    'frac': round(ach / peak, 4), 'traffic': None, 'flop_per_launch': flop,
+                    'frac': round(ach / peak, 4), 'traffic': round(PMC_TRAFFIC_BYTES[prec]), 'traffic_unit': 'bytes/launch (rocprofv3 PMC, profiles/)',
+                    'flop_per_launch': flop,
                     'avg_launch_ms': round(ms_front, 4)}
 
         clips = BATCH * a.steps * world
