@@ -17,7 +17,6 @@
 //     of the input patch), because at this speed the VALU version would cost as much as conv2-4;
 //   * activations live in LDS as two bf16 planes (hi, lo), pixel-major, same XOR-swizzled 16-byte
 //     chunks and the same row->pixel maps as the fp32 kernel, so pooling stays in-lane.
-#include <stdlib.h>
 #include "common.hpp"
 #include "layout.hpp"
 #include "../../include/nisqa_hip.h"
@@ -53,7 +52,7 @@ NQ_DEV float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
 template <int CIN, int MT, int NT, int H, int W, bool APF>
 NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* zero,
                          const unsigned short* __restrict__ wb, const int (&py)[MT], const int (&px)[MT],
-                         const bool (&pvalid)[MT], int lane, int dbg = 0) {
+                         const bool (&pvalid)[MT], int lane) {
     constexpr int S16 = CIN / 16;             // K=16 steps per tap
     constexpr int TOTAL = 9 * S16;
     constexpr int Cc = CIN / 8;               // 16-byte chunks per pixel row (per plane)
@@ -66,9 +65,8 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
     auto load_b = [&](int g, int slot) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int gg = (dbg & 4) ? 0 : g;
-            bh[slot][nt] = wl[((gg * NT + nt) * 2 + 0) * 64];
-            bl[slot][nt] = wl[((gg * NT + nt) * 2 + 1) * 64];
+            bh[slot][nt] = wl[((g * NT + nt) * 2 + 0) * 64];
+            bl[slot][nt] = wl[((g * NT + nt) * 2 + 1) * 64];
         }
     };
     auto load_a = [&](int g, int slot) {
@@ -77,7 +75,7 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const int y = py[t] + dy, x = px[t] + dx;
-            const bool ok = !(dbg & 8) && pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const bool ok = pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
             const int pix = y * W + x;
             const int swz = ((pix * Cc) >> 4) & (Cc - 1);
             const char* ph = ok ? act_in + pix * (CIN * 2) + (((2 * s + h) ^ swz) << 4) : zero;
@@ -137,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
     const float* __restrict__ clip_floor, int n_clips, int seg_hop,
     const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ p3,
-    float* __restrict__ feat, const float* __restrict__ seg_x, int seg_L, int dbg) {
+    float* __restrict__ feat, const float* __restrict__ seg_x, int seg_L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -254,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             py[t] = 2 * (6 * hfi + gl) + yy;
             px[t] = w - 7 * yy;
         }
-        conv3x3_bf16<16, 6, 1, 24, 7, false>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane, dbg);
+        conv3x3_bf16<16, 6, 1, 24, 7, false>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane);
         const float tn = cw[CNN_T2 + n];
 #pragma unroll
         for (int gl = 0; gl < 6; ++gl)
@@ -291,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<32, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W3, py, px, pv, lane, dbg);
+        conv3x3_bf16<32, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W3, py, px, pv, lane);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int c = n + 32 * nt;
@@ -321,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<64, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W4, py, px, pv, lane, dbg);
+        conv3x3_bf16<64, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W4, py, px, pv, lane);
         __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
         float* dst = p3 ? p3 + (size_t)p * (18 * 64) : nullptr;
 #pragma unroll
@@ -486,7 +484,7 @@ extern "C" int nisqa_cnn_adapt_bf16(const float* mel_tm, const int32_t* frame_of
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
                        mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat,
-                       (const float*)nullptr, 0, getenv("NQ_DBG") ? atoi(getenv("NQ_DBG")) : 0);
+                       (const float*)nullptr, 0);
     return NQ_LAUNCH_STATUS();
 }
 
@@ -498,6 +496,6 @@ extern "C" int nisqa_cnn_adapt_segments_bf16(const float* x, int32_t seg_len_pad
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
                        (const float*)nullptr, (const int32_t*)nullptr, tok_off, n_wins, (const float*)nullptr, n_clips, 1,
-                       cnn_w, cnn_wb, (float*)nullptr, feat, x, seg_len_padded, 0);
+                       cnn_w, cnn_wb, (float*)nullptr, feat, x, seg_len_padded);
     return NQ_LAUNCH_STATUS();
 }

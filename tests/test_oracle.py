@@ -156,3 +156,29 @@ def test_net_oracle_tts_architecture_matches_reference_fixture(name):
         if 'feat_%d' % n in g.files:
             np.testing.assert_allclose(st['feat'], g['feat_%d' % n], rtol=0, atol=3e-5)
             np.testing.assert_allclose(st['td'], g['td_%d' % n], rtol=0, atol=3e-5)
+
+
+def _hf_melspec_db(y, sr, n_fft=4096, hop_s=0.01, win_s=0.02, n_mels=48, fmax=20000.0):
+    """The same mel front end computed by an INDEPENDENT implementation: transformers.audio_utils, whose
+    slaney filter bank / centred reflect-padded STFT / amplitude_to_db are written (and tested upstream) to
+    reproduce librosa.  It is not the reference's librosa 0.8.1, but it shares no code with oracle/mel.py."""
+    au = pytest.importorskip('transformers.audio_utils')
+    hop, win = int(sr * hop_s), int(sr * win_s)
+    fb = au.mel_filter_bank(1 + n_fft // 2, n_mels, 0.0, fmax, sr, norm='slaney', mel_scale='slaney')
+    S = au.spectrogram(np.asarray(y, np.float64), au.window_function(win, 'hann', periodic=True), frame_length=win,
+                       hop_length=hop, fft_length=n_fft, power=1.0, center=True, pad_mode='reflect',
+                       mel_filters=fb, mel_floor=0.0, dtype=np.float64)
+    return fb, au.amplitude_to_db(S, reference=1.0, min_value=1e-4, db_range=80.0)
+
+
+@pytest.mark.parametrize('sr', [48000, 16000])
+def test_mel_oracle_against_independent_librosa_compatible_implementation(sr):
+    pcm = synth.synth_pcm16(11, 1.7, sr=sr)
+    y = pcm.astype(np.float32) / np.float32(32768.0)
+    fb, want = _hf_melspec_db(y, sr, fmax=min(20000.0, sr / 2))
+    ofb = omel.mel_filterbank(sr, 4096, 48, 0.0, min(20000.0, sr / 2))
+    np.testing.assert_allclose(ofb.T, fb, rtol=0, atol=1e-8)
+    got = omel.melspec_db_from_audio(y, sr, fmax=min(20000.0, sr / 2))
+    assert got.shape == want.shape
+    # float32 (librosa's dtype discipline, oracle) against float64 (transformers): measured 1.2e-5 dB
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
