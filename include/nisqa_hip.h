@@ -166,7 +166,8 @@ int nisqa_pool_final(const int32_t* tok_off, const int32_t* n_wins, int32_t n_cl
  * nisqa_tts.tar architecture.
  * nisqa_cnn_standard replaces segment_specs + Framewise.forward + StandardCNN.forward incl. fc_out
  * (NISQA_lib.py:2239-2282, 487-502, 811-836): feat20[NP][20]; p3_ws scratch [NP][12][64] floats; cnn_std_w from
- * nisqa_amd.weights.pack_standard_cnn.
+ * nisqa_amd.weights.pack_standard_cnn.  nisqa_cnn_standard_bf16 is the same operator on split-bf16 MFMA (one
+ * kernel, no scratch; cnn_wb from nisqa_amd.weights.pack_adapt_cnn_bf16 -- the conv shapes are the AdaptCNN's).
  * nisqa_lstm_laststep replaces LSTM.forward (bidirectional, hidden 128; NISQA_lib.py:925-943) and
  * PoolLastStepBi.forward (NISQA_lib.py:1107-1115): out[B][1]; hfin_ws scratch [B][256] floats; seq_opt (may be
  * NULL) receives the full [NP][256] LSTM output; lstm_w from nisqa_amd.weights.pack_lstm_laststep.
@@ -175,6 +176,10 @@ int nisqa_cnn_standard(const float* mel_tm, const int32_t* frame_off, const int3
                        const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                        int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
                        float* p3_ws, float* feat20, void* stream);
+int nisqa_cnn_standard_bf16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                            const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                            int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
+                            const uint16_t* cnn_wb, float* feat20, void* stream);
 int nisqa_lstm_laststep(const float* feat20, const int32_t* tok_off, const int32_t* n_wins,
                         int32_t n_clips, const float* lstm_w, float* hfin_ws, float* seq_opt,
                         float* out, void* stream);

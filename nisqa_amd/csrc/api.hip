@@ -60,8 +60,11 @@ extern "C" int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, co
     if (model->arch == 1) {
         // StandardCNN + BiLSTM + last-step pooling; scratch: p3 region holds [NP][12][64], feat region [NP][20],
         // td region the [B][256] final LSTM states
-        rc = nisqa_cnn_standard(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
-                                model->cnn_w, p3, feat, stream);
+        rc = model->cnn_mode == 1
+                 ? nisqa_cnn_standard_bf16(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded,
+                                           model->seg_hop, model->cnn_w, model->cnn_wb, feat, stream)
+                 : nisqa_cnn_standard(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded,
+                                      model->seg_hop, model->cnn_w, p3, feat, stream);
         if (rc) return rc;
         NQ_STAGE(2);
         NQ_STAGE(3);

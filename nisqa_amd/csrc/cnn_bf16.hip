@@ -1,5 +1,6 @@
-// AdaptCNN conv1..conv4 on split-bf16 MFMA ("bf16x3") -- same role, inputs and outputs as
-// cnn_front_kernel in cnn.hip (reference nisqa/NISQA_lib.py:2239-2282, 487-502, 688-702).
+// The whole AdaptCNN (conv1..conv6, BatchNorm folded, adaptive max-pools) on split-bf16 MFMA ("bf16x3") --
+// same role, inputs and outputs as cnn_front_kernel + cnn_back_kernel in cnn.hip (reference
+// nisqa/NISQA_lib.py:2239-2282, 487-502, 688-710).
 //
 // Every fp32 operand x is carried as x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 mantissa
 // bits) and each product is formed as hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32
@@ -8,33 +9,19 @@
 // products (K is one MFMA step, so this is nearly free).  Measured effect on the outputs with the
 // real nisqa.tar weights: |dMOS| <= 6e-6 (pure bf16: 4.5e-3, pure f16: 5e-4; bar 1e-3) -- DESIGN.md 4.5.
 //
-// Structure differences from the fp32 kernel, all consequences of the 5x faster matrix pipe:
-//   * weight fragments no longer stream from L2 per wave (that would need ~25 TB/s of L2): a workgroup
-//     is FOUR waves = four segments that walk the K-steps in lockstep, and each 8 KiB chunk of
-//     fragments is brought in once per workgroup with global_load_lds_dwordx4 (direct to LDS, lane-
-//     linear, double-buffered, one barrier per chunk) and read by all four waves;
-//   * conv1 moves from the VALU to the matrix pipe (im2col gather of the 9 taps from three bf16 planes
-//     of the input patch), because at this speed the VALU version would cost as much as conv2-4;
-//   * activations live in LDS as two bf16 planes (hi, lo), pixel-major, same XOR-swizzled 16-byte
-//     chunks and the same row->pixel maps as the fp32 kernel, so pooling stays in-lane.
+// Structure (differences from the fp32 kernels are consequences of the 5x faster matrix pipe):
+//   * a workgroup is FOUR waves = four segments; conv1..conv4 are wave-private and barrier-free: each wave
+//     streams its weight fragments from L2 into a 3-deep register ring (conv_bf16.hpp) and keeps its
+//     activations in its own LDS region as two bf16 planes (hi, lo), pixel-major, XOR-swizzled 16-byte
+//     chunks, with the same row->pixel maps as the fp32 kernel so the adaptive max-pools stay in-lane;
+//   * conv1 runs on the matrix pipe too (im2col gather of the 9 taps from three zero-bordered bf16 planes of
+//     the input patch), because at this speed the VALU version would cost as much as conv2-4;
+//   * conv5/conv6 (18 / 6 output pixels per segment) are batched over the workgroup's four segments with the
+//     output channels split over the waves (16x16x32 MFMA tiles), so no tile is mostly padding.
 #include "common.hpp"
 #include "layout.hpp"
+#include "conv_bf16.hpp"
 #include "../../include/nisqa_hip.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-NQ_DEV f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-NQ_DEV f32x4 mfma_bf16x16(f32x4 a, f32x4 b, f32x4 c) {     // 16x16x32: A[i = l&15][k = 8*(l>>4)+e], D row 4*(l>>4)+r
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// round-to-nearest-even fp32 -> bf16 (finite inputs)
-NQ_DEV unsigned bf16_bits(float v) {
-    const unsigned u = __float_as_uint(v);
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-NQ_DEV float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
 
 #define FB_ACT 15872                       /* per-wave activation region (planes alias as layers retire) */
 #define FB_ZERO FB_ACT                     /* 128 B of zeros per wave */
@@ -43,92 +30,10 @@ NQ_DEV float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
 #define FB_PATCH 10752                     /* conv1 input: three zero-bordered bf16 planes [17][50] behind the A1 planes */
 #define FB_PPLANE 1700                     /* bytes per patch plane (850 bf16) */
 
-// One conv layer (3x3, padding 1) for this wave's segment, barrier-free.
-//   act_in : this wave's input planes (hi at +0, lo at +PLANE), pixel rows of CIN bf16, swizzled chunks
-//   wb     : layer fragments [TOTAL steps][NT][2][64][8] bf16, streamed from L2: one contiguous 1 KiB
-//            global_load_dwordx4 per fragment, requested TWO K-steps ahead into a 3-deep register ring
-//            (an L2 round trip is ~600 clk, a step of MFMAs 200-800 clk); ~10 TB/s of L2 reads chip-wide
-//   APF    : also double-buffer the A rows from LDS one step ahead (off for conv2: 6 M-tiles of registers)
-template <int CIN, int MT, int NT, int H, int W, bool APF>
-NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* zero,
-                         const unsigned short* __restrict__ wb, const int (&py)[MT], const int (&px)[MT],
-                         const bool (&pvalid)[MT], int lane) {
-    constexpr int S16 = CIN / 16;             // K=16 steps per tap
-    constexpr int TOTAL = 9 * S16;
-    constexpr int Cc = CIN / 8;               // 16-byte chunks per pixel row (per plane)
-    constexpr int PLANE = H * W * CIN * 2;    // bytes per plane
-    constexpr int AB = APF ? 2 : 1;
-    const int h = lane >> 5;
-    const f32x4* wl = (const f32x4*)wb + lane;
-    f32x4 bh[3][NT], bl[3][NT], ah[AB][MT], al[AB][MT];
-
-    auto load_b = [&](int g, int slot) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            bh[slot][nt] = wl[((g * NT + nt) * 2 + 0) * 64];
-            bl[slot][nt] = wl[((g * NT + nt) * 2 + 1) * 64];
-        }
-    };
-    auto load_a = [&](int g, int slot) {
-        const int tap = g / S16, s = g - tap * S16;
-        const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const int y = py[t] + dy, x = px[t] + dx;
-            const bool ok = pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            const int pix = y * W + x;
-            const int swz = ((pix * Cc) >> 4) & (Cc - 1);
-            const char* ph = ok ? act_in + pix * (CIN * 2) + (((2 * s + h) ^ swz) << 4) : zero;
-            ah[slot][t] = *(const f32x4*)ph;
-            al[slot][t] = *(const f32x4*)(ok ? ph + PLANE : zero);
-        }
-    };
-
-    load_b(0, 0);
-    load_b(1, 1);
-    if (APF) load_a(0, 0);
-#pragma unroll
-    for (int g = 0; g < TOTAL; ++g) {
-        if (g + 2 < TOTAL) load_b(g + 2, (g + 2) % 3);
-        if (APF) { if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1); } else load_a(g, 0);
-        const int sa = APF ? (g & 1) : 0, sb = g % 3;
-        // product-major: consecutive MFMAs go to DIFFERENT accumulators (no dependent-accumulate bubbles)
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bl[sb][nt], acc[t][nt]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(al[sa][t], bh[sb][nt], acc[t][nt]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bh[sb][nt], acc[t][nt]);
-
-    }
-}
-
 __device__ constexpr int bwin75_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 2 : b == 3 ? 4 : 5; }
 __device__ constexpr int bwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b == 2 ? 5 : b == 3 ? 6 : 7; }
 __device__ constexpr int bwin53_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : 3; }
 __device__ constexpr int bwin53_hi(int b) { return b == 0 ? 2 : b == 1 ? 4 : 5; }
-
-// fp32 -> bf16 (round to nearest even), two values per instruction: the compiler selects v_cvt_pk_bf16_f32 for
-// this conversion, and -- unlike an inline-asm statement -- tracks its hazards and schedules around it
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-NQ_DEV unsigned cvt_pk_bf16(float a, float b) {
-    const f32x2_t v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-// store v = hi + lo into the two bf16 planes at byte offset `off` of the hi plane
-NQ_DEV void store_split(char* plane_hi, int plane_bytes, int off, float v) {
-    const unsigned hi = cvt_pk_bf16(v, 0.f);
-    const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
-    *(unsigned short*)(plane_hi + off) = (unsigned short)hi;
-    *(unsigned short*)(plane_hi + plane_bytes + off) = (unsigned short)lo;
-}
 
 __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,

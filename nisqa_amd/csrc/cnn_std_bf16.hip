@@ -1,0 +1,319 @@
+// StandardCNN (fixed 2x2 max-pools) + fc_out on split-bf16 MFMA ("bf16x3") for the nisqa_tts.tar
+// architecture -- same role, inputs and outputs as cnn_std_front_kernel + cnn_std_back_kernel in cnn_std.hip
+// (reference nisqa/NISQA_lib.py:2239-2282, 487-502, 811-836), built from the blocks of conv_bf16.hpp exactly
+// like cnn_front_bf16_kernel (cnn_bf16.hip); only the geometry differs:
+//   48x15 -conv1-> pool 2x2 pad (0,1) -> 24x8 -conv2-> pool -> 12x4 -conv3,conv4-> pool -> 6x2 -conv5,conv6->
+//   64 x 6 x 2 = 768 -fc_out-> 20.
+// conv2 fills its 32-row tiles completely (a pooled row of a lane half is one 16-row half tile), conv3/4 use 24
+// of 32 rows; conv5/conv6 batch the workgroup's four segments (48 rows = three full 16-row tiles per wave, N
+// split over the waves).  conv6 leaves its output in LDS as fp32 and fc_out (768 -> 20, 0.2 % of the FLOPs)
+// runs on the VALU, one wave per segment.
+#include "common.hpp"
+#include "layout.hpp"
+#include "conv_bf16.hpp"
+#include "../../include/nisqa_hip.h"
+
+#define SS_A1PLANE 6144                    /* 192 px x 16 ch bf16 */
+#define SS_PATCH 12288                     /* conv1 input: three zero-bordered bf16 planes [17][50] behind the A1 planes */
+#define SS_PPLANE 1700
+#define SS_ZERO 17408                      /* 128 B of zeros per wave */
+#define SS_WAVE 17536
+#define SS_LDS (4 * SS_WAVE)               /* 70144 B -> two workgroups (8 waves) per CU */
+#define SS_PLANE 6144                      /* S4 / S5: 48 rows x 64 ch bf16 */
+
+__global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
+    const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
+    const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
+    const float* __restrict__ clip_floor, int n_clips, int seg_hop,
+    const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ feat20) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p0 = blockIdx.x * 4;                      // tok_off is a multiple of 32: no clip straddling
+    const int b = find_segment(tok_off, n_clips, p0);
+    const int k0 = p0 - tok_off[b];
+    const int nvalid = min(4, n_wins[b] - k0);
+    if (nvalid <= 0) return;
+    const bool valid = wave < nvalid;                    // padding waves still walk the barriers (on zeros)
+    const int k = k0 + wave;
+    char* act = smem + wave * SS_WAVE;
+    char* zero = act + SS_ZERO;
+
+    // ---- the 15-frame window as three zero-bordered bf16 planes (hi, mid, lo) [frame j + 1][mel m + 1]
+    {
+        char* pb = act + SS_PATCH;
+        for (int q = lane; q < (3 * SS_PPLANE + 15) / 16; q += 64) *(f32x4*)(pb + q * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (lane < 32) ((float*)zero)[lane] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        const float fl = clip_floor[b];
+        const float* src = mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
+        for (int i0 = lane; i0 < 720; i0 += 64) {
+            const int j = i0 / 48, m = i0 - 48 * j;
+            const float v = valid ? fmaxf(src[i0], fl) : 0.f;
+            const unsigned hi = cvt_pk_bf16(v, 0.f);
+            const float r1 = v - __uint_as_float(hi << 16);
+            const unsigned mid = cvt_pk_bf16(r1, 0.f);
+            const unsigned lo = cvt_pk_bf16(r1 - __uint_as_float(mid << 16), 0.f);
+            const int o = ((j + 1) * 50 + (m + 1)) * 2;
+            *(unsigned short*)(pb + o) = (unsigned short)hi;
+            *(unsigned short*)(pb + SS_PPLANE + o) = (unsigned short)mid;
+            *(unsigned short*)(pb + 2 * SS_PPLANE + o) = (unsigned short)lo;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int i = lane & 31, hfi = (i >> 2) & 1, qi = (i & 3) + 4 * (i >> 3);
+    const int n = lane & 31, hf = lane >> 5, h = lane >> 5;
+
+    // ---- conv1 1->16 on the matrix pipe + MaxPool2d(2, stride 2, padding (0,1)): 48x15 -> 24x8; pooled column
+    //      bb covers conv columns {2bb-1, 2bb} (column -1 is pool padding and is ignored, as -inf would be)
+    {
+        const char* pb = act + SS_PATCH;
+        f32x4 w1[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) w1[t] = *(const f32x4*)(wb + CNNB_W1 + t * 512 + lane * 8);
+        const float tn = cw[CNN_T1 + (n & 15)];
+        int toff[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) toff[e] = h ? 2 * (2 * 50 + 2) : 2 * ((e % 3) * 50 + e / 3);
+        for (int gl = 0; gl < 12; ++gl) {
+            f32x16 acc[2];
+            f32x4 xa[2][3];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int u = min(16 * tt + qi, 29);      // rows 30, 31 of the pair are padding (results unused)
+                const int yy = u >= 15 ? 1 : 0, x = u - 15 * yy;
+                const int y = 2 * (12 * hfi + gl) + yy;
+                const char* base = pb + (x * 50 + y) * 2;
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const unsigned lo16 = *(const unsigned short*)(base + t * SS_PPLANE + toff[2 * q]);
+                        const unsigned hi16 = *(const unsigned short*)(base + t * SS_PPLANE + toff[2 * q + 1]);
+                        xa[tt][t][q] = __uint_as_float(lo16 | (hi16 << 16));
+                    }
+            }
+            acc[0] = zero16();
+            acc[1] = zero16();
+            acc[0] = mfma_bf(xa[0][2], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][2], w1[0], acc[1]);
+            acc[0] = mfma_bf(xa[0][1], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[1], acc[1]);
+            acc[0] = mfma_bf(xa[0][0], w1[2], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[2], acc[1]);
+            acc[0] = mfma_bf(xa[0][1], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[0], acc[1]);
+            acc[0] = mfma_bf(xa[0][0], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[1], acc[1]);
+            acc[0] = mfma_bf(xa[0][0], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[0], acc[1]);
+#pragma unroll
+            for (int bb = 0; bb < 8; ++bb) {
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                    for (int x = (bb ? 2 * bb - 1 : 0); x <= (bb < 7 ? 2 * bb : 14); ++x) {
+                        const int u = 15 * yy + x;
+                        mx = fmaxf(mx, acc[u >> 4][u & 15]);
+                    }
+                const int pp = (12 * hf + gl) * 8 + bb;
+                if (n < 16)
+                    store_split(act, SS_A1PLANE, pp * 32 + (((n >> 3) ^ ((pp >> 3) & 1)) << 4) + (n & 7) * 2,
+                                fmaxf(mx + tn, 0.f));
+            }
+        }
+    }
+
+    // ---- conv2 16->32 on 24x8, pool 2x2 -> 12x4: tile t of a lane half = pooled row 6*half + t (2 rows x 8 cols)
+    {
+        f32x16 acc[6][1];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc[t][0] = zero16();
+        int py[6], px[6];
+        bool pv[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            pv[t] = true;
+            py[t] = 2 * (6 * hfi + t) + (qi >> 3);
+            px[t] = qi & 7;
+        }
+        conv3x3_bf16<16, 6, 1, 24, 8, false>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane);
+        const float tn = cw[CNN_T2 + n];
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const float mx = fmaxf(fmaxf(acc[t][0][2 * bb], acc[t][0][2 * bb + 1]),
+                                       fmaxf(acc[t][0][8 + 2 * bb], acc[t][0][8 + 2 * bb + 1]));
+                const int pp = (6 * hf + t) * 4 + bb;
+                store_split(act, 3072, pp * 64 + (((n >> 3) ^ ((pp >> 2) & 3)) << 4) + (n & 7) * 2, fmaxf(mx + tn, 0.f));
+            }
+    }
+
+    // conv3 / conv4 on 12x4: a lane half owns 3 pooled rows = 3 groups of 8 pixels; u = 8*gl + 4*yy + x
+    int py[2], px[2];
+    bool pv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int u = 16 * t + qi;
+        pv[t] = u < 24;
+        py[t] = 2 * (3 * hfi + (u >> 3)) + ((u >> 2) & 1);
+        px[t] = u & 3;
+    }
+    {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
+        conv3x3_bf16<32, 2, 2, 12, 4, true>(acc, act, zero, wb + CNNB_W3, py, px, pv, lane);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = n + 32 * nt;
+            const float tn = cw[CNN_T3 + c];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int u = 16 * t + r;
+                    if (u < 24) {
+                        const int pp = (2 * (3 * hf + (u >> 3)) + ((u >> 2) & 1)) * 4 + (u & 3);
+                        store_split(act, 6144, pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2,
+                                    fmaxf(acc[t][nt][r] + tn, 0.f));
+                    }
+                }
+        }
+    }
+
+    // ---- conv4 64->64 on 12x4, pool -> 6x2.  The pooled outputs of the four segments go to a SHARED pair of
+    //      bf16 planes S4[48 rows][64 ch] (row = 12 * wave + pixel) for the N-split conv5 / conv6.
+    char* s4 = smem;                       // wave 0's region (its A3 is dead by then)
+    char* s5 = smem + SS_WAVE;             // wave 1's region
+    float* s6 = (float*)smem;              // conv6 output, fp32 [48][64], over S4
+    {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
+        conv3x3_bf16<64, 2, 2, 12, 4, true>(acc, act, zero, wb + CNNB_W4, py, px, pv, lane);
+        __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = n + 32 * nt;
+            const float tn = cw[CNN_T4 + c];
+#pragma unroll
+            for (int gl = 0; gl < 3; ++gl)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                        for (int xx = 0; xx < 2; ++xx) {
+                            const int u = 8 * gl + 4 * yy + 2 * bb + xx;
+                            mx = fmaxf(mx, acc[u >> 4][nt][u & 15]);
+                        }
+                    const int pp = 12 * wave + (3 * hf + gl) * 2 + bb;
+                    store_split(s4, SS_PLANE, pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2,
+                                fmaxf(mx + tn, 0.f));
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv5 / conv6 (3x3, padding 1, on 6x2) with N split over the waves: wave w owns output channels
+    //      16w..16w+15 of all four segments; rows rho = 16 t + i16 <-> (slot = rho / 12, pixel = rho % 12)
+    {
+        const int i16 = lane & 15, kg = lane >> 4;
+        const int ch = 16 * wave + i16;
+        const char* zero3 = smem + 3 * SS_WAVE + SS_ZERO;  // wave 3's zero block: S4 / S5 / S6 never cover it
+        int ry[3], rx[3], rb[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int rho = 16 * t + i16;
+            const int slot = rho / 12, pix = rho - 12 * slot;
+            ry[t] = pix >> 1;
+            rx[t] = pix & 1;
+            rb[t] = slot * 12;
+        }
+#pragma unroll 1
+        for (int layer = 0; layer < 2; ++layer) {
+            const char* src = layer ? s5 : s4;
+            f32x4 acc5[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc5[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4* w5 = (const f32x4*)(wb + (layer ? CNNB_W6 : CNNB_W5)) + (size_t)wave * (18 * 2 * 64) + lane;
+            f32x4 bq[2][2];
+            bq[0][0] = w5[0]; bq[0][1] = w5[64];
+#pragma unroll
+            for (int g = 0; g < 18; ++g) {
+                if (g + 1 < 18) { bq[(g + 1) & 1][0] = w5[(g + 1) * 128]; bq[(g + 1) & 1][1] = w5[(g + 1) * 128 + 64]; }
+                const int tap = g >> 1, s = g & 1;
+                const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+                f32x4 ah[3], al[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int y = ry[t] + dy, x = rx[t] + dx;
+                    const bool ok = (unsigned)y < 6u && (unsigned)x < 2u;
+                    const int pix = rb[t] + y * 2 + x;
+                    const char* ph = ok ? src + pix * 128 + (((4 * s + kg) ^ ((pix >> 1) & 7)) << 4) : zero3;
+                    ah[t] = *(const f32x4*)ph;
+                    al[t] = *(const f32x4*)(ok ? ph + SS_PLANE : zero3);
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][1], acc5[t]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(al[t], bq[g & 1][0], acc5[t]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][0], acc5[t]);
+            }
+            const float tn = cw[(layer ? CNN_T6 : CNN_T5) + ch];
+            // conv6's fp32 output goes over S4, which every wave finished reading before the barrier that ended conv5
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rho = 16 * t + 4 * kg + r;
+                    const float v = fmaxf(acc5[t][r] + tn, 0.f);
+                    if (layer) s6[rho * 64 + ch] = v;
+                    else store_split(s5, SS_PLANE, rho * 128 + (((ch >> 3) ^ ((rho >> 1) & 7)) << 4) + (ch & 7) * 2, v);
+                }
+            __syncthreads();
+        }
+    }
+
+    // ---- fc_out 768 -> 20: wave w = segment slot w; lane takes k' = lane + 64 m (k' = pixel * 64 + c)
+    if (valid) {
+        float o[20];
+#pragma unroll
+        for (int j = 0; j < 20; ++j) o[j] = 0.f;
+        const float* wfc = cw + CNNS_FC_W;
+#pragma unroll 2
+        for (int m = 0; m < 12; ++m) {
+            const float a = s6[(12 * wave + m) * 64 + lane];
+            const f32x4* wr = (const f32x4*)(wfc + (size_t)(m * 64 + lane) * 20);
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const f32x4 w4 = wr[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[4 * q + e] = fmaf(a, w4[e], o[4 * q + e]);
+            }
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < 20; ++j) {
+            const float v = wave_sum(o[j]);
+            if (lane == j) mine = v;
+        }
+        if (lane < 20) feat20[(size_t)(p0 + wave) * 20 + lane] = mine + cw[CNNS_FC_B + lane];
+    }
+}
+
+extern "C" int nisqa_cnn_standard_bf16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                                       const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                                       int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
+                                       const uint16_t* cnn_wb, float* feat20, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat20)
+        return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(cnn_std_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), SS_LDS, (hipStream_t)stream, mel_tm,
+                       frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_std_w, cnn_wb, feat20);
+    return NQ_LAUNCH_STATUS();
+}

@@ -1,0 +1,102 @@
+// Split-bf16 ("bf16x3") building blocks shared by the AdaptCNN and StandardCNN kernels: MFMA wrappers, the
+// compiler-visible fp32 -> bf16 split, and the barrier-free 3x3 conv layer over wave-private LDS activations.
+#pragma once
+#include "common.hpp"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+NQ_DEV f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+NQ_DEV f32x4 mfma_bf16x16(f32x4 a, f32x4 b, f32x4 c) {     // 16x16x32: A[i = l&15][k = 8*(l>>4)+e], D row 4*(l>>4)+r
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// round-to-nearest-even fp32 -> bf16 (finite inputs)
+NQ_DEV unsigned bf16_bits(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+NQ_DEV float bf16_val(unsigned b) { return __uint_as_float(b << 16); }
+
+// fp32 -> bf16 (round to nearest even), two values per instruction: the compiler selects v_cvt_pk_bf16_f32 for
+// this conversion, and -- unlike an inline-asm statement -- tracks its hazards and schedules around it
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+NQ_DEV unsigned cvt_pk_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// store v = hi + lo into the two bf16 planes at byte offset `off` of the hi plane
+NQ_DEV void store_split(char* plane_hi, int plane_bytes, int off, float v) {
+    const unsigned hi = cvt_pk_bf16(v, 0.f);
+    const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
+    *(unsigned short*)(plane_hi + off) = (unsigned short)hi;
+    *(unsigned short*)(plane_hi + plane_bytes + off) = (unsigned short)lo;
+}
+
+// One conv layer (3x3, padding 1) for this wave's segment, barrier-free.
+//   act_in : this wave's input planes (hi at +0, lo at +PLANE), pixel rows of CIN bf16, swizzled chunks
+//   wb     : layer fragments [TOTAL steps][NT][2][64][8] bf16, streamed from L2: one contiguous 1 KiB
+//            global_load_dwordx4 per fragment, requested TWO K-steps ahead into a 3-deep register ring
+//            (an L2 round trip is ~600 clk, a step of MFMAs 200-800 clk); ~10 TB/s of L2 reads chip-wide
+//   APF    : also double-buffer the A rows from LDS one step ahead (off for conv2: 6 M-tiles of registers)
+template <int CIN, int MT, int NT, int H, int W, bool APF>
+NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* zero,
+                         const unsigned short* __restrict__ wb, const int (&py)[MT], const int (&px)[MT],
+                         const bool (&pvalid)[MT], int lane) {
+    constexpr int S16 = CIN / 16;             // K=16 steps per tap
+    constexpr int TOTAL = 9 * S16;
+    constexpr int Cc = CIN / 8;               // 16-byte chunks per pixel row (per plane)
+    constexpr int PLANE = H * W * CIN * 2;    // bytes per plane
+    constexpr int AB = APF ? 2 : 1;
+    const int h = lane >> 5;
+    const f32x4* wl = (const f32x4*)wb + lane;
+    f32x4 bh[3][NT], bl[3][NT], ah[AB][MT], al[AB][MT];
+
+    auto load_b = [&](int g, int slot) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bh[slot][nt] = wl[((g * NT + nt) * 2 + 0) * 64];
+            bl[slot][nt] = wl[((g * NT + nt) * 2 + 1) * 64];
+        }
+    };
+    auto load_a = [&](int g, int slot) {
+        const int tap = g / S16, s = g - tap * S16;
+        const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const int y = py[t] + dy, x = px[t] + dx;
+            const bool ok = pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const int pix = y * W + x;
+            const int swz = ((pix * Cc) >> 4) & (Cc - 1);
+            const char* ph = ok ? act_in + pix * (CIN * 2) + (((2 * s + h) ^ swz) << 4) : zero;
+            ah[slot][t] = *(const f32x4*)ph;
+            al[slot][t] = *(const f32x4*)(ok ? ph + PLANE : zero);
+        }
+    };
+
+    load_b(0, 0);
+    load_b(1, 1);
+    if (APF) load_a(0, 0);
+#pragma unroll
+    for (int g = 0; g < TOTAL; ++g) {
+        if (g + 2 < TOTAL) load_b(g + 2, (g + 2) % 3);
+        if (APF) { if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1); } else load_a(g, 0);
+        const int sa = APF ? (g & 1) : 0, sb = g % 3;
+        // product-major: consecutive MFMAs go to DIFFERENT accumulators (no dependent-accumulate bubbles)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bl[sb][nt], acc[t][nt]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(al[sa][t], bh[sb][nt], acc[t][nt]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bh[sb][nt], acc[t][nt]);
+
+    }
+}
+

@@ -124,22 +124,23 @@ class HipNisqa(object):
         self.max_segments = a['ms_max_segments']
         self.dim = a['model'] == 'NISQA_DIM'
         up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        self.precision = precision or os.environ.get('NISQA_HIP_PRECISION', 'bf16x3')
+        if self.precision not in ('f32', 'bf16x3'):
+            raise ValueError('precision must be f32 or bf16x3, got {}'.format(self.precision))
         if self.arch == 1:
-            # StandardCNN + BiLSTM + last-step pooling: exact fp32 kernels only
-            self.precision, self.n_layers, self.n_heads = 'f32', 0, 1
+            # StandardCNN (split-bf16 or exact-fp32 MFMA) + BiLSTM + last-step pooling (fp32 VALU)
+            self.n_layers, self.n_heads = 0, 1
             self.cnn_w = up(_w.pack_standard_cnn(state_dict))
             self.td_w = up(_w.pack_lstm_laststep(state_dict))
             self.pool_w = torch.zeros(4, dtype=torch.float32, device=self.device)
-            self.cnn_wb = self.td_wb = self.pool_wb = None
+            self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict).view(np.int16)) if self.precision == 'bf16x3' else None
+            self.td_wb = self.pool_wb = None
             self._mel = {}
             self._ws = {}
             return
         self.n_layers = int(a['td_sa_num_layers'])
         heads = ['pool_layers.%d.model.' % h for h in range(5)] if self.dim else ['pool.model.']
         self.n_heads = len(heads)
-        self.precision = precision or os.environ.get('NISQA_HIP_PRECISION', 'bf16x3')
-        if self.precision not in ('f32', 'bf16x3'):
-            raise ValueError('precision must be f32 or bf16x3, got {}'.format(self.precision))
         self.cnn_w = up(_w.pack_adapt_cnn(state_dict))
         bf = self.precision == 'bf16x3'
         self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict).view(np.int16)) if bf else None
@@ -270,8 +271,14 @@ class HipNisqa(object):
     def cnn_std(self, mel_tm, clip_floor, plan):
         """StandardCNN + fc_out -> feat20 [NP, 20]"""
         d = plan.to(self.device)
-        p3 = torch.empty((plan.total_tok, 12, 64), dtype=torch.float32, device=self.device)
         feat = torch.zeros((plan.total_tok, 20), dtype=torch.float32, device=self.device)
+        if self.precision == 'bf16x3':
+            _lib.check(self.lib.nisqa_cnn_standard_bf16(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']),
+                                                        _ptr(d['n_wins']), _ptr(clip_floor), plan.n_clips, plan.total_tok,
+                                                        self.seg_hop, _ptr(self.cnn_w), _ptr(self.cnn_wb), _ptr(feat),
+                                                        self._stream()), 'nisqa_cnn_standard_bf16')
+            return feat
+        p3 = torch.empty((plan.total_tok, 12, 64), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.nisqa_cnn_standard(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']),
                                                _ptr(clip_floor), plan.n_clips, plan.total_tok, self.seg_hop,
                                                _ptr(self.cnn_w), _ptr(p3), _ptr(feat), self._stream()), 'nisqa_cnn_standard')

@@ -26,14 +26,19 @@ def import_reference_lib():
     if not reference_available():
         raise ImportError('reference tree not present at ' + REFERENCE_ROOT)
     sys.dont_write_bytecode = True            # keep /root/reference clean
-    if 'librosa' not in sys.modules:
+    standin = 'librosa' not in sys.modules
+    if standin:
         sys.modules['librosa'] = types.ModuleType('librosa')   # the stand-in
     import matplotlib
     matplotlib.use('Agg')
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     import importlib
-    return importlib.import_module('nisqa.NISQA_lib')
+    try:
+        return importlib.import_module('nisqa.NISQA_lib')
+    finally:
+        if standin:                            # the reference keeps its own `lb`; nobody else should see the stand-in
+            del sys.modules['librosa']
 
 
 MODEL_ARG_KEYS = [

@@ -301,8 +301,9 @@ def test_inner_operator_forward_on_segment_tensors(eng_rand, batch):
 TTS_CLIPS = [0, 3, 4, 5, 6, 1]            # indices into CLIPS, same set as tests/golden/net_tts_*.npz
 
 
+@pytest.mark.parametrize('precision', PRECISIONS)
 @pytest.mark.parametrize('name', ['tts_rand', 'tts_real'])
-def test_tts_architecture_stages_and_fixture(name):
+def test_tts_architecture_stages_and_fixture(name, precision):
     g = helpers.golden('net_%s.npz' % name)
     if name == 'tts_real':
         path = helpers.find_weights('nisqa_tts.tar')
@@ -311,8 +312,8 @@ def test_tts_architecture_stages_and_fixture(name):
         args, sd = helpers.load_checkpoint(path)
     else:
         args, sd = dict(helpers.TTS_ARGS), helpers.random_state_dict(9, 'NISQA_TTS')
-    eng = _engine(args, sd)
-    assert eng.arch == 1 and eng.seg_hop == 1
+    eng = _engine(args, sd, precision)
+    assert eng.arch == 1 and eng.seg_hop == 1 and eng.precision == precision
     pcm = [clip_pcm(i) for i in TTS_CLIPS]
     dev_pcm, plan = _upload(eng, pcm)
     assert list(plan.n_wins) == list(g['n_wins'])
@@ -335,8 +336,8 @@ def test_tts_architecture_stages_and_fixture(name):
         worst['td'] = max(worst['td'], np.abs(seq_h[t0:t0 + nw] - st['td']).max())
         worst['out'] = max(worst['out'], np.abs(out_h[n] - ref_out).max(), np.abs(outs_h[n] - ref_out).max())
     err_fix = np.abs(out_h - g['out']).max()
-    print(name, 'stage max|d|', worst, 'vs reference fixture', err_fix)
-    assert worst['mel'] < 2e-3 and worst['feat'] < 2e-4 and worst['td'] < 2e-4
+    print(name, precision, 'stage max|d|', worst, 'vs reference fixture', err_fix)
+    assert worst['mel'] < 2e-3 and worst['feat'] < TOL[precision][0] and worst['td'] < TOL[precision][0]
     assert worst['out'] < 1e-3 and err_fix < 1e-3
 
 
