@@ -11,7 +11,6 @@ Out of scope here (raise NotImplementedError): training, evaluation metrics, NIS
 alternative blocks no shipped checkpoint uses.
 """
 import os
-from concurrent.futures import ThreadPoolExecutor
 from contextlib import nullcontext as _nullcontext
 
 import numpy as np
@@ -20,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import dist as _dist
+from . import ingest as _ingest
 from .wavio import read_wav
 
 
@@ -268,62 +268,51 @@ def _predict(model, ds, bs, dev, num_workers):
         raise RuntimeError('nisqa_amd has no CPU path: device {} requested but the hot path runs only as HIP kernels '
                            'on an MI355X'.format(dev))
     eng = model.engine(dev if dev.index is not None else None)
-    pin = eng.device.type == 'cuda'
+    on_gpu = eng.device.type == 'cuda'
     n = len(ds)
     lo, hi = _dist.shard_range(n)
     bs = max(1, int(bs))
     heads = eng.n_heads
     y_local = np.zeros((hi - lo, heads), dtype=np.float32)
-    pool = ThreadPoolExecutor(max_workers=max(1, int(num_workers))) if num_workers and num_workers > 0 else None
+    batches = [list(range(s, min(s + bs, hi))) for s in range(lo, hi, bs)]
+    # host side (ingest.py): a producer thread + num_workers readers stage batches two ahead in page-locked buffers;
+    # device side: two HIP streams, the H2D copy + forward of batch i+1 are enqueued while batch i is still running,
+    # and the D2H of batch i's [B, heads] rows is waited for one batch late (no device-wide sync in the loop)
+    ing = _ingest.Ingest(ds, batches, pin=on_gpu, num_workers=num_workers)
+    streams = [torch.cuda.Stream(device=eng.device) for _ in range(2)] if on_gpu else [None, None]
+    inflight = []                                                   # (ids, out tensor, stream)
+
+    def drain(keep):
+        while len(inflight) > keep:
+            ids, out, st = inflight.pop(0)
+            if st is not None:
+                st.synchronize()
+            y_local[np.asarray(ids) - lo] = out.cpu().numpy()
+
     try:
-        def load_batch(s):
-            idx = list(range(s, min(s + bs, hi)))
-            items = list(pool.map(ds.load_audio, idx)) if pool else [ds.load_audio(i) for i in idx]
-            return idx, items
-
-        starts = list(range(lo, hi, bs))
-        nxt = load_batch(starts[0]) if starts else None
-        # two HIP streams: the H2D copy + forward of batch i+1 are enqueued while batch i is still running, and the
-        # D2H of batch i's [B, heads] rows is waited for one batch late (no device-wide sync in the loop)
-        use_streams = eng.device.type == 'cuda'
-        streams = [torch.cuda.Stream(device=eng.device) for _ in range(2)] if use_streams else [None, None]
-        inflight = []                                               # (ids, out tensor, stream)
-
-        def drain(keep):
-            while len(inflight) > keep:
-                ids, out, st = inflight.pop(0)
-                if st is not None:
-                    st.synchronize()
-                y_local[np.asarray(ids) - lo] = out.cpu().numpy()
-
-        for bi, s in enumerate(starts):
-            idx, items = nxt
-            fut = None
-            if bi + 1 < len(starts) and pool is not None:          # overlap ingest of the next batch
-                fut = pool.submit(load_batch, starts[bi + 1])
-            by_sr = {}
-            for i, (y, sr) in zip(idx, items):
-                by_sr.setdefault(sr, []).append((i, y))
+        for bi, staged in enumerate(ing):
             st = streams[bi % 2]
+            raw = ing.ring.buf[staged.slot]
             ctx = torch.cuda.stream(st) if st is not None else _nullcontext()
-            with ctx:
-                for sr, grp in by_sr.items():                      # files of one rate share the mel tables
-                    plan = eng.plan([len(y) for _, y in grp], sr, names=[ds.file_path(i) for i, _ in grp])
-                    if all(y.dtype == np.int16 for _, y in grp):
-                        host = torch.from_numpy(np.concatenate([y for _, y in grp]))
-                        pcm = eng.pcm16_to_f32((host.pin_memory() if pin else host).to(eng.device, non_blocking=True))
-                    else:
-                        host = torch.from_numpy(np.concatenate(
-                            [y.astype(np.float32) / np.float32(32768.0) if y.dtype == np.int16 else y for _, y in grp]))
-                        pcm = (host.pin_memory() if pin else host).to(eng.device, non_blocking=True)
-                    inflight.append(([i for i, _ in grp], eng.forward_pcm(pcm, plan, sr), st))
-            drain(keep=len(by_sr))                                  # results of the previous batch
-            if bi + 1 < len(starts):
-                nxt = fut.result() if fut is not None else load_batch(starts[bi + 1])
+            try:
+                with ctx:
+                    for g in staged.groups:                          # files of one rate share the mel tables
+                        plan = eng.plan(g.lengths, g.sr, names=[ds.file_path(i) for i in g.ids])
+                        host = raw[g.offset:g.offset + g.nbytes].view(torch.int16 if g.is_i16 else torch.float32)
+                        pcm = host.to(eng.device, non_blocking=True)
+                        if g.is_i16:
+                            pcm = eng.pcm16_to_f32(pcm)              # 2 bytes/sample cross PCIe, scaled on the GPU
+                        inflight.append((g.ids, eng.forward_pcm(pcm, plan, g.sr), st))
+            finally:
+                ev = None
+                if st is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                ing.ring.release_after(staged.slot, ev)
+            drain(keep=len(staged.groups))                           # results of the previous batch
         drain(keep=0)
     finally:
-        if pool is not None:
-            pool.shutdown(wait=True)
+        ing.close()
     return _dist.gather_rows(y_local, n, lo, hi, dev)
 
 

@@ -1,0 +1,212 @@
+// libnisqa_ingest.so -- native WAV ingest for the predict loop (include/nisqa_ingest.h).
+//
+// Replaces the per-file lb.load of the reference's DataLoader workers (nisqa/NISQA_lib.py:2299-2306) for RIFF/WAVE
+// input.  A persistent pool of threads walks the RIFF chunks of a whole batch (probe) and then pread()s every data
+// chunk straight into the caller's staging buffer (read): one host copy per sample -- page cache -> page-locked
+// memory -- with no interpreter in the loop.  Decoding of the sample format is NOT done here: mono PCM16 goes to
+// the GPU verbatim (nisqa_pcm16_to_f32 scales it there); everything else is decoded by the host mirror
+// (nisqa_amd/wavio.py) with lb.load's semantics.
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <fcntl.h>
+#include <functional>
+#include <mutex>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
+#include <vector>
+
+#include "../../include/nisqa_ingest.h"
+
+namespace {
+
+// ---- a small persistent pool: run(job, n) executes job(i) for i in [0, n) on up to `want` threads + the caller ----
+class Pool {
+public:
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    template <class F>
+    void run(int n, int want, F&& job) {
+        std::lock_guard<std::mutex> serial(run_m_);              // one batch at a time
+        if (n <= 0) return;
+        int helpers = want - 1;
+        if (helpers > n - 1) helpers = n - 1;
+        grow(helpers);
+        std::function<void(int)> fn = job;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = &fn;
+            next_.store(0);
+            n_ = n;
+            active_ = helpers;
+            allowed_ = helpers;
+            ++epoch_;
+        }
+        if (helpers > 0) cv_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(m_);
+        done_cv_.wait(g, [&] { return active_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void grow(int helpers) {
+        while ((int)threads_.size() < helpers) {
+            const int id = (int)threads_.size();
+            threads_.emplace_back([this, id] { loop(id); });
+        }
+    }
+    void work() {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= n_) break;
+            (*fn_)(i);
+        }
+    }
+    void loop(int id) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                cv_.wait(g, [&] { return quit_ || (epoch_ != seen && id < allowed_); });
+                if (quit_) return;
+                seen = epoch_;
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> g(m_);
+                if (--active_ == 0) done_cv_.notify_one();
+            }
+        }
+    }
+    std::mutex m_, run_m_;
+    std::condition_variable cv_, done_cv_;
+    std::vector<std::thread> threads_;
+    std::function<void(int)>* fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int n_ = 0, active_ = 0, allowed_ = 0;
+    uint64_t epoch_ = 0;
+    bool quit_ = false;
+};
+
+Pool& pool() {
+    static Pool* p = new Pool();                                   // leaked on purpose: no join at process exit
+    return *p;
+}
+
+int thread_count(int requested) {
+    if (requested > 0) return requested > 256 ? 256 : requested;
+    long c = sysconf(_SC_NPROCESSORS_ONLN);
+    if (c < 1) c = 1;
+    return c > 64 ? 64 : (int)c;
+}
+
+inline uint32_t le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint32_t le16(const unsigned char* p) { return p[0] | (p[1] << 8); }
+
+bool pread_full(int fd, void* dst, size_t want, off_t at) {
+    char* d = (char*)dst;
+    while (want > 0) {
+        const ssize_t r = pread(fd, d, want, at);
+        if (r <= 0) return false;
+        d += r;
+        at += r;
+        want -= (size_t)r;
+    }
+    return true;
+}
+
+// Walk the RIFF chunks like soundfile/libsndfile does for the cases lb.load meets: 'fmt ' (PCM, IEEE float,
+// WAVE_FORMAT_EXTENSIBLE with the sub-format in the GUID's first two bytes) then 'data'; other chunks are skipped
+// (word-aligned); a data size of 0xFFFFFFFF or one that overruns the file means "to end of file".
+void probe_one(const char* path, nisqa_wav_info* out) {
+    std::memset(out, 0, sizeof(*out));
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) { out->status = NISQA_WAV_ERR_OPEN; return; }
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); out->status = NISQA_WAV_ERR_OPEN; return; }
+    const int64_t fsize = sb.st_size;
+    unsigned char head[4096];
+    const ssize_t got = pread(fd, head, sizeof(head), 0);
+    out->status = NISQA_WAV_ERR_FORMAT;
+    if (got >= 12 && (!std::memcmp(head, "RIFF", 4) || !std::memcmp(head, "RF64", 4)) && !std::memcmp(head + 8, "WAVE", 4)) {
+        int64_t pos = 12;
+        bool have_fmt = false;
+        while (pos + 8 <= fsize) {
+            unsigned char hb[8];
+            const unsigned char* h = hb;
+            if (pos + 8 <= got) h = head + pos;
+            else if (!pread_full(fd, hb, 8, pos)) break;
+            const uint32_t size = le32(h + 4);
+            const int64_t body = pos + 8;
+            if (!std::memcmp(h, "fmt ", 4)) {
+                unsigned char fb[26] = {0};
+                const size_t need = size >= 26 ? 26 : 16;
+                if (size < 16) break;
+                if (body + (int64_t)need <= got) std::memcpy(fb, head + body, need);
+                else if (!pread_full(fd, fb, need, body)) break;
+                int tag = (int)le16(fb);
+                out->channels = (int)le16(fb + 2);
+                out->sample_rate = (int32_t)le32(fb + 4);
+                out->block_align = (int)le16(fb + 12);
+                out->bits = (int)le16(fb + 14);
+                if (tag == 0xFFFE && size >= 26) tag = (int)le16(fb + 24);
+                out->tag = tag;
+                have_fmt = true;
+            } else if (!std::memcmp(h, "data", 4)) {
+                if (!have_fmt) break;
+                int64_t dsize = size;
+                if (size == 0xFFFFFFFFu || body + dsize > fsize) dsize = fsize - body;
+                const int bytes = (out->bits + 7) / 8;
+                const bool enc_ok = (out->tag == NISQA_WAV_TAG_PCM && (out->bits == 8 || out->bits == 16 || out->bits == 24 || out->bits == 32)) ||
+                                    (out->tag == NISQA_WAV_TAG_FLOAT && (out->bits == 32 || out->bits == 64));
+                if (out->channels < 1 || out->block_align != out->channels * bytes || !enc_ok) break;
+                out->data_offset = body;
+                out->n_frames = dsize / out->block_align;
+                out->status = NISQA_WAV_OK;
+                break;
+            }
+            pos = body + (int64_t)size + (size & 1);
+        }
+    }
+    close(fd);
+}
+
+void read_one(const char* path, nisqa_wav_info* info, char* dst) {
+    if (info->status != NISQA_WAV_OK) return;
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) { info->status = NISQA_WAV_ERR_OPEN; return; }
+    const size_t want = (size_t)info->n_frames * (size_t)info->block_align;
+    if (!pread_full(fd, dst, want, (off_t)info->data_offset)) info->status = NISQA_WAV_ERR_READ;
+    close(fd);
+}
+
+}  // namespace
+
+extern "C" int nisqa_ingest_abi_version(void) { return NISQA_INGEST_ABI_VERSION; }
+
+extern "C" int nisqa_ingest_probe(const char* const* paths, int32_t n, nisqa_wav_info* info, int32_t n_threads) {
+    if (n < 0 || (n > 0 && (!paths || !info))) return -1;
+    pool().run(n, thread_count(n_threads), [&](int i) { probe_one(paths[i], info + i); });
+    int bad = 0;
+    for (int i = 0; i < n; ++i) bad += info[i].status != NISQA_WAV_OK;
+    return bad;
+}
+
+extern "C" int nisqa_ingest_read(const char* const* paths, int32_t n, nisqa_wav_info* info, void* dst,
+                                 const int64_t* dst_off, int32_t n_threads) {
+    if (n < 0 || (n > 0 && (!paths || !info || !dst || !dst_off))) return -1;
+    pool().run(n, thread_count(n_threads), [&](int i) {
+        if (dst_off[i] >= 0) read_one(paths[i], info + i, (char*)dst + dst_off[i]);
+    });
+    int bad = 0;
+    for (int i = 0; i < n; ++i) bad += dst_off[i] >= 0 && info[i].status != NISQA_WAV_OK;
+    return bad;
+}

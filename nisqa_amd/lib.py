@@ -87,6 +87,48 @@ def load():
     return lib
 
 
+# ---- libnisqa_ingest.so (include/nisqa_ingest.h): native WAV ingest, plain C++ -- loadable without a GPU ----------
+INGEST_PATH = os.path.join(_HERE, 'libnisqa_ingest.so')
+INGEST_ABI_VERSION = 1
+WAV_OK, WAV_ERR_OPEN, WAV_ERR_FORMAT, WAV_ERR_READ = 0, 1, 2, 3
+
+
+class WavInfo(ctypes.Structure):
+    """nisqa_wav_info"""
+    _fields_ = [('status', c_i32), ('tag', c_i32), ('channels', c_i32), ('bits', c_i32), ('block_align', c_i32),
+                ('sample_rate', c_i32), ('data_offset', c_i64), ('n_frames', c_i64)]
+
+
+INGEST_SYMBOLS = {
+    'nisqa_ingest_abi_version': (ctypes.c_int, []),
+    'nisqa_ingest_probe': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), c_i32, ctypes.POINTER(WavInfo), c_i32]),
+    'nisqa_ingest_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), c_i32, ctypes.POINTER(WavInfo), c_p,
+                                         ctypes.POINTER(c_i64), c_i32]),
+}
+
+_ingest = None
+
+
+def load_ingest():
+    """Load (once) and return libnisqa_ingest.so with typed entry points; raises if it has not been built."""
+    global _ingest
+    if _ingest is not None:
+        return _ingest
+    if not os.path.isfile(INGEST_PATH):
+        raise RuntimeError('nisqa_amd: native ingest library not built: %s is missing (run __graft_entry__.build() '
+                           'or `make -C nisqa_amd/csrc`)' % INGEST_PATH)
+    lib = ctypes.CDLL(INGEST_PATH)
+    for name, (res, args) in INGEST_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.nisqa_ingest_abi_version() != INGEST_ABI_VERSION:
+        raise RuntimeError('nisqa_amd: libnisqa_ingest.so ABI %d != expected %d'
+                           % (lib.nisqa_ingest_abi_version(), INGEST_ABI_VERSION))
+    _ingest = lib
+    return lib
+
+
 class NisqaHipError(RuntimeError):
     pass
 

@@ -7,6 +7,7 @@ soundfile semantics: integer PCM -> float32 scaled by 1/2**(bits-1) (8-bit is un
 Mono PCM16 -- the common case -- is returned as int16 so that only 2 bytes/sample cross PCIe; the
 1/32768 scaling then happens on the GPU (nisqa_pcm16_to_f32), bit-identical to the host scaling.
 """
+import os
 import struct
 
 import numpy as np
@@ -14,66 +15,136 @@ import numpy as np
 _PCM, _FLOAT, _EXT = 1, 3, 0xFFFE
 
 
-def _parse(path):
-    with open(path, 'rb') as f:
-        raw = f.read()
-    if len(raw) < 12 or raw[0:4] not in (b'RIFF', b'RF64') or raw[8:12] != b'WAVE':
+class Header(object):
+    """An opened WAV file whose RIFF chunks have been walked: format fields, position and frame count of the data
+    chunk.  ``fast`` marks mono PCM16, whose data chunk can be copied verbatim (2 bytes/sample cross PCIe)."""
+    __slots__ = ('path', 'fd', 'tag', 'ch', 'sr', 'blk', 'bits', 'data_off', 'n', 'fast', 'ms_channel')
+
+    def close(self):
+        if self.fd is not None:
+            os.close(self.fd)
+            self.fd = None
+
+
+def _walk(fd):
+    size_file = os.fstat(fd).st_size
+    head = os.pread(fd, 4096, 0)
+    if len(head) < 12 or head[0:4] not in (b'RIFF', b'RF64') or head[8:12] != b'WAVE':
         raise ValueError('not a RIFF/WAVE file')
-    pos, fmt, data = 12, None, None
-    while pos + 8 <= len(raw):
-        cid, size = raw[pos:pos + 4], struct.unpack('<I', raw[pos + 4:pos + 8])[0]
+    pos, fmt = 12, None
+    while pos + 8 <= size_file:
+        hdr = head[pos:pos + 8] if pos + 8 <= len(head) else os.pread(fd, 8, pos)
+        if len(hdr) < 8:
+            break
+        cid, size = hdr[0:4], struct.unpack('<I', hdr[4:8])[0]
         body = pos + 8
         if cid == b'fmt ':
-            tag, ch, sr, _, blk, bits = struct.unpack('<HHIIHH', raw[body:body + 16])
+            raw = head[body:body + 26] if body + 26 <= len(head) else os.pread(fd, 26, body)
+            tag, ch, sr, _, blk, bits = struct.unpack('<HHIIHH', raw[:16])
             if tag == _EXT and size >= 26:
-                tag = struct.unpack('<H', raw[body + 24:body + 26])[0]
+                tag = struct.unpack('<H', raw[24:26])[0]
             fmt = (tag, ch, sr, blk, bits)
         elif cid == b'data':
-            if size == 0xFFFFFFFF or body + size > len(raw):
-                size = len(raw) - body
-            data = raw[body:body + size]
-            break
+            if size == 0xFFFFFFFF or body + size > size_file:
+                size = size_file - body
+            if fmt is None:
+                break
+            return fmt, body, size
         pos = body + size + (size & 1)
-    if fmt is None or data is None:
-        raise ValueError('missing fmt/data chunk')
-    return fmt, data
+    raise ValueError('missing fmt/data chunk')
+
+
+def probe(path, ms_channel=None):
+    """Open ``path`` and parse its header -> Header (caller closes).  Raises the reference's load error."""
+    fd = None
+    try:
+        fd = os.open(path, os.O_RDONLY)
+        (tag, ch, sr, blk, bits), off, size = _walk(fd)
+        if ch < 1 or blk != ch * ((bits + 7) // 8):
+            raise ValueError('bad block align')
+        if not ((tag == _PCM and bits in (8, 16, 24, 32)) or (tag == _FLOAT and bits in (32, 64))):
+            raise ValueError('unsupported WAV encoding tag={} bits={}'.format(tag, bits))
+        h = Header()
+        h.path, h.fd, h.tag, h.ch, h.sr, h.blk, h.bits = path, fd, tag, ch, int(sr), blk, bits
+        h.data_off, h.n, h.ms_channel = off, size // blk, ms_channel
+        h.fast = tag == _PCM and bits == 16 and ch == 1
+        return h
+    except Exception:
+        if fd is not None:
+            os.close(fd)
+        raise ValueError('Could not load file {}'.format(path))      # NISQA_lib.py:2305-2306
+
+
+def read_data_into(h, out):
+    """Copy the data chunk of ``h`` (h.n * h.blk bytes) into the writable buffer ``out`` with preadv."""
+    try:
+        mv = memoryview(out).cast('B')
+        want, got = h.n * h.blk, 0
+        if len(mv) != want:
+            raise ValueError('staging slice has the wrong size')
+        while got < want:
+            r = os.preadv(h.fd, [mv[got:]], h.data_off + got)
+            if r <= 0:
+                raise ValueError('short read')
+            got += r
+    except Exception:
+        raise ValueError('Could not load file {}'.format(h.path))
+
+
+def _decode(h, data):
+    """bytes of the data chunk -> int16 [n] (mono PCM16) or float32 [n], with lb.load's semantics."""
+    tag, ch, bits, n = h.tag, h.ch, h.bits, h.n
+    if tag == _PCM and bits == 16:
+        x = np.frombuffer(data, dtype='<i2').reshape(n, ch)
+        if ch == 1:
+            return x[:, 0]
+        y = x.astype(np.float32) / np.float32(32768.0)
+    elif tag == _PCM and bits == 8:
+        y = (np.frombuffer(data, dtype=np.uint8).reshape(n, ch).astype(np.float32) - np.float32(128.0)) \
+            / np.float32(128.0)
+    elif tag == _PCM and bits == 24:
+        b = np.frombuffer(data, dtype=np.uint8).reshape(n, ch, 3).astype(np.int32)
+        v = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16)
+        v = np.where(v >= (1 << 23), v - (1 << 24), v)
+        y = (v.astype(np.float64) / 8388608.0).astype(np.float32)
+    elif tag == _PCM and bits == 32:
+        y = (np.frombuffer(data, dtype='<i4').reshape(n, ch).astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif tag == _FLOAT and bits == 32:
+        y = np.frombuffer(data, dtype='<f4').reshape(n, ch).astype(np.float32)
+    else:
+        y = np.frombuffer(data, dtype='<f8').reshape(n, ch).astype(np.float32)
+    if ch == 1:
+        y = y[:, 0]
+    elif h.ms_channel is not None:
+        y = y[:, h.ms_channel]                     # NISQA_lib.py:2300-2302
+    else:
+        y = np.mean(y.T, axis=0, dtype=np.float32)  # librosa.to_mono
+    return np.ascontiguousarray(y, dtype=np.float32)
+
+
+def _read_decoded(h):
+    data = bytearray(h.n * h.blk)
+    read_data_into(h, data)
+    return _decode(h, data)
+
+
+def decode_f32(h):
+    """float32 [h.n] samples of an opened file (any supported encoding)."""
+    try:
+        y = _read_decoded(h)
+        if y.dtype == np.int16:
+            y = y.astype(np.float32) / np.float32(32768.0)
+        return y
+    except Exception:
+        raise ValueError('Could not load file {}'.format(h.path))
 
 
 def read_wav(path, ms_channel=None):
     """-> (samples, sr); samples is int16 [n] (mono PCM16) or float32 [n]."""
+    h = probe(path, ms_channel)
     try:
-        (tag, ch, sr, blk, bits), data = _parse(path)
-        if ch < 1 or blk != ch * ((bits + 7) // 8):
-            raise ValueError('bad block align')
-        n = len(data) // blk
-        data = data[:n * blk]
-        if tag == _PCM and bits == 16:
-            x = np.frombuffer(data, dtype='<i2').reshape(n, ch)
-            if ch == 1:
-                return np.ascontiguousarray(x[:, 0]), int(sr)
-            y = x.astype(np.float32) / np.float32(32768.0)
-        elif tag == _PCM and bits == 8:
-            y = (np.frombuffer(data, dtype=np.uint8).reshape(n, ch).astype(np.float32) - np.float32(128.0)) \
-                / np.float32(128.0)
-        elif tag == _PCM and bits == 24:
-            b = np.frombuffer(data, dtype=np.uint8).reshape(n, ch, 3).astype(np.int32)
-            v = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16)
-            v = np.where(v >= (1 << 23), v - (1 << 24), v)
-            y = (v.astype(np.float64) / 8388608.0).astype(np.float32)
-        elif tag == _PCM and bits == 32:
-            y = (np.frombuffer(data, dtype='<i4').reshape(n, ch).astype(np.float64) / 2147483648.0).astype(np.float32)
-        elif tag == _FLOAT and bits == 32:
-            y = np.frombuffer(data, dtype='<f4').reshape(n, ch).astype(np.float32)
-        elif tag == _FLOAT and bits == 64:
-            y = np.frombuffer(data, dtype='<f8').reshape(n, ch).astype(np.float32)
-        else:
-            raise ValueError('unsupported WAV encoding tag={} bits={}'.format(tag, bits))
-        if ch == 1:
-            y = y[:, 0]
-        elif ms_channel is not None:
-            y = y[:, ms_channel]                       # NISQA_lib.py:2300-2302
-        else:
-            y = np.mean(y.T, axis=0, dtype=np.float32)  # librosa.to_mono
-        return np.ascontiguousarray(y, dtype=np.float32), int(sr)
+        return np.ascontiguousarray(_read_decoded(h)), h.sr
     except Exception:
         raise ValueError('Could not load file {}'.format(path))      # NISQA_lib.py:2305-2306
+    finally:
+        h.close()

@@ -1,6 +1,7 @@
 """CPU tests of the host side: packed layouts vs the device header, plan arithmetic, WAV ingest vs the
 oracle's decoder, the C-ABI library (loads, exports every declared symbol -- no compute without a GPU),
 the nisqaModel / run_predict plumbing, and the clip-sharded predict loop under gloo (world_size 2)."""
+import ctypes
 import os
 import re
 import subprocess
@@ -179,6 +180,167 @@ def test_wav_24bit_and_errors(tmp_path):
         wavio.read_wav(str(bad))
     with pytest.raises(ValueError, match='Could not load file'):
         wavio.read_wav(str(tmp_path / 'missing.wav'))
+
+
+# ---- native ingest (include/nisqa_ingest.h) and the staging iterator ------------------------------------------
+def _ingest_lib():
+    from nisqa_amd import lib
+    if not os.path.isfile(lib.INGEST_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return lib, lib.load_ingest()
+
+
+def test_ingest_library_exports_every_declared_symbol():
+    lib, L = _ingest_lib()
+    hdr = open(os.path.join(ROOT, 'include', 'nisqa_ingest.h')).read()
+    declared = set(re.findall(r'^\s*int\s+(nisqa_ingest_[a-z0-9_]+)\s*\(', hdr, re.M))
+    assert declared == set(lib.INGEST_SYMBOLS), declared ^ set(lib.INGEST_SYMBOLS)
+    out = subprocess.check_output(['nm', '-D', '--defined-only', lib.INGEST_PATH]).decode()
+    assert declared <= set(re.findall(r' T (nisqa_\w+)', out))
+    assert L.nisqa_ingest_abi_version() == 1 and ctypes.sizeof(lib.WavInfo) == 40
+
+
+def _riff(fmt_body, data, extra_before=b'', data_size=None, riff=b'RIFF'):
+    import struct
+    chunks = b'fmt ' + struct.pack('<I', len(fmt_body)) + fmt_body + extra_before \
+        + b'data' + struct.pack('<I', len(data) if data_size is None else data_size) + data
+    return riff + struct.pack('<I', 4 + len(chunks)) + b'WAVE' + chunks
+
+
+def test_native_probe_and_read_match_the_python_decoder(tmp_path):
+    import struct
+    lib, L = _ingest_lib()
+    files = _cases(tmp_path)
+    rng = np.random.default_rng(5)
+    pcm = (rng.standard_normal(3001) * 2000).astype(np.int16)
+    fmt16 = struct.pack('<HHIIHH', 1, 1, 32000, 64000, 2, 16)
+    odd = b'LIST' + struct.pack('<I', 5) + b'abcde' + b'\0'                  # odd-sized chunk + pad byte before data
+    big = b'junk' + struct.pack('<I', 6000) + bytes(6000)                     # pushes 'data' past the 4 KiB header read
+    ext = struct.pack('<HHIIHHHHIH', 0xFFFE, 1, 32000, 64000, 2, 16, 22, 16, 4, 1) + bytes(14)   # WAVE_FORMAT_EXTENSIBLE
+    special = {
+        'odd': _riff(fmt16, pcm.tobytes(), odd),
+        'far': _riff(fmt16, pcm.tobytes(), big),
+        'ext': _riff(ext, pcm.tobytes()),
+        'stream': _riff(fmt16, pcm.tobytes(), data_size=0xFFFFFFFF),          # size unknown: to end of file
+        'trunc': _riff(fmt16, pcm.tobytes()[:4001], data_size=len(pcm) * 2),  # data size overruns the file
+    }
+    for k, blob in special.items():
+        (tmp_path / (k + '.wav')).write_bytes(blob)
+        files[k] = str(tmp_path / (k + '.wav'))
+    names = sorted(files)
+    n = len(names)
+    paths = (ctypes.c_char_p * n)(*[os.fsencode(files[k]) for k in names])
+    infos = (lib.WavInfo * n)()
+    assert L.nisqa_ingest_probe(paths, n, infos, 4) == 0
+    off, total = [], 0
+    for i in range(n):
+        off.append(total)
+        total += infos[i].n_frames * infos[i].block_align
+    dst = np.zeros(total, np.uint8)
+    assert L.nisqa_ingest_read(paths, n, infos, dst.ctypes.data, (ctypes.c_int64 * n)(*off), 3) == 0
+    for i, k in enumerate(names):
+        h = wavio.probe(files[k])
+        try:
+            assert (infos[i].tag, infos[i].channels, infos[i].bits, infos[i].block_align, infos[i].sample_rate,
+                    infos[i].data_offset, infos[i].n_frames) == (h.tag, h.ch, h.bits, h.blk, h.sr, h.data_off, h.n), k
+            want = bytearray(h.n * h.blk)
+            wavio.read_data_into(h, want)
+        finally:
+            h.close()
+        assert dst[off[i]:off[i] + len(want)].tobytes() == bytes(want), k
+    for k in ('odd', 'far', 'ext', 'stream'):
+        y, sr = wavio.read_wav(files[k])
+        assert sr == 32000 and np.array_equal(y, pcm), k
+    assert len(wavio.read_wav(files['trunc'])[0]) == 2000
+
+
+def test_native_probe_reports_unusable_files(tmp_path):
+    import struct
+    lib, L = _ingest_lib()
+    fmt16 = struct.pack('<HHIIHH', 1, 1, 32000, 64000, 2, 16)
+    cases = {
+        'notriff': b'not a wav at all, just text',
+        'nodata': b'RIFF' + struct.pack('<I', 28) + b'WAVE' + b'fmt ' + struct.pack('<I', 16) + fmt16,
+        'badalign': _riff(struct.pack('<HHIIHH', 1, 2, 32000, 64000, 2, 16), bytes(64)),
+        'adpcm': _riff(struct.pack('<HHIIHH', 2, 1, 32000, 16000, 1, 4), bytes(64)),
+        'datafirst': b'RIFF' + struct.pack('<I', 20) + b'WAVE' + b'data' + struct.pack('<I', 8) + bytes(8),
+        'empty': b'',
+    }
+    names = sorted(cases) + ['missing']
+    for k, blob in cases.items():
+        (tmp_path / (k + '.wav')).write_bytes(blob)
+    n = len(names)
+    paths = (ctypes.c_char_p * n)(*[os.fsencode(str(tmp_path / (k + '.wav'))) for k in names])
+    infos = (lib.WavInfo * n)()
+    assert L.nisqa_ingest_probe(paths, n, infos, 2) == n
+    for i, k in enumerate(names):
+        assert infos[i].status == (lib.WAV_ERR_OPEN if k == 'missing' else lib.WAV_ERR_FORMAT), k
+        with pytest.raises(ValueError, match='Could not load file'):
+            wavio.read_wav(str(tmp_path / (k + '.wav')))
+    assert L.nisqa_ingest_probe(None, 0, None, 1) == 0 and L.nisqa_ingest_probe(None, 3, None, 1) == -1
+
+
+class _ListDataset(object):
+    ms_channel = None
+
+    def __init__(self, paths):
+        self.paths = paths
+
+    def file_path(self, i):
+        return self.paths[i]
+
+
+@pytest.mark.parametrize('workers', [0, 5])
+def test_staging_iterator_lays_batches_out_like_concatenated_read_wav(tmp_path, workers):
+    from nisqa_amd import ingest
+    files = _cases(tmp_path)
+    rng = np.random.default_rng(6)
+    paths = []
+    for i in range(11):                                            # mono PCM16 at two rates, ragged lengths
+        p = str(tmp_path / ('m%02d.wav' % i))
+        synth.write_wav(p, (rng.standard_normal(700 + 37 * i) * 1000).astype(np.int16), 48000 if i % 3 else 16000)
+        paths.append(p)
+    paths[4:4] = [files['st16'], files['f32'], files['u8']]         # 44.1 k stereo, 16 k float stereo, 22.05 k 8-bit
+    ds = _ListDataset(paths)
+    batches = [list(range(s, min(s + 4, len(paths)))) for s in range(0, len(paths), 4)] * 2   # slots are recycled
+    ing = ingest.Ingest(ds, batches, pin=False, num_workers=workers)
+    seen = []
+    try:
+        for staged in ing:
+            raw = ing.ring.buf[staged.slot]
+            got = []
+            for g in staged.groups:
+                host = raw[g.offset:g.offset + g.nbytes].view(torch.int16 if g.is_i16 else torch.float32).numpy()
+                ref = [wavio.read_wav(paths[i]) for i in g.ids]
+                assert all(sr == g.sr for _, sr in ref) and g.lengths == [len(y) for y, _ in ref]
+                assert g.is_i16 == all(y.dtype == np.int16 for y, _ in ref)
+                want = np.concatenate([y if g.is_i16 or y.dtype != np.int16 else y.astype(np.float32) / np.float32(32768.0)
+                                       for y, _ in ref])
+                np.testing.assert_array_equal(host, want)
+                got += g.ids
+            seen.append(sorted(got))
+            ing.ring.release_after(staged.slot, None)
+    finally:
+        ing.close()
+    assert seen == [sorted(b) for b in batches]
+
+
+def test_staging_iterator_surfaces_load_errors_in_order(tmp_path):
+    from nisqa_amd import ingest
+    good = str(tmp_path / 'g.wav')
+    synth.write_wav(good, np.zeros(500, np.int16), 48000)
+    ds = _ListDataset([good, good, str(tmp_path / 'gone.wav'), good])
+    ing = ingest.Ingest(ds, [[0, 1], [2, 3]], pin=False, num_workers=2)
+    try:
+        it = iter(ing)
+        first = next(it)
+        assert [g.ids for g in first.groups] == [[0, 1]]
+        ing.ring.release_after(first.slot, None)
+        with pytest.raises(ValueError, match='Could not load file .*gone.wav'):
+            next(it)
+    finally:
+        ing.close()
 
 
 # ---- C ABI ------------------------------------------------------------------------------------------------
