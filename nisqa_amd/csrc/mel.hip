@@ -26,12 +26,16 @@
 #include "common.hpp"
 #include "../../include/nisqa_hip.h"
 
-struct c32 { float x, y; };
-NQ_DEV c32 cmk(float x, float y) { c32 r; r.x = x; r.y = y; return r; }
-NQ_DEV c32 cadd(c32 a, c32 b) { return cmk(a.x + b.x, a.y + b.y); }
-NQ_DEV c32 csub(c32 a, c32 b) { return cmk(a.x - b.x, a.y - b.y); }
-NQ_DEV c32 cmul(c32 a, c32 b) { return cmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-NQ_DEV c32 cnegi(c32 a) { return cmk(a.y, -a.x); }     // a * (-i)
+// complex numbers as 64-bit register pairs: add / sub / multiply map onto v_pk_add_f32 / v_pk_mul_f32 /
+// v_pk_fma_f32 (two flops per lane and instruction; swaps and sign flips ride on op_sel / neg modifiers)
+typedef float c32 __attribute__((ext_vector_type(2)));
+NQ_DEV c32 cmk(float x, float y) { return c32{x, y}; }
+NQ_DEV c32 cadd(c32 a, c32 b) { return a + b; }
+NQ_DEV c32 csub(c32 a, c32 b) { return a - b; }
+NQ_DEV c32 cmul(c32 a, c32 b) {                        // (a.x b.x - a.y b.y, a.x b.y + a.y b.x)
+    return __builtin_elementwise_fma(c32{a.y, a.y}, c32{-b.y, b.x}, c32{a.x, a.x} * b);
+}
+NQ_DEV c32 cnegi(c32 a) { return c32{a.y, -a.x}; }     // a * (-i)
 
 NQ_DEV void dft4(c32& a0, c32& a1, c32& a2, c32& a3) {
     const c32 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cnegi(csub(a1, a3));
@@ -45,9 +49,9 @@ NQ_DEV void dft8(c32 (&v)[8]) {
     dft4(e0, e1, e2, e3);
     dft4(o0, o1, o2, o3);
     const float r = 0.70710678118654752440f;
-    o1 = cmk(r * (o1.x + o1.y), r * (o1.y - o1.x));      // * W8^1 = (r, -r)
+    o1 = (o1 + cnegi(o1)) * r;                            // * W8^1 = (r, -r):  r (x + y, y - x)
     o2 = cnegi(o2);                                       // * W8^2 = -i
-    o3 = cmk(r * (o3.y - o3.x), -r * (o3.x + o3.y));     // * W8^3 = (-r, -r)
+    o3 = (cnegi(o3) - o3) * r;                            // * W8^3 = (-r, -r): r (y - x, -x - y)
     v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
     v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
     v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
@@ -72,16 +76,17 @@ NQ_DEV float row16_sum(float v) {
     return v;
 }
 
-NQ_DEV c32 shfl_c(c32 v, int src) { return cmk(__shfl(v.x, src), __shfl(v.y, src)); }
+NQ_DEV c32 shfl_c(c32 v, int src) { return cmk(__shfl((float)v.x, src), __shfl((float)v.y, src)); }
 
 // |X[K]| for K = 4k + r from za = Z[K], zb = Z[2048-K], W4096^K = wl * wc (per-lane x constant part;
 // applied one after the other so that nothing loop-invariant can be hoisted into 64 extra registers)
 NQ_DEV float xmag(c32 za, c32 zb, c32 wl, c32 wc) {
-    const float ar = za.x + zb.x, ai = za.y - zb.y;     // Za + conj(Zb)
-    const c32 d = cmul(cmk(za.x - zb.x, za.y + zb.y), wl);   // (Za - conj(Zb)) * wl
-    const float wr = wc.x * d.x - wc.y * d.y, wi = wc.x * d.y + wc.y * d.x;
-    const float xr = 0.5f * (ar + wi), xi = 0.5f * (ai - wr);
-    return __builtin_amdgcn_sqrtf(xr * xr + xi * xi);   // v_sqrt_f32 (1 ulp): 5e-7 dB, saves ~10 VALU per bin
+    const c32 zc = c32{zb.x, -zb.y};                     // conj(Zb)
+    const c32 a = za + zc;                               // Za + conj(Zb)
+    const c32 w = cmul(cmul(za - zc, wl), wc);           // W4096^K (Za - conj(Zb))
+    const c32 x = a + c32{w.y, -w.x};                    // 2 X[K] = a - i w
+    const c32 x2 = x * x;
+    return 0.5f * __builtin_amdgcn_sqrtf(x2.x + x2.y);   // v_sqrt_f32 (1 ulp): 5e-7 dB, saves ~10 VALU per bin
 }
 
 struct mel_twiddles {
