@@ -7,7 +7,8 @@ argument meaning and error behaviour, with the arithmetic moved to the HIP engin
   NISQA / NISQA_DIM     (NL:29-268)                parameter containers with the reference's
                                                    state_dict keys; forward() runs the HIP path
 
-Out of scope here (raise NotImplementedError): training, evaluation metrics, NISQA_DE,
+Evaluation statistics (eval_results and helpers, NL:1469-1852) are re-exported from nisqa_amd/evaluation.py.
+Out of scope here (raise NotImplementedError): training, NISQA_DE,
 alternative blocks no shipped checkpoint uses.
 """
 import os
@@ -19,6 +20,8 @@ import torch
 import torch.nn as nn
 
 from . import dist as _dist
+from .evaluation import (calc_eval_metrics, calc_mapped, calc_mapping, calc_rmse, calc_rmse_star, eval_results,  # noqa: F401
+                         fit_first_order, fit_monotonic_third_order, fit_second_order, fit_third_order, is_const)
 from . import ingest as _ingest
 from .wavio import read_wav
 

@@ -2,9 +2,9 @@
 constructor argument dict, attributes (``.args .dev .model .ds_val``), printed lines, result frame
 and ``NISQA_results.csv`` -- with the hot path behind it running as HIP kernels on an MI355X.
 
-Only what ``run_predict.py`` reaches is implemented (reference NISQA_model.py:26-39, 54-81,
-732-847, 928-1051).  ``train()`` / ``evaluate()`` raise NotImplementedError (out of scope,
-SURVEY.md section 2 rows 16-19).
+What ``run_predict.py`` and ``run_evaluate.py`` reach is implemented (reference NISQA_model.py:26-81, 572-716,
+732-847, 928-1051): the three predict modes and ``evaluate()`` on their predictions (host-side P.1401 statistics,
+nisqa_amd/evaluation.py).  ``train()`` raises NotImplementedError (not built yet).
 """
 import datetime
 import os
@@ -36,7 +36,44 @@ class nisqaModel(object):
         raise NotImplementedError('training is out of scope of nisqa_amd (inference hot path only)')
 
     def evaluate(self, mapping='first_order', do_print=True, do_plot=False):
-        raise NotImplementedError('evaluation metrics are out of scope of nisqa_amd (inference hot path only)')
+        """reference NISQA_model.py:48-52: per-database / overall statistics of the predictions in ``ds_val.df``
+        (needs ``predict()`` first and the subjective columns ``mos`` [, ``noi dis col loud``], ``db`` in the CSV)."""
+        if self.args['dim'] == True:  # noqa: E712
+            self._evaluate_dim(mapping=mapping, do_print=do_print, do_plot=do_plot)
+        else:
+            self._evaluate_mos(mapping=mapping, do_print=do_print, do_plot=do_plot)
+
+    def _eval_one(self, label, target, mapping, do_print, do_plot, con_line_has_star=True):
+        print('--> %s:' % label)
+        db_results, r = NL.eval_results(self.ds_val.df, dcon=self.ds_val.df_con, target_mos=target,
+                                        target_ci=target + '_ci', pred=target + '_pred', mapping=mapping,
+                                        do_print=do_print, do_plot=do_plot)
+        if self.ds_val.df_con is None:
+            print('r_p_mean_file: {:0.2f}, rmse_mean_file: {:0.2f}'.format(r['r_p_mean_file'], r['rmse_mean_file']))
+        elif con_line_has_star:
+            print('r_p_mean_con: {:0.2f}, rmse_mean_con: {:0.2f}, rmse_star_map_mean_con: {:0.2f}'
+                  .format(r['r_p_mean_con'], r['rmse_mean_con'], r['rmse_star_map_mean_con']))
+        else:                                   # the reference's NOI line omits RMSE* (NISQA_model.py:636-638)
+            print('r_p_mean_con: {:0.2f}, rmse_mean_con: {:0.2f}'.format(r['r_p_mean_con'], r['rmse_mean_con']))
+        return db_results, r
+
+    def _evaluate_mos(self, mapping='first_order', do_print=True, do_plot=False):
+        """reference NISQA_model.py:572-594"""
+        self.db_results, self.r = self._eval_one('MOS', 'mos', mapping, do_print, do_plot)
+
+    def _evaluate_dim(self, mapping='first_order', do_print=True, do_plot=False):
+        """reference NISQA_model.py:596-716: MOS, then noisiness, discontinuity, coloration, loudness"""
+        self.db_results_val_mos, r_mos = self._eval_one('MOS', 'mos', mapping, do_print, do_plot)
+        self.db_results_val_noi, r_noi = self._eval_one('NOI', 'noi', mapping, do_print, do_plot, con_line_has_star=False)
+        self.db_results_val_dis, r_dis = self._eval_one('DIS', 'dis', mapping, do_print, do_plot)
+        self.db_results_val_col, r_col = self._eval_one('COL', 'col', mapping, do_print, do_plot)
+        self.db_results_val_loud, r_loud = self._eval_one('LOUD', 'loud', mapping, do_print, do_plot)
+        self.r = dict(r_mos)
+        for sfx, r in (('_noi', r_noi), ('_dis', r_dis), ('_col', r_col), ('_loud', r_loud)):
+            self.r.update({k + sfx: v for k, v in r.items()})
+        r_mean = 1 / 5 * (self.r['r_p_mean_con'] + self.r['r_p_mean_con_noi'] + self.r['r_p_mean_con_col']
+                          + self.r['r_p_mean_con_dis'] + self.r['r_p_mean_con_loud'])
+        print('\nAverage over MOS and dimensions: r_p={:0.3f}'.format(r_mean))
 
     def predict(self):
         """reference NISQA_model.py:54-81"""

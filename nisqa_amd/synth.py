@@ -176,3 +176,25 @@ def random_state_dict(seed, model='NISQA_DIM'):
     return sd
 
 
+
+
+def eval_corpus(seed, n_db=3, n_con=12, per_con=6):
+    """Seeded synthetic "listening test" for the evaluation statistics (tests/golden/make_golden_eval.py):
+    -> (per-file frame: db, con, filepath_deg, mos, mos_pred; per-condition frame: db, con, mos, mos_ci)."""
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    files, cons = [], []
+    for d in range(n_db):
+        db = 'DB_%c' % 'CAB'[d % 3] + ('' if d < 3 else str(d))       # not in sorted order on purpose
+        gain, off = 0.8 + 0.15 * d, 0.3 - 0.2 * d                       # per-database bias of the predictor
+        for c in range(1, n_con + 1):
+            q = rng.uniform(1.2, 4.8)
+            votes = np.clip(q + rng.normal(0, 0.45, per_con), 1, 5)
+            pred = np.clip(off + gain * votes + 0.05 * (votes - 3) ** 2 + rng.normal(0, 0.25, per_con), 0.5, 5.5)
+            for k in range(per_con):
+                files.append({'db': db, 'con': c, 'filepath_deg': '%s/c%02d_f%d.wav' % (db, c, k), 'mos': votes[k],
+                              'mos_pred': pred[k]})
+            cons.append({'db': db, 'con': c, 'mos': votes.mean(),
+                         'mos_ci': 1.96 * votes.std(ddof=1) / np.sqrt(per_con)})
+    df = pd.DataFrame(files).sample(frac=1.0, random_state=seed).reset_index(drop=True)    # shuffled file order
+    return df, pd.DataFrame(cons)

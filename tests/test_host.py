@@ -471,6 +471,46 @@ def test_nisqa_model_predict_file_mos_only_and_errors(tmp_path, wav_dir):
         ms.predict()
 
 
+def test_nisqa_model_evaluate_after_predict_csv(tmp_path, wav_dir, capsys):
+    """run_evaluate.py's sequence: predict_csv with csv_con, then evaluate() (reference NISQA_model.py:48-52, 572-716)."""
+    from nisqa_amd.NISQA_model import nisqaModel
+    rng = np.random.default_rng(3)
+    rows = []
+    for db in ('DB2', 'DB1'):
+        for con in (1, 2, 3):
+            for k in range(2):
+                rows.append({'name': 'c%d.wav' % ((con + k) % 5), 'db': db, 'con': con,
+                             **{t: 1 + 4 * rng.random() for t in ('mos', 'noi', 'dis', 'col', 'loud')}})
+    dfile = pd.DataFrame(rows)
+    dfile.to_csv(wav_dir / 'files.csv', index=False)
+    dcon = dfile.groupby(['db', 'con'], as_index=False)[['mos', 'noi', 'dis', 'col', 'loud']].mean()
+    for t in ('mos', 'noi', 'dis', 'col', 'loud'):
+        dcon[t + '_ci'] = 0.2
+    dcon.to_csv(wav_dir / 'cons.csv', index=False)
+    m = nisqaModel(_args('predict_csv', _ckpt(tmp_path), data_dir=str(wav_dir), csv_file='files.csv', csv_deg='name',
+                         csv_con='cons.csv'))
+    m.model._engine = FakeEngine(5)
+    m.predict()
+    capsys.readouterr()
+    m.evaluate(mapping='first_order', do_print=True, do_plot=False)
+    out = capsys.readouterr().out
+    assert [l for l in out.splitlines() if l.startswith('-->')] == ['--> MOS:', '--> NOI:', '--> DIS:', '--> COL:', '--> LOUD:']
+    assert 'DB1:' in out and 'rmse_star_map_con' in out and 'Average over MOS and dimensions: r_p=' in out
+    assert list(m.db_results_val_mos['db']) == ['DB1', 'DB2'] and 'r_p_mean_con_loud' in m.r and 'rmse_all' in m.r
+    assert 'y_hat_map' in m.ds_val.df
+    # MOS-only model, no per-condition file
+    m1 = nisqaModel(_args('predict_csv', _ckpt(tmp_path, 'NISQA'), data_dir=str(wav_dir), csv_file='files.csv',
+                          csv_deg='name'))
+    m1.model._engine = FakeEngine(1)
+    m1.predict()
+    capsys.readouterr()
+    m1.evaluate()
+    out = capsys.readouterr().out
+    assert out.startswith('--> MOS:') and 'r_p_mean_file' in out and np.isnan(m1.r['r_p_mean_con'])
+    with pytest.raises(NotImplementedError):
+        m1.train()
+
+
 def test_predict_without_gpu_raises_no_cpu_path(tmp_path, wav_dir):
     if torch.cuda.is_available():
         pytest.skip('GPU present')
