@@ -1,0 +1,102 @@
+"""oracle/train.py (training-step restatement) against fixtures written by the reference's own modules in train mode
+(tests/golden/make_golden_train.py), and its explicit-mask dropout against plain autograd."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from nisqa_amd import synth
+from oracle import net as onet, train as otrain
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+import make_golden_train as mk  # noqa: E402
+
+
+def _conv_bias(k):
+    return k.startswith('cnn.model.conv') and k.endswith('.bias')
+
+
+def _case(name):
+    g = helpers.golden('train_%s.npz' % name)
+    args = dict(synth.MOS_ARGS if name == 'mos' else synth.DIM_ARGS)
+    sd = synth.random_state_dict(int(g['seed_sd']), args['model'])
+    heads = 5 if name == 'dim' else 1
+    specs, y = mk.batch(int(g['seed_batch']), int(g['n_clips']), heads)
+    segs = torch.cat([onet.segment_specs(s, 15, 4, None)[0] for s in specs])
+    return g, args, sd, segs, [int(v) for v in g['n_wins']], y
+
+
+@pytest.mark.parametrize('name', ['mos', 'dim'])
+def test_train_step_oracle_matches_reference_fixture(name):
+    g, args, sd, segs, n_wins, y = _case(name)
+    assert segs.shape[0] == sum(n_wins)
+    r1 = otrain.train_step(sd, args, segs, n_wins, y, lr=float(g['lr']))
+    assert r1['loss'] == pytest.approx(float(g['loss1']), rel=2e-5)
+    np.testing.assert_allclose(r1['y_hat'], g['y_hat1'], rtol=0, atol=2e-5)
+    worst = 0.0
+    for k in otrain.param_keys(sd):
+        want = g['grad/' + k]
+        if _conv_bias(k):
+            # train-mode BatchNorm cancels the conv bias: its gradient is analytically zero, what autograd returns
+            # is rounding noise (1e-6) -- and Adam turns the SIGN of that noise into a +-lr step, so neither the
+            # gradient nor the updated bias is comparable between two fp32 evaluation orders
+            assert np.abs(want).max() < 1e-4 and np.abs(r1['grads'][k]).max() < 1e-4
+            continue
+        scale = max(1e-3, float(np.abs(want).max()))
+        worst = max(worst, float(np.abs(r1['grads'][k] - want).max()) / scale)
+    assert worst < 2e-4, worst                                   # relative to each tensor's largest gradient entry
+    lr = float(g['lr'])
+    for k, v in r1['sd'].items():
+        want = g['sd1/' + k]
+        if k.endswith('num_batches_tracked'):
+            assert int(v) == int(want) == int(np.asarray(sd[k])) + 1
+        elif 'running' in k:
+            np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=1e-4 * max(1, np.abs(want).max()))
+        else:
+            # Adam's first step is lr * g / (|g| + eps): where the reference gradient is not rounding noise the two
+            # updates agree closely; where it is (analytically zero gradients: conv biases under BatchNorm, key and
+            # score biases under softmax, dead ReLU rows) the step is +-lr with the sign of the noise
+            gref = g['grad/' + k]
+            solid = (np.abs(gref) > 1e-4 * max(1e-3, np.abs(gref).max())) & (not _conv_bias(k))
+            d = np.abs(v.numpy() - want)
+            assert d[solid].max(initial=0) < 2e-5 and d.max() <= 2.002 * lr, k
+            assert solid.mean() > 0.5 or _conv_bias(k) or k.endswith(('in_proj_bias', 'linear2.bias')), k
+    r2 = otrain.train_step(r1['sd'], args, segs, n_wins, y, lr=float(g['lr']), adam=r1['adam'])
+    assert r2['loss'] == pytest.approx(float(g['loss2']), rel=2e-3)
+    np.testing.assert_allclose(r2['y_hat'], g['y_hat2'], rtol=0, atol=2e-3)
+    for k, v in r2['sd'].items():
+        if 'running' in k:
+            want = g['sd2/' + k]
+            np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=2e-4 * max(1, np.abs(want).max()))
+
+
+def test_explicit_dropout_masks_and_bias_mapping():
+    _, args, sd, segs, n_wins, y = _case('mos')
+    rng = np.random.default_rng(0)
+    S = segs.shape[0]
+    drop = lambda shape, p: torch.as_tensor((rng.random(shape) >= p).astype(np.float32) / (1 - p))
+    masks = {'cnn_d1': drop((S, 32, 1, 1), 0.2), 'cnn_d2': drop((S, 64, 1, 1), 0.2), 'cnn_d3': drop((S, 64, 1, 1), 0.2),
+             'cnn_d4': drop((S, 64, 1, 1), 0.2)}
+    for b, n in enumerate(n_wins):
+        for l in range(2):
+            masks[(b, 'td%d_p' % l)] = drop((n, n), 0.1)
+            for t in ('1', 'f', '2'):
+                masks[(b, 'td%d_%s' % (l, t))] = drop((n, 64), 0.1)
+    bias = np.tile(np.array([[0.1, 0.9, 0.02, -0.001]], np.float32), (len(n_wins), 1))
+    r = otrain.train_step(sd, args, segs, n_wins, y, masks=masks, bias=bias)
+    r0 = otrain.train_step(sd, args, segs, n_wins, y)
+    assert np.isfinite(r['loss']) and abs(r['loss'] - r0['loss']) > 1e-4
+    # an all-ones mask set is the same as no masks
+    ones = {k: torch.ones_like(v) for k, v in masks.items()}
+    r1 = otrain.train_step(sd, args, segs, n_wins, y, masks=ones)
+    assert r1['loss'] == pytest.approx(r0['loss'], rel=1e-6)
+    # dropped channels of the last CNN dropout get no gradient through conv6's input: its weight gradient w.r.t. a
+    # channel that is dropped for EVERY segment is exactly zero
+    m = {k: v.clone() for k, v in ones.items()}
+    m['cnn_d4'][:, 5] = 0
+    rz = otrain.train_step(sd, args, segs, n_wins, y, masks=m)
+    assert np.abs(rz['grads']['cnn.model.conv6.weight'][:, 5]).max() == 0
+    assert np.abs(rz['grads']['cnn.model.conv6.weight'][:, 6]).max() > 0
