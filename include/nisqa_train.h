@@ -1,0 +1,102 @@
+/* nisqa_train.h -- C ABI of the training-step kernels in libnisqa_hip.so (BASELINE config 5).
+ *
+ * One optimiser step of the CNN-SA-AP model -- what the reference does at nisqa/NISQA_model.py:131-152 / 330-352
+ * (model.train(); model(x, n_wins); biasLoss.get_loss; backward; Adam.step) -- is driven from the host
+ * (nisqa_amd/train.py) as a sequence of these operators.  Train-mode BatchNorm needs statistics over every valid
+ * segment of the batch between a convolution and its activation, so the per-segment fusion of the inference
+ * kernels does not apply; convolutions run as im2col + GEMM on fp32 MFMA, activations live in HBM.
+ *
+ * Conventions: float32 row-major everywhere; activations are pixel-major, channels contiguous: act[S][H*W][C];
+ * token matrices are [tokens][features].  All pointers are device memory owned by the caller, all work is enqueued
+ * on `stream`; return 0 or NISQA_ERR_* (nisqa_hip.h).
+ */
+#ifndef NISQA_TRAIN_H
+#define NISQA_TRAIN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Grouped GEMM on v_mfma_f32_32x32x2_f32: for every group g, C_g (+)= alpha * op(A_g) op(B_g).
+ * desc[g][10] (int64): a_off, b_off, c_off (element offsets into A, B, C), M, N, K, lda, ldb, ldc, tile_start
+ * (exclusive prefix sum of ceil(M/64)*ceil(N/64) over the groups; total_tiles = the sum).
+ * trans_a: A_g is stored [K][M] (lda = row stride of the stored matrix); trans_b: B_g is stored [N][K] (a Linear /
+ * conv weight).  ksplit > 1 splits K over blockIdx.y and accumulates with atomicAdd into a C the caller zeroed
+ * (weight gradients: K = number of rows of the batch).  Replaces every F.linear / F.conv2d / torch.bmm and their
+ * autograd counterparts of the training step. */
+int nisqa_gemm_f32(const float* a, const float* b, float* c, const int64_t* desc, int32_t n_groups,
+                   int32_t total_tiles, int32_t trans_a, int32_t trans_b, int32_t ksplit, float alpha, void* stream);
+/* the single-group case without a descriptor in device memory: C[m][n] (+)= alpha * op(A) op(B) */
+int nisqa_gemm_f32_one(const float* a, const float* b, float* c, int64_t m, int64_t n, int64_t k, int64_t lda,
+                       int64_t ldb, int64_t ldc, int32_t trans_a, int32_t trans_b, int32_t ksplit, float alpha,
+                       void* stream);
+
+/* conv1 patches straight from the dB spectrogram (Framewise + segment_specs, NISQA_lib.py:2239-2282, 487-502):
+ * col[s*720 + m*15 + j][dy*3+dx] = max(mel_tm[frame_off[b] + k*seg_hop + j+dx-1][m+dy-1], clip_floor[b]) or 0
+ * outside the 48x15 segment; s = seg_off[b] + k runs over the VALID segments of the batch only. */
+int nisqa_im2col_mel(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
+                     int32_t n_clips, int32_t n_segments, int32_t seg_hop, float* col, void* stream);
+/* 3x3 patches, padding (1, pad_w): x[S][H*W][C] -> col[S*H*Wo][9*C], Wo = W + 2*pad_w - 2, k = (dy*3+dx)*C + c */
+int nisqa_im2col3x3(const float* x, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w, float* col,
+                    void* stream);
+/* adjoint of nisqa_im2col3x3 (gather form, no atomics): dx[S][H*W][C] = sum of the patch entries that read it */
+int nisqa_col2im3x3(const float* dcol, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w, float* dx,
+                    void* stream);
+
+/* out[0..C) += sum_rows a[r][c], out[C..2C) += sum_rows a[r][c]*b[r][c] in float64 (caller zeroes out).
+ * BatchNorm statistics (b = a), BatchNorm / LayerNorm / bias gradients. */
+int nisqa_col_dot(const float* a, const float* b, int64_t rows, int32_t c, double* out, void* stream);
+
+/* BatchNorm2d (batch statistics) + ReLU + adaptive_max_pool2d + Dropout2d (NISQA_lib.py:690-705, train mode).
+ * sums = nisqa_col_dot(z, z) over rows = S*H*W.  Writes mean_rstd[2C], updates running_mean / running_var
+ * (momentum 0.1, unbiased variance), y[S][Ho*Wo][C] and the arg-max pixel of every output (int32, for backward).
+ * drop (may be NULL): [S][C] multipliers (0 or 1/(1-p)). */
+int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float* mean_rstd, int32_t n_segments, int32_t h,
+                          int32_t w, int32_t c, int32_t ho, int32_t wo, const float* drop, float* y, int32_t* arg,
+                          void* stream);
+/* backward of the above in two passes around a nisqa_col_dot(dyb, z):
+ * pass 1: dyb[S][H*W][C] = d loss / d (BatchNorm output) from dy[S][Ho*Wo][C] (pool scatter, dropout, ReLU gate);
+ * pass 2: in place dyb -> dz = gamma*rstd*(dyb - mean(dyb) - xhat*mean(dyb*xhat)); dgamma, dbeta from sums2. */
+int nisqa_bn_act_pool_bwd1(const float* dy, const int32_t* arg, const float* drop, const float* z,
+                           const float* mean_rstd, const float* gamma, const float* beta, int32_t n_segments,
+                           int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo, float* dyb, void* stream);
+int nisqa_bn_bwd2(float* dyb_to_dz, const float* z, const double* sums2, const float* mean_rstd, const float* gamma,
+                  int64_t rows, int32_t c, float* dgamma, float* dbeta, void* stream);
+
+/* LayerNorm over rows of 64 (NISQA_lib.py:991, 1033, 1037): y = gamma*xhat + beta; saves xhat and rstd */
+int nisqa_layernorm_fwd(const float* x, const float* gamma, const float* beta, int64_t rows, float* y, float* xhat,
+                        float* rstd, void* stream);
+/* dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma (parameter gradients: nisqa_col_dot(dy, xhat)) */
+int nisqa_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int64_t rows,
+                        float* dx, void* stream);
+
+/* Row softmax over ragged rows: row r has len[r] entries at x + off[r]; p = softmax(scale * x) (in place allowed).
+ * Attention probabilities (one row per query token) and attention pooling (one row per clip and head). */
+int nisqa_softmax_rows_fwd(const float* x, const int64_t* off, const int32_t* len, int64_t rows, float scale,
+                           float* p, void* stream);
+/* ds = scale * p * (dp - sum_j dp_j p_j)  (in place on dp allowed) */
+int nisqa_softmax_rows_bwd(const float* p, const float* dp, const int64_t* off, const int32_t* len, int64_t rows,
+                           float scale, float* ds, void* stream);
+
+/* Elementwise helpers on [rows][cols] matrices (cols = row length, bias / vectors of length cols):
+ *   op 0: y = x + bias                      op 1: y = relu(x + bias)
+ *   op 2: y = x * (aux > 0)   (ReLU gate)   op 3: y = x * aux        (dropout mask)
+ *   op 4: y = x + aux          (residual)   op 5: y = x * bias[col]  (per-column scale) */
+int nisqa_elementwise(int32_t op, const float* x, const float* aux, const float* bias, int64_t rows, int32_t cols,
+                      float* y, void* stream);
+
+/* biasLoss.get_loss (NISQA_lib.py:1880-1892, 1946-1950): loss = sum_h mean_{b: y not NaN} (map_b(y_hat) - y)^2,
+ * map_b = cubic with coefficients bias[b][4] (NULL: identity).  Writes loss[1] and dy_hat[B][heads]. */
+int nisqa_mse_loss(const float* y_hat, const float* y, const float* bias, int32_t n_clips, int32_t n_heads,
+                   float* loss, float* dy_hat, void* stream);
+
+/* torch.optim.Adam (betas 0.9 / 0.999, eps 1e-8, no weight decay), step counter t >= 1, on flat buffers */
+int nisqa_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr, int32_t t, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

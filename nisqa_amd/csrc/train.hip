@@ -1,0 +1,593 @@
+// Operators of the training step (include/nisqa_train.h; SURVEY.md section 8f-3, BASELINE config 5): what
+// model.train(); model(x, n_wins); loss.backward(); opt.step() executes in the reference
+// (nisqa/NISQA_model.py:131-152, NISQA_lib.py:688-710, 988-1040, 1171-1183, 1880-1950).
+//
+// Train-mode BatchNorm couples every valid segment of the batch between a convolution and its activation, so the
+// wave-owns-a-segment fusion of the inference kernels does not apply.  First version, built for correctness:
+// convolutions are im2col + a grouped GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), activations and patches live in
+// HBM (a 32 x 10 s batch needs ~4 GB of the 288), reductions that feed normalisation statistics accumulate in
+// float64.  The GEMM also serves every Linear, the attention products (ragged, one group per clip) and all their
+// gradients (transposed operands; split-K with atomics where K is the row count of the batch).
+#include "common.hpp"
+#include "../../include/nisqa_hip.h"
+#include "../../include/nisqa_train.h"
+
+#define GB_M 64
+#define GB_N 64
+#define GB_K 16
+
+// ---------------------------------------------------------------------------------------------------------
+// grouped GEMM: 256 threads = 4 waves, each a 32 x 32 output block of the 64 x 64 tile; operands staged k-major
+// in LDS so that a lane's fragment element (row/col = lane & 31, k = lane >> 5) is a conflict-free ds_read_b32
+// ---------------------------------------------------------------------------------------------------------
+struct gemm_one { int64_t v[10]; };                       // the descriptor of a single-group call, passed by value
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                       float* __restrict__ C, const int64_t* __restrict__ desc,
+                                                       gemm_one one, int n_groups, int trans_a, int trans_b, int ksplit,
+                                                       float alpha) {
+    __shared__ float As[GB_K][GB_M + 4];
+    __shared__ float Bs[GB_K][GB_N + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int lo = 0, hi = n_groups;                            // group of this tile: desc[g][9] <= tile < desc[g+1][9]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (desc[(int64_t)mid * 10 + 9] <= (int64_t)blockIdx.x) lo = mid; else hi = mid;
+    }
+    const int64_t* d = n_groups > 0 ? desc + (int64_t)lo * 10 : one.v;
+    const float* Ag = A + d[0];
+    const float* Bg = B + d[1];
+    float* Cg = C + d[2];
+    const int M = (int)d[3], N = (int)d[4], K = (int)d[5];
+    const int64_t lda = d[6], ldb = d[7], ldc = d[8];
+    const int t = (int)((int64_t)blockIdx.x - d[9]);
+    const int tiles_n = (N + GB_N - 1) / GB_N;
+    const int m0 = (t / tiles_n) * GB_M, n0 = (t % tiles_n) * GB_N;
+    int kc = (K + ksplit - 1) / ksplit;
+    kc = (kc + GB_K - 1) / GB_K * GB_K;
+    const int k_begin = blockIdx.y * kc, k_end = min(K, k_begin + kc);
+    if (k_begin >= k_end) return;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc = zero16();
+    for (int k0 = k_begin; k0 < k_end; k0 += GB_K) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int mm, kk;
+            if (!trans_a) { kk = tid & 15; mm = (tid >> 4) + 16 * j; } else { mm = tid & 63; kk = (tid >> 6) + 4 * j; }
+            float v = 0.f;
+            if (m0 + mm < M && k0 + kk < k_end)
+                v = trans_a ? Ag[(int64_t)(k0 + kk) * lda + m0 + mm] : Ag[(int64_t)(m0 + mm) * lda + k0 + kk];
+            As[kk][mm] = v;
+            int nn, kb;
+            if (!trans_b) { nn = tid & 63; kb = (tid >> 6) + 4 * j; } else { kb = tid & 15; nn = (tid >> 4) + 16 * j; }
+            float u = 0.f;
+            if (n0 + nn < N && k0 + kb < k_end)
+                u = trans_b ? Bg[(int64_t)(n0 + nn) * ldb + k0 + kb] : Bg[(int64_t)(k0 + kb) * ldb + n0 + nn];
+            Bs[kb][nn] = u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < GB_K / 2; ++s)
+            acc = mfma32(As[2 * s + (lane >> 5)][wm + (lane & 31)], Bs[2 * s + (lane >> 5)][wn + (lane & 31)], acc);
+        __syncthreads();
+    }
+    const int col = n0 + wn + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + NQ_DROW(r, lane >> 5);
+        if (row < M && col < N) {
+            const float v = alpha * acc[r];
+            if (ksplit > 1) atomicAdd(Cg + (int64_t)row * ldc + col, v);
+            else Cg[(int64_t)row * ldc + col] = v;
+        }
+    }
+}
+
+extern "C" int nisqa_gemm_f32(const float* a, const float* b, float* c, const int64_t* desc, int32_t n_groups,
+                              int32_t total_tiles, int32_t trans_a, int32_t trans_b, int32_t ksplit, float alpha,
+                              void* stream) {
+    if (!a || !b || !c || !desc || n_groups <= 0 || total_tiles < 0 || ksplit < 1 || ksplit > 65535) return NISQA_ERR_ARG;
+    if (total_tiles == 0) return NISQA_OK;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3(total_tiles, ksplit), dim3(256), 0, (hipStream_t)stream, a, b, c, desc,
+                       gemm_one{}, n_groups, trans_a, trans_b, ksplit, alpha);
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_gemm_f32_one(const float* a, const float* b, float* c, int64_t m, int64_t n, int64_t k, int64_t lda,
+                                  int64_t ldb, int64_t ldc, int32_t trans_a, int32_t trans_b, int32_t ksplit, float alpha,
+                                  void* stream) {
+    if (!a || !b || !c || m < 0 || n < 0 || k <= 0 || ksplit < 1 || ksplit > 65535) return NISQA_ERR_ARG;
+    const int64_t tiles = ((m + GB_M - 1) / GB_M) * ((n + GB_N - 1) / GB_N);
+    if (tiles == 0) return NISQA_OK;
+    if (tiles > 0x7fffffff) return NISQA_ERR_ARG;
+    gemm_one one;
+    const int64_t v[10] = {0, 0, 0, m, n, k, lda, ldb, ldc, 0};
+    for (int i = 0; i < 10; ++i) one.v[i] = v[i];
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)tiles, ksplit), dim3(256), 0, (hipStream_t)stream, a, b, c,
+                       (const int64_t*)nullptr, one, 0, trans_a, trans_b, ksplit, alpha);
+    return NQ_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// patches
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_mel_kernel(const float* __restrict__ mel_tm,
+                                                         const int32_t* __restrict__ frame_off,
+                                                         const int32_t* __restrict__ seg_off,
+                                                         const float* __restrict__ clip_floor, int n_clips, int seg_hop,
+                                                         float* __restrict__ col) {
+    const int s = blockIdx.x;
+    const int b = find_segment(seg_off, n_clips, s);
+    const int k = s - seg_off[b];
+    const float fl = clip_floor[b];
+    const float* src = mel_tm + (int64_t)(frame_off[b] + k * seg_hop) * 48;      // [15 frames][48 bands]
+    float* dst = col + (int64_t)s * (720 * 9);
+    for (int i = threadIdx.x; i < 720 * 9; i += 256) {
+        const int p = i / 9, tap = i - 9 * p;
+        const int m = p / 15 + tap / 3 - 1, j = p % 15 + tap % 3 - 1;
+        dst[i] = ((unsigned)m < 48u && (unsigned)j < 15u) ? fmaxf(src[j * 48 + m], fl) : 0.f;
+    }
+}
+
+extern "C" int nisqa_im2col_mel(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off,
+                                const float* clip_floor, int32_t n_clips, int32_t n_segments, int32_t seg_hop,
+                                float* col, void* stream) {
+    if (!mel_tm || !frame_off || !seg_off || !clip_floor || !col || n_clips <= 0 || n_segments <= 0 || seg_hop <= 0)
+        return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(im2col_mel_kernel, dim3(n_segments), dim3(256), 0, (hipStream_t)stream, mel_tm, frame_off,
+                       seg_off, clip_floor, n_clips, seg_hop, col);
+    return NQ_LAUNCH_STATUS();
+}
+
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, int64_t total, int h, int w, int c,
+                                                        int pad_w, float* __restrict__ col) {
+    const int wo = w + 2 * pad_w - 2, kc = 9 * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / kc;
+        const int k = (int)(i - row * kc);
+        const int tap = k / c, ch = k - tap * c;
+        const int64_t s = row / (h * wo);
+        const int po = (int)(row - s * (h * wo));
+        const int y = po / wo + tap / 3 - 1, xx = po % wo + tap % 3 - pad_w;
+        col[i] = ((unsigned)y < (unsigned)h && (unsigned)xx < (unsigned)w) ? x[(s * (h * w) + y * w + xx) * c + ch] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcol, int64_t total, int h, int w, int c,
+                                                        int pad_w, float* __restrict__ dx) {
+    const int wo = w + 2 * pad_w - 2, kc = 9 * c;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % c);
+        const int64_t pix = i / c;
+        const int64_t s = pix / (h * w);
+        const int p = (int)(pix - s * (h * w));
+        const int y = p / w, xx = p % w;
+        float acc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yo = y - tap / 3 + 1, xo = xx - tap % 3 + pad_w;
+            if ((unsigned)yo < (unsigned)h && (unsigned)xo < (unsigned)wo)
+                acc += dcol[(s * (h * wo) + yo * wo + xo) * kc + tap * c + ch];
+        }
+        dx[i] = acc;
+    }
+}
+
+static int grid_for(int64_t total) {
+    int64_t g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+extern "C" int nisqa_im2col3x3(const float* x, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w,
+                               float* col, void* stream) {
+    const int wo = w + 2 * pad_w - 2;
+    if (!x || !col || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 || pad_w < 0 || pad_w > 1 || wo <= 0) return NISQA_ERR_ARG;
+    const int64_t total = (int64_t)n_segments * h * wo * 9 * c;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, total, h, w, c,
+                       pad_w, col);
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_col2im3x3(const float* dcol, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w,
+                               float* dx, void* stream) {
+    const int wo = w + 2 * pad_w - 2;
+    if (!dcol || !dx || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 || pad_w < 0 || pad_w > 1 || wo <= 0) return NISQA_ERR_ARG;
+    const int64_t total = (int64_t)n_segments * h * w * c;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(col2im3x3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dcol, total, h, w, c,
+                       pad_w, dx);
+    return NQ_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// column reductions in float64: thread (channel = tid % c, row lane = tid / c) walks rows, LDS tree, atomics
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void col_dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      int64_t rows, int c, int64_t rows_per_block, double* __restrict__ out) {
+    __shared__ double s1[256], s2[256];
+    const int tid = threadIdx.x;
+    const int rl = 256 / c;                               // row lanes per block (c divides 256 or c <= 256)
+    const int ch = tid % c, r0 = tid / c;
+    double x1 = 0.0, x2 = 0.0;
+    if (r0 < rl) {
+        const int64_t begin = (int64_t)blockIdx.x * rows_per_block, end = min(rows, begin + rows_per_block);
+        for (int64_t r = begin + r0; r < end; r += rl) {
+            const float av = a[r * c + ch], bv = b[r * c + ch];
+            x1 += (double)av;
+            x2 += (double)av * (double)bv;
+        }
+    }
+    s1[tid] = x1;
+    s2[tid] = x2;
+    __syncthreads();
+    if (tid < c) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int q = 0; q < rl; ++q) { t1 += s1[q * c + tid]; t2 += s2[q * c + tid]; }
+        atomicAdd(out + tid, t1);
+        atomicAdd(out + c + tid, t2);
+    }
+}
+
+extern "C" int nisqa_col_dot(const float* a, const float* b, int64_t rows, int32_t c, double* out, void* stream) {
+    if (!a || !b || !out || rows <= 0 || c <= 0 || c > 256) return NISQA_ERR_ARG;
+    int64_t blocks = (rows * c + 256 * 64 - 1) / (256 * 64);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    const int64_t rpb = (rows + blocks - 1) / blocks;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(col_dot_kernel, dim3((int)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, a, b, rows,
+                       c, rpb, out);
+    return NQ_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BatchNorm (batch statistics) + ReLU + adaptive max pool + Dropout2d
+// ---------------------------------------------------------------------------------------------------------
+NQ_DEV int win_lo(int i, int n_in, int n_out) { return (i * n_in) / n_out; }
+NQ_DEV int win_hi(int i, int n_in, int n_out) { return ((i + 1) * n_in + n_out - 1) / n_out; }
+
+NQ_DEV void bn_stats(const double* __restrict__ sums, int c, int ch, double m_rows, float& mean, float& rstd, double& var) {
+    const double mu = sums[ch] / m_rows;
+    var = sums[c + ch] / m_rows - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + 1e-5));
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int c, int64_t m_rows, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ mean_rstd) {
+    const int ch = threadIdx.x;
+    if (ch >= c) return;
+    float mean, rstd;
+    double var;
+    bn_stats(sums, c, ch, (double)m_rows, mean, rstd, var);
+    mean_rstd[ch] = mean;
+    mean_rstd[c + ch] = rstd;
+    const double unb = m_rows > 1 ? var * ((double)m_rows / (double)(m_rows - 1)) : var;
+    running_mean[ch] = 0.9f * running_mean[ch] + 0.1f * mean;
+    running_var[ch] = 0.9f * running_var[ch] + 0.1f * (float)unb;
+}
+
+__global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mean_rstd, int64_t total, int h, int w, int c, int ho, int wo,
+    const float* __restrict__ drop, float* __restrict__ y, int32_t* __restrict__ arg) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % c);
+        const int64_t op = i / c;
+        const int64_t s = op / (ho * wo);
+        const int o = (int)(op - s * (ho * wo));
+        const int oy = o / wo, ox = o % wo;
+        const float g = gamma[ch] * mean_rstd[c + ch], bsh = beta[ch] - mean_rstd[ch] * g;
+        float best = -3.0e38f;
+        int bp = 0;
+        for (int yy = win_lo(oy, h, ho); yy < win_hi(oy, h, ho); ++yy)
+            for (int xx = win_lo(ox, w, wo); xx < win_hi(ox, w, wo); ++xx) {
+                const int p = yy * w + xx;
+                const float v = fmaxf(fmaf(z[(s * (h * w) + p) * c + ch], g, bsh), 0.f);
+                if (v > best) { best = v; bp = p; }
+            }
+        y[i] = drop ? best * drop[s * c + ch] : best;
+        arg[i] = bp;
+    }
+}
+
+extern "C" int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float* mean_rstd, int32_t n_segments,
+                                     int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo, const float* drop, float* y,
+                                     int32_t* arg, void* stream) {
+    if (!z || !sums || !gamma || !beta || !running_mean || !running_var || !mean_rstd || !y || !arg || n_segments <= 0 ||
+        h <= 0 || w <= 0 || c <= 0 || c > 256 || ho <= 0 || wo <= 0 || ho > h || wo > w)
+        return NISQA_ERR_ARG;
+    const int64_t total = (int64_t)n_segments * ho * wo * c;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, c,
+                       (int64_t)n_segments * h * w, running_mean, running_var, mean_rstd);
+    hipLaunchKernelGGL(bn_act_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, z, gamma, beta,
+                       (const float*)mean_rstd, total, h, w, c, ho, wo, drop, y, arg);
+    return NQ_LAUNCH_STATUS();
+}
+
+__global__ __launch_bounds__(256) void bn_act_pool_bwd1_kernel(
+    const float* __restrict__ dy, const int32_t* __restrict__ arg, const float* __restrict__ drop,
+    const float* __restrict__ z, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int64_t total, int h, int w, int c, int ho, int wo, float* __restrict__ dyb) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % c);
+        const int64_t pix = i / c;
+        const int64_t s = pix / (h * w);
+        const int p = (int)(pix - s * (h * w));
+        const int yy = p / w, xx = p % w;
+        const float g = gamma[ch] * mean_rstd[c + ch];
+        const float yb = fmaf(z[i], g, beta[ch] - mean_rstd[ch] * g);
+        float acc = 0.f;
+        if (yb > 0.f) {                                    // ReLU gate
+            const int oy0 = max(0, (yy * ho) / h - 1), oy1 = min(ho - 1, ((yy + 1) * ho) / h + 1);
+            const int ox0 = max(0, (xx * wo) / w - 1), ox1 = min(wo - 1, ((xx + 1) * wo) / w + 1);
+            for (int oy = oy0; oy <= oy1; ++oy) {
+                if (yy < win_lo(oy, h, ho) || yy >= win_hi(oy, h, ho)) continue;
+                for (int ox = ox0; ox <= ox1; ++ox) {
+                    if (xx < win_lo(ox, w, wo) || xx >= win_hi(ox, w, wo)) continue;
+                    const int64_t o = (s * (ho * wo) + oy * wo + ox) * c + ch;
+                    if (arg[o] == p) acc += dy[o];
+                }
+            }
+            if (drop) acc *= drop[s * c + ch];
+        }
+        dyb[i] = acc;
+    }
+}
+
+extern "C" int nisqa_bn_act_pool_bwd1(const float* dy, const int32_t* arg, const float* drop, const float* z,
+                                      const float* mean_rstd, const float* gamma, const float* beta, int32_t n_segments,
+                                      int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo, float* dyb, void* stream) {
+    if (!dy || !arg || !z || !mean_rstd || !gamma || !beta || !dyb || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 ||
+        ho <= 0 || wo <= 0 || ho > h || wo > w)
+        return NISQA_ERR_ARG;
+    const int64_t total = (int64_t)n_segments * h * w * c;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(bn_act_pool_bwd1_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, arg, drop, z,
+                       mean_rstd, gamma, beta, total, h, w, c, ho, wo, dyb);
+    return NQ_LAUNCH_STATUS();
+}
+
+__global__ __launch_bounds__(256) void bn_bwd2_kernel(float* __restrict__ d, const float* __restrict__ z,
+                                                      const double* __restrict__ sums2, const float* __restrict__ mean_rstd,
+                                                      const float* __restrict__ gamma, int64_t rows, int c,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < c) {
+        const int ch = threadIdx.x;
+        const double mean = mean_rstd[ch], rstd = mean_rstd[c + ch];
+        dbeta[ch] = (float)sums2[ch];
+        dgamma[ch] = (float)(rstd * (sums2[c + ch] - mean * sums2[ch]));
+    }
+    const int64_t total = rows * c;
+    const double inv = 1.0 / (double)rows;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ch = (int)(i % c);
+        const float mean = mean_rstd[ch], rstd = mean_rstd[c + ch];
+        const float m1 = (float)(sums2[ch] * inv);                                           // mean(dyb)
+        const float m2 = (float)((double)rstd * (sums2[c + ch] - (double)mean * sums2[ch]) * inv);   // mean(dyb * xhat)
+        const float xh = (z[i] - mean) * rstd;
+        d[i] = gamma[ch] * rstd * (d[i] - m1 - xh * m2);
+    }
+}
+
+extern "C" int nisqa_bn_bwd2(float* dyb_to_dz, const float* z, const double* sums2, const float* mean_rstd,
+                             const float* gamma, int64_t rows, int32_t c, float* dgamma, float* dbeta, void* stream) {
+    if (!dyb_to_dz || !z || !sums2 || !mean_rstd || !gamma || !dgamma || !dbeta || rows <= 0 || c <= 0 || c > 256)
+        return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(bn_bwd2_kernel, dim3(grid_for(rows * c)), dim3(256), 0, (hipStream_t)stream, dyb_to_dz, z, sums2,
+                       mean_rstd, gamma, rows, c, dgamma, dbeta);
+    return NQ_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm over rows of 64: one wave per row
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int64_t rows,
+                                                            float* __restrict__ y, float* __restrict__ xhat,
+                                                            float* __restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float v = x[r * 64 + lane];
+    const float mean = wave_sum(v) * (1.0f / 64.0f);
+    const float dv = v - mean;
+    const float var = wave_sum(dv * dv) * (1.0f / 64.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float xh = dv * rstd;
+    xhat[r * 64 + lane] = xh;
+    y[r * 64 + lane] = fmaf(xh, gamma[lane], beta[lane]);
+    if (lane == 0) rstd_out[r] = rstd;
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                            const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                            int64_t rows, float* __restrict__ dx) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float g = dy[r * 64 + lane] * gamma[lane], xh = xhat[r * 64 + lane];
+    const float m1 = wave_sum(g) * (1.0f / 64.0f), m2 = wave_sum(g * xh) * (1.0f / 64.0f);
+    dx[r * 64 + lane] = rstd[r] * (g - m1 - xh * m2);
+}
+
+extern "C" int nisqa_layernorm_fwd(const float* x, const float* gamma, const float* beta, int64_t rows, float* y,
+                                   float* xhat, float* rstd, void* stream) {
+    if (!x || !gamma || !beta || !y || !xhat || !rstd || rows <= 0) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       rows, y, xhat, rstd);
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int64_t rows,
+                                   float* dx, void* stream) {
+    if (!dy || !xhat || !rstd || !gamma || !dx || rows <= 0) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, xhat, rstd,
+                       gamma, rows, dx);
+    return NQ_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ragged row softmax: one wave per row
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ off,
+                                                               const int32_t* __restrict__ len, int64_t rows, float scale,
+                                                               float* __restrict__ p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + off[r];
+    float* pr = p + off[r];
+    const int n = len[r];
+    float mx = -3.0e38f;
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, xr[j] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < n; j += 64) sum += expf(xr[j] * scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < n; j += 64) pr[j] = expf(xr[j] * scale - mx) * inv;
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp,
+                                                               const int64_t* __restrict__ off, const int32_t* __restrict__ len,
+                                                               int64_t rows, float scale, float* __restrict__ ds) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* pr = p + off[r];
+    const float* dr = dp + off[r];
+    float* sr = ds + off[r];
+    const int n = len[r];
+    float dot = 0.f;
+    for (int j = lane; j < n; j += 64) dot += pr[j] * dr[j];
+    dot = wave_sum(dot);
+    for (int j = lane; j < n; j += 64) sr[j] = scale * pr[j] * (dr[j] - dot);
+}
+
+extern "C" int nisqa_softmax_rows_fwd(const float* x, const int64_t* off, const int32_t* len, int64_t rows, float scale,
+                                      float* p, void* stream) {
+    if (!x || !off || !len || !p || rows <= 0) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(softmax_rows_fwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, off, len,
+                       rows, scale, p);
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_softmax_rows_bwd(const float* p, const float* dp, const int64_t* off, const int32_t* len, int64_t rows,
+                                      float scale, float* ds, void* stream) {
+    if (!p || !dp || !off || !len || !ds || rows <= 0) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3((int)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, dp, off,
+                       len, rows, scale, ds);
+    return NQ_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// elementwise, loss, optimiser
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void elementwise_kernel(int op, const float* __restrict__ x, const float* __restrict__ aux,
+                                                          const float* __restrict__ bias, int64_t total, int cols,
+                                                          float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i];
+        float o;
+        switch (op) {
+            case 0: o = v + bias[i % cols]; break;
+            case 1: o = fmaxf(v + bias[i % cols], 0.f); break;
+            case 2: o = aux[i] > 0.f ? v : 0.f; break;
+            case 3: o = v * aux[i]; break;
+            case 4: o = v + aux[i]; break;
+            default: o = v * bias[i % cols]; break;
+        }
+        y[i] = o;
+    }
+}
+
+extern "C" int nisqa_elementwise(int32_t op, const float* x, const float* aux, const float* bias, int64_t rows,
+                                 int32_t cols, float* y, void* stream) {
+    if (op < 0 || op > 5 || !x || !y || rows <= 0 || cols <= 0) return NISQA_ERR_ARG;
+    if ((op == 0 || op == 1 || op == 5) && !bias) return NISQA_ERR_ARG;
+    if ((op == 2 || op == 3 || op == 4) && !aux) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(elementwise_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, (hipStream_t)stream, op, x, aux, bias,
+                       rows * cols, cols, y);
+    return NQ_LAUNCH_STATUS();
+}
+
+__global__ __launch_bounds__(64) void mse_loss_kernel(const float* __restrict__ y_hat, const float* __restrict__ y,
+                                                      const float* __restrict__ bias, int n_clips, int n_heads,
+                                                      float* __restrict__ loss, float* __restrict__ dy_hat) {
+    __shared__ float part[64];
+    const int hd = threadIdx.x;
+    float l = 0.f;
+    if (hd < n_heads) {
+        int cnt = 0;
+        for (int b = 0; b < n_clips; ++b) cnt += !isnan(y[b * n_heads + hd]);
+        const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+        for (int b = 0; b < n_clips; ++b) {
+            const float t = y[b * n_heads + hd], v = y_hat[b * n_heads + hd];
+            float mapped = v, slope = 1.f;
+            if (bias) {
+                const float* q = bias + b * 4;
+                mapped = q[0] + v * (q[1] + v * (q[2] + v * q[3]));
+                slope = q[1] + v * (2.f * q[2] + 3.f * v * q[3]);
+            }
+            float g = 0.f;
+            if (!isnan(t)) {
+                const float e = mapped - t;
+                l += e * e * inv;
+                g = 2.f * e * inv * slope;
+            }
+            dy_hat[b * n_heads + hd] = g;
+        }
+    }
+    part[hd] = l;
+    __syncthreads();
+    if (hd == 0) {
+        float s = 0.f;
+        for (int q = 0; q < n_heads; ++q) s += part[q];
+        loss[0] = s;
+    }
+}
+
+extern "C" int nisqa_mse_loss(const float* y_hat, const float* y, const float* bias, int32_t n_clips, int32_t n_heads,
+                              float* loss, float* dy_hat, void* stream) {
+    if (!y_hat || !y || !loss || !dy_hat || n_clips <= 0 || n_heads <= 0 || n_heads > 64) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, y_hat, y, bias, n_clips, n_heads, loss,
+                       dy_hat);
+    return NQ_LAUNCH_STATUS();
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float step_size, float bc2_sqrt) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = 0.9f * m[i] + 0.1f * gi;
+        const float vi = 0.999f * v[i] + 0.001f * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) / bc2_sqrt + 1e-8f);
+    }
+}
+
+extern "C" int nisqa_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr, int32_t t,
+                               void* stream) {
+    if (!param || !grad || !m || !v || n <= 0 || t < 1) return NISQA_ERR_ARG;
+    const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n,
+                       (float)(lr / bc1), (float)sqrt(bc2));
+    return NQ_LAUNCH_STATUS();
+}

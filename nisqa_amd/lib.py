@@ -60,6 +60,30 @@ SYMBOLS = {
     'nisqa_selftest_mfma': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_p]),
 }
 
+# include/nisqa_train.h: operators of the training step (same shared library)
+c_f = ctypes.c_float
+TRAIN_SYMBOLS = {
+    'nisqa_gemm_f32': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_p]),
+    'nisqa_gemm_f32_one': (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32,
+                                          c_f, c_p]),
+    'nisqa_im2col_mel': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p]),
+    'nisqa_im2col3x3': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
+    'nisqa_col2im3x3': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
+    'nisqa_col_dot': (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_p]),
+    'nisqa_bn_act_pool_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                             c_p, c_p, c_p, c_p]),
+    'nisqa_bn_act_pool_bwd1': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                              c_p, c_p]),
+    'nisqa_bn_bwd2': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p, c_p, c_p]),
+    'nisqa_layernorm_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    'nisqa_layernorm_bwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
+    'nisqa_softmax_rows_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_f, c_p, c_p]),
+    'nisqa_softmax_rows_bwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_p, c_p]),
+    'nisqa_elementwise': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i64, c_i32, c_p, c_p]),
+    'nisqa_mse_loss': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p]),
+    'nisqa_adam_step': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_i32, c_p]),
+}
+
 _lib = None
 
 
@@ -77,7 +101,7 @@ def load():
             'nisqa_amd: HIP library not built: %s is missing (run __graft_entry__.build() or '
             '`make -C nisqa_amd/csrc`); there is no CPU fallback.' % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SYMBOLS.items():
+    for name, (res, args) in list(SYMBOLS.items()) + list(TRAIN_SYMBOLS.items()):
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -1,0 +1,432 @@
+"""One optimiser step of the CNN-SA-AP model on the GPU (BASELINE config 5).
+
+Host-side driver of the training operators of include/nisqa_train.h: it does what the reference does per batch at
+nisqa/NISQA_model.py:131-152 (``model.train(); y_hat = model(x, n_wins); loss = biasLoss.get_loss(...);
+loss.backward(); opt.step(); opt.zero_grad()``) for ``model`` = NISQA / NISQA_DIM with cnn_model=adapt, td=self_att,
+pool=att -- forward in train mode (BatchNorm on batch statistics over all valid segments, the reference's dropouts),
+the gradient of every parameter, BatchNorm buffer updates and the Adam update -- with every operator a HIP kernel.
+PyTorch here is device memory, the dropout random numbers and dtype casts of a few per-channel vectors; there is
+no autograd and no torch.nn call in the step.
+
+Parameters live in ONE flat device buffer in "kernel layout" (conv weights as [C_out][3*3*C_in], the 384 columns of
+the first Linear in [y][c] order); ``state_dict()`` / ``load_state_dict()`` convert to and from the reference's keys
+and shapes, so checkpoints interoperate with the reference and with the inference engine.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .engine import HipNisqa, BatchPlan, SEG_LEN
+
+_CONV = [(1, 16), (16, 32), (32, 64), (64, 64), (64, 64), (64, 64)]      # (C_in, C_out) of conv1..conv6
+_DROP_AFTER = {2: 'cnn_d1', 3: 'cnn_d2', 4: 'cnn_d3', 5: 'cnn_d4'}       # Dropout2d sites (NISQA_lib.py:696-705)
+
+
+def _ptr(t, off=0):
+    return t.data_ptr() + 4 * off
+
+
+class HipTrainer(object):
+    def __init__(self, args, state_dict, device=None, lr=1e-3):
+        a = args
+        if not (a.get('cnn_model') == 'adapt' and a.get('td') == 'self_att' and a.get('pool') == 'att') \
+                or a.get('td_2') not in (None, 'skip') or a['model'] not in ('NISQA', 'NISQA_DIM'):
+            raise NotImplementedError('HIP training step covers NISQA / NISQA_DIM with cnn_model=adapt, td=self_att, '
+                                      'pool=att (config/train_nisqa_cnn_sa_ap.yaml)')
+        self.eng = HipNisqa(args, state_dict, device, precision='f32')       # mel front end + geometry checks
+        self.lib, self.device, self.args = self.eng.lib, self.eng.device, args
+        self.lr = float(lr)
+        self.n_layers = int(a['td_sa_num_layers'])
+        self.heads = ['pool_layers.%d.model.' % h for h in range(5)] if a['model'] == 'NISQA_DIM' else ['pool.model.']
+        self.pools = [tuple(a['cnn_pool_1']), tuple(a['cnn_pool_2']), tuple(a['cnn_pool_3'])]
+        self.p_cnn, self.p_td, self.p_pool = float(a['cnn_dropout']), float(a['td_sa_dropout']), float(a['pool_att_dropout'] or 0)
+        if self.p_pool:
+            raise NotImplementedError('pool_att_dropout > 0 is not built (0 in every shipped config)')
+        self.t = 0
+        self._layout(state_dict)
+        self.load_state_dict(state_dict)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+
+    # ---- parameters ------------------------------------------------------------------------------------
+    def _layout(self, sd):
+        keys = [k for k in sd if k.split('.')[-1] not in ('running_mean', 'running_var', 'num_batches_tracked')]
+        self.keys, self.off, self.kshape = keys, {}, {}
+        n = 0
+        for k in keys:
+            shape = tuple(sd[k].shape)
+            if k.startswith('cnn.model.conv') and k.endswith('.weight'):
+                shape = (shape[0], 9 * shape[1])
+            self.off[k], self.kshape[k] = n, shape
+            n += int(np.prod(shape))
+            n = (n + 3) // 4 * 4
+        self.flat = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.gflat = torch.zeros_like(self.flat)
+        self.P = {k: self.flat[self.off[k]:self.off[k] + int(np.prod(self.kshape[k]))].view(self.kshape[k]) for k in keys}
+        self.G = {k: self.gflat[self.off[k]:self.off[k] + int(np.prod(self.kshape[k]))].view(self.kshape[k]) for k in keys}
+
+    @staticmethod
+    def _to_kernel(k, v):
+        if k.startswith('cnn.model.conv') and k.endswith('.weight'):
+            return v.permute(0, 2, 3, 1).reshape(v.shape[0], -1)
+        if k == 'time_dependency.model.linear.weight':                         # columns c*6+y -> y*64+c
+            return v.reshape(v.shape[0], 64, 6).permute(0, 2, 1).reshape(v.shape[0], 384)
+        return v
+
+    @staticmethod
+    def _from_kernel(k, v, ref_shape):
+        if k.startswith('cnn.model.conv') and k.endswith('.weight'):
+            co, ci = ref_shape[0], ref_shape[1]
+            return v.reshape(co, 3, 3, ci).permute(0, 3, 1, 2)
+        if k == 'time_dependency.model.linear.weight':
+            return v.reshape(v.shape[0], 6, 64).permute(0, 2, 1).reshape(v.shape[0], 384)
+        return v
+
+    def load_state_dict(self, sd):
+        self._ref_shape = {k: tuple(sd[k].shape) for k in sd}
+        for k in self.keys:
+            v = torch.as_tensor(np.asarray(sd[k]) if not torch.is_tensor(sd[k]) else sd[k]).float()
+            self.P[k].copy_(self._to_kernel(k, v).contiguous().to(self.device))
+        self.bn = {}
+        for i in range(1, 7):
+            p = 'cnn.model.bn%d.' % i
+            self.bn[i] = {'mean': torch.as_tensor(np.asarray(sd[p + 'running_mean'])).float().to(self.device).clone(),
+                          'var': torch.as_tensor(np.asarray(sd[p + 'running_var'])).float().to(self.device).clone(),
+                          'n': int(np.asarray(sd[p + 'num_batches_tracked'])) if p + 'num_batches_tracked' in sd else 0}
+
+    def state_dict(self):
+        """Reference keys and shapes (CPU tensors): loads into the reference's model and into HipNisqa."""
+        out = {}
+        for k, shape in self._ref_shape.items():
+            last = k.split('.')[-1]
+            if last in ('running_mean', 'running_var', 'num_batches_tracked'):
+                i = int(k.split('.')[2][2:])
+                out[k] = (torch.tensor(self.bn[i]['n']) if last == 'num_batches_tracked'
+                          else self.bn[i]['mean' if last == 'running_mean' else 'var'].cpu().clone())
+            else:
+                out[k] = self._from_kernel(k, self.P[k].cpu(), shape).contiguous().clone()
+        return out
+
+    def grads(self):
+        """Gradients of the last step in the reference's shapes (CPU tensors)."""
+        return {k: self._from_kernel(k, self.G[k].cpu(), self._ref_shape[k]).contiguous().clone() for k in self.keys}
+
+    # ---- thin wrappers over the C ABI ------------------------------------------------------------------------
+    def _st(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _ck(self, rc, what):
+        _lib.check(rc, what)
+
+    def _new(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, ksplit=1, ao=0, bo=0, co=0):
+        self._ck(self.lib.nisqa_gemm_f32_one(_ptr(A, ao), _ptr(B, bo), _ptr(C, co), M, N, K, lda, ldb, ldc, ta, tb, ksplit,
+                                             1.0, self._st()), 'nisqa_gemm_f32_one')
+
+    def _ggemm(self, kind, A, B, C, ta=0, tb=0, ao=0, bo=0, co=0):
+        d, tiles = self._desc[kind]
+        self._ck(self.lib.nisqa_gemm_f32(_ptr(A, ao), _ptr(B, bo), _ptr(C, co), d.data_ptr(), d.shape[0], tiles, ta, tb, 1,
+                                         1.0, self._st()), 'nisqa_gemm_f32')
+
+    def _ew(self, op, x, aux=None, bias=None, rows=None, cols=None, out=None):
+        out = x if out is None else out
+        rows = x.numel() // (cols or x.shape[-1]) if rows is None else rows
+        cols = cols or x.shape[-1]
+        self._ck(self.lib.nisqa_elementwise(op, _ptr(x), _ptr(aux) if aux is not None else None,
+                                            _ptr(bias) if bias is not None else None, rows, cols, _ptr(out), self._st()),
+                 'nisqa_elementwise')
+        return out
+
+    def _coldot(self, a, b, rows, c):
+        s = self._sums[self._sum_i]
+        self._sum_i += 1
+        self._ck(self.lib.nisqa_col_dot(_ptr(a), _ptr(b), rows, c, s.data_ptr(), self._st()), 'nisqa_col_dot')
+        return s
+
+    def _ksplit(self, rows):
+        return int(max(1, min(256, rows // 2048)))
+
+    def _linear_fwd(self, X, wk, bk, rows, n_in, n_out, relu=False):
+        Y = self._new(rows, n_out)
+        self._gemm(X, self.P[wk], Y, rows, n_out, n_in, n_in, n_in, n_out, tb=1)
+        return self._ew(1 if relu else 0, Y, bias=self.P[bk], rows=rows, cols=n_out)
+
+    def _linear_bwd(self, dY, X, wk, bk, rows, n_in, n_out, need_dx=True):
+        s = self._coldot(dY, dY, rows, n_out)
+        self.G[bk].copy_(s[:n_out])
+        self._gemm(dY, X, self.G[wk], n_out, n_in, rows, n_out, n_in, n_in, ta=1, ksplit=self._ksplit(rows))
+        if not need_dx:
+            return None
+        dX = self._new(rows, n_in)
+        self._gemm(dY, self.P[wk], dX, rows, n_in, n_out, n_out, n_in, n_in)
+        return dX
+
+    def _ln_fwd(self, X, gk, bk, rows):
+        y, xh, rs = self._new(rows, 64), self._new(rows, 64), self._new(rows)
+        self._ck(self.lib.nisqa_layernorm_fwd(_ptr(X), _ptr(self.P[gk]), _ptr(self.P[bk]), rows, _ptr(y), _ptr(xh), _ptr(rs),
+                                              self._st()), 'nisqa_layernorm_fwd')
+        return y, xh, rs
+
+    def _ln_bwd(self, dY, xh, rs, gk, bk, rows):
+        s = self._coldot(dY, xh, rows, 64)
+        self.G[bk].copy_(s[:64])
+        self.G[gk].copy_(s[64:128])
+        dX = self._new(rows, 64)
+        self._ck(self.lib.nisqa_layernorm_bwd(_ptr(dY), _ptr(xh), _ptr(rs), _ptr(self.P[gk]), rows, _ptr(dX), self._st()),
+                 'nisqa_layernorm_bwd')
+        return dX
+
+    # ---- batch bookkeeping ---------------------------------------------------------------------------------
+    def _prepare(self, n_wins):
+        L = np.asarray(n_wins, dtype=np.int64)
+        B, S = len(L), int(L.sum())
+        tok = np.concatenate(([0], np.cumsum(L)))
+        sq = np.concatenate(([0], np.cumsum(L * L)))
+        self.B, self.S, self.L, self.tok, self.sq = B, S, L, tok, sq
+        up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
+        self.seg_off = up(tok.astype(np.int32))
+
+        def desc(kind, a_off, b_off, c_off, M, N, K, lda, ldb, ldc):
+            z = np.zeros((B, 10), np.int64)
+            for j, col in enumerate((a_off, b_off, c_off, M, N, K, lda, ldb, ldc)):
+                z[:, j] = col
+            tiles = ((z[:, 3] + 63) // 64) * ((z[:, 4] + 63) // 64)
+            z[:, 9] = np.concatenate(([0], np.cumsum(tiles)[:-1]))
+            return kind, (up(z), int(tiles.sum()))
+
+        t, s, b = tok[:-1], sq[:-1], np.arange(B)
+        self._desc = dict([
+            desc('qk', t * 192, t * 192, s, L, L, 64, 192, 192, L),
+            desc('pv', s, t * 192, t * 64, L, 64, L, L, 192, 64),
+            desc('dp', t * 64, t * 192, s, L, L, 64, 64, 192, L),
+            desc('dv', s, t * 64, t * 192, L, 64, L, L, 64, 192),
+            desc('dq', s, t * 192, t * 192, L, 64, L, L, 192, 192),
+            desc('dk', s, t * 192, t * 192, L, 64, L, L, 192, 192),
+            desc('pool', t, t * 64, b * 64, 1, 64, L, L, 64, 64),
+            desc('datt', b * 64, t * 64, t, 1, L, 64, 64, 64, L),
+            desc('outer', t, b * 64, t * 64, L, 64, 1, L, 64, 64),
+        ])
+        rows_b = np.repeat(np.arange(B), L)
+        within = np.arange(S) - tok[rows_b]
+        self.att_off = up((sq[rows_b] + within * L[rows_b]).astype(np.int64))
+        self.att_len = up(L[rows_b].astype(np.int32))
+        self.pool_off = up(tok[:-1].astype(np.int64))
+        self.pool_len = up(L.astype(np.int32))
+        self._sums = torch.zeros((96 + 24 * len(self.heads), 512), dtype=torch.float64, device=self.device)
+        self._sum_i = 0
+
+    def _mask(self, masks, key, shape, p):
+        """Dropout multipliers (0 or 1/(1-p)): explicit ``masks[key]`` (tests) or fresh Bernoulli draws."""
+        if masks is not None:
+            m = masks.get(key)
+            return None if m is None else torch.as_tensor(m, dtype=torch.float32).reshape(shape).contiguous().to(self.device)
+        if p <= 0:
+            return None
+        return (torch.rand(shape, device=self.device) >= p).float() / (1.0 - p)
+
+    # ---- the step ------------------------------------------------------------------------------------------
+    def step_pcm(self, pcm, plan, sr, y, masks=None, bias=None):
+        """pcm: float32 device tensor (clips back to back), plan: BatchPlan -- mel front end fused into the step."""
+        mel, floor = self.eng.mel(pcm, plan, sr, clamp=False)
+        d = plan.to(self.device)
+        return self._step(mel, d['frame_off'], plan.n_wins, floor, y, masks, bias)
+
+    def step_spec(self, specs, y, masks=None, bias=None):
+        """specs: list of [48, T] dB spectrograms (the input of segment_specs) -- used by the parity tests."""
+        T = np.array([s.shape[1] for s in specs], dtype=np.int64)
+        hop = int(self.args['ms_seg_hop_length'])
+        n_wins = np.ceil((T - (SEG_LEN - 1)) / hop).astype(np.int64)
+        mel = torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(s, np.float32).T for s in specs], 0))).to(self.device)
+        frame_off = torch.from_numpy(np.concatenate(([0], np.cumsum(T))).astype(np.int32)).to(self.device)
+        floor = torch.full((len(specs),), -3.0e38, dtype=torch.float32, device=self.device)
+        return self._step(mel, frame_off, n_wins, floor, y, masks, bias)
+
+    def _step(self, mel, frame_off, n_wins, floor, y, masks, bias):
+        L_ = self.lib
+        self._prepare(n_wins)
+        B, S, st = self.B, self.S, self._st()
+        hop = int(self.args['ms_seg_hop_length'])
+        self.gflat.zero_()
+        y_dev = torch.as_tensor(np.asarray(y, np.float32)).reshape(B, len(self.heads)).contiguous().to(self.device)
+        bias_dev = None if bias is None else torch.as_tensor(np.asarray(bias, np.float32)).reshape(B, 4).contiguous().to(self.device)
+
+        # ================= forward: AdaptCNN in train mode =================
+        geo = [(48, 15, self.pools[0]), (24, 7, self.pools[1]), (12, 5, (12, 5)), (12, 5, self.pools[2]), (6, 3, (6, 3)),
+               (6, 1, (6, 1))]                                               # conv output (H, W) and the pool after it
+        cnn = []
+        act = None
+        for i in range(1, 7):
+            ci, co = _CONV[i - 1]
+            h, w, (ho, wo) = geo[i - 1]
+            rows = S * h * w
+            col = self._new(rows, 9 * ci)
+            if i == 1:
+                self._ck(L_.nisqa_im2col_mel(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop, _ptr(col),
+                                             st), 'nisqa_im2col_mel')
+            else:
+                hi, wi = geo[i - 2][2]
+                self._ck(L_.nisqa_im2col3x3(_ptr(act), S, hi, wi, ci, 0 if i == 6 else 1, _ptr(col), st), 'nisqa_im2col3x3')
+            z = self._new(rows, co)
+            wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
+            self._gemm(col, self.P[wk], z, rows, co, 9 * ci, 9 * ci, 9 * ci, co, tb=1)
+            self._ew(0, z, bias=self.P[bk], rows=rows, cols=co)
+            sums = self._coldot(z, z, rows, co)
+            drop = self._mask(masks, _DROP_AFTER.get(i), (S, co), self.p_cnn) if i in _DROP_AFTER else None
+            out = self._new(S, ho * wo, co)
+            arg = self._new(S, ho * wo, co, dtype=torch.int32)
+            mr = self._new(2 * co)
+            self._ck(L_.nisqa_bn_act_pool_fwd(_ptr(z), sums.data_ptr(), _ptr(self.P['cnn.model.bn%d.weight' % i]),
+                                              _ptr(self.P['cnn.model.bn%d.bias' % i]), _ptr(self.bn[i]['mean']),
+                                              _ptr(self.bn[i]['var']), _ptr(mr), S, h, w, co, ho, wo,
+                                              _ptr(drop) if drop is not None else None, _ptr(out), arg.data_ptr(), st),
+                     'nisqa_bn_act_pool_fwd')
+            self.bn[i]['n'] += 1
+            cnn.append(dict(col=col, z=z, arg=arg, mr=mr, drop=drop, h=h, w=w, ho=ho, wo=wo, ci=ci, co=co, rows=rows))
+            act = out
+        feat = act                                                             # [S][6][64] = [S][384] in (y, c) order
+
+        # ================= forward: self-attention =================
+        pfx = 'time_dependency.model.'
+        x0 = self._linear_fwd(feat, pfx + 'linear.weight', pfx + 'linear.bias', S, 384, 64)
+        x, xh0, rs0 = self._ln_fwd(x0, pfx + 'norm1.weight', pfx + 'norm1.bias', S)
+        scale = 1.0 / math.sqrt(64.0)
+        n_sq = int(self.sq[-1])
+        td = []
+        for l in range(self.n_layers):
+            p = pfx + 'layers.%d.' % l
+            r = {'x_in': x}
+            qkv = self._linear_fwd(x, p + 'self_attn.in_proj_weight', p + 'self_attn.in_proj_bias', S, 64, 192)
+            prob = self._new(n_sq)
+            self._ggemm('qk', qkv, qkv, prob, tb=1, bo=64)
+            self._ck(L_.nisqa_softmax_rows_fwd(_ptr(prob), self.att_off.data_ptr(), self.att_len.data_ptr(), S, scale,
+                                               _ptr(prob), st), 'nisqa_softmax_rows_fwd')
+            mp = self._mask(masks, 'td%d_p' % l, (n_sq,), self.p_td)
+            pd = prob if mp is None else self._ew(3, prob, aux=mp, rows=1, cols=n_sq, out=self._new(n_sq))
+            ctx = self._new(S, 64)
+            self._ggemm('pv', pd, qkv, ctx, bo=128)
+            att = self._linear_fwd(ctx, p + 'self_attn.out_proj.weight', p + 'self_attn.out_proj.bias', S, 64, 64)
+            m1 = self._mask(masks, 'td%d_1' % l, (S, 64), self.p_td)
+            if m1 is not None:
+                self._ew(3, att, aux=m1)
+            r1 = self._ew(4, att, aux=x, out=self._new(S, 64))
+            x1, xh1, rs1 = self._ln_fwd(r1, p + 'norm1.weight', p + 'norm1.bias', S)
+            hh = self._linear_fwd(x1, p + 'linear1.weight', p + 'linear1.bias', S, 64, 64, relu=True)
+            mf = self._mask(masks, 'td%d_f' % l, (S, 64), self.p_td)
+            hd = hh if mf is None else self._ew(3, hh, aux=mf, out=self._new(S, 64))
+            f = self._linear_fwd(hd, p + 'linear2.weight', p + 'linear2.bias', S, 64, 64)
+            m2 = self._mask(masks, 'td%d_2' % l, (S, 64), self.p_td)
+            if m2 is not None:
+                self._ew(3, f, aux=m2)
+            r2 = self._ew(4, f, aux=x1, out=self._new(S, 64))
+            x, xh2, rs2 = self._ln_fwd(r2, p + 'norm2.weight', p + 'norm2.bias', S)
+            r.update(qkv=qkv, prob=prob, mp=mp, pd=pd, ctx=ctx, m1=m1, x1=x1, xh1=xh1, rs1=rs1, hh=hh, mf=mf, hd=hd, m2=m2,
+                     xh2=xh2, rs2=rs2)
+            td.append(r)
+
+        # ================= forward: attention pooling heads, loss =================
+        H = len(self.heads)
+        y_hat = self._new(B, H)
+        pool = []
+        for hi_, hp in enumerate(self.heads):
+            u = self._linear_fwd(x, hp + 'linear1.weight', hp + 'linear1.bias', S, 64, 128, relu=True)
+            sc = self._linear_fwd(u, hp + 'linear2.weight', hp + 'linear2.bias', S, 128, 1)
+            att = self._new(S)
+            self._ck(L_.nisqa_softmax_rows_fwd(_ptr(sc), self.pool_off.data_ptr(), self.pool_len.data_ptr(), B, 1.0,
+                                               _ptr(att), st), 'nisqa_softmax_rows_fwd')
+            pooled = self._new(B, 64)
+            self._ggemm('pool', att, x, pooled)
+            self._gemm(pooled, self.P[hp + 'linear3.weight'], y_hat, B, 1, 64, 64, 64, H, tb=1, co=hi_)
+            pool.append(dict(u=u, att=att, pooled=pooled))
+        b3 = torch.cat([self.P[hp + 'linear3.bias'] for hp in self.heads])
+        self._ew(0, y_hat, bias=b3, rows=B, cols=H)
+        loss = self._new(1)
+        dyh = self._new(B, H)
+        self._ck(L_.nisqa_mse_loss(_ptr(y_hat), _ptr(y_dev), _ptr(bias_dev) if bias_dev is not None else None, B, H,
+                                   _ptr(loss), _ptr(dyh), st), 'nisqa_mse_loss')
+
+        # ================= backward: pooling heads =================
+        s = self._coldot(dyh, dyh, B, H)
+        dx = torch.zeros((S, 64), dtype=torch.float32, device=self.device)
+        tmp = self._new(S, 64)
+        for hi_, hp in enumerate(self.heads):
+            pr = pool[hi_]
+            self.G[hp + 'linear3.bias'].copy_(s[hi_:hi_ + 1])
+            self._gemm(dyh, pr['pooled'], self.G[hp + 'linear3.weight'], 1, 64, B, H, 64, 64, ta=1, ao=hi_)
+            dpooled = self._new(B, 64)
+            self._gemm(dyh, self.P[hp + 'linear3.weight'], dpooled, B, 64, 1, H, 64, 64, ao=hi_)
+            datt = self._new(S)
+            self._ggemm('datt', dpooled, x, datt, tb=1)
+            self._ggemm('outer', pr['att'], dpooled, tmp, ta=1)
+            self._ew(4, dx, aux=tmp)
+            self._ck(L_.nisqa_softmax_rows_bwd(_ptr(pr['att']), _ptr(datt), self.pool_off.data_ptr(), self.pool_len.data_ptr(),
+                                               B, 1.0, _ptr(datt), st), 'nisqa_softmax_rows_bwd')
+            du = self._linear_bwd(datt, pr['u'], hp + 'linear2.weight', hp + 'linear2.bias', S, 128, 1)
+            self._ew(2, du, aux=pr['u'])
+            dxh = self._linear_bwd(du, x, hp + 'linear1.weight', hp + 'linear1.bias', S, 64, 128)
+            self._ew(4, dx, aux=dxh)
+
+        # ================= backward: self-attention layers =================
+        for l in reversed(range(self.n_layers)):
+            p = pfx + 'layers.%d.' % l
+            r = td[l]
+            dr2 = self._ln_bwd(dx, r['xh2'], r['rs2'], p + 'norm2.weight', p + 'norm2.bias', S)
+            df = dr2 if r['m2'] is None else self._ew(3, dr2, aux=r['m2'], out=self._new(S, 64))
+            dhd = self._linear_bwd(df, r['hd'], p + 'linear2.weight', p + 'linear2.bias', S, 64, 64)
+            if r['mf'] is not None:
+                self._ew(3, dhd, aux=r['mf'])
+            self._ew(2, dhd, aux=r['hh'])
+            dx1 = self._linear_bwd(dhd, r['x1'], p + 'linear1.weight', p + 'linear1.bias', S, 64, 64)
+            self._ew(4, dx1, aux=dr2)
+            dr1 = self._ln_bwd(dx1, r['xh1'], r['rs1'], p + 'norm1.weight', p + 'norm1.bias', S)
+            datt = dr1 if r['m1'] is None else self._ew(3, dr1, aux=r['m1'], out=self._new(S, 64))
+            dctx = self._linear_bwd(datt, r['ctx'], p + 'self_attn.out_proj.weight', p + 'self_attn.out_proj.bias', S, 64, 64)
+            dqkv = self._new(S, 192)
+            dp = self._new(n_sq)
+            self._ggemm('dp', dctx, r['qkv'], dp, tb=1, bo=128)
+            self._ggemm('dv', r['pd'], dctx, dqkv, ta=1, co=128)
+            if r['mp'] is not None:
+                self._ew(3, dp, aux=r['mp'], rows=1, cols=n_sq)
+            self._ck(L_.nisqa_softmax_rows_bwd(_ptr(r['prob']), _ptr(dp), self.att_off.data_ptr(), self.att_len.data_ptr(), S,
+                                               scale, _ptr(dp), st), 'nisqa_softmax_rows_bwd')
+            self._ggemm('dq', dp, r['qkv'], dqkv, bo=64)
+            self._ggemm('dk', dp, r['qkv'], dqkv, ta=1, co=64)
+            dxin = self._linear_bwd(dqkv, r['x_in'], p + 'self_attn.in_proj_weight', p + 'self_attn.in_proj_bias', S, 64, 192)
+            dx = self._ew(4, dxin, aux=dr1)
+        dx0 = self._ln_bwd(dx, xh0, rs0, pfx + 'norm1.weight', pfx + 'norm1.bias', S)
+        da = self._linear_bwd(dx0, feat, pfx + 'linear.weight', pfx + 'linear.bias', S, 384, 64)        # [S][6][64]
+
+        # ================= backward: AdaptCNN =================
+        for i in range(6, 0, -1):
+            c = cnn[i - 1]
+            rows, co, ci = c['rows'], c['co'], c['ci']
+            dz = self._new(rows, co)
+            g, b_ = self.P['cnn.model.bn%d.weight' % i], self.P['cnn.model.bn%d.bias' % i]
+            self._ck(L_.nisqa_bn_act_pool_bwd1(_ptr(da), c['arg'].data_ptr(), _ptr(c['drop']) if c['drop'] is not None else None,
+                                               _ptr(c['z']), _ptr(c['mr']), _ptr(g), _ptr(b_), S, c['h'], c['w'], co, c['ho'],
+                                               c['wo'], _ptr(dz), st), 'nisqa_bn_act_pool_bwd1')
+            s2 = self._coldot(dz, c['z'], rows, co)
+            self._ck(L_.nisqa_bn_bwd2(_ptr(dz), _ptr(c['z']), s2.data_ptr(), _ptr(c['mr']), _ptr(g), rows, co,
+                                      _ptr(self.G['cnn.model.bn%d.weight' % i]), _ptr(self.G['cnn.model.bn%d.bias' % i]), st),
+                     'nisqa_bn_bwd2')
+            wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
+            sb = self._coldot(dz, dz, rows, co)
+            self.G[bk].copy_(sb[:co])
+            self._gemm(dz, c['col'], self.G[wk], co, 9 * ci, rows, co, 9 * ci, 9 * ci, ta=1, ksplit=self._ksplit(rows))
+            if i > 1:
+                dcol = self._new(rows, 9 * ci)
+                self._gemm(dz, self.P[wk], dcol, rows, 9 * ci, co, co, 9 * ci, 9 * ci)
+                hi, wi = geo[i - 2][2]
+                da = self._new(S, hi * wi, ci)
+                self._ck(L_.nisqa_col2im3x3(_ptr(dcol), S, hi, wi, ci, 0 if i == 6 else 1, _ptr(da), st), 'nisqa_col2im3x3')
+            c['col'] = None
+
+        # ================= Adam =================
+        self.t += 1
+        self._ck(L_.nisqa_adam_step(_ptr(self.flat), _ptr(self.gflat), _ptr(self.m), _ptr(self.v), self.flat.numel(), self.lr,
+                                    self.t, st), 'nisqa_adam_step')
+        self.last = {'y_hat': y_hat, 'loss': loss}
+        return loss

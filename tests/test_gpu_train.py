@@ -1,0 +1,374 @@
+"""GPU parity of the training step (include/nisqa_train.h, nisqa_amd/train.py).
+
+Operators are checked one by one against plain PyTorch fp32 (autograd for the backward passes), the whole step against
+the fixtures written by the reference's own modules in train mode (tests/golden/make_golden_train.py) and against
+the oracle restatement (oracle/train.py) with explicit dropout masks and the bias-mapped loss."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import helpers
+from nisqa_amd import synth
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+
+DEV = 'cuda:0'
+
+
+def _L():
+    from nisqa_amd import lib
+    return lib, lib.load()
+
+
+def _p(t, off=0):
+    return t.data_ptr() + 4 * off
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _r(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+def _gemm_one(A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, ks=1, ao=0, bo=0, co=0):
+    lib, L = _L()
+    lib.check(L.nisqa_gemm_f32_one(_p(A, ao), _p(B, bo), _p(C, co), M, N, K, lda, ldb, ldc, ta, tb, ks, 1.0, _st()), 'gemm')
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 64, 16), (1, 1, 1), (130, 70, 37), (5, 200, 3), (300, 17, 1000)])
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_single_group_all_layouts(M, N, K, ta, tb):
+    A, B = _r(M, K, seed=1), _r(K, N, seed=2)
+    want = (A.double() @ B.double()).float()
+    As = A.t().contiguous() if ta else A
+    Bs = B.t().contiguous() if tb else B
+    C = torch.full((M, N + 3), 7.0, device=DEV)                      # padded ldc: the pad must stay untouched
+    _gemm_one(As, Bs, C, M, N, K, As.shape[1], Bs.shape[1], N + 3, ta, tb)
+    torch.cuda.synchronize()
+    assert (C[:, N:] == 7.0).all()
+    tol = 1e-5 * max(1.0, float(want.abs().max())) * math.sqrt(K)
+    assert (C[:, :N] - want).abs().max() < tol
+    # split-K accumulates into a zeroed C
+    C2 = torch.zeros((M, N), device=DEV)
+    _gemm_one(As, Bs, C2, M, N, K, As.shape[1], Bs.shape[1], N, ta, tb, ks=7)
+    torch.cuda.synchronize()
+    assert (C2 - want).abs().max() < tol
+
+
+def test_gemm_grouped_ragged_attention_shapes():
+    lib, L = _L()
+    Ls = np.array([5, 70, 1, 33], np.int64)
+    tok = np.concatenate(([0], np.cumsum(Ls)))
+    sq = np.concatenate(([0], np.cumsum(Ls * Ls)))
+    S = int(tok[-1])
+    qkv = _r(S, 192, seed=3)
+    z = np.zeros((4, 10), np.int64)
+    for j, col in enumerate((tok[:-1] * 192, tok[:-1] * 192, sq[:-1], Ls, Ls, 64, 192, 192, Ls)):
+        z[:, j] = col
+    tiles = ((z[:, 3] + 63) // 64) * ((z[:, 4] + 63) // 64)
+    z[:, 9] = np.concatenate(([0], np.cumsum(tiles)[:-1]))
+    d = torch.from_numpy(z).to(DEV)
+    out = torch.zeros(int(sq[-1]), device=DEV)
+    lib.check(L.nisqa_gemm_f32(_p(qkv), _p(qkv, 64), _p(out), d.data_ptr(), 4, int(tiles.sum()), 0, 1, 1, 1.0, _st()), 'gemm')
+    torch.cuda.synchronize()
+    for b in range(4):
+        q, k = qkv[tok[b]:tok[b + 1], :64], qkv[tok[b]:tok[b + 1], 64:128]
+        got = out[sq[b]:sq[b + 1]].view(int(Ls[b]), int(Ls[b]))
+        assert (got - q @ k.t()).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize('h,w,c,pad_w', [(24, 7, 16, 1), (12, 5, 32, 1), (6, 3, 64, 0), (6, 3, 64, 1)])
+def test_im2col_col2im_against_unfold_and_adjointness(h, w, c, pad_w):
+    lib, L = _L()
+    S = 3
+    x = _r(S, h * w, c, seed=4)
+    wo = w + 2 * pad_w - 2
+    col = torch.empty(S * h * wo, 9 * c, device=DEV)
+    lib.check(L.nisqa_im2col3x3(_p(x), S, h, w, c, pad_w, _p(col), _st()), 'im2col')
+    xn = x.view(S, h, w, c).permute(0, 3, 1, 2)                      # NCHW
+    u = F.unfold(xn, 3, padding=(1, pad_w)).view(S, c, 9, h * wo)     # [S][c][tap][pixel]
+    want = u.permute(0, 3, 2, 1).reshape(S * h * wo, 9 * c)
+    torch.cuda.synchronize()
+    assert torch.equal(col, want)
+    dcol = _r(S * h * wo, 9 * c, seed=5)
+    dx = torch.empty_like(x)
+    lib.check(L.nisqa_col2im3x3(_p(dcol), S, h, w, c, pad_w, _p(dx), _st()), 'col2im')
+    torch.cuda.synchronize()
+    lhs, rhs = float((col.double() * dcol.double()).sum()), float((x.double() * dx.double()).sum())
+    assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))                # <im2col(x), d> == <x, col2im(d)>
+
+
+def test_im2col_mel_segments_and_floor():
+    lib, L = _L()
+    T = [40, 15]
+    mel = _r(sum(T), 48, seed=6, scale=20.0)
+    frame_off = torch.tensor([0, 40, 55], dtype=torch.int32, device=DEV)
+    n_wins = [7, 1]
+    seg_off = torch.tensor([0, 7, 8], dtype=torch.int32, device=DEV)
+    floor = torch.tensor([-10.0, -3.0e38], device=DEV)
+    col = torch.empty(8 * 720, 9, device=DEV)
+    lib.check(L.nisqa_im2col_mel(_p(mel), frame_off.data_ptr(), seg_off.data_ptr(), _p(floor), 2, 8, 4, _p(col), _st()), 'im2col_mel')
+    torch.cuda.synchronize()
+    segs = []
+    for b, (t0, n) in enumerate(zip([0, 40], n_wins)):
+        sp = torch.maximum(mel[t0:t0 + T[b]], floor[b]).t()          # [48, T]
+        segs += [sp[:, 4 * k:4 * k + 15] for k in range(n)]
+    x = torch.stack(segs)[:, None]                                    # [8,1,48,15]
+    want = F.unfold(x, 3, padding=1).permute(0, 2, 1).reshape(8 * 720, 9)
+    assert torch.equal(col, want)
+
+
+def test_col_dot_float64_accumulation():
+    lib, L = _L()
+    rows, c = 100003, 48
+    a = _r(rows, c, seed=7) + 50.0
+    b = _r(rows, c, seed=8)
+    out = torch.zeros(2 * c, dtype=torch.float64, device=DEV)
+    lib.check(L.nisqa_col_dot(_p(a), _p(b), rows, c, out.data_ptr(), _st()), 'col_dot')
+    torch.cuda.synchronize()
+    assert (out[:c] - a.double().sum(0)).abs().max() < 1e-6 * rows
+    assert (out[c:] - (a.double() * b.double()).sum(0)).abs().max() < 1e-6 * rows
+
+
+@pytest.mark.parametrize('h,w,c,ho,wo,use_drop', [(48, 15, 16, 24, 7, False), (24, 7, 32, 12, 5, True), (12, 5, 64, 12, 5, True),
+                                                  (12, 5, 64, 6, 3, True), (6, 1, 64, 6, 1, False)])
+def test_batchnorm_relu_pool_dropout_forward_and_backward(h, w, c, ho, wo, use_drop):
+    lib, L = _L()
+    S = 5
+    z = (_r(S, h * w, c, seed=9) * 2 + 0.3).requires_grad_(True)
+    gamma, beta = (_r(c, seed=10) * 0.5 + 1).requires_grad_(True), _r(c, seed=11).requires_grad_(True)
+    drop = ((torch.rand(S, c, device=DEV) > 0.3).float() / 0.7) if use_drop else None
+    rm, rv = _r(c, seed=12), _r(c, seed=13).abs() + 0.5
+    # torch reference
+    zn = z.view(S, h, w, c).permute(0, 3, 1, 2)
+    rm_t, rv_t = rm.clone(), rv.clone()
+    y_t = F.adaptive_max_pool2d(F.relu(F.batch_norm(zn, rm_t, rv_t, gamma, beta, True, 0.1, 1e-5)), (ho, wo))
+    if drop is not None:
+        y_t = y_t * drop[:, :, None, None]
+    dy = _r(S, ho * wo, c, seed=14)
+    (y_t.permute(0, 2, 3, 1).reshape(S, ho * wo, c) * dy).sum().backward()
+    # kernels
+    zd = z.detach()
+    sums = torch.zeros(2 * c, dtype=torch.float64, device=DEV)
+    lib.check(L.nisqa_col_dot(_p(zd), _p(zd), S * h * w, c, sums.data_ptr(), _st()), 'col_dot')
+    y = torch.empty(S, ho * wo, c, device=DEV)
+    arg = torch.empty(S, ho * wo, c, dtype=torch.int32, device=DEV)
+    mr = torch.empty(2 * c, device=DEV)
+    dp = _p(drop) if drop is not None else None
+    lib.check(L.nisqa_bn_act_pool_fwd(_p(zd), sums.data_ptr(), _p(gamma), _p(beta), _p(rm), _p(rv), _p(mr), S, h, w, c, ho, wo,
+                                      dp, _p(y), arg.data_ptr(), _st()), 'bn fwd')
+    dyb = torch.empty(S, h * w, c, device=DEV)
+    lib.check(L.nisqa_bn_act_pool_bwd1(_p(dy), arg.data_ptr(), dp, _p(zd), _p(mr), _p(gamma), _p(beta), S, h, w, c, ho, wo,
+                                       _p(dyb), _st()), 'bn bwd1')
+    s2 = torch.zeros(2 * c, dtype=torch.float64, device=DEV)
+    lib.check(L.nisqa_col_dot(_p(dyb), _p(zd), S * h * w, c, s2.data_ptr(), _st()), 'col_dot')
+    dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    lib.check(L.nisqa_bn_bwd2(_p(dyb), _p(zd), s2.data_ptr(), _p(mr), _p(gamma), S * h * w, c, _p(dg), _p(db), _st()), 'bn bwd2')
+    torch.cuda.synchronize()
+    want_y = y_t.detach().permute(0, 2, 3, 1).reshape(S, ho * wo, c)
+    assert (y - want_y).abs().max() < 2e-5
+    assert (rm - rm_t).abs().max() < 1e-5 and (rv - rv_t).abs().max() < 1e-4
+    assert (dyb - z.grad).abs().max() < 2e-4 * max(1.0, float(z.grad.abs().max()))
+    assert (dg - gamma.grad).abs().max() < 2e-4 * max(1.0, float(gamma.grad.abs().max()))
+    assert (db - beta.grad).abs().max() < 2e-4 * max(1.0, float(beta.grad.abs().max()))
+
+
+def test_layernorm_softmax_elementwise_loss_adam():
+    lib, L = _L()
+    rows = 77
+    x = _r(rows, 64, seed=15).requires_grad_(True)
+    g, b = (_r(64, seed=16) + 1).requires_grad_(True), _r(64, seed=17).requires_grad_(True)
+    dy = _r(rows, 64, seed=18)
+    yt = F.layer_norm(x, (64,), g, b, 1e-5)
+    (yt * dy).sum().backward()
+    y, xh, rs, dx = (torch.empty(rows, 64, device=DEV), torch.empty(rows, 64, device=DEV), torch.empty(rows, device=DEV),
+                     torch.empty(rows, 64, device=DEV))
+    lib.check(L.nisqa_layernorm_fwd(_p(x.detach()), _p(g), _p(b), rows, _p(y), _p(xh), _p(rs), _st()), 'ln fwd')
+    lib.check(L.nisqa_layernorm_bwd(_p(dy), _p(xh), _p(rs), _p(g), rows, _p(dx), _st()), 'ln bwd')
+    s = torch.zeros(128, dtype=torch.float64, device=DEV)
+    lib.check(L.nisqa_col_dot(_p(dy), _p(xh), rows, 64, s.data_ptr(), _st()), 'col_dot')
+    torch.cuda.synchronize()
+    assert (y - yt.detach()).abs().max() < 1e-5 and (dx - x.grad).abs().max() < 1e-4
+    assert (s[:64].float() - b.grad).abs().max() < 1e-4 and (s[64:].float() - g.grad).abs().max() < 1e-4
+
+    lens = np.array([1, 64, 65, 300], np.int32)
+    off = np.concatenate(([0], np.cumsum(lens)[:-1])).astype(np.int64)
+    n = int(lens.sum())
+    sx = _r(n, seed=19, scale=3.0).requires_grad_(True)
+    dp = _r(n, seed=20)
+    rows_t = [torch.softmax(0.125 * sx[o:o + l], 0) for o, l in zip(off, lens)]
+    (torch.cat(rows_t) * dp).sum().backward()
+    p, ds = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    od, ld = torch.from_numpy(off).to(DEV), torch.from_numpy(lens).to(DEV)
+    lib.check(L.nisqa_softmax_rows_fwd(_p(sx.detach()), od.data_ptr(), ld.data_ptr(), 4, 0.125, _p(p), _st()), 'softmax fwd')
+    lib.check(L.nisqa_softmax_rows_bwd(_p(p), _p(dp), od.data_ptr(), ld.data_ptr(), 4, 0.125, _p(ds), _st()), 'softmax bwd')
+    torch.cuda.synchronize()
+    assert (p - torch.cat(rows_t).detach()).abs().max() < 1e-6 and (ds - sx.grad).abs().max() < 1e-6
+
+    a, aux, bias = _r(9, 20, seed=21), _r(9, 20, seed=22), _r(20, seed=23)
+    want = [a + bias, F.relu(a + bias), a * (aux > 0), a * aux, a + aux, a * bias]
+    for op, w_ in enumerate(want):
+        out = torch.empty_like(a)
+        lib.check(L.nisqa_elementwise(op, _p(a), _p(aux), _p(bias), 9, 20, _p(out), _st()), 'ew')
+        torch.cuda.synchronize()
+        assert torch.equal(out, w_), op
+
+    yh = _r(6, 5, seed=24).requires_grad_(True)
+    yv = _r(6, 5, seed=25)
+    yv[2, 1] = float('nan')
+    bias4 = torch.tensor([[0.1, 0.9, 0.02, -0.003]] * 6, device=DEV)
+    for bb in (None, bias4):
+        if yh.grad is not None:
+            yh.grad = None
+        tot = 0
+        for h in range(5):
+            v = yh[:, h] if bb is None else bb[:, 0] + bb[:, 1] * yh[:, h] + bb[:, 2] * yh[:, h] ** 2 + bb[:, 3] * yh[:, h] ** 3
+            ok = ~torch.isnan(yv[:, h])
+            tot = tot + ((yv[ok, h] - v[ok]) ** 2).mean()
+        tot.backward()
+        loss, dyh = torch.empty(1, device=DEV), torch.empty(6, 5, device=DEV)
+        lib.check(L.nisqa_mse_loss(_p(yh.detach()), _p(yv), _p(bb) if bb is not None else None, 6, 5, _p(loss), _p(dyh), _st()), 'mse')
+        torch.cuda.synchronize()
+        assert abs(float(loss) - float(tot)) < 1e-5 and (dyh - yh.grad).abs().max() < 1e-6
+
+    n = 1000
+    pt = torch.nn.Parameter(_r(n, seed=26))
+    opt = torch.optim.Adam([pt], lr=1e-3)
+    pk, m, v = pt.detach().clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for t in (1, 2, 3):
+        gr = _r(n, seed=30 + t)
+        pt.grad = gr.clone()
+        opt.step()
+        lib.check(L.nisqa_adam_step(_p(pk), _p(gr), _p(m), _p(v), n, 1e-3, t, _st()), 'adam')
+    torch.cuda.synchronize()
+    assert (pk - pt.detach()).abs().max() < 1e-6
+
+
+# ---- the whole step --------------------------------------------------------------------------------------------
+def _conv_bias(k):
+    return k.startswith('cnn.model.conv') and k.endswith('.bias')
+
+
+def _case(name):
+    import make_golden_train as mk
+    g = helpers.golden('train_%s.npz' % name)
+    args = dict(synth.MOS_ARGS if name == 'mos' else synth.DIM_ARGS)
+    args.update({'cnn_dropout': 0.0, 'td_sa_dropout': 0.0, 'pool_att_dropout': 0.0})
+    sd = synth.random_state_dict(int(g['seed_sd']), args['model'])
+    specs, y = mk.batch(int(g['seed_batch']), int(g['n_clips']), 5 if name == 'dim' else 1)
+    return g, args, sd, specs, y
+
+
+@pytest.mark.parametrize('name', ['mos', 'dim'])
+def test_training_step_matches_reference_fixture(name):
+    from nisqa_amd.train import HipTrainer
+    g, args, sd, specs, y = _case(name)
+    tr = HipTrainer(args, sd, DEV, lr=float(g['lr']))
+    loss = tr.step_spec(specs, y)
+    torch.cuda.synchronize()
+    assert float(loss) == pytest.approx(float(g['loss1']), rel=1e-4)
+    assert (tr.last['y_hat'].cpu().numpy() - g['y_hat1']).__abs__().max() < 1e-4
+    grads = tr.grads()
+    worst, wk = 0.0, None
+    for k, gr in grads.items():
+        want = g['grad/' + k]
+        assert tuple(gr.shape) == want.shape, k
+        if _conv_bias(k):
+            assert np.abs(gr.numpy()).max() < 1e-4              # analytically zero under train-mode BatchNorm
+            continue
+        e = float(np.abs(gr.numpy() - want).max()) / max(1e-3, float(np.abs(want).max()))
+        if e > worst:
+            worst, wk = e, k
+    print(name, 'worst relative gradient error', worst, wk)
+    assert worst < 1e-3, (worst, wk)
+    lr = float(g['lr'])
+    new = tr.state_dict()
+    for k, v in new.items():
+        want = g['sd1/' + k]
+        if k.endswith('num_batches_tracked'):
+            assert int(v) == int(want)
+        elif 'running' in k:
+            assert np.abs(v.numpy() - want).max() < 2e-4 * max(1.0, np.abs(want).max()), k
+        else:
+            gref = g['grad/' + k]
+            solid = (np.abs(gref) > 1e-3 * max(1e-3, np.abs(gref).max())) & (not _conv_bias(k))
+            d = np.abs(v.numpy() - want)
+            assert d[solid].max(initial=0) < 1e-4 and d.max() <= 2.002 * lr, k
+    loss2 = tr.step_spec(specs, y)
+    torch.cuda.synchronize()
+    assert float(loss2) == pytest.approx(float(g['loss2']), rel=2e-2)
+    for k, v in tr.state_dict().items():
+        if 'running' in k:
+            want = g['sd2/' + k]
+            assert np.abs(v.numpy() - want).max() < 1e-3 * max(1.0, np.abs(want).max()), k
+    # the trained weights load into the inference engine
+    from nisqa_amd.engine import HipNisqa
+    HipNisqa(args, tr.state_dict(), DEV)
+
+
+def test_training_step_with_dropout_masks_and_bias_loss_matches_oracle():
+    from nisqa_amd.train import HipTrainer
+    from oracle import net as onet, train as otrain
+    g, args, sd, specs, y = _case('dim')
+    segs = torch.cat([onet.segment_specs(s, 15, 4, None)[0] for s in specs])
+    n_wins = [int(v) for v in g['n_wins']]
+    S = sum(n_wins)
+    rng = np.random.default_rng(1)
+    drop = lambda shape, p: ((rng.random(shape) >= p).astype(np.float32) / (1 - p))
+    mk, mo = {}, {}
+    for key, c in (('cnn_d1', 32), ('cnn_d2', 64), ('cnn_d3', 64), ('cnn_d4', 64)):
+        mk[key] = drop((S, c), 0.2)
+        mo[key] = torch.as_tensor(mk[key])[:, :, None, None]
+    tok = np.concatenate(([0], np.cumsum(n_wins)))
+    for l in range(2):
+        pk = []
+        for b, n in enumerate(n_wins):
+            m = drop((n, n), 0.1)
+            mo[(b, 'td%d_p' % l)] = torch.as_tensor(m)
+            pk.append(m.reshape(-1))
+        mk['td%d_p' % l] = np.concatenate(pk)
+        for t in ('1', 'f', '2'):
+            m = drop((S, 64), 0.1)
+            mk['td%d_%s' % (l, t)] = m
+            for b in range(len(n_wins)):
+                mo[(b, 'td%d_%s' % (l, t))] = torch.as_tensor(m[tok[b]:tok[b + 1]])
+    bias = np.tile(np.array([[0.1, 0.9, 0.02, -0.001]], np.float32), (len(n_wins), 1))
+    ref = otrain.train_step(sd, args, segs, n_wins, y, masks=mo, bias=bias)
+    tr = HipTrainer(args, sd, DEV, lr=1e-3)
+    loss = tr.step_spec(specs, y, masks=mk, bias=bias)
+    torch.cuda.synchronize()
+    assert float(loss) == pytest.approx(ref['loss'], rel=1e-4)
+    worst, wk = 0.0, None
+    for k, gr in tr.grads().items():
+        if _conv_bias(k):
+            continue
+        want = ref['grads'][k]
+        e = float(np.abs(gr.numpy() - want).max()) / max(1e-3, float(np.abs(want).max()))
+        if e > worst:
+            worst, wk = e, k
+    print('masked step: worst relative gradient error', worst, wk)
+    assert worst < 1e-3, (worst, wk)
+
+
+def test_training_from_pcm_reduces_the_loss():
+    from nisqa_amd.train import HipTrainer
+    args = dict(synth.DIM_ARGS)
+    tr = HipTrainer(args, synth.random_state_dict(7, 'NISQA_DIM'), DEV, lr=1e-3)
+    pcm = [synth.synth_pcm16(i, 1.0 + 0.5 * i) for i in range(6)]
+    plan = tr.eng.plan([len(p) for p in pcm], 48000)
+    dev = tr.eng.pcm16_to_f32(torch.from_numpy(np.concatenate(pcm)).to(DEV))
+    y = np.random.default_rng(0).uniform(1, 5, (6, 5)).astype(np.float32)
+    losses = [float(tr.step_pcm(dev, plan, 48000, y)) for _ in range(12)]
+    torch.cuda.synchronize()
+    print('losses', [round(v, 3) for v in losses])
+    assert all(np.isfinite(losses)) and min(losses[-3:]) < 0.7 * losses[0]
+    assert all(int(v) == 112 for k, v in tr.state_dict().items() if k.endswith('num_batches_tracked'))

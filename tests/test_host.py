@@ -361,6 +361,19 @@ def test_library_exports_every_declared_symbol():
     assert declared <= exported
 
 
+def test_training_operators_are_declared_and_exported():
+    from nisqa_amd import lib
+    hdr = open(os.path.join(ROOT, 'include', 'nisqa_train.h')).read()
+    declared = set(re.findall(r'^\s*int\s+(nisqa_[a-z0-9_]+)\s*\(', hdr, re.M))
+    assert declared == set(lib.TRAIN_SYMBOLS), declared ^ set(lib.TRAIN_SYMBOLS)
+    L = lib.load()
+    out = subprocess.check_output(['nm', '-D', '--defined-only', lib.LIB_PATH]).decode()
+    assert declared <= set(re.findall(r' T (nisqa_\w+)', out))
+    assert L.nisqa_gemm_f32_one(None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1.0, None) == lib.NISQA_ERR_ARG
+    assert L.nisqa_adam_step(None, None, None, None, 10, 1e-3, 1, None) == lib.NISQA_ERR_ARG
+    assert L.nisqa_elementwise(9, None, None, None, 1, 1, None, None) == lib.NISQA_ERR_ARG
+
+
 def test_abi_argument_validation_without_gpu():
     from nisqa_amd import lib
     L = lib.load()
