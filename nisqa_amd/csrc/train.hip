@@ -12,22 +12,76 @@
 #include "../../include/nisqa_hip.h"
 #include "../../include/nisqa_train.h"
 
-#define GB_M 64
-#define GB_N 64
-#define GB_K 16
+#define GB_K 32
 
-// ---------------------------------------------------------------------------------------------------------
-// grouped GEMM: 256 threads = 4 waves, each a 32 x 32 output block of the 64 x 64 tile; operands staged k-major
-// in LDS so that a lane's fragment element (row/col = lane & 31, k = lane >> 5) is a conflict-free ds_read_b32
-// ---------------------------------------------------------------------------------------------------------
 struct gemm_one { int64_t v[10]; };                       // the descriptor of a single-group call, passed by value
 
+// One operand tile [R rows][GB_K] from global memory into registers, then into LDS as T[k][r] (k-major, so that a
+// lane's MFMA fragment element -- row/col = lane & 31, k = lane >> 5 -- is a conflict-free ds_read_b32).
+//   KC = true : k is the contiguous index in memory, element (r, k) at g[r * ld + k]   (A as stored, B = a weight [N][K])
+//   KC = false: r is the contiguous index,           element (r, k) at g[k * ld + r]   (A stored [K][M], B stored [K][N])
+// Each thread owns NV groups of four consecutive elements along the contiguous index: one 128-bit load when the
+// group is aligned and fully inside the matrix, four guarded scalar loads otherwise.
+template <int R, bool KC>
+struct tile_loader {
+    static constexpr int NV = R * GB_K / 4 / 256;
+    f32x4 v[NV];
+    __device__ __forceinline__ void load(const float* __restrict__ g, int64_t ld, int r0, int r_lim, int k0, int k_lim, bool vec_ok, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + 256 * j;
+            int r, k;
+            if (KC) { r = i / (GB_K / 4); k = 4 * (i % (GB_K / 4)); } else { k = i / (R / 4); r = 4 * (i % (R / 4)); }
+            const int gr = r0 + r, gk = k0 + k;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (KC) {
+                if (gr < r_lim) {
+                    const float* p = g + (int64_t)gr * ld + gk;
+                    if (vec_ok && gk + 3 < k_lim) x = *(const f32x4*)p;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (gk + e < k_lim) x[e] = p[e];
+                    }
+                }
+            } else {
+                if (gk < k_lim) {
+                    const float* p = g + (int64_t)gk * ld + gr;
+                    if (vec_ok && gr + 3 < r_lim) x = *(const f32x4*)p;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (gr + e < r_lim) x[e] = p[e];
+                    }
+                }
+            }
+            v[j] = x;
+        }
+    }
+    __device__ __forceinline__ void store(float (*T)[R + 4], int tid) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + 256 * j;
+            if (KC) {
+                const int r = i / (GB_K / 4), k = 4 * (i % (GB_K / 4));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) T[k + e][r] = v[j][e];
+            } else {
+                const int k = i / (R / 4), r = 4 * (i % (R / 4));
+                *(f32x4*)&T[k][r] = v[j];
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// grouped GEMM: 256 threads = 4 waves, one 32 x 32 MFMA block each (2 x 2 waves on a 64 x 64 tile, or 4 x 1 on a
+// 128 x 32 tile for narrow outputs); the next K-tile travels global -> registers while the current one is multiplied
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, const int64_t* __restrict__ desc,
-                                                       gemm_one one, int n_groups, int trans_a, int trans_b, int ksplit,
-                                                       float alpha) {
-    __shared__ float As[GB_K][GB_M + 4];
-    __shared__ float Bs[GB_K][GB_N + 4];
+                                                       gemm_one one, int n_groups, int ksplit, float alpha) {
+    __shared__ __attribute__((aligned(16))) float As[GB_K][BM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[GB_K][BN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int lo = 0, hi = n_groups;                            // group of this tile: desc[g][9] <= tile < desc[g+1][9]
     while (hi - lo > 1) {
@@ -41,35 +95,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int M = (int)d[3], N = (int)d[4], K = (int)d[5];
     const int64_t lda = d[6], ldb = d[7], ldc = d[8];
     const int t = (int)((int64_t)blockIdx.x - d[9]);
-    const int tiles_n = (N + GB_N - 1) / GB_N;
-    const int m0 = (t / tiles_n) * GB_M, n0 = (t % tiles_n) * GB_N;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
     int kc = (K + ksplit - 1) / ksplit;
     kc = (kc + GB_K - 1) / GB_K * GB_K;
     const int k_begin = blockIdx.y * kc, k_end = min(K, k_begin + kc);
     if (k_begin >= k_end) return;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const bool va = ((((uintptr_t)Ag) & 15) == 0) && ((lda & 3) == 0);
+    const bool vb = ((((uintptr_t)Bg) & 15) == 0) && ((ldb & 3) == 0);
+    constexpr int WN = BN / 32;                            // waves along N
+    const int wm = (wave / WN) * 32, wn = (wave % WN) * 32;
+    tile_loader<BM, !TA> la;
+    tile_loader<BN, TB> lb;
+    la.load(Ag, lda, m0, M, k_begin, k_end, va, tid);
+    lb.load(Bg, ldb, n0, N, k_begin, k_end, vb, tid);
+    la.store(As, tid);
+    lb.store(Bs, tid);
+    __syncthreads();
     f32x16 acc = zero16();
     for (int k0 = k_begin; k0 < k_end; k0 += GB_K) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int mm, kk;
-            if (!trans_a) { kk = tid & 15; mm = (tid >> 4) + 16 * j; } else { mm = tid & 63; kk = (tid >> 6) + 4 * j; }
-            float v = 0.f;
-            if (m0 + mm < M && k0 + kk < k_end)
-                v = trans_a ? Ag[(int64_t)(k0 + kk) * lda + m0 + mm] : Ag[(int64_t)(m0 + mm) * lda + k0 + kk];
-            As[kk][mm] = v;
-            int nn, kb;
-            if (!trans_b) { nn = tid & 63; kb = (tid >> 6) + 4 * j; } else { kb = tid & 15; nn = (tid >> 4) + 16 * j; }
-            float u = 0.f;
-            if (n0 + nn < N && k0 + kb < k_end)
-                u = trans_b ? Bg[(int64_t)(n0 + nn) * ldb + k0 + kb] : Bg[(int64_t)(k0 + kb) * ldb + n0 + nn];
-            Bs[kb][nn] = u;
+        const bool more = k0 + GB_K < k_end;
+        if (more) {
+            la.load(Ag, lda, m0, M, k0 + GB_K, k_end, va, tid);
+            lb.load(Bg, ldb, n0, N, k0 + GB_K, k_end, vb, tid);
         }
-        __syncthreads();
 #pragma unroll
         for (int s = 0; s < GB_K / 2; ++s)
             acc = mfma32(As[2 * s + (lane >> 5)][wm + (lane & 31)], Bs[2 * s + (lane >> 5)][wn + (lane & 31)], acc);
         __syncthreads();
+        if (more) {
+            la.store(As, tid);
+            lb.store(Bs, tid);
+            __syncthreads();
+        }
     }
     const int col = n0 + wn + (lane & 31);
 #pragma unroll
@@ -83,14 +141,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     }
 }
 
+template <int BM, int BN>
+static void gemm_launch(dim3 grid, hipStream_t st, const float* a, const float* b, float* c, const int64_t* desc, gemm_one one,
+                        int n_groups, int ta, int tb, int ksplit, float alpha) {
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
+}
+
 extern "C" int nisqa_gemm_f32(const float* a, const float* b, float* c, const int64_t* desc, int32_t n_groups,
                               int32_t total_tiles, int32_t trans_a, int32_t trans_b, int32_t ksplit, float alpha,
                               void* stream) {
     if (!a || !b || !c || !desc || n_groups <= 0 || total_tiles < 0 || ksplit < 1 || ksplit > 65535) return NISQA_ERR_ARG;
     if (total_tiles == 0) return NISQA_OK;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(total_tiles, ksplit), dim3(256), 0, (hipStream_t)stream, a, b, c, desc,
-                       gemm_one{}, n_groups, trans_a, trans_b, ksplit, alpha);
+    gemm_launch<64, 64>(dim3(total_tiles, ksplit), (hipStream_t)stream, a, b, c, desc, gemm_one{}, n_groups, trans_a, trans_b,
+                        ksplit, alpha);
     return NQ_LAUNCH_STATUS();
 }
 
@@ -98,15 +165,19 @@ extern "C" int nisqa_gemm_f32_one(const float* a, const float* b, float* c, int6
                                   int64_t ldb, int64_t ldc, int32_t trans_a, int32_t trans_b, int32_t ksplit, float alpha,
                                   void* stream) {
     if (!a || !b || !c || m < 0 || n < 0 || k <= 0 || ksplit < 1 || ksplit > 65535) return NISQA_ERR_ARG;
-    const int64_t tiles = ((m + GB_M - 1) / GB_M) * ((n + GB_N - 1) / GB_N);
+    const bool narrow = n <= 32 && m > 64;                 // conv1 / conv2 outputs: 128 x 32 tiles waste no MFMA columns
+    const int64_t bm = narrow ? 128 : 64, bn = narrow ? 32 : 64;
+    const int64_t tiles = ((m + bm - 1) / bm) * ((n + bn - 1) / bn);
     if (tiles == 0) return NISQA_OK;
     if (tiles > 0x7fffffff) return NISQA_ERR_ARG;
     gemm_one one;
     const int64_t v[10] = {0, 0, 0, m, n, k, lda, ldb, ldc, 0};
     for (int i = 0; i < 10; ++i) one.v[i] = v[i];
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)tiles, ksplit), dim3(256), 0, (hipStream_t)stream, a, b, c,
-                       (const int64_t*)nullptr, one, 0, trans_a, trans_b, ksplit, alpha);
+    if (narrow)
+        gemm_launch<128, 32>(dim3((unsigned)tiles, ksplit), (hipStream_t)stream, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha);
+    else
+        gemm_launch<64, 64>(dim3((unsigned)tiles, ksplit), (hipStream_t)stream, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha);
     return NQ_LAUNCH_STATUS();
 }
 
