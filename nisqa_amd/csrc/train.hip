@@ -76,7 +76,7 @@ struct tile_loader {
 // grouped GEMM: 256 threads = 4 waves, one 32 x 32 MFMA block each (2 x 2 waves on a 64 x 64 tile, or 4 x 1 on a
 // 128 x 32 tile for narrow outputs); the next K-tile travels global -> registers while the current one is multiplied
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool TA, bool TB>
+template <int BM, int BN, int MT, int NT, bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, const int64_t* __restrict__ desc,
                                                        gemm_one one, int n_groups, int ksplit, float alpha) {
@@ -103,8 +103,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     if (k_begin >= k_end) return;
     const bool va = ((((uintptr_t)Ag) & 15) == 0) && ((lda & 3) == 0);
     const bool vb = ((((uintptr_t)Bg) & 15) == 0) && ((ldb & 3) == 0);
-    constexpr int WN = BN / 32;                            // waves along N
-    const int wm = (wave / WN) * 32, wn = (wave % WN) * 32;
+    constexpr int WN = BN / (32 * NT);                     // waves along N; each wave owns MT x NT blocks of 32 x 32
+    static_assert((BM / (32 * MT)) * WN == 4, "four waves per workgroup");
+    const int wm = (wave / WN) * 32 * MT, wn = (wave % WN) * 32 * NT;
     tile_loader<BM, !TA> la;
     tile_loader<BN, TB> lb;
     la.load(Ag, lda, m0, M, k_begin, k_end, va, tid);
@@ -112,7 +113,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     la.store(As, tid);
     lb.store(Bs, tid);
     __syncthreads();
-    f32x16 acc = zero16();
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero16();
     for (int k0 = k_begin; k0 < k_end; k0 += GB_K) {
         const bool more = k0 + GB_K < k_end;
         if (more) {
@@ -120,8 +125,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             lb.load(Bg, ldb, n0, N, k0 + GB_K, k_end, vb, tid);
         }
 #pragma unroll
-        for (int s = 0; s < GB_K / 2; ++s)
-            acc = mfma32(As[2 * s + (lane >> 5)][wm + (lane & 31)], Bs[2 * s + (lane >> 5)][wn + (lane & 31)], acc);
+        for (int s = 0; s < GB_K / 2; ++s) {
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = As[2 * s + (lane >> 5)][wm + 32 * i + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = Bs[2 * s + (lane >> 5)][wn + 32 * j + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
+        }
         __syncthreads();
         if (more) {
             la.store(As, tid);
@@ -129,25 +143,30 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             __syncthreads();
         }
     }
-    const int col = n0 + wn + (lane & 31);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + NQ_DROW(r, lane >> 5);
-        if (row < M && col < N) {
-            const float v = alpha * acc[r];
-            if (ksplit > 1) atomicAdd(Cg + (int64_t)row * ldc + col, v);
-            else Cg[(int64_t)row * ldc + col] = v;
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + NQ_DROW(r, lane >> 5);
+                if (row < M && col < N) {
+                    const float v = alpha * acc[i][j][r];
+                    if (ksplit > 1) atomicAdd(Cg + (int64_t)row * ldc + col, v);
+                    else Cg[(int64_t)row * ldc + col] = v;
+                }
+            }
         }
-    }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int MT, int NT>
 static void gemm_launch(dim3 grid, hipStream_t st, const float* a, const float* b, float* c, const int64_t* desc, gemm_one one,
                         int n_groups, int ta, int tb, int ksplit, float alpha) {
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, false>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, false, true>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, false>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, true, true>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, false, false>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, false, true>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, true, false>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, true, true>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
 }
 
 extern "C" int nisqa_gemm_f32(const float* a, const float* b, float* c, const int64_t* desc, int32_t n_groups,
@@ -156,8 +175,8 @@ extern "C" int nisqa_gemm_f32(const float* a, const float* b, float* c, const in
     if (!a || !b || !c || !desc || n_groups <= 0 || total_tiles < 0 || ksplit < 1 || ksplit > 65535) return NISQA_ERR_ARG;
     if (total_tiles == 0) return NISQA_OK;
     NQ_LAUNCH_BEGIN();
-    gemm_launch<64, 64>(dim3(total_tiles, ksplit), (hipStream_t)stream, a, b, c, desc, gemm_one{}, n_groups, trans_a, trans_b,
-                        ksplit, alpha);
+    gemm_launch<64, 64, 1, 1>(dim3(total_tiles, ksplit), (hipStream_t)stream, a, b, c, desc, gemm_one{}, n_groups, trans_a,
+                              trans_b, ksplit, alpha);
     return NQ_LAUNCH_STATUS();
 }
 
@@ -165,19 +184,31 @@ extern "C" int nisqa_gemm_f32_one(const float* a, const float* b, float* c, int6
                                   int64_t ldb, int64_t ldc, int32_t trans_a, int32_t trans_b, int32_t ksplit, float alpha,
                                   void* stream) {
     if (!a || !b || !c || m < 0 || n < 0 || k <= 0 || ksplit < 1 || ksplit > 65535) return NISQA_ERR_ARG;
-    const bool narrow = n <= 32 && m > 64;                 // conv1 / conv2 outputs: 128 x 32 tiles waste no MFMA columns
-    const int64_t bm = narrow ? 128 : 64, bn = narrow ? 32 : 64;
+    // tile shape by problem shape: (BM, BN) and the 32 x 32 blocks per wave (more blocks = fewer LDS reads and
+    // barriers per MFMA): conv1/2 outputs are narrow, conv/Linear forward is tall (N = 64), the patch gradient is
+    // tall and wide, weight gradients are short and wide with K = the row count of the batch
+    int cfg = 0;
+    int64_t bm = 64, bn = 64;
+    if (n <= 32 && m > 64) { cfg = 1; bm = 128; bn = 32; }
+    else if (m >= 256 && n >= 128) { cfg = 2; bm = 128; bn = 128; }
+    else if (m >= 512 && n > 32) { cfg = 3; bm = 256; bn = 64; }
+    else if (m <= 64 && n >= 256) { cfg = 4; bm = 64; bn = 256; }
     const int64_t tiles = ((m + bm - 1) / bm) * ((n + bn - 1) / bn);
     if (tiles == 0) return NISQA_OK;
     if (tiles > 0x7fffffff) return NISQA_ERR_ARG;
     gemm_one one;
     const int64_t v[10] = {0, 0, 0, m, n, k, lda, ldb, ldc, 0};
     for (int i = 0; i < 10; ++i) one.v[i] = v[i];
+    const dim3 grid((unsigned)tiles, ksplit);
+    hipStream_t st = (hipStream_t)stream;
     NQ_LAUNCH_BEGIN();
-    if (narrow)
-        gemm_launch<128, 32>(dim3((unsigned)tiles, ksplit), (hipStream_t)stream, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha);
-    else
-        gemm_launch<64, 64>(dim3((unsigned)tiles, ksplit), (hipStream_t)stream, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha);
+    switch (cfg) {
+        case 1: gemm_launch<128, 32, 1, 1>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha); break;
+        case 2: gemm_launch<128, 128, 2, 2>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha); break;
+        case 3: gemm_launch<256, 64, 2, 2>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha); break;
+        case 4: gemm_launch<64, 256, 2, 2>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha); break;
+        default: gemm_launch<64, 64, 1, 1>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha); break;
+    }
     return NQ_LAUNCH_STATUS();
 }
 
@@ -213,8 +244,12 @@ extern "C" int nisqa_im2col_mel(const float* mel_tm, const int32_t* frame_off, c
     return NQ_LAUNCH_STATUS();
 }
 
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, int64_t total, int h, int w, int c,
-                                                        int pad_w, float* __restrict__ col) {
+// The geometry template arguments make the index arithmetic divisions by constants (0 = use the run-time values):
+// these kernels move 4 bytes per ~10 integer divisions, so that arithmetic -- not HBM -- was their cost.
+template <int H, int W, int C, int PW>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, int64_t total, int h_, int w_, int c_,
+                                                        int pad_, float* __restrict__ col) {
+    const int h = H ? H : h_, w = W ? W : w_, c = C ? C : c_, pad_w = H ? PW : pad_;
     const int wo = w + 2 * pad_w - 2, kc = 9 * c;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t row = i / kc;
@@ -227,8 +262,10 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcol, int64_t total, int h, int w, int c,
-                                                        int pad_w, float* __restrict__ dx) {
+template <int H, int W, int C, int PW>
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcol, int64_t total, int h_, int w_, int c_,
+                                                        int pad_, float* __restrict__ dx) {
+    const int h = H ? H : h_, w = W ? W : w_, c = C ? C : c_, pad_w = H ? PW : pad_;
     const int wo = w + 2 * pad_w - 2, kc = 9 * c;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ch = (int)(i % c);
@@ -252,14 +289,24 @@ static int grid_for(int64_t total) {
     return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
 }
 
+// geometries of the CNN-SA-AP model get their own instantiation, anything else the generic one
+#define NQ_GEOM_DISPATCH(KERNEL, GRID, ST, ...)                                                                   \
+    do {                                                                                                          \
+        if (h == 24 && w == 7 && c == 16 && pad_w == 1) hipLaunchKernelGGL((KERNEL<24, 7, 16, 1>), GRID, dim3(256), 0, ST, __VA_ARGS__);      \
+        else if (h == 12 && w == 5 && c == 32 && pad_w == 1) hipLaunchKernelGGL((KERNEL<12, 5, 32, 1>), GRID, dim3(256), 0, ST, __VA_ARGS__); \
+        else if (h == 12 && w == 5 && c == 64 && pad_w == 1) hipLaunchKernelGGL((KERNEL<12, 5, 64, 1>), GRID, dim3(256), 0, ST, __VA_ARGS__); \
+        else if (h == 6 && w == 3 && c == 64 && pad_w == 1) hipLaunchKernelGGL((KERNEL<6, 3, 64, 1>), GRID, dim3(256), 0, ST, __VA_ARGS__);   \
+        else if (h == 6 && w == 3 && c == 64 && pad_w == 0) hipLaunchKernelGGL((KERNEL<6, 3, 64, 0>), GRID, dim3(256), 0, ST, __VA_ARGS__);   \
+        else hipLaunchKernelGGL((KERNEL<0, 0, 0, 0>), GRID, dim3(256), 0, ST, __VA_ARGS__);                        \
+    } while (0)
+
 extern "C" int nisqa_im2col3x3(const float* x, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w,
                                float* col, void* stream) {
     const int wo = w + 2 * pad_w - 2;
     if (!x || !col || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 || pad_w < 0 || pad_w > 1 || wo <= 0) return NISQA_ERR_ARG;
     const int64_t total = (int64_t)n_segments * h * wo * 9 * c;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, total, h, w, c,
-                       pad_w, col);
+    NQ_GEOM_DISPATCH(im2col3x3_kernel, dim3(grid_for(total)), (hipStream_t)stream, x, total, h, w, c, pad_w, col);
     return NQ_LAUNCH_STATUS();
 }
 
@@ -269,8 +316,7 @@ extern "C" int nisqa_col2im3x3(const float* dcol, int32_t n_segments, int32_t h,
     if (!dcol || !dx || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 || pad_w < 0 || pad_w > 1 || wo <= 0) return NISQA_ERR_ARG;
     const int64_t total = (int64_t)n_segments * h * w * c;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(col2im3x3_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dcol, total, h, w, c,
-                       pad_w, dx);
+    NQ_GEOM_DISPATCH(col2im3x3_kernel, dim3(grid_for(total)), (hipStream_t)stream, dcol, total, h, w, c, pad_w, dx);
     return NQ_LAUNCH_STATUS();
 }
 
@@ -286,11 +332,25 @@ __global__ __launch_bounds__(256) void col_dot_kernel(const float* __restrict__ 
     double x1 = 0.0, x2 = 0.0;
     if (r0 < rl) {
         const int64_t begin = (int64_t)blockIdx.x * rows_per_block, end = min(rows, begin + rows_per_block);
-        for (int64_t r = begin + r0; r < end; r += rl) {
-            const float av = a[r * c + ch], bv = b[r * c + ch];
-            x1 += (double)av;
-            x2 += (double)av * (double)bv;
+        const bool same = a == b;
+        double p1[4] = {0.0, 0.0, 0.0, 0.0}, p2[4] = {0.0, 0.0, 0.0, 0.0};
+        int64_t r = begin + r0;
+        for (; r + 3 * rl < end; r += 4 * rl) {            // four loads in flight per thread
+            float av[4], bv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) av[q] = a[(r + q * rl) * c + ch];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[q] = same ? av[q] : b[(r + q * rl) * c + ch];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { p1[q] += (double)av[q]; p2[q] += (double)av[q] * (double)bv[q]; }
         }
+        for (; r < end; r += rl) {
+            const float av = a[r * c + ch], bv = same ? av : b[r * c + ch];
+            p1[0] += (double)av;
+            p2[0] += (double)av * (double)bv;
+        }
+        x1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
+        x2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
     }
     s1[tid] = x1;
     s2[tid] = x2;
@@ -343,10 +403,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int c, int64
     running_var[ch] = 0.9f * running_var[ch] + 0.1f * (float)unb;
 }
 
+template <int H, int W, int C, int HO, int WO>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ mean_rstd, int64_t total, int h, int w, int c, int ho, int wo,
+    const float* __restrict__ mean_rstd, int64_t total, int h_, int w_, int c_, int ho_, int wo_,
     const float* __restrict__ drop, float* __restrict__ y, int32_t* __restrict__ arg) {
+    const int h = H ? H : h_, w = H ? W : w_, c = H ? C : c_, ho = H ? HO : ho_, wo = H ? WO : wo_;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ch = (int)(i % c);
         const int64_t op = i / c;
@@ -367,6 +429,17 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(
     }
 }
 
+#define NQ_POOL_DISPATCH(KERNEL, GRID, ST, ...)                                                                   \
+    do {                                                                                                          \
+        if (h == 48 && w == 15 && c == 16 && ho == 24 && wo == 7) hipLaunchKernelGGL((KERNEL<48, 15, 16, 24, 7>), GRID, dim3(256), 0, ST, __VA_ARGS__);   \
+        else if (h == 24 && w == 7 && c == 32 && ho == 12 && wo == 5) hipLaunchKernelGGL((KERNEL<24, 7, 32, 12, 5>), GRID, dim3(256), 0, ST, __VA_ARGS__); \
+        else if (h == 12 && w == 5 && c == 64 && ho == 12 && wo == 5) hipLaunchKernelGGL((KERNEL<12, 5, 64, 12, 5>), GRID, dim3(256), 0, ST, __VA_ARGS__); \
+        else if (h == 12 && w == 5 && c == 64 && ho == 6 && wo == 3) hipLaunchKernelGGL((KERNEL<12, 5, 64, 6, 3>), GRID, dim3(256), 0, ST, __VA_ARGS__);   \
+        else if (h == 6 && w == 3 && c == 64 && ho == 6 && wo == 3) hipLaunchKernelGGL((KERNEL<6, 3, 64, 6, 3>), GRID, dim3(256), 0, ST, __VA_ARGS__);     \
+        else if (h == 6 && w == 1 && c == 64 && ho == 6 && wo == 1) hipLaunchKernelGGL((KERNEL<6, 1, 64, 6, 1>), GRID, dim3(256), 0, ST, __VA_ARGS__);     \
+        else hipLaunchKernelGGL((KERNEL<0, 0, 0, 0, 0>), GRID, dim3(256), 0, ST, __VA_ARGS__);                     \
+    } while (0)
+
 extern "C" int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const float* gamma, const float* beta,
                                      float* running_mean, float* running_var, float* mean_rstd, int32_t n_segments,
                                      int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo, const float* drop, float* y,
@@ -378,15 +451,17 @@ extern "C" int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const f
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, c,
                        (int64_t)n_segments * h * w, running_mean, running_var, mean_rstd);
-    hipLaunchKernelGGL(bn_act_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, z, gamma, beta,
-                       (const float*)mean_rstd, total, h, w, c, ho, wo, drop, y, arg);
+    NQ_POOL_DISPATCH(bn_act_pool_fwd_kernel, dim3(grid_for(total)), (hipStream_t)stream, z, gamma, beta,
+                     (const float*)mean_rstd, total, h, w, c, ho, wo, drop, y, arg);
     return NQ_LAUNCH_STATUS();
 }
 
+template <int H, int W, int C, int HO, int WO>
 __global__ __launch_bounds__(256) void bn_act_pool_bwd1_kernel(
     const float* __restrict__ dy, const int32_t* __restrict__ arg, const float* __restrict__ drop,
     const float* __restrict__ z, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, int64_t total, int h, int w, int c, int ho, int wo, float* __restrict__ dyb) {
+    const float* __restrict__ beta, int64_t total, int h_, int w_, int c_, int ho_, int wo_, float* __restrict__ dyb) {
+    const int h = H ? H : h_, w = H ? W : w_, c = H ? C : c_, ho = H ? HO : ho_, wo = H ? WO : wo_;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ch = (int)(i % c);
         const int64_t pix = i / c;
@@ -396,7 +471,10 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd1_kernel(
         const float g = gamma[ch] * mean_rstd[c + ch];
         const float yb = fmaf(z[i], g, beta[ch] - mean_rstd[ch] * g);
         float acc = 0.f;
-        if (yb > 0.f) {                                    // ReLU gate
+        if (yb > 0.f && h == ho && w == wo) {              // identity pooling: the only window of pixel p is p itself
+            acc = dy[i];
+            if (drop) acc *= drop[s * c + ch];
+        } else if (yb > 0.f) {                             // ReLU gate
             const int oy0 = max(0, (yy * ho) / h - 1), oy1 = min(ho - 1, ((yy + 1) * ho) / h + 1);
             const int ox0 = max(0, (xx * wo) / w - 1), ox1 = min(wo - 1, ((xx + 1) * wo) / w + 1);
             for (int oy = oy0; oy <= oy1; ++oy) {
@@ -421,8 +499,8 @@ extern "C" int nisqa_bn_act_pool_bwd1(const float* dy, const int32_t* arg, const
         return NISQA_ERR_ARG;
     const int64_t total = (int64_t)n_segments * h * w * c;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(bn_act_pool_bwd1_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, arg, drop, z,
-                       mean_rstd, gamma, beta, total, h, w, c, ho, wo, dyb);
+    NQ_POOL_DISPATCH(bn_act_pool_bwd1_kernel, dim3(grid_for(total)), (hipStream_t)stream, dy, arg, drop, z, mean_rstd, gamma,
+                     beta, total, h, w, c, ho, wo, dyb);
     return NQ_LAUNCH_STATUS();
 }
 
