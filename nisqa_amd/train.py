@@ -147,8 +147,11 @@ class HipTrainer(object):
         self._ck(self.lib.nisqa_col_dot(_ptr(a), _ptr(b), rows, c, s.data_ptr(), self._st()), 'nisqa_col_dot')
         return s
 
-    def _ksplit(self, rows):
-        return int(max(1, min(256, rows // 2048)))
+    def _ksplit(self, rows, m=64, n=64):
+        """K-chunks of a weight-gradient GEMM (K = rows of the batch): enough workgroups to fill 256 CUs a few times
+        over (tiles x chunks ~ 2048), chunks of at least 512 rows."""
+        tiles = ((m + 63) // 64) * ((n + 63) // 64)
+        return int(max(1, min(2048 // tiles, rows // 512, 4096)))
 
     def _linear_fwd(self, X, wk, bk, rows, n_in, n_out, relu=False):
         Y = self._new(rows, n_out)
@@ -158,7 +161,7 @@ class HipTrainer(object):
     def _linear_bwd(self, dY, X, wk, bk, rows, n_in, n_out, need_dx=True):
         s = self._coldot(dY, dY, rows, n_out)
         self.G[bk].copy_(s[:n_out])
-        self._gemm(dY, X, self.G[wk], n_out, n_in, rows, n_out, n_in, n_in, ta=1, ksplit=self._ksplit(rows))
+        self._gemm(dY, X, self.G[wk], n_out, n_in, rows, n_out, n_in, n_in, ta=1, ksplit=self._ksplit(rows, n_out, n_in))
         if not need_dx:
             return None
         dX = self._new(rows, n_in)
@@ -415,7 +418,7 @@ class HipTrainer(object):
             wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
             sb = self._coldot(dz, dz, rows, co)
             self.G[bk].copy_(sb[:co])
-            self._gemm(dz, c['col'], self.G[wk], co, 9 * ci, rows, co, 9 * ci, 9 * ci, ta=1, ksplit=self._ksplit(rows))
+            self._gemm(dz, c['col'], self.G[wk], co, 9 * ci, rows, co, 9 * ci, 9 * ci, ta=1, ksplit=self._ksplit(rows, co, 9 * ci))
             if i > 1:
                 dcol = self._new(rows, 9 * ci)
                 self._gemm(dz, self.P[wk], dcol, rows, 9 * ci, co, co, 9 * ci, 9 * ci)
