@@ -28,16 +28,24 @@ extern "C" {
  * autograd counterparts of the training step. */
 int nisqa_gemm_f32(const float* a, const float* b, float* c, const int64_t* desc, int32_t n_groups,
                    int32_t total_tiles, int32_t trans_a, int32_t trans_b, int32_t ksplit, float alpha, void* stream);
-/* the single-group case without a descriptor in device memory: C[m][n] (+)= alpha * op(A) op(B) */
+/* the single-group case without a descriptor in device memory: C[m][n] (+)= alpha * op(A) op(B), with an optional
+ * epilogue (ksplit == 1 only): + bias[n] (may be NULL), then ReLU if relu != 0 */
 int nisqa_gemm_f32_one(const float* a, const float* b, float* c, int64_t m, int64_t n, int64_t k, int64_t lda,
                        int64_t ldb, int64_t ldc, int32_t trans_a, int32_t trans_b, int32_t ksplit, float alpha,
-                       void* stream);
+                       const float* bias, int32_t relu, void* stream);
 
 /* conv1 patches straight from the dB spectrogram (Framewise + segment_specs, NISQA_lib.py:2239-2282, 487-502):
  * col[s*720 + m*15 + j][dy*3+dx] = max(mel_tm[frame_off[b] + k*seg_hop + j+dx-1][m+dy-1], clip_floor[b]) or 0
  * outside the 48x15 segment; s = seg_off[b] + k runs over the VALID segments of the batch only. */
 int nisqa_im2col_mel(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
                      int32_t n_clips, int32_t n_segments, int32_t seg_hop, float* col, void* stream);
+/* conv1 (1 -> 16 channels) without a patch matrix: z[s*720 + m*15 + j][co] = bias[co] + sum_tap w[co][tap] * patch, and
+ * its weight gradient dw[co][tap] += sum dz * patch (dw zeroed by the caller); w is [16][9] with tap = dy*3 + dx */
+int nisqa_conv1_fwd(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
+                    int32_t n_clips, int32_t n_segments, int32_t seg_hop, const float* w, const float* bias, float* z,
+                    void* stream);
+int nisqa_conv1_wgrad(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
+                      int32_t n_clips, int32_t n_segments, int32_t seg_hop, const float* dz, float* dw, void* stream);
 /* 3x3 patches, padding (1, pad_w): x[S][H*W][C] -> col[S*H*Wo][9*C], Wo = W + 2*pad_w - 2, k = (dy*3+dx)*C + c */
 int nisqa_im2col3x3(const float* x, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w, float* col,
                     void* stream);

@@ -22,14 +22,25 @@ struct gemm_one { int64_t v[10]; };                       // the descriptor of a
 //   KC = false: r is the contiguous index,           element (r, k) at g[k * ld + r]   (A stored [K][M], B stored [K][N])
 // Each thread owns NV groups of four consecutive elements along the contiguous index: one 128-bit load when the
 // group is aligned and fully inside the matrix, four guarded scalar loads otherwise.
-template <int R, bool KC>
+template <int R, bool KC, int NTH>
 struct tile_loader {
-    static constexpr int NV = R * GB_K / 4 / 256;
+    static constexpr int NV = R * GB_K / 4 / NTH;
+    static_assert(NV >= 1 && NV * NTH * 4 == R * GB_K, "tile must split evenly over the workgroup");
     f32x4 v[NV];
-    __device__ __forceinline__ void load(const float* __restrict__ g, int64_t ld, int r0, int r_lim, int k0, int k_lim, bool vec_ok, int tid) {
+    // interior tile with aligned rows: straight-line 128-bit loads, no per-element guards (wave-uniform choice)
+    __device__ __forceinline__ void load_fast(const float* __restrict__ g, int64_t ld, int r0, int k0, int tid) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid + 256 * j;
+            const int i = tid + NTH * j;
+            if (KC) v[j] = *(const f32x4*)(g + (int64_t)(r0 + i / (GB_K / 4)) * ld + k0 + 4 * (i % (GB_K / 4)));
+            else v[j] = *(const f32x4*)(g + (int64_t)(k0 + i / (R / 4)) * ld + r0 + 4 * (i % (R / 4)));
+        }
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ g, int64_t ld, int r0, int r_lim, int k0, int k_lim, bool vec_ok, int tid) {
+        if (vec_ok && r0 + R <= r_lim && k0 + GB_K <= k_lim) { load_fast(g, ld, r0, k0, tid); return; }
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + NTH * j;
             int r, k;
             if (KC) { r = i / (GB_K / 4); k = 4 * (i % (GB_K / 4)); } else { k = i / (R / 4); r = 4 * (i % (R / 4)); }
             const int gr = r0 + r, gk = k0 + k;
@@ -59,7 +70,7 @@ struct tile_loader {
     __device__ __forceinline__ void store(float (*T)[R + 4], int tid) const {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int i = tid + 256 * j;
+            const int i = tid + NTH * j;
             if (KC) {
                 const int r = i / (GB_K / 4), k = 4 * (i % (GB_K / 4));
 #pragma unroll
@@ -77,9 +88,10 @@ struct tile_loader {
 // 128 x 32 tile for narrow outputs); the next K-tile travels global -> registers while the current one is multiplied
 // ---------------------------------------------------------------------------------------------------------
 template <int BM, int BN, int MT, int NT, bool TA, bool TB>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
+__global__ __launch_bounds__((BM / (32 * MT)) * (BN / (32 * NT)) * 64) void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                        float* __restrict__ C, const int64_t* __restrict__ desc,
-                                                       gemm_one one, int n_groups, int ksplit, float alpha) {
+                                                       gemm_one one, int n_groups, int ksplit, float alpha,
+                                                       const float* __restrict__ bias, int relu) {
     __shared__ __attribute__((aligned(16))) float As[GB_K][BM + 4];
     __shared__ __attribute__((aligned(16))) float Bs[GB_K][BN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -104,10 +116,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const bool va = ((((uintptr_t)Ag) & 15) == 0) && ((lda & 3) == 0);
     const bool vb = ((((uintptr_t)Bg) & 15) == 0) && ((ldb & 3) == 0);
     constexpr int WN = BN / (32 * NT);                     // waves along N; each wave owns MT x NT blocks of 32 x 32
-    static_assert((BM / (32 * MT)) * WN == 4, "four waves per workgroup");
+    constexpr int NTH = (BM / (32 * MT)) * WN * 64;        // 4 or 8 waves
     const int wm = (wave / WN) * 32 * MT, wn = (wave % WN) * 32 * NT;
-    tile_loader<BM, !TA> la;
-    tile_loader<BN, TB> lb;
+    tile_loader<BM, !TA, NTH> la;
+    tile_loader<BN, TB, NTH> lb;
     la.load(Ag, lda, m0, M, k_begin, k_end, va, tid);
     lb.load(Bg, ldb, n0, N, k_begin, k_end, vb, tid);
     la.store(As, tid);
@@ -152,9 +164,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + 32 * i + NQ_DROW(r, lane >> 5);
                 if (row < M && col < N) {
-                    const float v = alpha * acc[i][j][r];
+                    float v = alpha * acc[i][j][r];
                     if (ksplit > 1) atomicAdd(Cg + (int64_t)row * ldc + col, v);
-                    else Cg[(int64_t)row * ldc + col] = v;
+                    else {
+                        if (bias) v += bias[col];
+                        if (relu) v = fmaxf(v, 0.f);
+                        Cg[(int64_t)row * ldc + col] = v;
+                    }
                 }
             }
         }
@@ -162,11 +178,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
 template <int BM, int BN, int MT, int NT>
 static void gemm_launch(dim3 grid, hipStream_t st, const float* a, const float* b, float* c, const int64_t* desc, gemm_one one,
-                        int n_groups, int ta, int tb, int ksplit, float alpha) {
-    if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, false, false>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
-    else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, false, true>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
-    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, true, false>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
-    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, true, true>), grid, dim3(256), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha);
+                        int n_groups, int ta, int tb, int ksplit, float alpha, const float* bias = nullptr, int relu = 0) {
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, false, false>), grid, dim3((BM / (32 * MT)) * (BN / (32 * NT)) * 64), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha, bias, relu);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, false, true>), grid, dim3((BM / (32 * MT)) * (BN / (32 * NT)) * 64), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha, bias, relu);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, true, false>), grid, dim3((BM / (32 * MT)) * (BN / (32 * NT)) * 64), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha, bias, relu);
+    else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, MT, NT, true, true>), grid, dim3((BM / (32 * MT)) * (BN / (32 * NT)) * 64), 0, st, a, b, c, desc, one, n_groups, ksplit, alpha, bias, relu);
 }
 
 extern "C" int nisqa_gemm_f32(const float* a, const float* b, float* c, const int64_t* desc, int32_t n_groups,
@@ -182,8 +198,9 @@ extern "C" int nisqa_gemm_f32(const float* a, const float* b, float* c, const in
 
 extern "C" int nisqa_gemm_f32_one(const float* a, const float* b, float* c, int64_t m, int64_t n, int64_t k, int64_t lda,
                                   int64_t ldb, int64_t ldc, int32_t trans_a, int32_t trans_b, int32_t ksplit, float alpha,
-                                  void* stream) {
-    if (!a || !b || !c || m < 0 || n < 0 || k <= 0 || ksplit < 1 || ksplit > 65535) return NISQA_ERR_ARG;
+                                  const float* bias, int32_t relu, void* stream) {
+    if (!a || !b || !c || m < 0 || n < 0 || k <= 0 || ksplit < 1 || ksplit > 65535 || (ksplit > 1 && (bias || relu)))
+        return NISQA_ERR_ARG;
     // tile shape by problem shape: (BM, BN) and the 32 x 32 blocks per wave (more blocks = fewer LDS reads and
     // barriers per MFMA): conv1/2 outputs are narrow, conv/Linear forward is tall (N = 64), the patch gradient is
     // tall and wide, weight gradients are short and wide with K = the row count of the batch
@@ -203,11 +220,11 @@ extern "C" int nisqa_gemm_f32_one(const float* a, const float* b, float* c, int6
     hipStream_t st = (hipStream_t)stream;
     NQ_LAUNCH_BEGIN();
     switch (cfg) {
-        case 1: gemm_launch<128, 32, 1, 1>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha); break;
-        case 2: gemm_launch<128, 128, 2, 2>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha); break;
-        case 3: gemm_launch<256, 64, 2, 2>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha); break;
-        case 4: gemm_launch<64, 256, 2, 2>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha); break;
-        default: gemm_launch<64, 64, 1, 1>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha); break;
+        case 1: gemm_launch<128, 32, 1, 1>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha, bias, relu); break;
+        case 2: gemm_launch<128, 128, 2, 1>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha, bias, relu); break;
+        case 3: gemm_launch<256, 64, 2, 1>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha, bias, relu); break;
+        case 4: gemm_launch<64, 256, 2, 1>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha, bias, relu); break;
+        default: gemm_launch<64, 64, 1, 1>(grid, st, a, b, c, nullptr, one, 0, trans_a, trans_b, ksplit, alpha, bias, relu); break;
     }
     return NQ_LAUNCH_STATUS();
 }
@@ -231,6 +248,95 @@ __global__ __launch_bounds__(256) void im2col_mel_kernel(const float* __restrict
         const int m = p / 15 + tap / 3 - 1, j = p % 15 + tap % 3 - 1;
         dst[i] = ((unsigned)m < 48u && (unsigned)j < 15u) ? fmaxf(src[j * 48 + m], fl) : 0.f;
     }
+}
+
+// conv1 (1 -> 16 channels, 9 taps) is memory-bound and its K = 9 makes a poor GEMM: forward and weight gradient read
+// the 15 x 48 segment patch from the spectrogram directly (zero-bordered copy in LDS), no patch matrix in HBM.
+__device__ __forceinline__ void stage_patch(float (*patch)[50], const float* __restrict__ src, float fl, int tid) {
+    for (int i = tid; i < 17 * 50; i += 256) {
+        const int j = i / 50 - 1, m = i % 50 - 1;           // frame, mel band
+        patch[0][i] = ((unsigned)j < 15u && (unsigned)m < 48u) ? fmaxf(src[j * 48 + m], fl) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
+                                                        const int32_t* __restrict__ seg_off, const float* __restrict__ clip_floor,
+                                                        int n_clips, int seg_hop, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ z) {
+    __shared__ float patch[17][50];
+    __shared__ float ws[16 * 9 + 16];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int b = find_segment(seg_off, n_clips, s);
+    const int k = s - seg_off[b];
+    stage_patch(patch, mel_tm + (int64_t)(frame_off[b] + k * seg_hop) * 48, clip_floor[b], tid);
+    if (tid < 144) ws[tid] = w[tid];
+    else if (tid < 160) ws[tid] = bias[tid - 144];
+    __syncthreads();
+    for (int p = tid; p < 720; p += 256) {
+        const int m = p / 15, j = p % 15;                   // pixel (y = mel band, x = frame)
+        float x[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) x[t] = patch[j + t % 3][m + t / 3];      // tap = dy*3+dx: band m+dy-1, frame j+dx-1
+        f32x4* dst = (f32x4*)(z + ((int64_t)s * 720 + p) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float acc = ws[144 + 4 * q + e];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc = fmaf(x[t], ws[(4 * q + e) * 9 + t], acc);
+                o[e] = acc;
+            }
+            dst[q] = o;
+        }
+    }
+}
+
+// dW1[co][tap] += sum over this workgroup's segments and all pixels of dz[s][p][co] * x[s][p + tap]
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
+                                                          const int32_t* __restrict__ seg_off, const float* __restrict__ clip_floor,
+                                                          int n_clips, int n_segments, int seg_hop, const float* __restrict__ dz,
+                                                          float* __restrict__ dw) {
+    __shared__ float patch[17][50];
+    const int tid = threadIdx.x;
+    const int co = tid & 15, tap = tid >> 4;               // threads 0..143 own one (co, tap) pair each
+    const int dy = tap / 3, dx = tap % 3;
+    float acc = 0.f;
+    for (int s = blockIdx.x; s < n_segments; s += gridDim.x) {
+        const int b = find_segment(seg_off, n_clips, s);
+        const int k = s - seg_off[b];
+        __syncthreads();
+        stage_patch(patch, mel_tm + (int64_t)(frame_off[b] + k * seg_hop) * 48, clip_floor[b], tid);
+        __syncthreads();
+        if (tap < 9) {
+            const float* d = dz + (int64_t)s * 720 * 16 + co;
+#pragma unroll 5
+            for (int p = 0; p < 720; ++p) acc = fmaf(d[p * 16], patch[p % 15 + dx][p / 15 + dy], acc);
+        }
+    }
+    if (tap < 9) atomicAdd(dw + co * 9 + tap, acc);
+}
+
+extern "C" int nisqa_conv1_fwd(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
+                               int32_t n_clips, int32_t n_segments, int32_t seg_hop, const float* w, const float* bias,
+                               float* z, void* stream) {
+    if (!mel_tm || !frame_off || !seg_off || !clip_floor || !w || !bias || !z || n_clips <= 0 || n_segments <= 0 || seg_hop <= 0)
+        return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(n_segments), dim3(256), 0, (hipStream_t)stream, mel_tm, frame_off, seg_off,
+                       clip_floor, n_clips, seg_hop, w, bias, z);
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_conv1_wgrad(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
+                                 int32_t n_clips, int32_t n_segments, int32_t seg_hop, const float* dz, float* dw, void* stream) {
+    if (!mel_tm || !frame_off || !seg_off || !clip_floor || !dz || !dw || n_clips <= 0 || n_segments <= 0 || seg_hop <= 0)
+        return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(n_segments < 2048 ? n_segments : 2048), dim3(256), 0, (hipStream_t)stream, mel_tm,
+                       frame_off, seg_off, clip_floor, n_clips, n_segments, seg_hop, dz, dw);
+    return NQ_LAUNCH_STATUS();
 }
 
 extern "C" int nisqa_im2col_mel(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off,
@@ -323,39 +429,57 @@ extern "C" int nisqa_col2im3x3(const float* dcol, int32_t n_segments, int32_t h,
 // ---------------------------------------------------------------------------------------------------------
 // column reductions in float64: thread (channel = tid % c, row lane = tid / c) walks rows, LDS tree, atomics
 // ---------------------------------------------------------------------------------------------------------
+template <int V>                                          // V = 4: c % 4 == 0, 128-bit loads; V = 1: any c
 __global__ __launch_bounds__(256) void col_dot_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                       int64_t rows, int c, int64_t rows_per_block, double* __restrict__ out) {
-    __shared__ double s1[256], s2[256];
+    __shared__ double s1[256 * V], s2[256 * V];
     const int tid = threadIdx.x;
-    const int rl = 256 / c;                               // row lanes per block (c divides 256 or c <= 256)
-    const int ch = tid % c, r0 = tid / c;
-    double x1 = 0.0, x2 = 0.0;
+    const int cg = c / V;                                 // column groups of V channels
+    const int rl = 256 / cg;                              // row lanes per block
+    const int g = tid % cg, r0 = tid / cg;
+    double x1[V], x2[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { x1[e] = 0.0; x2[e] = 0.0; }
     if (r0 < rl) {
         const int64_t begin = (int64_t)blockIdx.x * rows_per_block, end = min(rows, begin + rows_per_block);
         const bool same = a == b;
-        double p1[4] = {0.0, 0.0, 0.0, 0.0}, p2[4] = {0.0, 0.0, 0.0, 0.0};
         int64_t r = begin + r0;
-        for (; r + 3 * rl < end; r += 4 * rl) {            // four loads in flight per thread
-            float av[4], bv[4];
+        for (; r + rl < end; r += 2 * rl) {                // two rows in flight per thread
+            float av[2][V], bv[2][V];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) av[q] = a[(r + q * rl) * c + ch];
+            for (int q = 0; q < 2; ++q) {
+                if (V == 4) {
+                    const f32x4 t = *(const f32x4*)(a + (r + q * rl) * c + 4 * g);
+                    av[q][0] = t[0]; av[q][1] = t[1]; av[q][2] = t[2]; av[q][3] = t[3];
+                } else av[q][0] = a[(r + q * rl) * c + g];
+            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bv[q] = same ? av[q] : b[(r + q * rl) * c + ch];
+            for (int q = 0; q < 2; ++q) {
+                if (same) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { p1[q] += (double)av[q]; p2[q] += (double)av[q] * (double)bv[q]; }
+                    for (int e = 0; e < V; ++e) bv[q][e] = av[q][e];
+                } else if (V == 4) {
+                    const f32x4 t = *(const f32x4*)(b + (r + q * rl) * c + 4 * g);
+                    bv[q][0] = t[0]; bv[q][1] = t[1]; bv[q][2] = t[2]; bv[q][3] = t[3];
+                } else bv[q][0] = b[(r + q * rl) * c + g];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < V; ++e) { x1[e] += (double)av[q][e]; x2[e] += (double)av[q][e] * (double)bv[q][e]; }
         }
-        for (; r < end; r += rl) {
-            const float av = a[r * c + ch], bv = same ? av : b[r * c + ch];
-            p1[0] += (double)av;
-            p2[0] += (double)av * (double)bv;
-        }
-        x1 = (p1[0] + p1[1]) + (p1[2] + p1[3]);
-        x2 = (p2[0] + p2[1]) + (p2[2] + p2[3]);
+        for (; r < end; r += rl)
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float av = a[r * c + V * g + e], bv = same ? av : b[r * c + V * g + e];
+                x1[e] += (double)av;
+                x2[e] += (double)av * (double)bv;
+            }
     }
-    s1[tid] = x1;
-    s2[tid] = x2;
+#pragma unroll
+    for (int e = 0; e < V; ++e) { s1[tid * V + e] = x1[e]; s2[tid * V + e] = x2[e]; }
     __syncthreads();
-    if (tid < c) {
+    if (tid < c) {                                         // channel tid = V * g + e of row lane q sits at (q * cg + g) * V + e
         double t1 = 0.0, t2 = 0.0;
         for (int q = 0; q < rl; ++q) { t1 += s1[q * c + tid]; t2 += s2[q * c + tid]; }
         atomicAdd(out + tid, t1);
@@ -370,8 +494,11 @@ extern "C" int nisqa_col_dot(const float* a, const float* b, int64_t rows, int32
     if (blocks > 2048) blocks = 2048;
     const int64_t rpb = (rows + blocks - 1) / blocks;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(col_dot_kernel, dim3((int)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, a, b, rows,
-                       c, rpb, out);
+    const bool vec = (c & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(col_dot_kernel<4>, dim3((int)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, a, b,
+                                rows, c, rpb, out);
+    else hipLaunchKernelGGL(col_dot_kernel<1>, dim3((int)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, a, b, rows,
+                            c, rpb, out);
     return NQ_LAUNCH_STATUS();
 }
 

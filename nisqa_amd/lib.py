@@ -65,7 +65,9 @@ c_f = ctypes.c_float
 TRAIN_SYMBOLS = {
     'nisqa_gemm_f32': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_p]),
     'nisqa_gemm_f32_one': (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32,
-                                          c_f, c_p]),
+                                          c_f, c_p, c_i32, c_p]),
+    'nisqa_conv1_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'nisqa_conv1_wgrad': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_im2col_mel': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p]),
     'nisqa_im2col3x3': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     'nisqa_col2im3x3': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),

@@ -123,9 +123,10 @@ class HipTrainer(object):
     def _new(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
-    def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, ksplit=1, ao=0, bo=0, co=0):
+    def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, ksplit=1, ao=0, bo=0, co=0, bias=None, relu=0):
         self._ck(self.lib.nisqa_gemm_f32_one(_ptr(A, ao), _ptr(B, bo), _ptr(C, co), M, N, K, lda, ldb, ldc, ta, tb, ksplit,
-                                             1.0, self._st()), 'nisqa_gemm_f32_one')
+                                             1.0, _ptr(bias) if bias is not None else None, relu, self._st()),
+                 'nisqa_gemm_f32_one')
 
     def _ggemm(self, kind, A, B, C, ta=0, tb=0, ao=0, bo=0, co=0):
         d, tiles = self._desc[kind]
@@ -155,8 +156,8 @@ class HipTrainer(object):
 
     def _linear_fwd(self, X, wk, bk, rows, n_in, n_out, relu=False):
         Y = self._new(rows, n_out)
-        self._gemm(X, self.P[wk], Y, rows, n_out, n_in, n_in, n_in, n_out, tb=1)
-        return self._ew(1 if relu else 0, Y, bias=self.P[bk], rows=rows, cols=n_out)
+        self._gemm(X, self.P[wk], Y, rows, n_out, n_in, n_in, n_in, n_out, tb=1, bias=self.P[bk], relu=1 if relu else 0)
+        return Y
 
     def _linear_bwd(self, dY, X, wk, bk, rows, n_in, n_out, need_dx=True):
         s = self._coldot(dY, dY, rows, n_out)
@@ -266,17 +267,17 @@ class HipTrainer(object):
             ci, co = _CONV[i - 1]
             h, w, (ho, wo) = geo[i - 1]
             rows = S * h * w
-            col = self._new(rows, 9 * ci)
-            if i == 1:
-                self._ck(L_.nisqa_im2col_mel(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop, _ptr(col),
-                                             st), 'nisqa_im2col_mel')
-            else:
-                hi, wi = geo[i - 2][2]
-                self._ck(L_.nisqa_im2col3x3(_ptr(act), S, hi, wi, ci, 0 if i == 6 else 1, _ptr(col), st), 'nisqa_im2col3x3')
             z = self._new(rows, co)
             wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
-            self._gemm(col, self.P[wk], z, rows, co, 9 * ci, 9 * ci, 9 * ci, co, tb=1)
-            self._ew(0, z, bias=self.P[bk], rows=rows, cols=co)
+            if i == 1:                                                         # straight from the spectrogram, no patches
+                col = None
+                self._ck(L_.nisqa_conv1_fwd(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
+                                            _ptr(self.P[wk]), _ptr(self.P[bk]), _ptr(z), st), 'nisqa_conv1_fwd')
+            else:
+                hi, wi = geo[i - 2][2]
+                col = self._new(rows, 9 * ci)
+                self._ck(L_.nisqa_im2col3x3(_ptr(act), S, hi, wi, ci, 0 if i == 6 else 1, _ptr(col), st), 'nisqa_im2col3x3')
+                self._gemm(col, self.P[wk], z, rows, co, 9 * ci, 9 * ci, 9 * ci, co, tb=1, bias=self.P[bk])
             sums = self._coldot(z, z, rows, co)
             drop = self._mask(masks, _DROP_AFTER.get(i), (S, co), self.p_cnn) if i in _DROP_AFTER else None
             out = self._new(S, ho * wo, co)
@@ -418,7 +419,12 @@ class HipTrainer(object):
             wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
             sb = self._coldot(dz, dz, rows, co)
             self.G[bk].copy_(sb[:co])
-            self._gemm(dz, c['col'], self.G[wk], co, 9 * ci, rows, co, 9 * ci, 9 * ci, ta=1, ksplit=self._ksplit(rows, co, 9 * ci))
+            if i == 1:
+                self._ck(L_.nisqa_conv1_wgrad(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop, _ptr(dz),
+                                              _ptr(self.G[wk]), st), 'nisqa_conv1_wgrad')
+            else:
+                self._gemm(dz, c['col'], self.G[wk], co, 9 * ci, rows, co, 9 * ci, 9 * ci, ta=1,
+                           ksplit=self._ksplit(rows, co, 9 * ci))
             if i > 1:
                 dcol = self._new(rows, 9 * ci)
                 self._gemm(dz, self.P[wk], dcol, rows, 9 * ci, co, co, 9 * ci, 9 * ci)

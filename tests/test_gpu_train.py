@@ -41,7 +41,7 @@ def _r(*shape, seed=0, scale=1.0):
 
 def _gemm_one(A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, ks=1, ao=0, bo=0, co=0):
     lib, L = _L()
-    lib.check(L.nisqa_gemm_f32_one(_p(A, ao), _p(B, bo), _p(C, co), M, N, K, lda, ldb, ldc, ta, tb, ks, 1.0, _st()), 'gemm')
+    lib.check(L.nisqa_gemm_f32_one(_p(A, ao), _p(B, bo), _p(C, co), M, N, K, lda, ldb, ldc, ta, tb, ks, 1.0, None, 0, _st()), 'gemm')
 
 
 @pytest.mark.parametrize('M,N,K', [(64, 64, 16), (1, 1, 1), (130, 70, 37), (5, 200, 3), (300, 17, 1000)])
@@ -62,6 +62,40 @@ def test_gemm_single_group_all_layouts(M, N, K, ta, tb):
     _gemm_one(As, Bs, C2, M, N, K, As.shape[1], Bs.shape[1], N, ta, tb, ks=7)
     torch.cuda.synchronize()
     assert (C2 - want).abs().max() < tol
+
+
+def test_gemm_bias_relu_epilogue_and_large_tiles():
+    lib, L = _L()
+    for M, N, K in [(700, 64, 288), (600, 300, 64), (64, 576, 3000), (1000, 16, 144)]:      # every tile configuration
+        A, W, b = _r(M, K, seed=40), _r(N, K, seed=41), _r(N, seed=42)
+        C = torch.empty(M, N, device=DEV)
+        lib.check(L.nisqa_gemm_f32_one(_p(A), _p(W), _p(C), M, N, K, K, K, N, 0, 1, 1, 1.0, _p(b), 1, _st()), 'gemm')
+        torch.cuda.synchronize()
+        want = F.relu(F.linear(A.double(), W.double(), b.double())).float()
+        assert (C - want).abs().max() < 1e-5 * math.sqrt(K) * max(1.0, float(want.abs().max()))
+    assert L.nisqa_gemm_f32_one(_p(A), _p(W), _p(C), M, N, K, K, K, N, 0, 1, 4, 1.0, _p(b), 0, _st()) == lib.NISQA_ERR_ARG
+
+
+def test_conv1_direct_kernels_match_patch_gemm():
+    lib, L = _L()
+    T = [40, 15, 27]
+    mel = _r(sum(T), 48, seed=43, scale=20.0)
+    frame_off = torch.tensor([0, 40, 55, 82], dtype=torch.int32, device=DEV)
+    seg_off = torch.tensor([0, 7, 8, 12], dtype=torch.int32, device=DEV)
+    floor = torch.tensor([-10.0, -3.0e38, 0.0], device=DEV)
+    S = 12
+    col = torch.empty(S * 720, 9, device=DEV)
+    lib.check(L.nisqa_im2col_mel(_p(mel), frame_off.data_ptr(), seg_off.data_ptr(), _p(floor), 3, S, 4, _p(col), _st()), 'im2col_mel')
+    w, b = _r(16, 9, seed=44), _r(16, seed=45)
+    z = torch.empty(S * 720, 16, device=DEV)
+    lib.check(L.nisqa_conv1_fwd(_p(mel), frame_off.data_ptr(), seg_off.data_ptr(), _p(floor), 3, S, 4, _p(w), _p(b), _p(z), _st()), 'conv1 fwd')
+    dz = _r(S * 720, 16, seed=46)
+    dw = torch.zeros(16, 9, device=DEV)
+    lib.check(L.nisqa_conv1_wgrad(_p(mel), frame_off.data_ptr(), seg_off.data_ptr(), _p(floor), 3, S, 4, _p(dz), _p(dw), _st()), 'conv1 wgrad')
+    torch.cuda.synchronize()
+    assert (z - (col @ w.t() + b)).abs().max() < 1e-3
+    want = dz.double().t() @ col.double()
+    assert (dw.double() - want).abs().max() < 1e-6 * float(want.abs().max()) * 10
 
 
 def test_gemm_grouped_ragged_attention_shapes():

@@ -369,7 +369,7 @@ def test_training_operators_are_declared_and_exported():
     L = lib.load()
     out = subprocess.check_output(['nm', '-D', '--defined-only', lib.LIB_PATH]).decode()
     assert declared <= set(re.findall(r' T (nisqa_\w+)', out))
-    assert L.nisqa_gemm_f32_one(None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1.0, None) == lib.NISQA_ERR_ARG
+    assert L.nisqa_gemm_f32_one(None, None, None, 1, 1, 1, 1, 1, 1, 0, 0, 1, 1.0, None, 0, None) == lib.NISQA_ERR_ARG
     assert L.nisqa_adam_step(None, None, None, None, 10, 1e-3, 1, None) == lib.NISQA_ERR_ARG
     assert L.nisqa_elementwise(9, None, None, None, 1, 1, None, None) == lib.NISQA_ERR_ARG
 
