@@ -97,7 +97,8 @@ int nisqa_elementwise(int32_t op, const float* x, const float* aux, const float*
                       float* y, void* stream);
 
 /* biasLoss.get_loss (NISQA_lib.py:1880-1892, 1946-1950): loss = sum_h mean_{b: y not NaN} (map_b(y_hat) - y)^2,
- * map_b = cubic with coefficients bias[b][4] (NULL: identity).  Writes loss[1] and dy_hat[B][heads]. */
+ * map_b = cubic with coefficients bias[b][4] (NULL: identity).  Writes loss[1 + heads] (total, then one term per head) and
+ * dy_hat[B][heads]. */
 int nisqa_mse_loss(const float* y_hat, const float* y, const float* bias, int32_t n_clips, int32_t n_heads,
                    float* loss, float* dy_hat, void* stream);
 

@@ -293,16 +293,22 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
 }
 
-// dW1[co][tap] += sum over this workgroup's segments and all pixels of dz[s][p][co] * x[s][p + tap]
+// dW1[co][tap] += sum over this workgroup's segments and all pixels of dz[s][p][co] * x[s][p + tap].
+// Thread (tap, pixel lane) keeps all 16 channels of its tap in registers: per pixel one LDS read of x and one 64-byte
+// row of dz (four 128-bit loads) feed 16 FMAs; the 28 pixel lanes of a tap are reduced through LDS atomics at the end.
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
                                                           const int32_t* __restrict__ seg_off, const float* __restrict__ clip_floor,
                                                           int n_clips, int n_segments, int seg_hop, const float* __restrict__ dz,
                                                           float* __restrict__ dw) {
     __shared__ float patch[17][50];
+    __shared__ float red[144];
     const int tid = threadIdx.x;
-    const int co = tid & 15, tap = tid >> 4;               // threads 0..143 own one (co, tap) pair each
+    const int tap = tid / 28, pl = tid % 28;               // 9 taps x 28 pixel lanes = 252 threads
     const int dy = tap / 3, dx = tap % 3;
-    float acc = 0.f;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    if (tid < 144) red[tid] = 0.f;
     for (int s = blockIdx.x; s < n_segments; s += gridDim.x) {
         const int b = find_segment(seg_off, n_clips, s);
         const int k = s - seg_off[b];
@@ -310,12 +316,24 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
         stage_patch(patch, mel_tm + (int64_t)(frame_off[b] + k * seg_hop) * 48, clip_floor[b], tid);
         __syncthreads();
         if (tap < 9) {
-            const float* d = dz + (int64_t)s * 720 * 16 + co;
-#pragma unroll 5
-            for (int p = 0; p < 720; ++p) acc = fmaf(d[p * 16], patch[p % 15 + dx][p / 15 + dy], acc);
+            const f32x4* d = (const f32x4*)(dz + (int64_t)s * 720 * 16);
+            for (int p = pl; p < 720; p += 28) {
+                const float x = patch[p % 15 + dx][p / 15 + dy];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = d[p * 4 + q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[4 * q + e] = fmaf(v[e], x, acc[4 * q + e]);
+                }
+            }
         }
     }
-    if (tap < 9) atomicAdd(dw + co * 9 + tap, acc);
+    if (tap < 9) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) atomicAdd(&red[c * 9 + tap], acc[c]);
+    }
+    __syncthreads();
+    if (tid < 144) atomicAdd(dw + tid, red[tid]);
 }
 
 extern "C" int nisqa_conv1_fwd(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
@@ -829,6 +847,7 @@ __global__ __launch_bounds__(64) void mse_loss_kernel(const float* __restrict__ 
         }
     }
     part[hd] = l;
+    if (hd < n_heads) loss[1 + hd] = l;
     __syncthreads();
     if (hd == 0) {
         float s = 0.f;

@@ -46,3 +46,32 @@ def gather_rows(local, n, lo, hi, dev):
         a, b = shard_bounds(n, k, w)
         out[a:b] = parts[k][:b - a].cpu().numpy()
     return out
+
+
+def all_reduce_sum_(t):
+    """In-place sum of a tensor over the ranks (no-op without a process group).  RCCL takes the device tensor as it
+    is; under gloo (CPU tests, shared-GPU tests) the tensor is staged through host memory."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    if dist.get_backend() == 'nccl' or not t.is_cuda:
+        dist.all_reduce(t)
+    else:
+        c = t.cpu()
+        dist.all_reduce(c)
+        t.copy_(c)
+    return t
+
+
+def broadcast_(t, src=0):
+    """In-place broadcast from rank ``src`` (same staging rule as all_reduce_sum_)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    if dist.get_backend() == 'nccl' or not t.is_cuda:
+        dist.broadcast(t, src)
+    else:
+        c = t.cpu()
+        dist.broadcast(c, src)
+        t.copy_(c)
+    return t

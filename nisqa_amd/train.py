@@ -8,6 +8,12 @@ the gradient of every parameter, BatchNorm buffer updates and the Adam update --
 PyTorch here is device memory, the dropout random numbers and dtype casts of a few per-channel vectors; there is
 no autograd and no torch.nn call in the step.
 
+Data parallel (one process per GPU, ``torch.distributed`` initialised -- RCCL on a node): every rank runs the step on its
+own clips, exactly like a replica of the reference's ``nn.DataParallel`` (NISQA_model.py:88-89: BatchNorm statistics
+per replica, loss normalised by the number of labelled clips of the WHOLE batch), then the flat gradient buffer --
+0.9 MB, one bucket -- is all-reduced and every rank applies the same Adam update; rank 0's BatchNorm buffers are
+broadcast, as DataParallel keeps replica 0's.
+
 Parameters live in ONE flat device buffer in "kernel layout" (conv weights as [C_out][3*3*C_in], the 384 columns of
 the first Linear in [y][c] order); ``state_dict()`` / ``load_state_dict()`` convert to and from the reference's keys
 and shapes, so checkpoints interoperate with the reference and with the inference engine.
@@ -17,6 +23,7 @@ import math
 import numpy as np
 import torch
 
+from . import dist as _dist
 from . import lib as _lib
 from .engine import HipNisqa, BatchPlan, SEG_LEN
 
@@ -347,10 +354,18 @@ class HipTrainer(object):
             pool.append(dict(u=u, att=att, pooled=pooled))
         b3 = torch.cat([self.P[hp + 'linear3.bias'] for hp in self.heads])
         self._ew(0, y_hat, bias=b3, rows=B, cols=H)
-        loss = self._new(1)
+        loss_v = self._new(1 + H)
         dyh = self._new(B, H)
         self._ck(L_.nisqa_mse_loss(_ptr(y_hat), _ptr(y_dev), _ptr(bias_dev) if bias_dev is not None else None, B, H,
-                                   _ptr(loss), _ptr(dyh), st), 'nisqa_mse_loss')
+                                   _ptr(loss_v), _ptr(dyh), st), 'nisqa_mse_loss')
+        loss = loss_v[:1]
+        if _dist.world()[1] > 1:
+            # the loss is a mean over the labelled clips of the WHOLE batch: rescale this rank's share per head
+            cnt = torch.as_tensor((~np.isnan(np.asarray(y, np.float32).reshape(B, H))).sum(0), dtype=torch.float32)
+            tot = _dist.all_reduce_sum_(cnt.clone())
+            share = torch.where(tot > 0, cnt / tot.clamp(min=1), torch.zeros_like(cnt)).to(self.device)
+            self._ew(5, dyh, bias=share, rows=B, cols=H)
+            loss = _dist.all_reduce_sum_((loss_v[1:] * share).sum().reshape(1))
 
         # ================= backward: pooling heads =================
         s = self._coldot(dyh, dyh, B, H)
@@ -432,6 +447,18 @@ class HipTrainer(object):
                 da = self._new(S, hi * wi, ci)
                 self._ck(L_.nisqa_col2im3x3(_ptr(dcol), S, hi, wi, ci, 0 if i == 6 else 1, _ptr(da), st), 'nisqa_col2im3x3')
             c['col'] = None
+
+        # ================= data parallel: one all-reduce of the flat gradient buffer =================
+        if _dist.world()[1] > 1:
+            _dist.all_reduce_sum_(self.gflat)
+            buf = torch.cat([torch.cat([self.bn[i]['mean'], self.bn[i]['var']]) for i in range(1, 7)])
+            _dist.broadcast_(buf, 0)
+            o = 0
+            for i in range(1, 7):
+                c = self.bn[i]['mean'].numel()
+                self.bn[i]['mean'].copy_(buf[o:o + c])
+                self.bn[i]['var'].copy_(buf[o + c:o + 2 * c])
+                o += 2 * c
 
         # ================= Adam =================
         self.t += 1

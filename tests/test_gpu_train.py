@@ -406,3 +406,81 @@ def test_training_from_pcm_reduces_the_loss():
     print('losses', [round(v, 3) for v in losses])
     assert all(np.isfinite(losses)) and min(losses[-3:]) < 0.7 * losses[0]
     assert all(int(v) == 112 for k, v in tr.state_dict().items() if k.endswith('num_batches_tracked'))
+
+
+# ---- data parallel: two processes (gloo, sharing the one GPU of the test box) ----------------------------------------
+_DP_WORKER = '''
+import os, sys
+import numpy as np, torch
+root = %(root)r
+for p in (root, os.path.join(root, 'tests'), os.path.join(root, 'tests', 'golden')):
+    sys.path.insert(0, p)
+import torch.distributed as dist
+rank = int(sys.argv[1])
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=%(port)r)
+dist.init_process_group('gloo', rank=rank, world_size=2)
+import make_golden_train as mk
+from nisqa_amd import synth
+from nisqa_amd.train import HipTrainer
+args = dict(synth.DIM_ARGS)
+args.update(cnn_dropout=0.0, td_sa_dropout=0.0, pool_att_dropout=0.0)
+sd = synth.random_state_dict(7, 'NISQA_DIM')
+specs, y = mk.batch(32, 5, 5)
+lo, hi = (0, 3) if rank == 0 else (3, 5)
+tr = HipTrainer(args, sd, 'cuda:0', lr=1e-3)
+loss = tr.step_spec(specs[lo:hi], y[lo:hi])
+torch.cuda.synchronize()
+out = {'loss': float(loss)}
+out.update({'g/' + k: v.numpy() for k, v in tr.grads().items()})
+out.update({'p/' + k: v.numpy() for k, v in tr.state_dict().items()})
+np.savez(os.path.join(%(out)r, 'dp%%d.npz' %% rank), **out)
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_step_matches_dataparallel_semantics(tmp_path):
+    """Each rank = a replica of nn.DataParallel (own BatchNorm statistics), loss normalised over the whole batch, one
+    all-reduce of the flat gradient buffer; checked against the oracle's autograd of exactly that composite."""
+    import socket
+    import subprocess
+    import make_golden_train as mk
+    from oracle import net as onet, train as otrain
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = str(s.getsockname()[1])
+    script = tmp_path / 'dp_worker.py'
+    script.write_text(_DP_WORKER % {'root': root, 'port': port, 'out': str(tmp_path)})
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], env=env) for r in range(2)]
+    assert [p.wait(timeout=600) for p in procs] == [0, 0]
+    r0, r1 = np.load(tmp_path / 'dp0.npz'), np.load(tmp_path / 'dp1.npz')
+    # the composite the two ranks implement, by autograd on the oracle
+    args = dict(synth.DIM_ARGS)
+    args.update(cnn_dropout=0.0, td_sa_dropout=0.0, pool_att_dropout=0.0)
+    sd = {k: torch.as_tensor(np.asarray(v)).clone() for k, v in synth.random_state_dict(7, 'NISQA_DIM').items()}
+    keys = otrain.param_keys(sd)
+    for k in keys:
+        sd[k] = sd[k].float().requires_grad_(True)
+    specs, y = mk.batch(32, 5, 5)
+    yt = torch.as_tensor(y)
+    outs = []
+    for lo, hi in ((0, 3), (3, 5)):
+        segs, nw = zip(*[onet.segment_specs(s_, 15, 4, None) for s_ in specs[lo:hi]])
+        outs.append(otrain.forward_train(sd, args, torch.cat(segs), list(nw))[0])
+    loss = otrain.nan_mse_loss(torch.cat(outs), yt)
+    grads = dict(zip(keys, torch.autograd.grad(loss, [sd[k] for k in keys])))
+    assert float(r0['loss']) == pytest.approx(float(loss), rel=1e-4) and float(r1['loss']) == pytest.approx(float(loss), rel=1e-4)
+    worst, wk = 0.0, None
+    for k in keys:
+        if _conv_bias(k):
+            continue
+        want = grads[k].numpy()
+        e = float(np.abs(r0['g/' + k] - want).max()) / max(1e-3, float(np.abs(want).max()))
+        if e > worst:
+            worst, wk = e, k
+    print('data parallel: worst relative gradient error', worst, wk)
+    assert worst < 1e-3, (worst, wk)
+    for k in r0.files:
+        if k.startswith(('g/', 'p/')):
+            assert np.array_equal(r0[k], r1[k]), k              # both ranks hold the same gradients, weights and buffers
