@@ -341,8 +341,11 @@ extern "C" int nisqa_mel_db(const float* pcm, const int64_t* clip_off, const int
     mag_stride += (8 - (mag_stride & 31) + 32) & 31;
     const int w_bytes = (w_floats * 4 + 15) & ~15;
     const size_t lds = (size_t)w_bytes + MEL_WAVES * (MEL_EXCH_BYTES + mag_stride * 16 + 512);
-    int frames_per_wave = 8;
-    if (const char* e = getenv("NISQA_MEL_FPW")) frames_per_wave = atoi(e) > 0 ? atoi(e) : 8;
+    // frames a wave walks over (amortises its per-lane twiddle / window / band-table loads); tuning knob, read once
+    static const int frames_per_wave = [] {
+        const char* e = getenv("NISQA_MEL_FPW");
+        return e && atoi(e) > 0 ? atoi(e) : 8;
+    }();
     const int per_wg = MEL_WAVES * frames_per_wave;
     hipLaunchKernelGGL(mel_frame_kernel, dim3((total_frames + per_wg - 1) / per_wg), dim3(64 * MEL_WAVES), lds,
                        (hipStream_t)stream, pcm, clip_off, frame_off, n_clips, total_frames, frames_per_wave, *cfg,
