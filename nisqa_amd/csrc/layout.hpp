@@ -38,6 +38,8 @@
 
 // ---- AdaptCNN split-bf16 weight fragments ("cnn_wb", uint16 units; biases stay in cnn_w) -------------
 // conv1: [3 terms hi/mid/lo][64 lanes][8]   B[k = tap (0..15, taps >= 9 are 0)][n (0..31, n >= 16 are 0)]
+//        (the AdaptCNN kernel uses the first two terms: 16 mantissa bits like every other layer; the StandardCNN
+//        kernel all three with the six lowest-order products -- its BiLSTM head amplifies input error 10x more)
 // conv5, conv6 (N split over 4 waves, 16x16x32 MFMA): [wave][step g = 2*tap + s][hl][64 lanes][8]:
 //   value(w, g, hl, lane, e) = split_hl( W[n = 16*w + (lane&15)][c = 32*s + 8*(lane>>4) + e][tap] * bn_scale[n] )
 // conv2..4: [step g = tap*(CIN/16) + s][ntile][hl (hi, lo)][64 lanes][8]:
