@@ -80,8 +80,10 @@ def cpu_baseline(n_distinct=6, min_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # a step is ~1 ms: 50 + 400 steps are under half a second of GPU time and let the clocks settle (20 steps after 3
+    # warm-up steps measure ~7 % low)
+    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--precision', default=None, choices=['bf16x3', 'f32'])
     ap.add_argument('--no-extras', action='store_true', help='skip the alt-precision and 3-stream passes (profiling runs)')
