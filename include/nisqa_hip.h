@@ -53,7 +53,7 @@ int nisqa_abi_version(void);
 typedef struct {
     int32_t n_fft;      /* must be 4096 */
     int32_t hop;        /* int(sr * ms_hop_length), NISQA_lib.py:2308 */
-    int32_t win;        /* int(sr * ms_win_length) <= 1024, NISQA_lib.py:2309 */
+    int32_t win;        /* int(sr * ms_win_length) <= n_fft, NISQA_lib.py:2309 (<= 1024: the fast instantiation) */
     int32_t n_mels;     /* must be 48 */
     int32_t n_bins;     /* number of FFT bins with a non-zero mel weight (k = 0 .. n_bins-1), <= 2049 */
     int32_t w_floats;   /* length of band_w (padded filterbank weights), <= 8192 */

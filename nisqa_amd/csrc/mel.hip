@@ -4,8 +4,9 @@
 //
 // One wave computes one STFT frame end to end (window -> FFT -> |.| -> mel -> dB) and walks over
 // FRAMES_PER_WAVE consecutive frames with all per-lane constants resident in registers:
-//   * pruned FFT: the hann window has `win` <= 1024 non-zero taps inside the 4096-sample frame, so
-//     after a (magnitude-preserving) circular shift the real sequence is supported on [0, 1024).
+//   * pruned FFT: at sr <= 51.2 kHz the hann window has `win` <= 1024 non-zero taps inside the 4096-sample frame,
+//     so after a (magnitude-preserving) circular shift the real sequence is supported on [0, 1024) (longer windows,
+//     e.g. 1920 taps at 96 kHz, take the NQ = 2 / 4 instantiations that fold the extra quarters in first).
 //     Packed as z[n] = x[2n] + i x[2n+1] (n < 512) the 2048-point complex FFT collapses to FOUR
 //     512-point FFTs of z[n] * W2048^(r n), r = 0..3, giving Z[4m + r]: the three outer radix-4
 //     stages of a 4096-point transform are never executed;
@@ -134,6 +135,9 @@ NQ_DEV void fft512(c32 (&u)[8], const c32 (&z)[8], const mel_twiddles& tw, char*
     dft8(u);                                                // over j1 -> q2 ; k = lane + 64 q2
 }
 
+// NQ = ceil(win / 1024) quarters of the frame carry non-zero window taps (1 for sr <= 51.2 kHz, 2 for 96 kHz, 4 up to the
+// full 4096): z[n] for n >= 512 q folds onto n - 512 q with the radix-4 factor (-i)^(q r) before the 512-point FFTs
+template <int NQ>
 __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
     const float* __restrict__ pcm, const int64_t* __restrict__ clip_off,
     const int32_t* __restrict__ frame_off, int n_clips, int total_frames, int frames_per_wave,
@@ -165,13 +169,13 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
     for (int q = 0; q < 8; ++q) { const float2 w = twg[(64 * (lane & 7) * q) & 4095]; tw.c[q] = cmk(w.x, w.y); }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const float2 w = twg[4 * lane + r]; tw.d[r] = cmk(w.x, w.y); }
-    float win[8][2];
+    float win[8][2];                                              // NQ == 1: window taps live in registers
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int m = 2 * (lane + 64 * a) + e;
-            win[a][e] = m < cfg.win ? window[m] : 0.f;
+            win[a][e] = (NQ == 1 && m < cfg.win) ? window[m] : 0.f;
         }
     // band tables of this lane's DPP row: pass ps handles band 4*ps + row
     const int row = lane >> 4, l16 = lane & 15;
@@ -196,11 +200,11 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
     float runmax = -3.0e38f;
 
     // raw (unwindowed) samples of frame f, reflect-padded like np.pad(mode='reflect')
-    auto load_frame = [&](int f, int bb, float (&raw)[8][2]) {
+    auto load_frame = [&](int f, int bb, int quarter, float (&raw)[8][2]) {
         const int64_t c0 = clip_off[bb];
         const int L = (int)(clip_off[bb + 1] - c0);
         const float* y = pcm + c0;
-        const int s0 = (f - frame_off[bb]) * cfg.hop + start0;
+        const int s0 = (f - frame_off[bb]) * cfg.hop + start0 + 1024 * quarter;
         if (s0 >= 0 && s0 + 1024 <= L) {              // interior frame (wave-uniform): plain coalesced loads
             const float* q = y + s0 + 2 * lane;
 #pragma unroll
@@ -220,22 +224,48 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
     };
 
     float raw[8][2];
-    load_frame(f_begin, b, raw);
+    if (NQ == 1) load_frame(f_begin, b, 0, raw);
     for (int f = f_begin; f < f_end; ++f) {
-        c32 z[8];
-#pragma unroll
-        for (int a = 0; a < 8; ++a) z[a] = cmk(raw[a][0] * win[a][0], raw[a][1] * win[a][1]);
-        // prefetch the next frame (clip may change)
+        c32 zq[NQ][8];
         const int fn = f + 1;
         int bn = b;
-        if (fn < f_end) {
+        if (fn < f_end)
             while (fn >= frame_off[bn + 1]) ++bn;
-            load_frame(fn, bn, raw);
+        if (NQ == 1) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) zq[0][a] = cmk(raw[a][0] * win[a][0], raw[a][1] * win[a][1]);
+            if (fn < f_end) load_frame(fn, bn, 0, raw);          // prefetch the next frame (clip may change)
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {                        // long windows: no prefetch, taps read through L1
+                load_frame(f, b, q, raw);
+#pragma unroll
+                for (int a = 0; a < 8; ++a) {
+                    const int m = 1024 * q + 2 * (lane + 64 * a);
+                    zq[q][a] = cmk(m < cfg.win ? raw[a][0] * window[m] : 0.f, m + 1 < cfg.win ? raw[a][1] * window[m + 1] : 0.f);
+                }
+            }
         }
+        // fold the quarters: z_r[n] = sum_q (-i)^(q r) z[n + 512 q]
+        auto fold = [&](int r, c32 (&o)[8]) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) {
+                c32 acc = zq[0][a];
+#pragma unroll
+                for (int q = 1; q < NQ; ++q) {
+                    const int e = (q * r) & 3;
+                    const c32 v = zq[q][a];
+                    acc = e == 0 ? cadd(acc, v) : e == 1 ? cadd(acc, cnegi(v)) : e == 2 ? csub(acc, v) : csub(acc, cnegi(v));
+                }
+                o[a] = acc;
+            }
+        };
+        c32 z[8];
 
         c32 u[8], u1[8];
         const int mir = 63 - lane;
         // r = 0: partner Z_0[512 - k] = lane (64 - l) & 63, register 7 - q2 (lane 0: register (8 - q2) & 7)
+        fold(0, z);
         fft512<0>(u, z, tw, exch, lane);
         {
             const int src = (64 - lane) & 63;
@@ -250,6 +280,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
 
         }
         // r = 2: partner Z_2[511 - k] = lane 63 - l, register 7 - q2
+        fold(2, z);
         fft512<2>(u, z, tw, exch, lane);
 #pragma unroll
         for (int q2 = 0; q2 < 8; ++q2) {
@@ -258,7 +289,9 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
                 mag[2 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tw.d[2], cmk(W16C[q2], W16S[q2]));
         }
         // r = 1 and r = 3 are each other's partners
+        fold(1, z);
         fft512<1>(u1, z, tw, exch, lane);
+        fold(3, z);
         fft512<3>(u, z, tw, exch, lane);
 #pragma unroll
         for (int q2 = 0; q2 < 8; ++q2) {
@@ -329,7 +362,7 @@ extern "C" int nisqa_mel_db(const float* pcm, const int64_t* clip_off, const int
                             const float* window, const float* twiddle, const int32_t* band_start,
                             const int32_t* band_len, const int32_t* band_woff, const float* band_w,
                             float* mel_tm, uint32_t* clip_max_enc, void* stream) {
-    if (!cfg || cfg->n_fft != NISQA_N_FFT || cfg->n_mels != NISQA_N_MELS || cfg->win < 2 || cfg->win > 1024 ||
+    if (!cfg || cfg->n_fft != NISQA_N_FFT || cfg->n_mels != NISQA_N_MELS || cfg->win < 2 || cfg->win > 4096 ||
         cfg->hop < 1 || cfg->n_bins < 1 || cfg->n_bins > 2049 || cfg->w_floats < 1 || cfg->w_floats > 8192 ||
         n_clips <= 0 || total_frames <= 0)
         return NISQA_ERR_ARG;
@@ -347,7 +380,18 @@ extern "C" int nisqa_mel_db(const float* pcm, const int64_t* clip_off, const int
         return e && atoi(e) > 0 ? atoi(e) : 8;
     }();
     const int per_wg = MEL_WAVES * frames_per_wave;
-    hipLaunchKernelGGL(mel_frame_kernel, dim3((total_frames + per_wg - 1) / per_wg), dim3(64 * MEL_WAVES), lds,
+    if (cfg->win <= 1024)
+        hipLaunchKernelGGL(mel_frame_kernel<1>, dim3((total_frames + per_wg - 1) / per_wg), dim3(64 * MEL_WAVES), lds,
+                       (hipStream_t)stream, pcm, clip_off, frame_off, n_clips, total_frames, frames_per_wave, *cfg,
+                       mag_stride, w_floats, window, (const float2*)twiddle, band_start, band_len, band_woff, band_w,
+                       mel_tm, clip_max_enc);
+    else if (cfg->win <= 2048)
+        hipLaunchKernelGGL(mel_frame_kernel<2>, dim3((total_frames + per_wg - 1) / per_wg), dim3(64 * MEL_WAVES), lds,
+                       (hipStream_t)stream, pcm, clip_off, frame_off, n_clips, total_frames, frames_per_wave, *cfg,
+                       mag_stride, w_floats, window, (const float2*)twiddle, band_start, band_len, band_woff, band_w,
+                       mel_tm, clip_max_enc);
+    else
+        hipLaunchKernelGGL(mel_frame_kernel<4>, dim3((total_frames + per_wg - 1) / per_wg), dim3(64 * MEL_WAVES), lds,
                        (hipStream_t)stream, pcm, clip_off, frame_off, n_clips, total_frames, frames_per_wave, *cfg,
                        mag_stride, w_floats, window, (const float2*)twiddle, band_start, band_len, band_woff, band_w,
                        mel_tm, clip_max_enc);

@@ -61,9 +61,9 @@ class MelTables(object):
         self.n_fft = int(n_fft)
         self.hop = int(sr * hop_s)                 # NISQA_lib.py:2308
         self.win = int(sr * win_s)                 # NISQA_lib.py:2309
-        if not (2 <= self.win <= 1024):
+        if not (2 <= self.win <= self.n_fft):
             raise NotImplementedError(
-                'HIP mel front end needs 2 <= win_length <= 1024 samples (sr {} gives {})'.format(sr, self.win))
+                'HIP mel front end needs 2 <= win_length <= n_fft samples (sr {} gives {})'.format(sr, self.win))
         self.n_mels = int(n_mels)
         n = np.arange(self.win, dtype=np.float64)
         self.window = (0.5 - 0.5 * np.cos(2.0 * np.pi * n / self.win)).astype(np.float32)

@@ -91,10 +91,11 @@ def test_mel_matches_oracle(eng_rand, batch):
             assert np.abs(got - g['mel_%d' % i]).max() < 2e-3
 
 
-@pytest.mark.parametrize('sr', [16000, 44100, 8000, 22050])
+@pytest.mark.parametrize('sr', [16000, 44100, 8000, 22050, 96000, 192000, 51300])
 def test_mel_other_sample_rates(eng_rand, sr):
     """ms_sr=None: hop/win/filterbank follow the file's native rate (NISQA_lib.py:2308-2309); at 16 kHz and
-    below the upper mel bands lie above Nyquist (empty filters -> -80 dB floor) and the Nyquist bin carries weight."""
+    below the upper mel bands lie above Nyquist (empty filters -> -80 dB floor) and the Nyquist bin carries weight.
+    Above 51.2 kHz the window spans more than 1024 samples (96 kHz: 1920, 192 kHz: 3840): the multi-quarter kernels."""
     pcm = [synth.synth_pcm16(40, 1.3, sr=sr), synth.synth_pcm16(41, 0.7, sr=sr)]
     flat = np.concatenate(pcm).astype(np.float32) / np.float32(32768.0)
     plan = eng_rand.plan([len(p) for p in pcm], sr)

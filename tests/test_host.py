@@ -113,7 +113,8 @@ def test_mel_tables_reject_unsupported():
     with pytest.raises(NotImplementedError):
         MelTables(48000, 2048, 0.01, 0.02, 48, 20000)
     with pytest.raises(NotImplementedError):
-        MelTables(96000, 4096, 0.01, 0.02, 48, 20000)       # 1920-sample window > 1024
+        MelTables(240000, 4096, 0.01, 0.02, 48, 20000)      # 4800-sample window > n_fft
+    assert MelTables(96000, 4096, 0.01, 0.02, 48, 20000).win == 1920     # long windows are supported (NQ = 2)
 
 
 # ---- plan ---------------------------------------------------------------------------------------------
