@@ -484,3 +484,33 @@ def test_data_parallel_step_matches_dataparallel_semantics(tmp_path):
     for k in r0.files:
         if k.startswith(('g/', 'p/')):
             assert np.array_equal(r0[k], r1[k]), k              # both ranks hold the same gradients, weights and buffers
+
+
+def test_training_step_edge_shapes_match_oracle():
+    """A one-segment clip (1 x 1 attention matrix), a 15-frame clip, ragged lengths, MOS-only model, partial labels."""
+    from nisqa_amd.train import HipTrainer
+    from oracle import net as onet, train as otrain
+    args = dict(synth.MOS_ARGS)
+    args.update({'cnn_dropout': 0.0, 'td_sa_dropout': 0.0, 'pool_att_dropout': 0.0})
+    sd = synth.random_state_dict(8, 'NISQA')
+    rng = np.random.default_rng(9)
+    specs = [(-40 + 18 * rng.standard_normal((48, T))).astype(np.float32) for T in (15, 18, 131, 16, 64)]
+    y = np.array([[2.5], [np.nan], [4.0], [1.5], [3.25]], np.float32)
+    segs, n_wins = zip(*[onet.segment_specs(s, 15, 4, None) for s in specs])
+    assert list(n_wins) == [1, 1, 30, 1, 13]
+    ref = otrain.train_step(sd, args, torch.cat(segs), list(n_wins), y)
+    tr = HipTrainer(args, sd, DEV, lr=1e-3)
+    loss = tr.step_spec(specs, y)
+    torch.cuda.synchronize()
+    assert float(loss) == pytest.approx(ref['loss'], rel=1e-4)
+    assert np.abs(tr.last['y_hat'].cpu().numpy() - ref['y_hat']).max() < 1e-4
+    worst, wk = 0.0, None
+    for k, gr in tr.grads().items():
+        if _conv_bias(k):
+            continue
+        want = ref['grads'][k]
+        e = float(np.abs(gr.numpy() - want).max()) / max(1e-3, float(np.abs(want).max()))
+        if e > worst:
+            worst, wk = e, k
+    print('edge shapes: worst relative gradient error', worst, wk)
+    assert worst < 1e-3, (worst, wk)
