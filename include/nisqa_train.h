@@ -67,12 +67,15 @@ int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const float* gamma
                           void* stream);
 /* backward of the above in two passes around a nisqa_col_dot(dyb, z):
  * pass 1: dyb[S][H*W][C] = d loss / d (BatchNorm output) from dy[S][Ho*Wo][C] (pool scatter, dropout, ReLU gate);
- * pass 2: in place dyb -> dz = gamma*rstd*(dyb - mean(dyb) - xhat*mean(dyb*xhat)); dgamma, dbeta from sums2. */
+ * pass 2: in place dyb -> dz = gamma*rstd*(dyb - mean(dyb) - xhat*mean(dyb*xhat)); dgamma, dbeta from sums2.
+ * When 256 % c == 0 the reductions ride along: pass 1 adds sum(dyb), sum(dyb*z) to sums2_opt[2c] (zeroed by the caller;
+ * NULL: run nisqa_col_dot yourself), pass 2 adds the column sums of dz (the conv bias gradient) to sum_dz_opt[2c]. */
 int nisqa_bn_act_pool_bwd1(const float* dy, const int32_t* arg, const float* drop, const float* z,
                            const float* mean_rstd, const float* gamma, const float* beta, int32_t n_segments,
-                           int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo, float* dyb, void* stream);
+                           int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo, float* dyb, double* sums2_opt,
+                           void* stream);
 int nisqa_bn_bwd2(float* dyb_to_dz, const float* z, const double* sums2, const float* mean_rstd, const float* gamma,
-                  int64_t rows, int32_t c, float* dgamma, float* dbeta, void* stream);
+                  int64_t rows, int32_t c, float* dgamma, float* dbeta, double* sum_dz_opt, void* stream);
 
 /* LayerNorm over rows of 64 (NISQA_lib.py:991, 1033, 1037): y = gamma*xhat + beta; saves xhat and rstd */
 int nisqa_layernorm_fwd(const float* x, const float* gamma, const float* beta, int64_t rows, float* y, float* xhat,

@@ -601,12 +601,30 @@ extern "C" int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const f
     return NQ_LAUNCH_STATUS();
 }
 
+// Grid-stride kernels over [rows][c] with 256 % c == 0 touch ONE channel per thread (channel = tid % c): two float64
+// partial sums per thread are reduced over the block in LDS and added to out[0..c) / out[c..2c) with atomics.
+NQ_DEV void block_channel_sums(double v1, double v2, int c, double* __restrict__ out) {
+    __shared__ double r1[256], r2[256];
+    const int tid = threadIdx.x;
+    r1[tid] = v1;
+    r2[tid] = v2;
+    __syncthreads();
+    if (tid < c) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int q = tid; q < 256; q += c) { t1 += r1[q]; t2 += r2[q]; }
+        atomicAdd(out + tid, t1);
+        atomicAdd(out + c + tid, t2);
+    }
+}
+
 template <int H, int W, int C, int HO, int WO>
 __global__ __launch_bounds__(256) void bn_act_pool_bwd1_kernel(
     const float* __restrict__ dy, const int32_t* __restrict__ arg, const float* __restrict__ drop,
     const float* __restrict__ z, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, int64_t total, int h_, int w_, int c_, int ho_, int wo_, float* __restrict__ dyb) {
+    const float* __restrict__ beta, int64_t total, int h_, int w_, int c_, int ho_, int wo_, float* __restrict__ dyb,
+    double* __restrict__ sums2) {
     const int h = H ? H : h_, w = H ? W : w_, c = H ? C : c_, ho = H ? HO : ho_, wo = H ? WO : wo_;
+    double a1 = 0.0, a2 = 0.0;                             // sums2 != NULL: sum(dyb), sum(dyb * z) of this thread's channel
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ch = (int)(i % c);
         const int64_t pix = i / c;
@@ -614,7 +632,8 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd1_kernel(
         const int p = (int)(pix - s * (h * w));
         const int yy = p / w, xx = p % w;
         const float g = gamma[ch] * mean_rstd[c + ch];
-        const float yb = fmaf(z[i], g, beta[ch] - mean_rstd[ch] * g);
+        const float zi = z[i];
+        const float yb = fmaf(zi, g, beta[ch] - mean_rstd[ch] * g);
         float acc = 0.f;
         if (yb > 0.f && h == ho && w == wo) {              // identity pooling: the only window of pixel p is p itself
             acc = dy[i];
@@ -633,26 +652,34 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd1_kernel(
             if (drop) acc *= drop[s * c + ch];
         }
         dyb[i] = acc;
+        a1 += (double)acc;
+        a2 += (double)acc * (double)zi;
     }
+    if (sums2) block_channel_sums(a1, a2, c, sums2);
 }
 
 extern "C" int nisqa_bn_act_pool_bwd1(const float* dy, const int32_t* arg, const float* drop, const float* z,
                                       const float* mean_rstd, const float* gamma, const float* beta, int32_t n_segments,
-                                      int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo, float* dyb, void* stream) {
+                                      int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo, float* dyb, double* sums2_opt,
+                                      void* stream) {
     if (!dy || !arg || !z || !mean_rstd || !gamma || !beta || !dyb || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 ||
-        ho <= 0 || wo <= 0 || ho > h || wo > w)
+        ho <= 0 || wo <= 0 || ho > h || wo > w || (sums2_opt && (256 % c) != 0))
         return NISQA_ERR_ARG;
     const int64_t total = (int64_t)n_segments * h * w * c;
     NQ_LAUNCH_BEGIN();
-    NQ_POOL_DISPATCH(bn_act_pool_bwd1_kernel, dim3(grid_for(total)), (hipStream_t)stream, dy, arg, drop, z, mean_rstd, gamma,
-                     beta, total, h, w, c, ho, wo, dyb);
+    // with the reductions riding along every block ends in 2c float64 atomics on the same addresses: 2048 blocks fill the
+    // chip (8 per CU) and keep that tail short
+    const int grid = sums2_opt ? (grid_for(total) < 2048 ? grid_for(total) : 2048) : grid_for(total);
+    NQ_POOL_DISPATCH(bn_act_pool_bwd1_kernel, dim3(grid), (hipStream_t)stream, dy, arg, drop, z, mean_rstd, gamma,
+                     beta, total, h, w, c, ho, wo, dyb, sums2_opt);
     return NQ_LAUNCH_STATUS();
 }
 
 __global__ __launch_bounds__(256) void bn_bwd2_kernel(float* __restrict__ d, const float* __restrict__ z,
                                                       const double* __restrict__ sums2, const float* __restrict__ mean_rstd,
                                                       const float* __restrict__ gamma, int64_t rows, int c,
-                                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      double* __restrict__ sum_dz) {
     if (blockIdx.x == 0 && (int)threadIdx.x < c) {
         const int ch = threadIdx.x;
         const double mean = mean_rstd[ch], rstd = mean_rstd[c + ch];
@@ -661,23 +688,30 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(float* __restrict__ d, con
     }
     const int64_t total = rows * c;
     const double inv = 1.0 / (double)rows;
+    double a1 = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int ch = (int)(i % c);
         const float mean = mean_rstd[ch], rstd = mean_rstd[c + ch];
         const float m1 = (float)(sums2[ch] * inv);                                           // mean(dyb)
         const float m2 = (float)((double)rstd * (sums2[c + ch] - (double)mean * sums2[ch]) * inv);   // mean(dyb * xhat)
         const float xh = (z[i] - mean) * rstd;
-        d[i] = gamma[ch] * rstd * (d[i] - m1 - xh * m2);
+        const float o = gamma[ch] * rstd * (d[i] - m1 - xh * m2);
+        d[i] = o;
+        a1 += (double)o;
     }
+    if (sum_dz) block_channel_sums(a1, 0.0, c, sum_dz);    // column sums of dz = the conv bias gradient (second half unused)
 }
 
 extern "C" int nisqa_bn_bwd2(float* dyb_to_dz, const float* z, const double* sums2, const float* mean_rstd,
-                             const float* gamma, int64_t rows, int32_t c, float* dgamma, float* dbeta, void* stream) {
-    if (!dyb_to_dz || !z || !sums2 || !mean_rstd || !gamma || !dgamma || !dbeta || rows <= 0 || c <= 0 || c > 256)
+                             const float* gamma, int64_t rows, int32_t c, float* dgamma, float* dbeta, double* sum_dz_opt,
+                             void* stream) {
+    if (!dyb_to_dz || !z || !sums2 || !mean_rstd || !gamma || !dgamma || !dbeta || rows <= 0 || c <= 0 || c > 256 ||
+        (sum_dz_opt && (256 % c) != 0))
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(bn_bwd2_kernel, dim3(grid_for(rows * c)), dim3(256), 0, (hipStream_t)stream, dyb_to_dz, z, sums2,
-                       mean_rstd, gamma, rows, c, dgamma, dbeta);
+    const int grid = sum_dz_opt ? (grid_for(rows * c) < 2048 ? grid_for(rows * c) : 2048) : grid_for(rows * c);
+    hipLaunchKernelGGL(bn_bwd2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dyb_to_dz, z, sums2,
+                       mean_rstd, gamma, rows, c, dgamma, dbeta, sum_dz_opt);
     return NQ_LAUNCH_STATUS();
 }
 

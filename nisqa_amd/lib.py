@@ -75,8 +75,8 @@ TRAIN_SYMBOLS = {
     'nisqa_bn_act_pool_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                              c_p, c_p, c_p, c_p]),
     'nisqa_bn_act_pool_bwd1': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
-                                              c_p, c_p]),
-    'nisqa_bn_bwd2': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p, c_p, c_p]),
+                                              c_p, c_p, c_p]),
+    'nisqa_bn_bwd2': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_layernorm_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
     'nisqa_layernorm_bwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     'nisqa_softmax_rows_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_f, c_p, c_p]),

@@ -424,15 +424,16 @@ class HipTrainer(object):
             rows, co, ci = c['rows'], c['co'], c['ci']
             dz = self._new(rows, co)
             g, b_ = self.P['cnn.model.bn%d.weight' % i], self.P['cnn.model.bn%d.bias' % i]
+            s2 = self._sums[self._sum_i]
+            sb = self._sums[self._sum_i + 1]
+            self._sum_i += 2
             self._ck(L_.nisqa_bn_act_pool_bwd1(_ptr(da), c['arg'].data_ptr(), _ptr(c['drop']) if c['drop'] is not None else None,
                                                _ptr(c['z']), _ptr(c['mr']), _ptr(g), _ptr(b_), S, c['h'], c['w'], co, c['ho'],
-                                               c['wo'], _ptr(dz), st), 'nisqa_bn_act_pool_bwd1')
-            s2 = self._coldot(dz, c['z'], rows, co)
+                                               c['wo'], _ptr(dz), s2.data_ptr(), st), 'nisqa_bn_act_pool_bwd1')
             self._ck(L_.nisqa_bn_bwd2(_ptr(dz), _ptr(c['z']), s2.data_ptr(), _ptr(c['mr']), _ptr(g), rows, co,
-                                      _ptr(self.G['cnn.model.bn%d.weight' % i]), _ptr(self.G['cnn.model.bn%d.bias' % i]), st),
-                     'nisqa_bn_bwd2')
+                                      _ptr(self.G['cnn.model.bn%d.weight' % i]), _ptr(self.G['cnn.model.bn%d.bias' % i]),
+                                      sb.data_ptr(), st), 'nisqa_bn_bwd2')
             wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
-            sb = self._coldot(dz, dz, rows, co)
             self.G[bk].copy_(sb[:co])
             if i == 1:
                 self._ck(L_.nisqa_conv1_wgrad(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop, _ptr(dz),

@@ -201,13 +201,18 @@ def test_batchnorm_relu_pool_dropout_forward_and_backward(h, w, c, ho, wo, use_d
     lib.check(L.nisqa_bn_act_pool_fwd(_p(zd), sums.data_ptr(), _p(gamma), _p(beta), _p(rm), _p(rv), _p(mr), S, h, w, c, ho, wo,
                                       dp, _p(y), arg.data_ptr(), _st()), 'bn fwd')
     dyb = torch.empty(S, h * w, c, device=DEV)
+    s2f = torch.zeros(2 * c, dtype=torch.float64, device=DEV)         # reductions fused into pass 1 ...
     lib.check(L.nisqa_bn_act_pool_bwd1(_p(dy), arg.data_ptr(), dp, _p(zd), _p(mr), _p(gamma), _p(beta), S, h, w, c, ho, wo,
-                                       _p(dyb), _st()), 'bn bwd1')
-    s2 = torch.zeros(2 * c, dtype=torch.float64, device=DEV)
+                                       _p(dyb), s2f.data_ptr(), _st()), 'bn bwd1')
+    s2 = torch.zeros(2 * c, dtype=torch.float64, device=DEV)          # ... equal the separate column reduction
     lib.check(L.nisqa_col_dot(_p(dyb), _p(zd), S * h * w, c, s2.data_ptr(), _st()), 'col_dot')
     dg, db = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
-    lib.check(L.nisqa_bn_bwd2(_p(dyb), _p(zd), s2.data_ptr(), _p(mr), _p(gamma), S * h * w, c, _p(dg), _p(db), _st()), 'bn bwd2')
+    sdz = torch.zeros(2 * c, dtype=torch.float64, device=DEV)
+    lib.check(L.nisqa_bn_bwd2(_p(dyb), _p(zd), s2.data_ptr(), _p(mr), _p(gamma), S * h * w, c, _p(dg), _p(db), sdz.data_ptr(),
+                              _st()), 'bn bwd2')
     torch.cuda.synchronize()
+    assert (s2f - s2).abs().max() < 1e-9 * max(1.0, float(s2.abs().max()))
+    assert (sdz[:c] - dyb.double().sum((0, 1))).abs().max() < 1e-9 * max(1.0, float(dyb.abs().sum()))
     want_y = y_t.detach().permute(0, 2, 3, 1).reshape(S, ho * wo, c)
     assert (y - want_y).abs().max() < 2e-5
     assert (rm - rm_t).abs().max() < 1e-5 and (rv - rv_t).abs().max() < 1e-4
