@@ -105,6 +105,15 @@ int nisqa_elementwise(int32_t op, const float* x, const float* aux, const float*
 int nisqa_mse_loss(const float* y_hat, const float* y, const float* bias, int32_t n_clips, int32_t n_heads,
                    float* loss, float* dy_hat, void* stream);
 
+/* Dropout multipliers (nn.Dropout / Dropout2d in train mode): out[i] = u_i >= p ? 1/(1-p) : 0 with u_i the i-th value of the
+ * Philox-4x32-10 stream (seed, offset counts groups of four values); the reference draws its masks from torch's global
+ * generator inside the modules, so only the distribution, not the bits, can agree. */
+int nisqa_dropout_mask(uint64_t seed, uint64_t offset, float p, int64_t n, float* out, void* stream);
+
+/* dst[table[e][1] + t] = (float)src[table[e][0] + t], t < table[e][2], for e < n_entries (table: int32 [n_entries][3]):
+ * the float64 column sums of a step that ARE gradients (biases, LayerNorm parameters) move to the flat gradient buffer */
+int nisqa_cast_scatter(const double* src, const int32_t* table, int32_t n_entries, float* dst, void* stream);
+
 /* torch.optim.Adam (betas 0.9 / 0.999, eps 1e-8, no weight decay), step counter t >= 1, on flat buffers */
 int nisqa_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr, int32_t t, void* stream);
 

@@ -911,6 +911,62 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// dropout multipliers from a counter-based generator (Philox-4x32-10): value i of the stream (seed, offset) does not
+// depend on the launch geometry, so a step's masks are reproducible from (seed, offset) alone
+// ---------------------------------------------------------------------------------------------------------
+NQ_DEV void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint64_t seed, uint64_t offset, float p, float keep_scale, int64_t n,
+                                                           float* __restrict__ out) {
+    const int64_t quads = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256) {
+        const uint64_t ctr = offset + (uint64_t)q;
+        uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            philox_round(c, k0, k1);
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t i = 4 * q + e;
+            if (i < n) out[i] = ((float)c[e] * 2.3283064365386963e-10f >= p) ? keep_scale : 0.f;      // u in [0, 1)
+        }
+    }
+}
+
+extern "C" int nisqa_dropout_mask(uint64_t seed, uint64_t offset, float p, int64_t n, float* out, void* stream) {
+    if (!out || n <= 0 || !(p >= 0.f) || !(p < 1.f)) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, seed, offset, p,
+                       1.0f / (1.0f - p), n, out);
+    return NQ_LAUNCH_STATUS();
+}
+
+// float64 reduction results -> float32 gradient slots, all pending copies of a step in one launch
+__global__ __launch_bounds__(256) void cast_scatter_kernel(const double* __restrict__ src, const int32_t* __restrict__ table,
+                                                           float* __restrict__ dst) {
+    const int32_t* e = table + 3 * blockIdx.x;
+    for (int t = threadIdx.x; t < e[2]; t += 256) dst[e[1] + t] = (float)src[e[0] + t];
+}
+
+extern "C" int nisqa_cast_scatter(const double* src, const int32_t* table, int32_t n_entries, float* dst, void* stream) {
+    if (!src || !table || !dst || n_entries <= 0) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(cast_scatter_kernel, dim3(n_entries), dim3(256), 0, (hipStream_t)stream, src, table, dst);
+    return NQ_LAUNCH_STATUS();
+}
+
 extern "C" int nisqa_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr, int32_t t,
                                void* stream) {
     if (!param || !grad || !m || !v || n <= 0 || t < 1) return NISQA_ERR_ARG;

@@ -83,6 +83,8 @@ TRAIN_SYMBOLS = {
     'nisqa_softmax_rows_bwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_p, c_p]),
     'nisqa_elementwise': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i64, c_i32, c_p, c_p]),
     'nisqa_mse_loss': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p]),
+    'nisqa_dropout_mask': (ctypes.c_int, [ctypes.c_uint64, ctypes.c_uint64, c_f, c_i64, c_p, c_p]),
+    'nisqa_cast_scatter': (ctypes.c_int, [c_p, c_p, c_i32, c_p, c_p]),
     'nisqa_adam_step': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_i32, c_p]),
 }
 

@@ -5,8 +5,8 @@ nisqa/NISQA_model.py:131-152 (``model.train(); y_hat = model(x, n_wins); loss = 
 loss.backward(); opt.step(); opt.zero_grad()``) for ``model`` = NISQA / NISQA_DIM with cnn_model=adapt, td=self_att,
 pool=att -- forward in train mode (BatchNorm on batch statistics over all valid segments, the reference's dropouts),
 the gradient of every parameter, BatchNorm buffer updates and the Adam update -- with every operator a HIP kernel.
-PyTorch here is device memory, the dropout random numbers and dtype casts of a few per-channel vectors; there is
-no autograd and no torch.nn call in the step.
+PyTorch here is device memory (and the collectives of the data-parallel mode); there is no autograd, no torch.nn call
+and no torch kernel in the step -- dropout masks come from a Philox kernel seeded by torch.initial_seed().
 
 Data parallel (one process per GPU, ``torch.distributed`` initialised -- RCCL on a node): every rank runs the step on its
 own clips, exactly like a replica of the reference's ``nn.DataParallel`` (NISQA_model.py:88-89: BatchNorm statistics
@@ -56,6 +56,9 @@ class HipTrainer(object):
         self.load_state_dict(state_dict)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
+        self._sums = torch.zeros((96 + 24 * len(self.heads), 512), dtype=torch.float64, device=self.device)
+        self._cast_table, self._cast_key = None, None
+        self._rng_seed, self._rng_off = int(torch.initial_seed()) & (2 ** 64 - 1), 0     # torch.manual_seed governs the masks
 
     # ---- parameters ------------------------------------------------------------------------------------
     def _layout(self, sd):
@@ -168,7 +171,7 @@ class HipTrainer(object):
 
     def _linear_bwd(self, dY, X, wk, bk, rows, n_in, n_out, need_dx=True):
         s = self._coldot(dY, dY, rows, n_out)
-        self.G[bk].copy_(s[:n_out])
+        self._defer_cast(s, 0, n_out, self.G[bk])
         self._gemm(dY, X, self.G[wk], n_out, n_in, rows, n_out, n_in, n_in, ta=1, ksplit=self._ksplit(rows, n_out, n_in))
         if not need_dx:
             return None
@@ -184,8 +187,8 @@ class HipTrainer(object):
 
     def _ln_bwd(self, dY, xh, rs, gk, bk, rows):
         s = self._coldot(dY, xh, rows, 64)
-        self.G[bk].copy_(s[:64])
-        self.G[gk].copy_(s[64:128])
+        self._defer_cast(s, 0, 64, self.G[bk])
+        self._defer_cast(s, 64, 64, self.G[gk])
         dX = self._new(rows, 64)
         self._ck(self.lib.nisqa_layernorm_bwd(_ptr(dY), _ptr(xh), _ptr(rs), _ptr(self.P[gk]), rows, _ptr(dX), self._st()),
                  'nisqa_layernorm_bwd')
@@ -227,8 +230,40 @@ class HipTrainer(object):
         self.att_len = up(L[rows_b].astype(np.int32))
         self.pool_off = up(tok[:-1].astype(np.int64))
         self.pool_len = up(L.astype(np.int32))
-        self._sums = torch.zeros((96 + 24 * len(self.heads), 512), dtype=torch.float64, device=self.device)
+        self._sums.zero_()
         self._sum_i = 0
+        self._casts = []
+        # every dropout mask of the step in one buffer, filled by two launches (Dropout2d sites, attention / FFN sites)
+        self._mask_buf, self._mask_pos = None, {}
+        n_sq = int(sq[-1])
+        sizes = [(k, S * c, self.p_cnn) for k, c in (('cnn_d1', 32), ('cnn_d2', 64), ('cnn_d3', 64), ('cnn_d4', 64))]
+        for l in range(self.n_layers):
+            sizes += [('td%d_p' % l, n_sq, self.p_td)] + [('td%d_%s' % (l, t), S * 64, self.p_td) for t in ('1', 'f', '2')]
+        o = 0
+        for k, n, p in sizes:
+            self._mask_pos[k] = (o, n)
+            o += (n + 3) // 4 * 4
+        self._mask_total, self._mask_split = o, self._mask_pos['td0_p'][0] if self.n_layers else o
+
+    def _draw_masks(self):
+        self._mask_buf = self._new(self._mask_total)
+        for lo, hi, p in ((0, self._mask_split, self.p_cnn), (self._mask_split, self._mask_total, self.p_td)):
+            if hi > lo and p > 0:
+                self._ck(self.lib.nisqa_dropout_mask(self._rng_seed, self._rng_off, p, hi - lo, _ptr(self._mask_buf, lo),
+                                                     self._st()), 'nisqa_dropout_mask')
+                self._rng_off += (hi - lo + 3) // 4
+
+    def _defer_cast(self, s, lo, n, dst):
+        """float64 sums s[lo:lo+n] -> float32 gradient view dst, executed by one nisqa_cast_scatter at the end of backward"""
+        self._casts.append(((s.data_ptr() - self._sums.data_ptr()) // 8 + lo, (dst.data_ptr() - self.gflat.data_ptr()) // 4, n))
+
+    def _flush_casts(self):
+        key = tuple(self._casts)
+        if key != self._cast_key:
+            self._cast_key = key
+            self._cast_table = torch.tensor(self._casts, dtype=torch.int32, device=self.device)
+        self._ck(self.lib.nisqa_cast_scatter(self._sums.data_ptr(), self._cast_table.data_ptr(), len(self._casts),
+                                             _ptr(self.gflat), self._st()), 'nisqa_cast_scatter')
 
     def _mask(self, masks, key, shape, p):
         """Dropout multipliers (0 or 1/(1-p)): explicit ``masks[key]`` (tests) or fresh Bernoulli draws."""
@@ -237,7 +272,10 @@ class HipTrainer(object):
             return None if m is None else torch.as_tensor(m, dtype=torch.float32).reshape(shape).contiguous().to(self.device)
         if p <= 0:
             return None
-        return (torch.rand(shape, device=self.device) >= p).float() / (1.0 - p)
+        if self._mask_buf is None:
+            self._draw_masks()
+        o, n = self._mask_pos[key]
+        return self._mask_buf[o:o + n].view(shape)
 
     # ---- the step ------------------------------------------------------------------------------------------
     def step_pcm(self, pcm, plan, sr, y, masks=None, bias=None):
@@ -373,7 +411,7 @@ class HipTrainer(object):
         tmp = self._new(S, 64)
         for hi_, hp in enumerate(self.heads):
             pr = pool[hi_]
-            self.G[hp + 'linear3.bias'].copy_(s[hi_:hi_ + 1])
+            self._defer_cast(s, hi_, 1, self.G[hp + 'linear3.bias'])
             self._gemm(dyh, pr['pooled'], self.G[hp + 'linear3.weight'], 1, 64, B, H, 64, 64, ta=1, ao=hi_)
             dpooled = self._new(B, 64)
             self._gemm(dyh, self.P[hp + 'linear3.weight'], dpooled, B, 64, 1, H, 64, 64, ao=hi_)
@@ -434,7 +472,7 @@ class HipTrainer(object):
                                       _ptr(self.G['cnn.model.bn%d.weight' % i]), _ptr(self.G['cnn.model.bn%d.bias' % i]),
                                       sb.data_ptr(), st), 'nisqa_bn_bwd2')
             wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
-            self.G[bk].copy_(sb[:co])
+            self._defer_cast(sb, 0, co, self.G[bk])
             if i == 1:
                 self._ck(L_.nisqa_conv1_wgrad(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop, _ptr(dz),
                                               _ptr(self.G[wk]), st), 'nisqa_conv1_wgrad')
@@ -448,6 +486,8 @@ class HipTrainer(object):
                 da = self._new(S, hi * wi, ci)
                 self._ck(L_.nisqa_col2im3x3(_ptr(dcol), S, hi, wi, ci, 0 if i == 6 else 1, _ptr(da), st), 'nisqa_col2im3x3')
             c['col'] = None
+
+        self._flush_casts()
 
         # ================= data parallel: one all-reduce of the flat gradient buffer =================
         if _dist.world()[1] > 1:

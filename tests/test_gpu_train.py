@@ -292,6 +292,30 @@ def test_layernorm_softmax_elementwise_loss_adam():
     assert (pk - pt.detach()).abs().max() < 1e-6
 
 
+def test_dropout_mask_stream_and_cast_scatter():
+    lib, L = _L()
+    n = 1_000_003
+    a, b, c = torch.empty(n, device=DEV), torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    for out, seed, off in ((a, 1234, 0), (b, 1234, 0), (c, 1234, 7)):
+        lib.check(L.nisqa_dropout_mask(seed, off, 0.2, n, _p(out), _st()), 'mask')
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert torch.equal(a[28:1028], c[:1000])                        # offset counts groups of four values
+    vals = torch.unique(a)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and float(vals[1]) == pytest.approx(1.25)
+    keep = float((a > 0).float().mean())
+    assert abs(keep - 0.8) < 4 * math.sqrt(0.16 / n)                 # binomial 4-sigma
+    assert abs(float((a[:-1] * a[1:]).mean()) / 1.5625 - 0.64) < 3e-3          # neighbours uncorrelated
+    src = torch.arange(100, dtype=torch.float64, device=DEV) + 0.5
+    tab = torch.tensor([[3, 0, 4], [50, 10, 1], [90, 20, 10]], dtype=torch.int32, device=DEV)
+    dst = torch.full((32,), -1.0, device=DEV)
+    lib.check(L.nisqa_cast_scatter(src.data_ptr(), tab.data_ptr(), 3, _p(dst), _st()), 'cast')
+    torch.cuda.synchronize()
+    want = torch.full((32,), -1.0)
+    want[0:4] = torch.tensor([3.5, 4.5, 5.5, 6.5]); want[10] = 50.5; want[20:30] = torch.arange(90, 100) + 0.5
+    assert torch.equal(dst.cpu(), want)
+
+
 # ---- the whole step --------------------------------------------------------------------------------------------
 def _conv_bias(k):
     return k.startswith('cnn.model.conv') and k.endswith('.bias')
