@@ -46,7 +46,8 @@ int nisqa_conv1_fwd(const float* mel_tm, const int32_t* frame_off, const int32_t
                     void* stream);
 int nisqa_conv1_wgrad(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
                       int32_t n_clips, int32_t n_segments, int32_t seg_hop, const float* dz, float* dw, void* stream);
-/* 3x3 patches, padding (1, pad_w): x[S][H*W][C] -> col[S*H*Wo][9*C], Wo = W + 2*pad_w - 2, k = (dy*3+dx)*C + c */
+/* 3x3 patches, padding (1, pad_w): x[S][H*W][C] -> col[S*H*Wo][9*C], Wo = W + 2*pad_w - 2, k = (dy*3+dx)*C + c
+ * (C % 4 == 0, 16-byte aligned buffers) */
 int nisqa_im2col3x3(const float* x, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w, float* col,
                     void* stream);
 /* adjoint of nisqa_im2col3x3 (gather form, no atomics): dx[S][H*W][C] = sum of the patch entries that read it */

@@ -369,42 +369,45 @@ extern "C" int nisqa_im2col_mel(const float* mel_tm, const int32_t* frame_off, c
 }
 
 // The geometry template arguments make the index arithmetic divisions by constants (0 = use the run-time values):
-// these kernels move 4 bytes per ~10 integer divisions, so that arithmetic -- not HBM -- was their cost.
+// with run-time divisors these kernels spent ~10 integer divisions per element moved -- arithmetic, not HBM, was their cost.
+// One thread moves four consecutive channels (c % 4 == 0: 128-bit accesses, a quarter of the index arithmetic).
 template <int H, int W, int C, int PW>
-__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, int64_t total, int h_, int w_, int c_,
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, int64_t total4, int h_, int w_, int c_,
                                                         int pad_, float* __restrict__ col) {
     const int h = H ? H : h_, w = W ? W : w_, c = C ? C : c_, pad_w = H ? PW : pad_;
-    const int wo = w + 2 * pad_w - 2, kc = 9 * c;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t row = i / kc;
-        const int k = (int)(i - row * kc);
-        const int tap = k / c, ch = k - tap * c;
+    const int wo = w + 2 * pad_w - 2, kc4 = 9 * c / 4, c4 = c / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / kc4;
+        const int k = (int)(i - row * kc4);
+        const int tap = k / c4, ch = 4 * (k - tap * c4);
         const int64_t s = row / (h * wo);
         const int po = (int)(row - s * (h * wo));
         const int y = po / wo + tap / 3 - 1, xx = po % wo + tap % 3 - pad_w;
-        col[i] = ((unsigned)y < (unsigned)h && (unsigned)xx < (unsigned)w) ? x[(s * (h * w) + y * w + xx) * c + ch] : 0.f;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)y < (unsigned)h && (unsigned)xx < (unsigned)w) v = *(const f32x4*)(x + (s * (h * w) + y * w + xx) * c + ch);
+        ((f32x4*)col)[i] = v;
     }
 }
 
 template <int H, int W, int C, int PW>
-__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcol, int64_t total, int h_, int w_, int c_,
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcol, int64_t total4, int h_, int w_, int c_,
                                                         int pad_, float* __restrict__ dx) {
     const int h = H ? H : h_, w = W ? W : w_, c = C ? C : c_, pad_w = H ? PW : pad_;
-    const int wo = w + 2 * pad_w - 2, kc = 9 * c;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int ch = (int)(i % c);
-        const int64_t pix = i / c;
+    const int wo = w + 2 * pad_w - 2, kc = 9 * c, c4 = c / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int ch = 4 * (int)(i % c4);
+        const int64_t pix = i / c4;
         const int64_t s = pix / (h * w);
         const int p = (int)(pix - s * (h * w));
         const int y = p / w, xx = p % w;
-        float acc = 0.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int yo = y - tap / 3 + 1, xo = xx - tap % 3 + pad_w;
             if ((unsigned)yo < (unsigned)h && (unsigned)xo < (unsigned)wo)
-                acc += dcol[(s * (h * wo) + yo * wo + xo) * kc + tap * c + ch];
+                acc += *(const f32x4*)(dcol + (s * (h * wo) + yo * wo + xo) * kc + tap * c + ch);
         }
-        dx[i] = acc;
+        ((f32x4*)dx)[i] = acc;
     }
 }
 
@@ -427,8 +430,10 @@ static int grid_for(int64_t total) {
 extern "C" int nisqa_im2col3x3(const float* x, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w,
                                float* col, void* stream) {
     const int wo = w + 2 * pad_w - 2;
-    if (!x || !col || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 || pad_w < 0 || pad_w > 1 || wo <= 0) return NISQA_ERR_ARG;
-    const int64_t total = (int64_t)n_segments * h * wo * 9 * c;
+    if (!x || !col || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || pad_w < 0 || pad_w > 1 || wo <= 0 ||
+        ((((uintptr_t)x) | ((uintptr_t)col)) & 15))
+        return NISQA_ERR_ARG;
+    const int64_t total = (int64_t)n_segments * h * wo * 9 * c / 4;
     NQ_LAUNCH_BEGIN();
     NQ_GEOM_DISPATCH(im2col3x3_kernel, dim3(grid_for(total)), (hipStream_t)stream, x, total, h, w, c, pad_w, col);
     return NQ_LAUNCH_STATUS();
@@ -437,8 +442,10 @@ extern "C" int nisqa_im2col3x3(const float* x, int32_t n_segments, int32_t h, in
 extern "C" int nisqa_col2im3x3(const float* dcol, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w,
                                float* dx, void* stream) {
     const int wo = w + 2 * pad_w - 2;
-    if (!dcol || !dx || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 || pad_w < 0 || pad_w > 1 || wo <= 0) return NISQA_ERR_ARG;
-    const int64_t total = (int64_t)n_segments * h * w * c;
+    if (!dcol || !dx || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 3) || pad_w < 0 || pad_w > 1 || wo <= 0 ||
+        ((((uintptr_t)dcol) | ((uintptr_t)dx)) & 15))
+        return NISQA_ERR_ARG;
+    const int64_t total = (int64_t)n_segments * h * w * c / 4;
     NQ_LAUNCH_BEGIN();
     NQ_GEOM_DISPATCH(col2im3x3_kernel, dim3(grid_for(total)), (hipStream_t)stream, dcol, total, h, w, c, pad_w, dx);
     return NQ_LAUNCH_STATUS();
