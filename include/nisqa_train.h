@@ -69,7 +69,7 @@ int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const float* gamma
 /* backward of the above in two passes around a nisqa_col_dot(dyb, z):
  * pass 1: dyb[S][H*W][C] = d loss / d (BatchNorm output) from dy[S][Ho*Wo][C] (pool scatter, dropout, ReLU gate);
  * pass 2: in place dyb -> dz = gamma*rstd*(dyb - mean(dyb) - xhat*mean(dyb*xhat)); dgamma, dbeta from sums2.
- * When 256 % c == 0 the reductions ride along: pass 1 adds sum(dyb), sum(dyb*z) to sums2_opt[2c] (zeroed by the caller;
+ * c must be a multiple of 4 (1024 % c == 0 for nisqa_bn_bwd2).  When 1024 % c == 0 the reductions ride along: pass 1 adds sum(dyb), sum(dyb*z) to sums2_opt[2c] (zeroed by the caller;
  * NULL: run nisqa_col_dot yourself), pass 2 adds the column sums of dz (the conv bias gradient) to sum_dz_opt[2c]. */
 int nisqa_bn_act_pool_bwd1(const float* dy, const int32_t* arg, const float* drop, const float* z,
                            const float* mean_rstd, const float* gamma, const float* beta, int32_t n_segments,

@@ -555,29 +555,48 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int c, int64
     running_var[ch] = 0.9f * running_var[ch] + 0.1f * (float)unb;
 }
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// per-channel affine form of the normalisation for four consecutive channels: y = z * g + b
+NQ_DEV void bn_affine4(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean_rstd, int c,
+                       int ch, f32x4& g, f32x4& b) {
+    const f32x4 ga = *(const f32x4*)(gamma + ch), be = *(const f32x4*)(beta + ch);
+    const f32x4 mu = *(const f32x4*)(mean_rstd + ch), rs = *(const f32x4*)(mean_rstd + c + ch);
+    g = ga * rs;
+    b = be - mu * g;
+}
+
+// One thread = four consecutive channels of one output pixel (c % 4 == 0): 128-bit accesses throughout.
 template <int H, int W, int C, int HO, int WO>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ mean_rstd, int64_t total, int h_, int w_, int c_, int ho_, int wo_,
+    const float* __restrict__ mean_rstd, int64_t total4, int h_, int w_, int c_, int ho_, int wo_,
     const float* __restrict__ drop, float* __restrict__ y, int32_t* __restrict__ arg) {
     const int h = H ? H : h_, w = H ? W : w_, c = H ? C : c_, ho = H ? HO : ho_, wo = H ? WO : wo_;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int ch = (int)(i % c);
-        const int64_t op = i / c;
+    const int c4 = c / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int ch = 4 * (int)(i % c4);
+        const int64_t op = i / c4;
         const int64_t s = op / (ho * wo);
         const int o = (int)(op - s * (ho * wo));
         const int oy = o / wo, ox = o % wo;
-        const float g = gamma[ch] * mean_rstd[c + ch], bsh = beta[ch] - mean_rstd[ch] * g;
-        float best = -3.0e38f;
-        int bp = 0;
+        f32x4 g, bsh;
+        bn_affine4(gamma, beta, mean_rstd, c, ch, g, bsh);
+        f32x4 best = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        i32x4 bp = {0, 0, 0, 0};
         for (int yy = win_lo(oy, h, ho); yy < win_hi(oy, h, ho); ++yy)
             for (int xx = win_lo(ox, w, wo); xx < win_hi(ox, w, wo); ++xx) {
                 const int p = yy * w + xx;
-                const float v = fmaxf(fmaf(z[(s * (h * w) + p) * c + ch], g, bsh), 0.f);
-                if (v > best) { best = v; bp = p; }
+                const f32x4 v = *(const f32x4*)(z + (s * (h * w) + p) * c + ch) * g + bsh;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r = fmaxf(v[e], 0.f);
+                    if (r > best[e]) { best[e] = r; bp[e] = p; }
+                }
             }
-        y[i] = drop ? best * drop[s * c + ch] : best;
-        arg[i] = bp;
+        if (drop) best *= *(const f32x4*)(drop + s * c + ch);
+        ((f32x4*)y)[i] = best;
+        ((i32x4*)arg)[i] = bp;
     }
 }
 
@@ -597,9 +616,9 @@ extern "C" int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const f
                                      int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo, const float* drop, float* y,
                                      int32_t* arg, void* stream) {
     if (!z || !sums || !gamma || !beta || !running_mean || !running_var || !mean_rstd || !y || !arg || n_segments <= 0 ||
-        h <= 0 || w <= 0 || c <= 0 || c > 256 || ho <= 0 || wo <= 0 || ho > h || wo > w)
+        h <= 0 || w <= 0 || c <= 0 || c > 256 || (c & 3) || ho <= 0 || wo <= 0 || ho > h || wo > w)
         return NISQA_ERR_ARG;
-    const int64_t total = (int64_t)n_segments * ho * wo * c;
+    const int64_t total = (int64_t)n_segments * ho * wo * c / 4;
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, c,
                        (int64_t)n_segments * h * w, running_mean, running_var, mean_rstd);
@@ -608,17 +627,18 @@ extern "C" int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const f
     return NQ_LAUNCH_STATUS();
 }
 
-// Grid-stride kernels over [rows][c] with 256 % c == 0 touch ONE channel per thread (channel = tid % c): two float64
-// partial sums per thread are reduced over the block in LDS and added to out[0..c) / out[c..2c) with atomics.
-NQ_DEV void block_channel_sums(double v1, double v2, int c, double* __restrict__ out) {
-    __shared__ double r1[256], r2[256];
+// Grid-stride kernels over [rows][c] in which a thread owns four consecutive channels and 1024 % c == 0 always meet the
+// SAME four channels (4 * (tid % (c/4))): eight float64 partial sums per thread are reduced over the block in LDS and
+// added to out[0..c) / out[c..2c) with atomics.
+NQ_DEV void block_channel_sums4(const double (&v1)[4], const double (&v2)[4], int c, double* __restrict__ out) {
+    __shared__ double r1[1024], r2[1024];
     const int tid = threadIdx.x;
-    r1[tid] = v1;
-    r2[tid] = v2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r1[4 * tid + e] = v1[e]; r2[4 * tid + e] = v2[e]; }
     __syncthreads();
-    if (tid < c) {
+    if (tid < c) {                                         // channel tid lives at positions tid, tid + c, ... of the 1024
         double t1 = 0.0, t2 = 0.0;
-        for (int q = tid; q < 256; q += c) { t1 += r1[q]; t2 += r2[q]; }
+        for (int q = tid; q < 1024; q += c) { t1 += r1[q]; t2 += r2[q]; }
         atomicAdd(out + tid, t1);
         atomicAdd(out + c + tid, t2);
     }
@@ -628,24 +648,26 @@ template <int H, int W, int C, int HO, int WO>
 __global__ __launch_bounds__(256) void bn_act_pool_bwd1_kernel(
     const float* __restrict__ dy, const int32_t* __restrict__ arg, const float* __restrict__ drop,
     const float* __restrict__ z, const float* __restrict__ mean_rstd, const float* __restrict__ gamma,
-    const float* __restrict__ beta, int64_t total, int h_, int w_, int c_, int ho_, int wo_, float* __restrict__ dyb,
+    const float* __restrict__ beta, int64_t total4, int h_, int w_, int c_, int ho_, int wo_, float* __restrict__ dyb,
     double* __restrict__ sums2) {
     const int h = H ? H : h_, w = H ? W : w_, c = H ? C : c_, ho = H ? HO : ho_, wo = H ? WO : wo_;
-    double a1 = 0.0, a2 = 0.0;                             // sums2 != NULL: sum(dyb), sum(dyb * z) of this thread's channel
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int ch = (int)(i % c);
-        const int64_t pix = i / c;
+    const int c4 = c / 4;
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};     // sums2 != NULL: sum(dyb), sum(dyb * z)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int ch = 4 * (int)(i % c4);
+        const int64_t pix = i / c4;
         const int64_t s = pix / (h * w);
         const int p = (int)(pix - s * (h * w));
         const int yy = p / w, xx = p % w;
-        const float g = gamma[ch] * mean_rstd[c + ch];
-        const float zi = z[i];
-        const float yb = fmaf(zi, g, beta[ch] - mean_rstd[ch] * g);
-        float acc = 0.f;
-        if (yb > 0.f && h == ho && w == wo) {              // identity pooling: the only window of pixel p is p itself
-            acc = dy[i];
-            if (drop) acc *= drop[s * c + ch];
-        } else if (yb > 0.f) {                             // ReLU gate
+        f32x4 g, bsh;
+        bn_affine4(gamma, beta, mean_rstd, c, ch, g, bsh);
+        const f32x4 zi = ((const f32x4*)z)[i];
+        const f32x4 yb = zi * g + bsh;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const bool live = yb[0] > 0.f || yb[1] > 0.f || yb[2] > 0.f || yb[3] > 0.f;
+        if (h == ho && w == wo) {                           // identity pooling: the only window of pixel p is p itself
+            acc = ((const f32x4*)dy)[i];
+        } else if (live) {
             const int oy0 = max(0, (yy * ho) / h - 1), oy1 = min(ho - 1, ((yy + 1) * ho) / h + 1);
             const int ox0 = max(0, (xx * wo) / w - 1), ox1 = min(wo - 1, ((xx + 1) * wo) / w + 1);
             for (int oy = oy0; oy <= oy1; ++oy) {
@@ -653,16 +675,23 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd1_kernel(
                 for (int ox = ox0; ox <= ox1; ++ox) {
                     if (xx < win_lo(ox, w, wo) || xx >= win_hi(ox, w, wo)) continue;
                     const int64_t o = (s * (ho * wo) + oy * wo + ox) * c + ch;
-                    if (arg[o] == p) acc += dy[o];
+                    const i32x4 ag = *(const i32x4*)(arg + o);
+                    const f32x4 d = *(const f32x4*)(dy + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (ag[e] == p) acc[e] += d[e];
                 }
             }
-            if (drop) acc *= drop[s * c + ch];
         }
-        dyb[i] = acc;
-        a1 += (double)acc;
-        a2 += (double)acc * (double)zi;
+        if (drop) acc *= *(const f32x4*)(drop + s * c + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (!(yb[e] > 0.f)) acc[e] = 0.f;               // ReLU gate
+            a1[e] += (double)acc[e];
+            a2[e] += (double)acc[e] * (double)zi[e];
+        }
+        ((f32x4*)dyb)[i] = acc;
     }
-    if (sums2) block_channel_sums(a1, a2, c, sums2);
+    if (sums2) block_channel_sums4(a1, a2, c, sums2);
 }
 
 extern "C" int nisqa_bn_act_pool_bwd1(const float* dy, const int32_t* arg, const float* drop, const float* z,
@@ -670,9 +699,9 @@ extern "C" int nisqa_bn_act_pool_bwd1(const float* dy, const int32_t* arg, const
                                       int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo, float* dyb, double* sums2_opt,
                                       void* stream) {
     if (!dy || !arg || !z || !mean_rstd || !gamma || !beta || !dyb || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 ||
-        ho <= 0 || wo <= 0 || ho > h || wo > w || (sums2_opt && (256 % c) != 0))
+        ho <= 0 || wo <= 0 || ho > h || wo > w || (c & 3) || (sums2_opt && (1024 % c) != 0))
         return NISQA_ERR_ARG;
-    const int64_t total = (int64_t)n_segments * h * w * c;
+    const int64_t total = (int64_t)n_segments * h * w * c / 4;
     NQ_LAUNCH_BEGIN();
     // with the reductions riding along every block ends in 2c float64 atomics on the same addresses: 2048 blocks fill the
     // chip (8 per CU) and keep that tail short
@@ -693,30 +722,40 @@ __global__ __launch_bounds__(256) void bn_bwd2_kernel(float* __restrict__ d, con
         dbeta[ch] = (float)sums2[ch];
         dgamma[ch] = (float)(rstd * (sums2[c + ch] - mean * sums2[ch]));
     }
-    const int64_t total = rows * c;
+    const int c4 = c / 4;
+    const int64_t total4 = rows * c4;
     const double inv = 1.0 / (double)rows;
-    double a1 = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int ch = (int)(i % c);
-        const float mean = mean_rstd[ch], rstd = mean_rstd[c + ch];
-        const float m1 = (float)(sums2[ch] * inv);                                           // mean(dyb)
-        const float m2 = (float)((double)rstd * (sums2[c + ch] - (double)mean * sums2[ch]) * inv);   // mean(dyb * xhat)
-        const float xh = (z[i] - mean) * rstd;
-        const float o = gamma[ch] * rstd * (d[i] - m1 - xh * m2);
-        d[i] = o;
-        a1 += (double)o;
+    // this thread's four channels never change (grid stride 256 * gridDim is a multiple of c / 4): per-channel constants once
+    const int ch = 4 * (int)(((int64_t)blockIdx.x * 256 + threadIdx.x) % c4);
+    f32x4 mean, rstd, m1, m2, gr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        mean[e] = mean_rstd[ch + e];
+        rstd[e] = mean_rstd[c + ch + e];
+        m1[e] = (float)(sums2[ch + e] * inv);                                                            // mean(dyb)
+        m2[e] = (float)((double)rstd[e] * (sums2[c + ch + e] - (double)mean[e] * sums2[ch + e]) * inv);   // mean(dyb * xhat)
+        gr[e] = gamma[ch + e] * rstd[e];
     }
-    if (sum_dz) block_channel_sums(a1, 0.0, c, sum_dz);    // column sums of dz = the conv bias gradient (second half unused)
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a0[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 xh = (((const f32x4*)z)[i] - mean) * rstd;
+        const f32x4 o = gr * (((f32x4*)d)[i] - m1 - xh * m2);
+        ((f32x4*)d)[i] = o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a1[e] += (double)o[e];
+    }
+    if (sum_dz) block_channel_sums4(a1, a0, c, sum_dz);    // column sums of dz = the conv bias gradient (second half unused)
 }
 
 extern "C" int nisqa_bn_bwd2(float* dyb_to_dz, const float* z, const double* sums2, const float* mean_rstd,
                              const float* gamma, int64_t rows, int32_t c, float* dgamma, float* dbeta, double* sum_dz_opt,
                              void* stream) {
     if (!dyb_to_dz || !z || !sums2 || !mean_rstd || !gamma || !dgamma || !dbeta || rows <= 0 || c <= 0 || c > 256 ||
-        (sum_dz_opt && (256 % c) != 0))
+        (1024 % c) != 0)
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    const int grid = sum_dz_opt ? (grid_for(rows * c) < 2048 ? grid_for(rows * c) : 2048) : grid_for(rows * c);
+    // gridDim * 256 must be a multiple of c / 4 (the kernel hoists its per-channel constants): any gridDim is, as c / 4 | 256
+    const int grid = grid_for(rows * c / 4) < 2048 ? grid_for(rows * c / 4) : 2048;
     hipLaunchKernelGGL(bn_bwd2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, dyb_to_dz, z, sums2,
                        mean_rstd, gamma, rows, c, dgamma, dbeta, sum_dz_opt);
     return NQ_LAUNCH_STATUS();
