@@ -50,6 +50,13 @@ int nisqa_conv1_wgrad(const float* mel_tm, const int32_t* frame_off, const int32
  * (C % 4 == 0, 16-byte aligned buffers) */
 int nisqa_im2col3x3(const float* x, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w, float* col,
                     void* stream);
+/* The same three convolution products without a patch matrix (implicit GEMM: the loaders gather the patches).
+ *   mode 0  z[S*H*Wo][co]  = conv(x[S][H*W][ci], w[co][9*ci]) (+ bias, may be NULL)      in: x,  w   out: z
+ *   mode 1  dx[S*H*W][ci]  = conv^T(dz[S][H*Wo][co], w)                                  in: dz, w   out: dx
+ *   mode 2  dw[co][9*ci]  += dz^T * patches(x)   (dw zeroed by the caller, ksplit chunks) in: x,  dz  out: dw
+ * ci, co powers of two >= 4; padding (1, pad_w) as in nisqa_im2col3x3. */
+int nisqa_conv3x3_gemm(int32_t mode, const float* x_or_dz, const float* w_or_dz, float* out, int32_t n_segments, int32_t h,
+                       int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, int32_t ksplit, void* stream);
 /* adjoint of nisqa_im2col3x3 (gather form, no atomics): dx[S][H*W][C] = sum of the patch entries that read it */
 int nisqa_col2im3x3(const float* dcol, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w, float* dx,
                     void* stream);

@@ -230,6 +230,229 @@ extern "C" int nisqa_gemm_f32_one(const float* a, const float* b, float* c, int6
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// 3 x 3 convolutions as IMPLICIT GEMMs: the patch matrix of im2col is never written -- the operand loaders gather it
+// from the activation tensor ([S][H*W][C], channels contiguous: a group of four k's is one 128-bit load inside one
+// tap).  Same tiles, LDS staging and MFMA core as gemm_f32_kernel.
+//   MODE 0 forward : z[(s,yo,xo)][co]   = sum_{tap,ci} x[s][(yo+dy-1, xo+dx-pad)][ci] * w[co][tap*CI+ci] (+ bias)
+//   MODE 1 dgrad   : dx[(s,y,x)][ci]    = sum_{tap,co} dz[s][(y-dy+1, x-dx+pad)][co]   * w[co][tap*CI+ci]
+//   MODE 2 wgrad   : dw[co][tap*CI+ci] += sum_{(s,yo,xo)} dz[(s,yo,xo)][co] * x[s][(yo+dy-1, xo+dx-pad)][ci]   (split-K, atomics)
+// ---------------------------------------------------------------------------------------------------------
+struct nq_fdiv { uint32_t m, s1, s2; };                       // q = (t + ((x - t) >> s1)) >> s2 with t = umulhi(m, x)
+NQ_DEV uint32_t fdiv_q(uint32_t x, nq_fdiv d) {
+    const uint32_t t = __umulhi(d.m, x);
+    return (t + ((x - t) >> d.s1)) >> d.s2;
+}
+static nq_fdiv fdiv_make(uint32_t d) {
+    nq_fdiv r = {0u, 0u, 0u};
+    if (d <= 1) return r;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;
+    r.m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+    r.s1 = 1;
+    r.s2 = l - 1;
+    return r;
+}
+
+struct conv_geom {
+    int hr, wr;            // spatial size the GEMM rows (pixels) run over
+    int hs, ws, lcs;       // spatial size and log2(channels) of the gathered tensor
+    int pad, sgn;          // padding along x; +1: source pixel = row pixel + (tap offset), -1: minus (dgrad)
+    int ci, co;            // channels of the layer
+    nq_fdiv d_img, d_row;     // division by hr*wr and by wr
+};
+
+NQ_DEV f32x4 conv_gather(const float* __restrict__ src, const conv_geom& g, int s, int yr, int xr, int tap, int c) {
+    const int ty = tap / 3, tx = tap - 3 * ty;
+    const int ys = yr + g.sgn * (ty - 1), xs = xr + g.sgn * (tx - g.pad);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)ys < (unsigned)g.hs && (unsigned)xs < (unsigned)g.ws)
+        v = *(const f32x4*)(src + ((((int64_t)s * g.hs + ys) * g.ws + xs) << g.lcs) + c);
+    return v;
+}
+
+template <int BM, int BN, int MT, int NT, int MODE>
+__global__ __launch_bounds__((BM / (32 * MT)) * (BN / (32 * NT)) * 64) void conv_gemm_kernel(
+    const float* __restrict__ G, const float* __restrict__ O, float* __restrict__ C, conv_geom g, int M, int N, int K, int ksplit,
+    const float* __restrict__ bias) {
+    // G: the gathered tensor (x for forward / wgrad, dz for dgrad); O: the other operand (weights, or dz for wgrad)
+    __shared__ __attribute__((aligned(16))) float As[GB_K][BM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[GB_K][BN + 4];
+    constexpr int WN = BN / (32 * NT);
+    constexpr int NTH = (BM / (32 * MT)) * WN * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int m0 = ((int)blockIdx.x / tiles_n) * BM, n0 = ((int)blockIdx.x % tiles_n) * BN;
+    int kc = (K + ksplit - 1) / ksplit;
+    kc = (kc + GB_K - 1) / GB_K * GB_K;
+    const int k_begin = blockIdx.y * kc, k_end = min(K, k_begin + kc);
+    if (k_begin >= k_end) return;
+    const int wm = (wave / WN) * 32 * MT, wn = (wave % WN) * 32 * NT;
+    tile_loader<BM, MODE != 2, NTH> la;                     // forward / dgrad: A rows are pixels, k contiguous; wgrad: A = dz [K][M]
+    tile_loader<BN, MODE == 0, NTH> lb;                     // forward: B = w [N][K]; dgrad / wgrad: n contiguous
+    const int csm = (1 << g.lcs) - 1;
+
+    // A rows of this thread (forward / dgrad): pixel coordinates once, they do not change along K
+    int a_s[la.NV], a_y[la.NV], a_x[la.NV];
+    if (MODE != 2) {
+#pragma unroll
+        for (int j = 0; j < la.NV; ++j) {
+            const int row = m0 + (tid + NTH * j) / (GB_K / 4);
+            const uint32_t s = fdiv_q((uint32_t)row, g.d_img);
+            const uint32_t rem = (uint32_t)row - s * (uint32_t)(g.hr * g.wr);
+            const uint32_t y = fdiv_q(rem, g.d_row);
+            a_s[j] = row < M ? (int)s : -1;
+            a_y[j] = (int)y;
+            a_x[j] = (int)(rem - y * (uint32_t)g.wr);
+        }
+    }
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < la.NV; ++j) {
+            const int i = tid + NTH * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (MODE != 2) {                                 // gather, k = tap * cs + c
+                const int kk = k0 + 4 * (i % (GB_K / 4));
+                if (a_s[j] >= 0 && kk < k_end) v = conv_gather(G, g, a_s[j], a_y[j], a_x[j], kk >> g.lcs, kk & csm);
+            } else {                                         // dz stored [K = pixel rows][M = co]
+                const int kk = k0 + i / (BM / 4), m = m0 + 4 * (i % (BM / 4));
+                if (kk < k_end && m < M) v = *(const f32x4*)(O + (int64_t)kk * g.co + m);
+            }
+            la.v[j] = v;
+        }
+    };
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < lb.NV; ++j) {
+            const int i = tid + NTH * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 0) {                                 // w [N = co][K = 9 ci], k contiguous
+                const int n = n0 + i / (GB_K / 4), kk = k0 + 4 * (i % (GB_K / 4));
+                if (n < N && kk < k_end) v = *(const f32x4*)(O + (int64_t)n * K + kk);
+            } else if (MODE == 1) {                          // w viewed as [k = tap * co_n + co][n = ci]
+                const int kk = k0 + i / (BN / 4), n = n0 + 4 * (i % (BN / 4));
+                if (kk < k_end && n < N) {
+                    const int tap = kk >> g.lcs, co = kk & csm;
+                    v = *(const f32x4*)(O + (int64_t)co * (9 * g.ci) + tap * g.ci + n);
+                }
+            } else {                                         // gather x at pixel row kk, column n = tap * ci + c
+                const int kk = k0 + i / (BN / 4), n = n0 + 4 * (i % (BN / 4));
+                if (kk < k_end && n < N) {
+                    const uint32_t s = fdiv_q((uint32_t)kk, g.d_img);
+                    const uint32_t rem = (uint32_t)kk - s * (uint32_t)(g.hr * g.wr);
+                    const uint32_t y = fdiv_q(rem, g.d_row);
+                    v = conv_gather(G, g, (int)s, (int)y, (int)(rem - y * (uint32_t)g.wr), n >> g.lcs, n & csm);
+                }
+            }
+            lb.v[j] = v;
+        }
+    };
+
+    load_a(k_begin);
+    load_b(k_begin);
+    la.store(As, tid);
+    lb.store(Bs, tid);
+    __syncthreads();
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero16();
+    for (int k0 = k_begin; k0 < k_end; k0 += GB_K) {
+        const bool more = k0 + GB_K < k_end;
+        if (more) {
+            load_a(k0 + GB_K);
+            load_b(k0 + GB_K);
+        }
+#pragma unroll
+        for (int s = 0; s < GB_K / 2; ++s) {
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) av[i] = As[2 * s + (lane >> 5)][wm + 32 * i + (lane & 31)];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bv[j] = Bs[2 * s + (lane >> 5)][wn + 32 * j + (lane & 31)];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = mfma32(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+        if (more) {
+            la.store(As, tid);
+            lb.store(Bs, tid);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + NQ_DROW(r, lane >> 5);
+                if (row < M && col < N) {
+                    const float v = acc[i][j][r];
+                    if (MODE == 2) atomicAdd(C + (int64_t)row * N + col, v);
+                    else C[(int64_t)row * N + col] = bias ? v + bias[col] : v;
+                }
+            }
+        }
+}
+
+template <int BM, int BN, int MT, int NT, int MODE>
+static void conv_launch(hipStream_t st, const float* gsrc, const float* other, float* c, const conv_geom& g, int M, int N, int K,
+                        int ksplit, const float* bias) {
+    const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, MT, NT, MODE>), dim3((unsigned)tiles, ksplit),
+                       dim3((BM / (32 * MT)) * (BN / (32 * NT)) * 64), 0, st, gsrc, other, c, g, M, N, K, ksplit, bias);
+}
+
+static int ilog2_exact(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return (1 << l) == v ? l : -1;
+}
+
+// mode 0: x -> z (bias may be NULL); mode 1: dz -> dx; mode 2: (x, dz) -> dw += (dw zeroed by the caller), ksplit chunks
+extern "C" int nisqa_conv3x3_gemm(int32_t mode, const float* x_or_dz, const float* w_or_dz, float* out, int32_t n_segments,
+                                  int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias,
+                                  int32_t ksplit, void* stream) {
+    const int wo = w + 2 * pad_w - 2;
+    if (mode < 0 || mode > 2 || !x_or_dz || !w_or_dz || !out || n_segments <= 0 || h <= 0 || w <= 0 || wo <= 0 || pad_w < 0 ||
+        pad_w > 1 || ilog2_exact(ci) < 2 || ilog2_exact(co) < 2 || ksplit < 1 || ksplit > 65535 || (mode != 2 && ksplit != 1) ||
+        (mode != 0 && bias))
+        return NISQA_ERR_ARG;
+    const int64_t rows_out = (int64_t)n_segments * h * wo, rows_in = (int64_t)n_segments * h * w;
+    if (rows_out > 0x7fffffff || rows_in > 0x7fffffff) return NISQA_ERR_ARG;
+    conv_geom g;
+    g.ci = ci;
+    g.co = co;
+    g.pad = pad_w;
+    hipStream_t st = (hipStream_t)stream;
+    NQ_LAUNCH_BEGIN();
+    if (mode == 1) {                                        // rows = input pixels, gather dz [H][Wo][co]
+        g.hr = h; g.wr = w; g.hs = h; g.ws = wo; g.lcs = ilog2_exact(co); g.sgn = -1;
+        g.d_img = fdiv_make((uint32_t)(h * w)); g.d_row = fdiv_make((uint32_t)w);
+        const int M = (int)rows_in, N = ci, K = 9 * co;
+        if (N > 32) conv_launch<256, 64, 2, 1, 1>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, nullptr);
+        else conv_launch<128, 32, 1, 1, 1>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, nullptr);
+    } else {                                                // rows = output pixels, gather x [H][W][ci]
+        g.hr = h; g.wr = wo; g.hs = h; g.ws = w; g.lcs = ilog2_exact(ci); g.sgn = 1;
+        g.d_img = fdiv_make((uint32_t)(h * wo)); g.d_row = fdiv_make((uint32_t)wo);
+        if (mode == 0) {
+            const int M = (int)rows_out, N = co, K = 9 * ci;
+            if (N > 32) conv_launch<256, 64, 2, 1, 0>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, bias);
+            else conv_launch<128, 32, 1, 1, 0>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, bias);
+        } else {
+            const int M = co, N = 9 * ci, K = (int)rows_out;
+            if (N >= 256) conv_launch<64, 256, 2, 1, 2>(st, x_or_dz, w_or_dz, out, g, M, N, K, ksplit, nullptr);
+            else conv_launch<64, 64, 1, 1, 2>(st, x_or_dz, w_or_dz, out, g, M, N, K, ksplit, nullptr);
+        }
+    }
+    return NQ_LAUNCH_STATUS();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // patches
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void im2col_mel_kernel(const float* __restrict__ mel_tm,
@@ -473,7 +696,7 @@ __global__ __launch_bounds__(256) void col_dot_kernel(const float* __restrict__ 
             float av[2][V], bv[2][V];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                if (V == 4) {
+                if constexpr (V == 4) {
                     const f32x4 t = *(const f32x4*)(a + (r + q * rl) * c + 4 * g);
                     av[q][0] = t[0]; av[q][1] = t[1]; av[q][2] = t[2]; av[q][3] = t[3];
                 } else av[q][0] = a[(r + q * rl) * c + g];
@@ -483,7 +706,7 @@ __global__ __launch_bounds__(256) void col_dot_kernel(const float* __restrict__ 
                 if (same) {
 #pragma unroll
                     for (int e = 0; e < V; ++e) bv[q][e] = av[q][e];
-                } else if (V == 4) {
+                } else if constexpr (V == 4) {
                     const f32x4 t = *(const f32x4*)(b + (r + q * rl) * c + 4 * g);
                     bv[q][0] = t[0]; bv[q][1] = t[1]; bv[q][2] = t[2]; bv[q][3] = t[3];
                 } else bv[q][0] = b[(r + q * rl) * c + g];

@@ -315,14 +315,12 @@ class HipTrainer(object):
             z = self._new(rows, co)
             wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
             if i == 1:                                                         # straight from the spectrogram, no patches
-                col = None
                 self._ck(L_.nisqa_conv1_fwd(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
                                             _ptr(self.P[wk]), _ptr(self.P[bk]), _ptr(z), st), 'nisqa_conv1_fwd')
-            else:
+            else:                                                              # implicit GEMM: patches gathered by the loaders
                 hi, wi = geo[i - 2][2]
-                col = self._new(rows, 9 * ci)
-                self._ck(L_.nisqa_im2col3x3(_ptr(act), S, hi, wi, ci, 0 if i == 6 else 1, _ptr(col), st), 'nisqa_im2col3x3')
-                self._gemm(col, self.P[wk], z, rows, co, 9 * ci, 9 * ci, 9 * ci, co, tb=1, bias=self.P[bk])
+                self._ck(L_.nisqa_conv3x3_gemm(0, _ptr(act), _ptr(self.P[wk]), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
+                                               _ptr(self.P[bk]), 1, st), 'nisqa_conv3x3_gemm fwd')
             sums = self._coldot(z, z, rows, co)
             drop = self._mask(masks, _DROP_AFTER.get(i), (S, co), self.p_cnn) if i in _DROP_AFTER else None
             out = self._new(S, ho * wo, co)
@@ -334,7 +332,7 @@ class HipTrainer(object):
                                               _ptr(drop) if drop is not None else None, _ptr(out), arg.data_ptr(), st),
                      'nisqa_bn_act_pool_fwd')
             self.bn[i]['n'] += 1
-            cnn.append(dict(col=col, z=z, arg=arg, mr=mr, drop=drop, h=h, w=w, ho=ho, wo=wo, ci=ci, co=co, rows=rows))
+            cnn.append(dict(x=act, z=z, arg=arg, mr=mr, drop=drop, h=h, w=w, ho=ho, wo=wo, ci=ci, co=co, rows=rows))
             act = out
         feat = act                                                             # [S][6][64] = [S][384] in (y, c) order
 
@@ -477,15 +475,14 @@ class HipTrainer(object):
                 self._ck(L_.nisqa_conv1_wgrad(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop, _ptr(dz),
                                               _ptr(self.G[wk]), st), 'nisqa_conv1_wgrad')
             else:
-                self._gemm(dz, c['col'], self.G[wk], co, 9 * ci, rows, co, 9 * ci, 9 * ci, ta=1,
-                           ksplit=self._ksplit(rows, co, 9 * ci))
-            if i > 1:
-                dcol = self._new(rows, 9 * ci)
-                self._gemm(dz, self.P[wk], dcol, rows, 9 * ci, co, co, 9 * ci, 9 * ci)
                 hi, wi = geo[i - 2][2]
+                pad = 0 if i == 6 else 1
+                self._ck(L_.nisqa_conv3x3_gemm(2, _ptr(c['x']), _ptr(dz), _ptr(self.G[wk]), S, hi, wi, ci, co, pad, None,
+                                               self._ksplit(rows, co, 9 * ci), st), 'nisqa_conv3x3_gemm wgrad')
                 da = self._new(S, hi * wi, ci)
-                self._ck(L_.nisqa_col2im3x3(_ptr(dcol), S, hi, wi, ci, 0 if i == 6 else 1, _ptr(da), st), 'nisqa_col2im3x3')
-            c['col'] = None
+                self._ck(L_.nisqa_conv3x3_gemm(1, _ptr(dz), _ptr(self.P[wk]), _ptr(da), S, hi, wi, ci, co, pad, None, 1, st),
+                         'nisqa_conv3x3_gemm dgrad')
+            c['x'] = None
 
         self._flush_casts()
 

@@ -141,6 +141,32 @@ def test_im2col_col2im_against_unfold_and_adjointness(h, w, c, pad_w):
     assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))                # <im2col(x), d> == <x, col2im(d)>
 
 
+@pytest.mark.parametrize('h,w,ci,co,pad_w', [(24, 7, 16, 32, 1), (12, 5, 32, 64, 1), (12, 5, 64, 64, 1), (6, 3, 64, 64, 1), (6, 3, 64, 64, 0)])
+def test_implicit_gemm_convolution_forward_dgrad_wgrad(h, w, ci, co, pad_w):
+    lib, L = _L()
+    S = 37                                                            # rows not a multiple of any tile
+    wo = w + 2 * pad_w - 2
+    x = _r(S, h * w, ci, seed=50).requires_grad_(True)
+    wt = (_r(co, ci, 3, 3, seed=51) * 0.2).requires_grad_(True)
+    b = _r(co, seed=52)
+    z_t = F.conv2d(x.view(S, h, w, ci).permute(0, 3, 1, 2), wt, b, padding=(1, pad_w))          # [S, co, h, wo]
+    dz = _r(S, h * wo, co, seed=53)
+    (z_t.permute(0, 2, 3, 1).reshape(S, h * wo, co) * dz).sum().backward()
+    wk = wt.detach().permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+    z = torch.empty(S * h * wo, co, device=DEV)
+    lib.check(L.nisqa_conv3x3_gemm(0, _p(x.detach()), _p(wk), _p(z), S, h, w, ci, co, pad_w, _p(b), 1, _st()), 'conv fwd')
+    dx = torch.empty(S, h * w, ci, device=DEV)
+    lib.check(L.nisqa_conv3x3_gemm(1, _p(dz), _p(wk), _p(dx), S, h, w, ci, co, pad_w, None, 1, _st()), 'conv dgrad')
+    dw = torch.zeros(co, 9 * ci, device=DEV)
+    lib.check(L.nisqa_conv3x3_gemm(2, _p(x.detach()), _p(dz), _p(dw), S, h, w, ci, co, pad_w, None, 5, _st()), 'conv wgrad')
+    torch.cuda.synchronize()
+    want_z = z_t.detach().permute(0, 2, 3, 1).reshape(S * h * wo, co)
+    assert (z - want_z).abs().max() < 2e-5 * max(1.0, float(want_z.abs().max())) * 3
+    assert (dx - x.grad).abs().max() < 2e-5 * max(1.0, float(x.grad.abs().max())) * 3
+    want_dw = wt.grad.permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    assert (dw - want_dw).abs().max() < 1e-4 * max(1.0, float(want_dw.abs().max()))
+
+
 def test_im2col_mel_segments_and_floor():
     lib, L = _L()
     T = [40, 15]
