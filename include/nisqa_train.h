@@ -4,7 +4,7 @@
  * (model.train(); model(x, n_wins); biasLoss.get_loss; backward; Adam.step) -- is driven from the host
  * (nisqa_amd/train.py) as a sequence of these operators.  Train-mode BatchNorm needs statistics over every valid
  * segment of the batch between a convolution and its activation, so the per-segment fusion of the inference
- * kernels does not apply; convolutions run as im2col + GEMM on fp32 MFMA, activations live in HBM.
+ * kernels does not apply; convolutions run as implicit GEMMs on fp32 MFMA, activations live in HBM.
  *
  * Conventions: float32 row-major everywhere; activations are pixel-major, channels contiguous: act[S][H*W][C];
  * token matrices are [tokens][features].  All pointers are device memory owned by the caller, all work is enqueued

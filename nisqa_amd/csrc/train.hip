@@ -3,11 +3,12 @@
 // (nisqa/NISQA_model.py:131-152, NISQA_lib.py:688-710, 988-1040, 1171-1183, 1880-1950).
 //
 // Train-mode BatchNorm couples every valid segment of the batch between a convolution and its activation, so the
-// wave-owns-a-segment fusion of the inference kernels does not apply.  First version, built for correctness:
-// convolutions are im2col + a grouped GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), activations and patches live in
-// HBM (a 32 x 10 s batch needs ~4 GB of the 288), reductions that feed normalisation statistics accumulate in
-// float64.  The GEMM also serves every Linear, the attention products (ragged, one group per clip) and all their
-// gradients (transposed operands; split-K with atomics where K is the row count of the batch).
+// wave-owns-a-segment fusion of the inference kernels does not apply: activations live in HBM ([S][H*W][C], channels
+// contiguous) and a layer is a short sequence of grid-wide kernels.  conv1 reads the spectrogram directly, conv2..6
+// are implicit GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32) whose loaders gather the 3x3 patches; reductions that
+// feed normalisation statistics accumulate in float64.  The same GEMM core serves every Linear, the attention
+// products (ragged, one group per clip) and all their gradients (transposed operands; split-K with atomics where K
+// is the row count of the batch).
 #include "common.hpp"
 #include "../../include/nisqa_hip.h"
 #include "../../include/nisqa_train.h"
