@@ -181,6 +181,41 @@ class _NisqaBase(nn.Module):
         return self.engine(dev).forward_segments(x, n_wins)
 
 
+def init_parameters_(model):
+    """Random initialisation with the distributions the reference's modules get from PyTorch (for training from
+    scratch, pretrained_model: false): Conv2d / Linear kaiming-uniform(a=sqrt 5) weights and U(+-1/sqrt(fan_in)) biases,
+    BatchNorm / LayerNorm at identity with fresh running statistics, nn.MultiheadAttention's xavier-uniform in_proj and
+    zero attention biases, and SelfAttention._reset_parameters (NL:981-984): xavier-uniform on every matrix of the
+    time-dependency block."""
+    import math
+    for name, mod in model.named_modules():
+        if not isinstance(mod, _Params):
+            continue
+        names = dict(mod.named_parameters(recurse=False))
+        bufs = dict(mod.named_buffers(recurse=False))
+        w = names.get('weight')
+        if 'running_mean' in bufs or (w is not None and w.dim() == 1):         # BatchNorm / LayerNorm
+            nn.init.ones_(w)
+            nn.init.zeros_(names['bias'])
+            if 'running_mean' in bufs:
+                bufs['running_mean'].zero_()
+                bufs['running_var'].fill_(1.0)
+                bufs['num_batches_tracked'].zero_()
+        elif w is not None:                                                      # Conv2d / Linear
+            nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+            fan_in = w[0].numel()
+            nn.init.uniform_(names['bias'], -1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+    td = getattr(model, 'time_dependency', None)
+    if td is not None and isinstance(td.model, _SelfAttentionParams):
+        for layer in td.model.layers:
+            nn.init.zeros_(layer.self_attn.in_proj_bias)
+            nn.init.zeros_(layer.self_attn.out_proj.bias)
+        for p_ in td.model.parameters():
+            if p_.dim() > 1:
+                nn.init.xavier_uniform_(p_)
+    return model
+
+
 class NISQA(_NisqaBase):
     def __init__(self, **kw):
         super().__init__(1, **kw)
@@ -254,8 +289,11 @@ class SpeechQualityDataset(object):
         return torch.from_numpy(np.ascontiguousarray(x)), self.labels(1)[0], (index, np.array(n_wins))
 
     def labels(self, n):
-        """predict_only labels: NaN rows like NL:2217-2231."""
-        return np.full((n, 5 if self.dim else 1), np.nan, dtype=np.float32)
+        """Labels of the first n items like NL:2217-2231: NaN rows in predict_only mode, else the csv columns."""
+        if self.mos_column == 'predict_only':
+            return np.full((n, 5 if self.dim else 1), np.nan, dtype=np.float32)
+        cols = ['mos', 'noi', 'dis', 'col', 'loud'] if self.dim else [self.mos_column]
+        return np.stack([self.df[c].to_numpy(dtype=np.float32)[:n] for c in cols], 1)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -264,8 +302,6 @@ class SpeechQualityDataset(object):
 def _predict(model, ds, bs, dev, num_workers):
     """Shared body of predict_mos / predict_dim: returns y_hat [N, heads] float32 for ALL items of ds
     (clip-sharded over ranks when torch.distributed is initialised, then gathered)."""
-    if ds.mos_column != 'predict_only':
-        raise NotImplementedError('only predict_only datasets are supported (evaluation is out of scope)')
     dev = torch.device(dev)
     if model._engine is None and dev.type != 'cuda':
         raise RuntimeError('nisqa_amd has no CPU path: device {} requested but the hot path runs only as HIP kernels '

@@ -4,7 +4,7 @@ and ``NISQA_results.csv`` -- with the hot path behind it running as HIP kernels 
 
 What ``run_predict.py`` and ``run_evaluate.py`` reach is implemented (reference NISQA_model.py:26-81, 572-716,
 732-847, 928-1051): the three predict modes and ``evaluate()`` on their predictions (host-side P.1401 statistics,
-nisqa_amd/evaluation.py).  ``train()`` raises NotImplementedError (not built yet).
+nisqa_amd/evaluation.py).  ``train()`` runs the reference's epoch loop (nisqa_amd/trainloop.py) around the HIP training step.
 """
 import datetime
 import os
@@ -33,7 +33,16 @@ class nisqaModel(object):
             print(yaml.dump(self.args, default_flow_style=None, sort_keys=False))
 
     def train(self):
-        raise NotImplementedError('training is out of scope of nisqa_amd (inference hot path only)')
+        """reference NISQA_model.py:41-46: _train_mos / _train_dim.  The per-batch step (train-mode forward, backward,
+        Adam) runs as HIP kernels (nisqa_amd/train.py); the epoch loop around it is nisqa_amd/trainloop.py."""
+        if self.args['mode'] != 'main' or not hasattr(self, 'ds_train'):
+            raise NotImplementedError("train() needs the training configuration (mode 'main': run_train.py --yaml ...)")
+        from . import trainloop
+        trainloop.train(self)
+
+    def _makeRunnameAndWriteYAML(self):
+        from . import trainloop
+        return trainloop.make_runname_and_write_yaml(self)
 
     def evaluate(self, mapping='first_order', do_print=True, do_plot=False):
         """reference NISQA_model.py:48-52: per-database / overall statistics of the predictions in ``ds_val.df``
@@ -105,14 +114,36 @@ class nisqaModel(object):
         elif self.args['mode'] == 'predict_csv':
             self._loadDatasetsCSVpredict()
         elif self.args['mode'] == 'main':
-            raise NotImplementedError('mode "main" (training / evaluation datasets) is out of scope of nisqa_amd')
+            self._loadDatasetsCSV()
         else:
             raise NotImplementedError('mode not available')
 
-    def _dataset(self, df, df_con, data_dir, filename_column, to_memory):
+    def _loadDatasetsCSV(self):
+        """Training and validation tables by database name (reference NISQA_model.py:851-926)."""
+        dfile = pd.read_csv(os.path.join(self.args['data_dir'], self.args['csv_file']))
+        wanted = set(self.args['csv_db_train'] + self.args['csv_db_val'])
+        if not wanted.issubset(dfile.db.unique().tolist()):
+            raise ValueError('Not all dbs found in csv:', wanted.difference(dfile.db.unique().tolist()))
+        df_train = dfile[dfile.db.isin(self.args['csv_db_train'])].reset_index()
+        df_val = dfile[dfile.db.isin(self.args['csv_db_val'])].reset_index()
+        if self.args['csv_con'] is not None:
+            dcon = pd.read_csv(os.path.join(self.args['data_dir'], self.args['csv_con']))
+            dcon_train = dcon[dcon.db.isin(self.args['csv_db_train'])].reset_index()
+            dcon_val = dcon[dcon.db.isin(self.args['csv_db_val'])].reset_index()
+        else:
+            dcon_train = dcon_val = None
+        print('Training size: {}, Validation size: {}'.format(len(df_train), len(df_val)))
+        self.ds_train = self._dataset(df_train, dcon_train, self.args['data_dir'], self.args['csv_deg'], False,
+                                      mos_column=self.args['csv_mos_train'])
+        self.ds_val = self._dataset(df_val, dcon_val, self.args['data_dir'], self.args['csv_deg'], False,
+                                    mos_column=self.args['csv_mos_val'])
+        self.runinfos['ds_train_len'] = len(self.ds_train)
+        self.runinfos['ds_val_len'] = len(self.ds_val)
+
+    def _dataset(self, df, df_con, data_dir, filename_column, to_memory, mos_column='predict_only'):
         a = self.args
         return NL.SpeechQualityDataset(
-            df, df_con=df_con, data_dir=data_dir, filename_column=filename_column, mos_column='predict_only',
+            df, df_con=df_con, data_dir=data_dir, filename_column=filename_column, mos_column=mos_column,
             seg_length=a['ms_seg_length'], max_length=a['ms_max_segments'], to_memory=to_memory,
             to_memory_workers=None, seg_hop_length=a['ms_seg_hop_length'], transform=None,
             ms_n_fft=a['ms_n_fft'], ms_hop_length=a['ms_hop_length'], ms_win_length=a['ms_win_length'],
@@ -151,11 +182,11 @@ class nisqaModel(object):
                 model_path = os.path.join(self.args['pretrained_model'])
             else:
                 model_path = os.path.join(os.getcwd(), self.args['pretrained_model'])
-            checkpoint = torch.load(model_path, map_location='cpu')   # packed to device blobs by the engine
+            checkpoint = torch.load(model_path, map_location='cpu', weights_only=False)   # full unpickle like the reference (args hold a datetime)
             checkpoint['args'].update(self.args)                      # caller keys win (NISQA_model.py:941)
             self.args = checkpoint['args']
         else:
-            raise NotImplementedError('nisqa_amd needs --pretrained_model (inference only)')
+            checkpoint = None                                         # training from scratch (pretrained_model: false)
 
         if self.args['model'] == 'NISQA_DIM':
             self.args['dim'] = True
@@ -188,6 +219,10 @@ class nisqaModel(object):
         else:
             raise NotImplementedError('Model not available')
 
+        if checkpoint is None:
+            NL.init_parameters_(self.model)
+            self.model.bind_args(self.args)
+            return
         missing_keys, unexpected_keys = self.model.load_state_dict(checkpoint['model_state_dict'], strict=True)
         print('Loaded pretrained model from ' + self.args['pretrained_model'])
         if missing_keys:
