@@ -35,6 +35,22 @@ res['tts_mixed_3_30s'] = {'clips_per_s': round(32 / dt, 1), 'audio_seconds_per_s
                           'stage_ms': {n: round(float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])), 3)
                                        for i, n in enumerate(['mel', 'cnn_front', 'cnn_back', 'lstm+pool'])}}
 
+# the same batches alternated over two streams, as the product's predict loop does: the LSTM of one batch (64
+# workgroups, latency-bound) overlaps the CNN of the next
+for ns in (2, 3, 4):
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(dev))
+    outs = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(12):
+        with torch.cuda.stream(streams[s % ns]):
+            outs.append(eng.forward_pcm(x, plan, 48000))
+    torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t0) / 12
+    res['tts_mixed_3_30s']['clips_per_s_%d_streams' % ns] = round(32 / dt2, 1)
+
 # ---- 2. PCIe-inclusive main path ------------------------------------------------------------------------
 eng = HipNisqa(dict(synth.DIM_ARGS), synth.random_state_dict(7), dev)
 b16 = np.concatenate([synth.synth_pcm16(i % 8, 10.0) for i in range(64)])
