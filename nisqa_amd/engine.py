@@ -6,7 +6,6 @@ the C ABI (include/nisqa_hip.h).  No fallback: constructing the engine without a
 the built library raises.
 """
 import ctypes
-import math
 import os
 
 import numpy as np

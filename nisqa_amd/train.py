@@ -25,7 +25,7 @@ import torch
 
 from . import dist as _dist
 from . import lib as _lib
-from .engine import HipNisqa, BatchPlan, SEG_LEN
+from .engine import HipNisqa, SEG_LEN
 
 _CONV = [(1, 16), (16, 32), (32, 64), (64, 64), (64, 64), (64, 64)]      # (C_in, C_out) of conv1..conv6
 _DROP_AFTER = {2: 'cnn_d1', 3: 'cnn_d2', 4: 'cnn_d3', 5: 'cnn_d4'}       # Dropout2d sites (NISQA_lib.py:696-705)

@@ -23,7 +23,6 @@ Dropout masks are explicit inputs here (dict name -> tensor already scaled by 1/
 """
 import math
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 
