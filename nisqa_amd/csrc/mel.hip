@@ -374,11 +374,14 @@ extern "C" int nisqa_mel_db(const float* pcm, const int64_t* clip_off, const int
     mag_stride += (8 - (mag_stride & 31) + 32) & 31;
     const int w_bytes = (w_floats * 4 + 15) & ~15;
     const size_t lds = (size_t)w_bytes + MEL_WAVES * (MEL_EXCH_BYTES + mag_stride * 16 + 512);
-    // frames a wave walks over (amortises its per-lane twiddle / window / band-table loads); tuning knob, read once
-    static const int frames_per_wave = [] {
+    // frames a wave walks over: more frames amortise its per-lane twiddle / window / band-table loads, but the chip
+    // holds 2048 waves of this kernel (8 per CU): enough frames per wave to cover the batch in one round, 4 to 32
+    static const int fpw_env = [] {
         const char* e = getenv("NISQA_MEL_FPW");
-        return e && atoi(e) > 0 ? atoi(e) : 8;
+        return e && atoi(e) > 0 ? atoi(e) : 0;
     }();
+    int frames_per_wave = fpw_env ? fpw_env : (total_frames + 2047) / 2048;
+    if (!fpw_env) frames_per_wave = frames_per_wave < 4 ? 4 : (frames_per_wave > 32 ? 32 : frames_per_wave);
     const int per_wg = MEL_WAVES * frames_per_wave;
     if (cfg->win <= 1024)
         hipLaunchKernelGGL(mel_frame_kernel<1>, dim3((total_frames + per_wg - 1) / per_wg), dim3(64 * MEL_WAVES), lds,
