@@ -60,8 +60,13 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
             bl[slot][nt] = wl[((g * NT + nt) * 2 + 1) * 64];
         }
     };
-    auto load_a = [&](int g, int slot) {
-        const int tap = g / S16, s = g - tap * S16;
+    // A operand of tile t at K-step (tap, s): 16 bytes at  pixel row + (((2s + h) ^ swz) << 4)  of each plane.  With
+    // t = h ^ swz this is  (pixel row | t << 4) ^ (32 s)  (pixel rows are aligned to their size, 32 s stays inside a
+    // row), so the bounds check, the swizzle and the row address are per TAP; a K-step costs one XOR per plane.
+    // Out-of-image taps point both planes at the wave's 128-byte zero block (aligned, so the XOR stays inside it).
+    int a_hi[MT], a_lo[MT];
+    const int zoff = (int)(zero - act_in);
+    auto tap_a = [&](int tap) {
         const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
@@ -69,9 +74,18 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
             const bool ok = pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
             const int pix = y * W + x;
             const int swz = ((pix * Cc) >> 4) & (Cc - 1);
-            const char* ph = ok ? act_in + pix * (CIN * 2) + (((2 * s + h) ^ swz) << 4) : zero;
-            ah[slot][t] = *(const f32x4*)ph;
-            al[slot][t] = *(const f32x4*)(ok ? ph + PLANE : zero);
+            const int row = pix * (CIN * 2) + ((h ^ swz) << 4);
+            a_hi[t] = ok ? row : zoff;
+            a_lo[t] = ok ? row + PLANE : zoff;
+        }
+    };
+    auto load_a = [&](int g, int slot) {
+        const int tap = g / S16, s = g - tap * S16;
+        if (s == 0) tap_a(tap);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            ah[slot][t] = *(const f32x4*)(act_in + (a_hi[t] ^ (32 * s)));
+            al[slot][t] = *(const f32x4*)(act_in + (a_lo[t] ^ (32 * s)));
         }
     };
 
