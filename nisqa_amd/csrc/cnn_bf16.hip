@@ -273,20 +273,29 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         const f32x4* w5 = (const f32x4*)(wb + CNNB_W5) + (size_t)wave * (18 * 2 * 64) + lane;
         f32x4 bq[2][2];
         bq[0][0] = w5[0]; bq[0][1] = w5[64];
+        const int zoff = (int)(zero - s4);                  // per tap: row | (kg ^ swz) << 4, per K-step: ^ 64 s (conv_bf16.hpp)
+        int a5h[5], a5l[5];
 #pragma unroll
         for (int g = 0; g < 18; ++g) {
             if (g + 1 < 18) { bq[(g + 1) & 1][0] = w5[(g + 1) * 128]; bq[(g + 1) & 1][1] = w5[(g + 1) * 128 + 64]; }
             const int tap = g >> 1, s = g & 1;
-            const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+            if (s == 0) {
+                const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    const int y = ry[t] + dy, x = rx[t] + dx;
+                    const bool ok = rv[t] && (unsigned)y < 6u && (unsigned)x < 3u;
+                    const int pix = rb[t] + y * 3 + x;
+                    const int row = pix * 128 + ((kg ^ ((pix >> 1) & 7)) << 4);
+                    a5h[t] = ok ? row : zoff;
+                    a5l[t] = ok ? row + 9216 : zoff;
+                }
+            }
             f32x4 ah[5], al[5];
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
-                const int y = ry[t] + dy, x = rx[t] + dx;
-                const bool ok = rv[t] && (unsigned)y < 6u && (unsigned)x < 3u;
-                const int pix = rb[t] + y * 3 + x;
-                const char* ph = ok ? s4 + pix * 128 + (((4 * s + kg) ^ ((pix >> 1) & 7)) << 4) : zero;
-                ah[t] = *(const f32x4*)ph;
-                al[t] = *(const f32x4*)(ok ? ph + 9216 : zero);
+                ah[t] = *(const f32x4*)(s4 + (a5h[t] ^ (64 * s)));
+                al[t] = *(const f32x4*)(s4 + (a5l[t] ^ (64 * s)));
             }
 #pragma unroll
             for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][1], acc5[t]);
@@ -327,20 +336,29 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         }
         const f32x4* w6 = (const f32x4*)(wb + CNNB_W6) + (size_t)wave * (18 * 2 * 64) + lane;
         bq[0][0] = w6[0]; bq[0][1] = w6[64];
+        const int zoff6 = (int)(zero - s5);
+        int a6h[2], a6l[2];
 #pragma unroll
         for (int g = 0; g < 18; ++g) {
             if (g + 1 < 18) { bq[(g + 1) & 1][0] = w6[(g + 1) * 128]; bq[(g + 1) & 1][1] = w6[(g + 1) * 128 + 64]; }
             const int tap = g >> 1, s = g & 1;
-            const int dy = tap / 3 - 1, xin = tap - 3 * (tap / 3);       // input column = dx (output at x = 1)
+            if (s == 0) {
+                const int dy = tap / 3 - 1, xin = tap - 3 * (tap / 3);       // input column = dx (output at x = 1)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int y = sy[t] + dy;
+                    const bool ok = sv[t] && (unsigned)y < 6u;
+                    const int pix = sb[t] + y * 3 + xin;
+                    const int row = pix * 128 + ((kg ^ ((pix >> 1) & 7)) << 4);
+                    a6h[t] = ok ? row : zoff6;
+                    a6l[t] = ok ? row + 9216 : zoff6;
+                }
+            }
             f32x4 ah[2], al[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int y = sy[t] + dy;
-                const bool ok = sv[t] && (unsigned)y < 6u;
-                const int pix = sb[t] + y * 3 + xin;
-                const char* ph = ok ? s5 + pix * 128 + (((4 * s + kg) ^ ((pix >> 1) & 7)) << 4) : zero;
-                ah[t] = *(const f32x4*)ph;
-                al[t] = *(const f32x4*)(ok ? ph + 9216 : zero);
+                ah[t] = *(const f32x4*)(s5 + (a6h[t] ^ (64 * s)));
+                al[t] = *(const f32x4*)(s5 + (a6l[t] ^ (64 * s)));
             }
             if (g & 1) {
 #pragma unroll

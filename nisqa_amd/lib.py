@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnisqa_hip.so')
+LIB_PATH = os.environ.get('NISQA_HIP_LIB') or os.path.join(_HERE, 'libnisqa_hip.so')     # override: A/B of two builds
 
 NISQA_OK, NISQA_ERR_ARG, NISQA_ERR_LAUNCH, NISQA_ERR_WORKSPACE = 0, 1, 2, 3
 ABI_VERSION = 1
