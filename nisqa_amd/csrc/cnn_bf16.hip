@@ -23,12 +23,21 @@
 #include "conv_bf16.hpp"
 #include "../../include/nisqa_hip.h"
 
-#define FB_ACT 15872                       /* per-wave activation region (planes alias as layers retire) */
-#define FB_ZERO FB_ACT                     /* 128 B of zeros per wave */
-#define FB_WAVE (FB_ACT + 128)
-#define FB_LDS (4 * FB_WAVE)               /* 64000 B -> two workgroups (8 waves) per CU */
-#define FB_PATCH 10752                     /* conv1 input: two zero-bordered bf16 planes [17][50] behind the A1 planes */
+// Activation planes: pixel rows of C bf16 padded by 16 bytes (row stride C*2 + 16, NOT swizzled): consecutive pixels land
+// 4 banks apart like with an XOR swizzle, and every LDS address is lane base + compile-time offset.
+#define FB_RS1 48                          /* A1: 168 px x 16 ch */
+#define FB_P1 (168 * FB_RS1)
+#define FB_RS2 80                          /* A2: 60 px x 32 ch */
+#define FB_P2 (60 * FB_RS2)
+#define FB_RS3 144                         /* A3: 60 px x 64 ch; S4 / S5: 72 rows x 64 ch */
+#define FB_P3 (60 * FB_RS3)
+#define FB_PS (72 * FB_RS3)
+#define FB_PATCH (2 * FB_P1)               /* conv1 input: two zero-bordered bf16 planes [17][50] behind the A1 planes */
 #define FB_PPLANE 1700                     /* bytes per patch plane (850 bf16) */
+#define FB_ZERO 19584                      /* 128 B of zeros per wave (128-byte aligned) */
+#define FB_WAVE (FB_ZERO + 128)
+#define FB_LDS (4 * FB_WAVE)               /* 78848 B -> two workgroups (8 waves) per CU */
+static_assert(FB_PATCH + 2 * FB_PPLANE <= FB_ZERO && 2 * FB_P3 <= FB_ZERO && 2 * FB_PS <= 2 * FB_WAVE, "LDS plan");
 
 __device__ constexpr int bwin75_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 2 : b == 3 ? 4 : 5; }
 __device__ constexpr int bwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b == 2 ? 5 : b == 3 ? 6 : 7; }
@@ -89,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 #pragma unroll
         for (int t = 0; t < 2; ++t) w1[t] = *(const f32x4*)(wb + CNNB_W1 + t * 512 + lane * 8);
         const float tn = cw[CNN_T1 + (n & 15)];
-        char* a1 = act;                                   // A1 planes: 168 px x 16 ch, plane 5376 B
+        char* a1 = act;                                   // A1 planes: 168 px x 16 ch
         // byte offset of tap 8h + e relative to the pixel's (dy, dx) = (0, 0) corner in the bordered patch; lane half
         // 1 only needs tap 8 (its taps 9..15 meet zero weights, any finite value will do)
         int toff[8];
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                     }
                 const int pp = (12 * hf + gl) * 7 + bb;
                 if (n < 16)
-                    store_split(a1, 5376, pp * 32 + (((n >> 3) ^ ((pp >> 3) & 1)) << 4) + (n & 7) * 2, fmaxf(mx + tn, 0.f));
+                    store_split(a1, FB_P1, pp * FB_RS1 + n * 2, fmaxf(mx + tn, 0.f));
             }
         }
     }
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             py[t] = 2 * (6 * hfi + gl) + yy;
             px[t] = w - 7 * yy;
         }
-        conv3x3_bf16<16, 6, 1, 24, 7, false>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane);
+        conv3x3_bf16<16, 6, 1, 24, 7, false, true>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane);
         const float tn = cw[CNN_T2 + n];
 #pragma unroll
         for (int gl = 0; gl < 6; ++gl)
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                         mx = fmaxf(mx, acc[u >> 4][0][u & 15]);
                     }
                 const int pp = (6 * hf + gl) * 5 + bb;
-                store_split(act, 3840, pp * 64 + (((n >> 3) ^ ((pp >> 2) & 3)) << 4) + (n & 7) * 2, fmaxf(mx + tn, 0.f));
+                store_split(act, FB_P2, pp * FB_RS2 + n * 2, fmaxf(mx + tn, 0.f));
             }
     }
 
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<32, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W3, py, px, pv, lane);
+        conv3x3_bf16<32, 2, 2, 12, 5, true, true>(acc, act, zero, wb + CNNB_W3, py, px, pv, lane);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int c = n + 32 * nt;
@@ -202,8 +211,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                     if (u < 30) {
                         const int gl = u / 10, w = u % 10, yy = w / 5, x = w - 5 * yy;
                         const int pp = (2 * (3 * hf + gl) + yy) * 5 + x;
-                        store_split(act, 7680, pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2,
-                                    fmaxf(acc[t][nt][r] + tn, 0.f));
+                        store_split(act, FB_P3, pp * FB_RS3 + c * 2, fmaxf(acc[t][nt][r] + tn, 0.f));
                     }
                 }
         }
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 
     // ---- conv4 64->64 on 12x5, pool -> 6x3.  The pooled outputs of the workgroup's four segments go to a
     //      SHARED pair of bf16 planes S4[72 px][64 ch] (row = 18 * wave + pixel) for the N-split conv5/conv6.
-    char* s4 = smem;                       // 2 planes x 9216 B (wave 0/1 regions; their A3 is dead by then)
+    char* s4 = smem;                       // 2 planes x FB_PS (wave 0/1 regions; their A3 is dead by then)
     char* s5 = smem + 2 * FB_WAVE;         // conv5 output, same shape (wave 2/3 regions)
     {
         f32x16 acc[2][2];
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<64, 2, 2, 12, 5, true>(acc, act, zero, wb + CNNB_W4, py, px, pv, lane);
+        conv3x3_bf16<64, 2, 2, 12, 5, true, true>(acc, act, zero, wb + CNNB_W4, py, px, pv, lane);
         __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
         float* dst = p3 ? p3 + (size_t)p * (18 * 64) : nullptr;
 #pragma unroll
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                     const int pl = (3 * hf + gl) * 3 + bb;
                     if (dst && valid) dst[pl * 64 + c] = v;                  // optional fp32 copy (debug / parity)
                     const int pp = 18 * wave + pl;
-                    store_split(s4, 9216, pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2, v);
+                    store_split(s4, FB_PS, pp * FB_RS3 + c * 2, v);
                 }
         }
     }
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         const f32x4* w5 = (const f32x4*)(wb + CNNB_W5) + (size_t)wave * (18 * 2 * 64) + lane;
         f32x4 bq[2][2];
         bq[0][0] = w5[0]; bq[0][1] = w5[64];
-        const int zoff = (int)(zero - s4);                  // per tap: row | (kg ^ swz) << 4, per K-step: ^ 64 s (conv_bf16.hpp)
+        const int zoff = (int)(zero - s4);                  // per tap: row + 16 kg, per K-step: + 64 s (an immediate offset)
         int a5h[5], a5l[5];
 #pragma unroll
         for (int g = 0; g < 18; ++g) {
@@ -286,16 +294,16 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                     const int y = ry[t] + dy, x = rx[t] + dx;
                     const bool ok = rv[t] && (unsigned)y < 6u && (unsigned)x < 3u;
                     const int pix = rb[t] + y * 3 + x;
-                    const int row = pix * 128 + ((kg ^ ((pix >> 1) & 7)) << 4);
+                    const int row = pix * FB_RS3 + (kg << 4);
                     a5h[t] = ok ? row : zoff;
-                    a5l[t] = ok ? row + 9216 : zoff;
+                    a5l[t] = ok ? row + FB_PS : zoff;
                 }
             }
             f32x4 ah[5], al[5];
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
-                ah[t] = *(const f32x4*)(s4 + (a5h[t] ^ (64 * s)));
-                al[t] = *(const f32x4*)(s4 + (a5l[t] ^ (64 * s)));
+                ah[t] = *(const f32x4*)(s4 + a5h[t] + 64 * s);
+                al[t] = *(const f32x4*)(s4 + a5l[t] + 64 * s);
             }
 #pragma unroll
             for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][1], acc5[t]);
@@ -312,8 +320,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                 for (int r = 0; r < 4; ++r) {
                     const int rho = 16 * t + 4 * kg + r;
                     if (rho < 72)
-                        store_split(s5, 9216, rho * 128 + (((ch >> 3) ^ ((rho >> 1) & 7)) << 4) + (ch & 7) * 2,
-                                    fmaxf(acc5[t][r] + tn, 0.f));
+                        store_split(s5, FB_PS, rho * FB_RS3 + ch * 2, fmaxf(acc5[t][r] + tn, 0.f));
                 }
         }
         __syncthreads();
@@ -349,16 +356,16 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                     const int y = sy[t] + dy;
                     const bool ok = sv[t] && (unsigned)y < 6u;
                     const int pix = sb[t] + y * 3 + xin;
-                    const int row = pix * 128 + ((kg ^ ((pix >> 1) & 7)) << 4);
+                    const int row = pix * FB_RS3 + (kg << 4);
                     a6h[t] = ok ? row : zoff6;
-                    a6l[t] = ok ? row + 9216 : zoff6;
+                    a6l[t] = ok ? row + FB_PS : zoff6;
                 }
             }
             f32x4 ah[2], al[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                ah[t] = *(const f32x4*)(s5 + (a6h[t] ^ (64 * s)));
-                al[t] = *(const f32x4*)(s5 + (a6l[t] ^ (64 * s)));
+                ah[t] = *(const f32x4*)(s5 + a6h[t] + 64 * s);
+                al[t] = *(const f32x4*)(s5 + a6l[t] + 64 * s);
             }
             if (g & 1) {
 #pragma unroll

@@ -40,14 +40,17 @@ NQ_DEV void store_split(char* plane_hi, int plane_bytes, int off, float v) {
 //            global_load_dwordx4 per fragment, requested TWO K-steps ahead into a 3-deep register ring
 //            (an L2 round trip is ~600 clk, a step of MFMAs 200-800 clk); ~10 TB/s of L2 reads chip-wide
 //   APF    : also double-buffer the A rows from LDS one step ahead (off for conv2: 6 M-tiles of registers)
-template <int CIN, int MT, int NT, int H, int W, bool APF>
+//   PAD    : pixel rows are CIN*2 + 16 bytes apart and NOT swizzled (the 16-byte pad spreads consecutive pixels over the
+//            banks like the XOR swizzle does, and every address becomes lane base + compile-time offset)
+template <int CIN, int MT, int NT, int H, int W, bool APF, bool PAD = false>
 NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* zero,
                          const unsigned short* __restrict__ wb, const int (&py)[MT], const int (&px)[MT],
                          const bool (&pvalid)[MT], int lane) {
     constexpr int S16 = CIN / 16;             // K=16 steps per tap
     constexpr int TOTAL = 9 * S16;
     constexpr int Cc = CIN / 8;               // 16-byte chunks per pixel row (per plane)
-    constexpr int PLANE = H * W * CIN * 2;    // bytes per plane
+    constexpr int RS = CIN * 2 + (PAD ? 16 : 0);   // bytes between pixel rows
+    constexpr int PLANE = H * W * RS;         // bytes per plane
     constexpr int AB = APF ? 2 : 1;
     const int h = lane >> 5;
     const f32x4* wl = (const f32x4*)wb + lane;
@@ -73,8 +76,8 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
             const int y = py[t] + dy, x = px[t] + dx;
             const bool ok = pvalid[t] && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
             const int pix = y * W + x;
-            const int swz = ((pix * Cc) >> 4) & (Cc - 1);
-            const int row = pix * (CIN * 2) + ((h ^ swz) << 4);
+            const int swz = PAD ? 0 : ((pix * Cc) >> 4) & (Cc - 1);
+            const int row = pix * RS + ((h ^ swz) << 4);
             a_hi[t] = ok ? row : zoff;
             a_lo[t] = ok ? row + PLANE : zoff;
         }
@@ -84,8 +87,9 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
         if (s == 0) tap_a(tap);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            ah[slot][t] = *(const f32x4*)(act_in + (a_hi[t] ^ (32 * s)));
-            al[slot][t] = *(const f32x4*)(act_in + (a_lo[t] ^ (32 * s)));
+            // PAD: plain + 32 s (an immediate offset of the LDS read); swizzled: ^ 32 s
+            ah[slot][t] = *(const f32x4*)(act_in + (PAD ? a_hi[t] + 32 * s : a_hi[t] ^ (32 * s)));
+            al[slot][t] = *(const f32x4*)(act_in + (PAD ? a_lo[t] + 32 * s : a_lo[t] ^ (32 * s)));
         }
     };
 
