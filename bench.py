@@ -121,7 +121,7 @@ def main():
     base = [synth.synth_pcm16(1000 * rank + i, SECONDS) for i in range(N_DISTINCT)]
     pcm16 = np.concatenate([base[i % N_DISTINCT] for i in range(BATCH)])
     plan = eng.plan([len(base[0])] * BATCH, SR)
-    pcm = eng.pcm16_to_f32(torch.from_numpy(pcm16).to(dev))
+    pcm = torch.from_numpy(pcm16).to(dev)        # int16, as read from the WAV data chunks; scaled inside the mel kernel
     plan.to(dev)
     torch.cuda.synchronize()
 

@@ -79,6 +79,16 @@ int nisqa_mel_db(const float* pcm, const int64_t* clip_off, const int32_t* frame
                  const float* band_w,
                  float* mel_tm, uint32_t* clip_max_enc, void* stream);
 
+/* The same on int16 PCM as it sits in the WAV data chunk: the x / 32768 of soundfile (lb.load, NISQA_lib.py:2304)
+ * is folded into the window taps (a power of two: bit-identical to nisqa_pcm16_to_f32 + nisqa_mel_db), so 2 bytes
+ * per sample are read and no float copy of the batch exists. */
+int nisqa_mel_db_pcm16(const int16_t* pcm, const int64_t* clip_off, const int32_t* frame_off,
+                       int32_t n_clips, int32_t total_frames, const nisqa_mel_cfg* cfg,
+                       const float* window, const float* twiddle,
+                       const int32_t* band_start, const int32_t* band_len, const int32_t* band_woff,
+                       const float* band_w,
+                       float* mel_tm, uint32_t* clip_max_enc, void* stream);
+
 /* Per-clip dB floor = max - top_db (the librosa top_db clamp, NISQA_lib.py:2330).  Writes
  * clip_floor[B]; when clamp_in_place != 0 also applies max(x, floor) to mel_tm so that it equals
  * the reference spectrogram (the CNN applies the floor on load, so the fused path passes 0). */
@@ -213,6 +223,14 @@ int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, const int32_t
                         int32_t total_frames, int32_t total_tok_padded,
                         const nisqa_mel_cfg* cfg, const nisqa_model_dev* model,
                         void* ws, size_t ws_bytes, float* out, void* stream);
+
+/* The same with the batch as int16 PCM (the WAV data chunks back to back): what predict_dir / predict_csv hand over,
+ * 2 bytes per sample across PCIe and in HBM.  Results are bit-identical to nisqa_pcm16_to_f32 + nisqa_predict_batch. */
+int nisqa_predict_batch_pcm16(const int16_t* pcm, const int64_t* clip_off, const int32_t* frame_off,
+                              const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                              int32_t total_frames, int32_t total_tok_padded,
+                              const nisqa_mel_cfg* cfg, const nisqa_model_dev* model,
+                              void* ws, size_t ws_bytes, float* out, void* stream);
 
 /* int16 PCM -> float32 (x / 32768), the soundfile scaling lb.load applies (NISQA_lib.py:2304). */
 int nisqa_pcm16_to_f32(const int16_t* pcm16, float* pcm, int64_t n, void* stream);

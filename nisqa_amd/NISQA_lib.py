@@ -275,9 +275,7 @@ class SpeechQualityDataset(object):
         eng = self._engine_factory()
         y, sr = self.load_audio(index)
         plan = eng.plan([len(y)], sr, names=[self.file_path(index)])
-        t = torch.from_numpy(y).to(eng.device)
-        pcm = eng.pcm16_to_f32(t) if y.dtype == np.int16 else t
-        mel, _ = eng.mel(pcm, plan, sr, clamp=True)
+        mel, _ = eng.mel(torch.from_numpy(y).to(eng.device), plan, sr, clamp=True)   # int16 PCM or float32 samples
         spec = mel.cpu().numpy()                                   # [T, n_mels]
         n_wins = int(plan.n_wins[0])
         idx = self.seg_hop_length * np.arange(n_wins)[:, None] + np.arange(self.seg_length)[None, :]
@@ -338,9 +336,7 @@ def _predict(model, ds, bs, dev, num_workers):
                     for g in staged.groups:                          # files of one rate share the mel tables
                         plan = eng.plan(g.lengths, g.sr, names=[ds.file_path(i) for i in g.ids])
                         host = raw[g.offset:g.offset + g.nbytes].view(torch.int16 if g.is_i16 else torch.float32)
-                        pcm = host.to(eng.device, non_blocking=True)
-                        if g.is_i16:
-                            pcm = eng.pcm16_to_f32(pcm)              # 2 bytes/sample cross PCIe, scaled on the GPU
+                        pcm = host.to(eng.device, non_blocking=True)     # PCM16 stays int16: 2 bytes/sample over PCIe
                         inflight.append((g.ids, eng.forward_pcm(pcm, plan, g.sr), st))
             finally:
                 ev = None

@@ -31,10 +31,10 @@ extern "C" size_t nisqa_workspace_bytes(int32_t n_clips, int32_t total_frames, i
     return plan_ws(n_clips, total_frames, total_tok_padded).total;
 }
 
-extern "C" int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, const int32_t* frame_off,
-                                   const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
-                                   int32_t total_frames, int32_t total_tok_padded, const nisqa_mel_cfg* cfg,
-                                   const nisqa_model_dev* model, void* ws, size_t ws_bytes, float* out, void* stream) {
+static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, const int32_t* frame_off,
+                         const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                         int32_t total_frames, int32_t total_tok_padded, const nisqa_mel_cfg* cfg,
+                         const nisqa_model_dev* model, void* ws, size_t ws_bytes, float* out, void* stream) {
     if (!cfg || !model || !ws || n_clips <= 0 || total_frames <= 0 || total_tok_padded <= 0) return NISQA_ERR_ARG;
     const ws_plan p = plan_ws(n_clips, total_frames, total_tok_padded);
     if (ws_bytes < p.total) return NISQA_ERR_WORKSPACE;
@@ -51,8 +51,12 @@ extern "C" int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, co
 #define NQ_STAGE(i) do { if (ev && hipEventRecord((hipEvent_t)ev[i], (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH; } while (0)
     if (hipMemsetAsync(cmax, 0, (size_t)n_clips * 4, (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH;
     NQ_STAGE(0);
-    int rc = nisqa_mel_db(pcm, clip_off, frame_off, n_clips, total_frames, cfg, model->window, model->twiddle,
-                          model->band_start, model->band_len, model->band_woff, model->band_w, mel, cmax, stream);
+    int rc = pcm16 ? nisqa_mel_db_pcm16((const int16_t*)pcm, clip_off, frame_off, n_clips, total_frames, cfg, model->window,
+                                        model->twiddle, model->band_start, model->band_len, model->band_woff,
+                                        model->band_w, mel, cmax, stream)
+                   : nisqa_mel_db((const float*)pcm, clip_off, frame_off, n_clips, total_frames, cfg, model->window,
+                                  model->twiddle, model->band_start, model->band_len, model->band_woff, model->band_w,
+                                  mel, cmax, stream);
     if (rc) return rc;
     rc = nisqa_mel_finalize(mel, frame_off, n_clips, total_frames, cmax, cfg->top_db, cfloor, 0, stream);
     if (rc) return rc;
@@ -100,6 +104,23 @@ extern "C" int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, co
     if (rc) return rc;
     NQ_STAGE(5);
     return NISQA_OK;
+}
+
+extern "C" int nisqa_predict_batch(const float* pcm, const int64_t* clip_off, const int32_t* frame_off,
+                                   const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                                   int32_t total_frames, int32_t total_tok_padded, const nisqa_mel_cfg* cfg,
+                                   const nisqa_model_dev* model, void* ws, size_t ws_bytes, float* out, void* stream) {
+    return predict_batch(pcm, false, clip_off, frame_off, tok_off, n_wins, n_clips, total_frames, total_tok_padded, cfg,
+                         model, ws, ws_bytes, out, stream);
+}
+
+extern "C" int nisqa_predict_batch_pcm16(const int16_t* pcm, const int64_t* clip_off, const int32_t* frame_off,
+                                         const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                                         int32_t total_frames, int32_t total_tok_padded, const nisqa_mel_cfg* cfg,
+                                         const nisqa_model_dev* model, void* ws, size_t ws_bytes, float* out,
+                                         void* stream) {
+    return predict_batch(pcm, true, clip_off, frame_off, tok_off, n_wins, n_clips, total_frames, total_tok_padded, cfg,
+                         model, ws, ws_bytes, out, stream);
 }
 
 // D[32][32] = A[32][k] * B[k][32] with the fragment maps of common.hpp (k even)

@@ -44,6 +44,19 @@ __device__ constexpr int bwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b =
 __device__ constexpr int bwin53_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : 3; }
 __device__ constexpr int bwin53_hi(int b) { return b == 0 ? 2 : b == 1 ? 4 : 5; }
 
+// -DNQ_PHASE_CLOCK (tools/phase_clock.sh): shader-clock stamps at the layer boundaries, summed per phase over all waves
+#ifdef NQ_PHASE_CLOCK
+__device__ unsigned long long g_phase_clk[16];
+#define NQ_CLK(i) clk[i] = clock64()
+extern "C" int nisqa_debug_phase_clock(unsigned long long* out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_clk), sizeof(g_phase_clk)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clk), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define NQ_CLK(i)
+#endif
+
 __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
@@ -51,6 +64,9 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ p3,
     float* __restrict__ feat, const float* __restrict__ seg_x, int seg_L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef NQ_PHASE_CLOCK
+    const long long clk_top = clock64(), wall_top = wall_clock64();
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p0 = blockIdx.x * 4;                      // tok_off is a multiple of 32: no clip straddling
@@ -62,29 +78,50 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const int p = p0 + wave, k = k0 + wave;
     char* act = smem + wave * FB_WAVE;
     char* zero = act + FB_ZERO;
+#ifdef NQ_PHASE_CLOCK
+    long long clk[13];
+#endif
+    NQ_CLK(0);
 
     // ---- stage the 15-frame window as two zero-bordered bf16 planes (hi, lo) [frame j + 1][mel m + 1]:
-    //      the 3x3 taps of any output pixel are then at constant offsets from it, no bounds checks
+    //      the 3x3 taps of any output pixel are then at constant offsets from it, no bounds checks.
+    //      All 12 global loads of the window (and the per-channel shifts of every layer) are requested up front: one
+    //      memory latency instead of twelve.
+    const float fl = seg_x ? -3.0e38f : clip_floor[b];
+    const float* src = seg_x ? seg_x + ((size_t)b * seg_L + k) * 720
+                             : mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
+    float vraw[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        const int i0 = lane + 64 * q;
+        vraw[q] = (valid && i0 < 720) ? src[i0] : 0.f;
+    }
+    const float tn1 = cw[CNN_T1 + (lane & 15)], tn2 = cw[CNN_T2 + (lane & 31)];
+    const float tn3[2] = {cw[CNN_T3 + (lane & 31)], cw[CNN_T3 + 32 + (lane & 31)]};
+    const float tn4[2] = {cw[CNN_T4 + (lane & 31)], cw[CNN_T4 + 32 + (lane & 31)]};
+    const float tn5 = cw[CNN_T5 + 16 * wave + (lane & 15)], tn6 = cw[CNN_T6 + 16 * wave + (lane & 15)];
     {
         char* pb = act + FB_PATCH;
         for (int q = lane; q < (2 * FB_PPLANE + 15) / 16; q += 64) *(f32x4*)(pb + q * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         if (lane < 32) ((float*)zero)[lane] = 0.f;
         __builtin_amdgcn_wave_barrier();
-        const float fl = seg_x ? -3.0e38f : clip_floor[b];
-        const float* src = seg_x ? seg_x + ((size_t)b * seg_L + k) * 720
-                                 : mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
-        for (int i0 = lane; i0 < 720; i0 += 64) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int i0 = lane + 64 * q;
             int j, m;
             if (seg_x) { m = i0 / 15; j = i0 - 15 * m; } else { j = i0 / 48; m = i0 - 48 * j; }
-            const float v = valid ? fmaxf(src[i0], fl) : 0.f;
+            const float v = valid ? fmaxf(vraw[q], fl) : 0.f;
             const unsigned hi = cvt_pk_bf16(v, 0.f);
             const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
             const int o = ((j + 1) * 50 + (m + 1)) * 2;
-            *(unsigned short*)(pb + o) = (unsigned short)hi;
-            *(unsigned short*)(pb + FB_PPLANE + o) = (unsigned short)lo;
+            if (i0 < 720) {
+                *(unsigned short*)(pb + o) = (unsigned short)hi;
+                *(unsigned short*)(pb + FB_PPLANE + o) = (unsigned short)lo;
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
+    NQ_CLK(1);
 
     const int i = lane & 31, hfi = (i >> 2) & 1, qi = (i & 3) + 4 * (i >> 3);
     const int n = lane & 31, hf = lane >> 5, h = lane >> 5;
@@ -97,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         f32x4 w1[2];                                      // weights hi and the first residual term (16 mantissa bits)
 #pragma unroll
         for (int t = 0; t < 2; ++t) w1[t] = *(const f32x4*)(wb + CNNB_W1 + t * 512 + lane * 8);
-        const float tn = cw[CNN_T1 + (n & 15)];
+        const float tn = tn1;
         char* a1 = act;                                   // A1 planes: 168 px x 16 ch
         // byte offset of tap 8h + e relative to the pixel's (dy, dx) = (0, 0) corner in the bordered patch; lane half
         // 1 only needs tap 8 (its taps 9..15 meet zero weights, any finite value will do)
@@ -146,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         }
     }
 
+    NQ_CLK(2);
     // ---- conv2 16->32 on 24x7, pool -> 12x5 (row maps as in cnn.hip)
     {
         f32x16 acc[6][1];
@@ -162,7 +200,8 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             px[t] = w - 7 * yy;
         }
         conv3x3_bf16<16, 6, 1, 24, 7, false, true>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane);
-        const float tn = cw[CNN_T2 + n];
+        NQ_CLK(3);
+        const float tn = tn2;
 #pragma unroll
         for (int gl = 0; gl < 6; ++gl)
 #pragma unroll
@@ -180,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             }
     }
 
+    NQ_CLK(4);
     int py[2], px[2];
     bool pv[2];
 #pragma unroll
@@ -199,10 +239,11 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
         conv3x3_bf16<32, 2, 2, 12, 5, true, true>(acc, act, zero, wb + CNNB_W3, py, px, pv, lane);
+        NQ_CLK(5);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int c = n + 32 * nt;
-            const float tn = cw[CNN_T3 + c];
+            const float tn = tn3[nt];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -219,8 +260,15 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 
     // ---- conv4 64->64 on 12x5, pool -> 6x3.  The pooled outputs of the workgroup's four segments go to a
     //      SHARED pair of bf16 planes S4[72 px][64 ch] (row = 18 * wave + pixel) for the N-split conv5/conv6.
+    NQ_CLK(6);
     char* s4 = smem;                       // 2 planes x FB_PS (wave 0/1 regions; their A3 is dead by then)
     char* s5 = smem + 2 * FB_WAVE;         // conv5 output, same shape (wave 2/3 regions)
+    // conv5 / conv6 weight fragments of this wave (its 16 output channels), [step][hi,lo][lane][8]: rings of 4 / 8
+    // K-steps, requested 3 / 7 steps ahead -- a step of conv5 (conv6) is only 15 (6) short MFMAs, an L2 round trip
+    // several steps long.  The first requests go out before the previous layer's epilogue.
+    const f32x4* w5 = (const f32x4*)(wb + CNNB_W5) + (size_t)wave * (18 * 2 * 64) + lane;
+    const f32x4* w6 = (const f32x4*)(wb + CNNB_W6) + (size_t)wave * (18 * 2 * 64) + lane;
+    f32x4 b5[4][2], b6[8][2];
     {
         f32x16 acc[2][2];
 #pragma unroll
@@ -228,12 +276,15 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
         conv3x3_bf16<64, 2, 2, 12, 5, true, true>(acc, act, zero, wb + CNNB_W4, py, px, pv, lane);
+        NQ_CLK(7);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { b5[g][0] = w5[g * 128]; b5[g][1] = w5[g * 128 + 64]; }
         __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
         float* dst = p3 ? p3 + (size_t)p * (18 * 64) : nullptr;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int c = n + 32 * nt;
-            const float tn = cw[CNN_T4 + c];
+            const float tn = tn4[nt];
 #pragma unroll
             for (int gl = 0; gl < 3; ++gl)
 #pragma unroll
@@ -255,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         }
     }
     __syncthreads();
+    NQ_CLK(8);
 
     // ---- conv5 / conv6 with N split over the waves: wave w owns output channels 16w..16w+15 of ALL four
     //      segments (72 / 24 output rows in 16-row tiles of v_mfma_f32_16x16x32_bf16) and streams its private
@@ -278,14 +330,10 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             rx[t] = pix - 3 * ry[t];
             rb[t] = slot * 18;
         }
-        const f32x4* w5 = (const f32x4*)(wb + CNNB_W5) + (size_t)wave * (18 * 2 * 64) + lane;
-        f32x4 bq[2][2];
-        bq[0][0] = w5[0]; bq[0][1] = w5[64];
         const int zoff = (int)(zero - s4);                  // per tap: row + 16 kg, per K-step: + 64 s (an immediate offset)
         int a5h[5], a5l[5];
-#pragma unroll
-        for (int g = 0; g < 18; ++g) {
-            if (g + 1 < 18) { bq[(g + 1) & 1][0] = w5[(g + 1) * 128]; bq[(g + 1) & 1][1] = w5[(g + 1) * 128 + 64]; }
+        f32x4 a5[2][5][2];                                  // A rows one step ahead: [buffer][tile][hi, lo]
+        auto load_a5 = [&](int g) {
             const int tap = g >> 1, s = g & 1;
             if (s == 0) {
                 const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
@@ -299,21 +347,29 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                     a5l[t] = ok ? row + FB_PS : zoff;
                 }
             }
-            f32x4 ah[5], al[5];
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
-                ah[t] = *(const f32x4*)(s4 + a5h[t] + 64 * s);
-                al[t] = *(const f32x4*)(s4 + a5l[t] + 64 * s);
+                a5[g & 1][t][0] = *(const f32x4*)(s4 + a5h[t] + 64 * s);
+                a5[g & 1][t][1] = *(const f32x4*)(s4 + a5l[t] + 64 * s);
             }
+        };
+        load_a5(0);
 #pragma unroll
-            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][1], acc5[t]);
+        for (int g = 0; g < 18; ++g) {
+            if (g + 3 < 18) { b5[(g + 3) & 3][0] = w5[(g + 3) * 128]; b5[(g + 3) & 3][1] = w5[(g + 3) * 128 + 64]; }
+            if (g + 1 < 18) load_a5(g + 1);
 #pragma unroll
-            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(al[t], bq[g & 1][0], acc5[t]);
+            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(a5[g & 1][t][0], b5[g & 3][1], acc5[t]);
 #pragma unroll
-            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][0], acc5[t]);
+            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(a5[g & 1][t][1], b5[g & 3][0], acc5[t]);
+#pragma unroll
+            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(a5[g & 1][t][0], b5[g & 3][0], acc5[t]);
         }
+        NQ_CLK(9);
+#pragma unroll
+        for (int g = 0; g < 7; ++g) { b6[g][0] = w6[g * 128]; b6[g][1] = w6[g * 128 + 64]; }
         {
-            const float tn = cw[CNN_T5 + ch];
+            const float tn = tn5;
 #pragma unroll
             for (int t = 0; t < 5; ++t)
 #pragma unroll
@@ -324,6 +380,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                 }
         }
         __syncthreads();
+        NQ_CLK(10);
 
         // conv6 (3 x 3 kernel, padding (1,0)) = padding-1 conv at the centre column: rows (slot, y), 24 of 32
         f32x4 acc6[2], acc6b[2];            // even / odd K-steps accumulate separately: four independent chains
@@ -341,13 +398,10 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             sy[t] = rho - 6 * slot;
             sb[t] = slot * 18;
         }
-        const f32x4* w6 = (const f32x4*)(wb + CNNB_W6) + (size_t)wave * (18 * 2 * 64) + lane;
-        bq[0][0] = w6[0]; bq[0][1] = w6[64];
         const int zoff6 = (int)(zero - s5);
         int a6h[2], a6l[2];
-#pragma unroll
-        for (int g = 0; g < 18; ++g) {
-            if (g + 1 < 18) { bq[(g + 1) & 1][0] = w6[(g + 1) * 128]; bq[(g + 1) & 1][1] = w6[(g + 1) * 128 + 64]; }
+        f32x4 a6[2][2][2];
+        auto load_a6 = [&](int g) {
             const int tap = g >> 1, s = g & 1;
             if (s == 0) {
                 const int dy = tap / 3 - 1, xin = tap - 3 * (tap / 3);       // input column = dx (output at x = 1)
@@ -361,43 +415,65 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                     a6l[t] = ok ? row + FB_PS : zoff6;
                 }
             }
-            f32x4 ah[2], al[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                ah[t] = *(const f32x4*)(s5 + a6h[t] + 64 * s);
-                al[t] = *(const f32x4*)(s5 + a6l[t] + 64 * s);
+                a6[g & 1][t][0] = *(const f32x4*)(s5 + a6h[t] + 64 * s);
+                a6[g & 1][t][1] = *(const f32x4*)(s5 + a6l[t] + 64 * s);
             }
+        };
+        load_a6(0);
+#pragma unroll
+        for (int g = 0; g < 18; ++g) {
+            if (g + 7 < 18) { b6[(g + 7) & 7][0] = w6[(g + 7) * 128]; b6[(g + 7) & 7][1] = w6[(g + 7) * 128 + 64]; }
+            if (g + 1 < 18) load_a6(g + 1);
             if (g & 1) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(ah[t], bq[1][1], acc6b[t]);
+                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(a6[1][t][0], b6[g & 7][1], acc6b[t]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(al[t], bq[1][0], acc6b[t]);
+                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(a6[1][t][1], b6[g & 7][0], acc6b[t]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(ah[t], bq[1][0], acc6b[t]);
+                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(a6[1][t][0], b6[g & 7][0], acc6b[t]);
             } else {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(ah[t], bq[0][1], acc6[t]);
+                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(a6[0][t][0], b6[g & 7][1], acc6[t]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(al[t], bq[0][0], acc6[t]);
+                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(a6[0][t][1], b6[g & 7][0], acc6[t]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(ah[t], bq[0][0], acc6[t]);
+                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(a6[0][t][0], b6[g & 7][0], acc6[t]);
             }
         }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc6[t][r] += acc6b[t][r];
-        const float tn = cw[CNN_T6 + ch];
+        NQ_CLK(11);
+        // this wave's 4 x 96 outputs (slot, channel * 6 + y) go through S4 (dead since the barrier above) so that the
+        // feature rows leave as 16-byte stores: 384 contiguous bytes per slot
+        float* fo = (float*)(s4 + wave * 2048);
+        const float tn = tn6;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rho = 16 * t + 4 * kg + r;
                 const int slot = rho / 6, y = rho - 6 * slot;
-                if (rho < 24 && slot < nvalid)
-                    feat[(size_t)(p0 + slot) * 384 + ch * 6 + y] = fmaxf(acc6[t][r] + tn, 0.f);
+                if (rho < 24) fo[slot * 96 + i16 * 6 + y] = fmaxf(acc6[t][r] + acc6b[t][r] + tn, 0.f);
             }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q0 = 0; q0 < 96; q0 += 64) {
+            const int q = q0 + lane;                                         // float4 index: slot = q / 24
+            const int slot = q / 24;
+            if (q < 96 && slot < nvalid)
+                *(f32x4*)(feat + (size_t)(p0 + slot) * 384 + 96 * wave + 4 * (q - 24 * slot)) = *(const f32x4*)(fo + 4 * q);
+        }
     }
+#ifdef NQ_PHASE_CLOCK
+    clk[12] = clock64();
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) atomicAdd(&g_phase_clk[q], (unsigned long long)(clk[q + 1] - clk[q]));
+        atomicAdd(&g_phase_clk[12], 1ull);
+        atomicAdd(&g_phase_clk[13], (unsigned long long)(wall_clock64() - wall_top));
+        atomicAdd(&g_phase_clk[14], (unsigned long long)(clk[0] - clk_top));
+    }
+#endif
 }
 
 extern "C" int nisqa_cnn_adapt_bf16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,

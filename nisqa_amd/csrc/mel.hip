@@ -38,9 +38,32 @@ NQ_DEV c32 cmul(c32 a, c32 b) {                        // (a.x b.x - a.y b.y, a.
 }
 NQ_DEV c32 cnegi(c32 a) { return c32{a.y, -a.x}; }     // a * (-i)
 
+// a +- (-i) b and a +- conj(b) in ONE packed add: the half swap and the sign ride on the op_sel / neg modifiers of
+// v_pk_add_f32 (the compiler materialises cnegi / conj as v_xor + v_mov first; same IEEE adds, same bits)
+NQ_DEV c32 cadd_mi(c32 a, c32 b) {                     // (a.x + b.y, a.y - b.x)
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+NQ_DEV c32 csub_mi(c32 a, c32 b) {                     // (a.x - b.y, a.y + b.x)
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+NQ_DEV c32 cadd_conj(c32 a, c32 b) {                   // (a.x + b.x, a.y - b.y)
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+NQ_DEV c32 csub_conj(c32 a, c32 b) {                   // (a.x - b.x, a.y + b.y)
+    c32 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 NQ_DEV void dft4(c32& a0, c32& a1, c32& a2, c32& a3) {
-    const c32 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cnegi(csub(a1, a3));
-    a0 = cadd(t0, t2); a1 = cadd(t1, t3); a2 = csub(t0, t2); a3 = csub(t1, t3);
+    const c32 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), d = csub(a1, a3);
+    a0 = cadd(t0, t2); a1 = cadd_mi(t1, d); a2 = csub(t0, t2); a3 = csub_mi(t1, d);
 }
 
 // v[p] <- sum_a v[a] * exp(-2 pi i a p / 8), natural order in and out
@@ -50,13 +73,12 @@ NQ_DEV void dft8(c32 (&v)[8]) {
     dft4(e0, e1, e2, e3);
     dft4(o0, o1, o2, o3);
     const float r = 0.70710678118654752440f;
-    o1 = (o1 + cnegi(o1)) * r;                            // * W8^1 = (r, -r):  r (x + y, y - x)
-    o2 = cnegi(o2);                                       // * W8^2 = -i
-    o3 = (cnegi(o3) - o3) * r;                            // * W8^3 = (-r, -r): r (y - x, -x - y)
+    const c32 s1 = cadd_mi(o1, o1);                       // o1 * W8^1 = r (x + y, y - x) = r s1
+    const c32 s3 = csub_mi(o3, o3);                       // o3 * W8^3 = r (y - x, -x - y) = -r s3
     v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
-    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
-    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
-    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+    v[1] = e1 + s1 * r; v[5] = e1 - s1 * r;
+    v[2] = cadd_mi(e2, o2); v[6] = csub_mi(e2, o2);       // o2 * W8^2 = -i o2
+    v[3] = e3 - s3 * r; v[7] = e3 + s3 * r;
 }
 
 // exp(-2 pi i m / 32) and exp(-2 pi i m / 16) as (cos, -sin)
@@ -82,10 +104,9 @@ NQ_DEV c32 shfl_c(c32 v, int src) { return cmk(__shfl((float)v.x, src), __shfl((
 // |X[K]| for K = 4k + r from za = Z[K], zb = Z[2048-K], W4096^K = wl * wc (per-lane x constant part;
 // applied one after the other so that nothing loop-invariant can be hoisted into 64 extra registers)
 NQ_DEV float xmag(c32 za, c32 zb, c32 wl, c32 wc) {
-    const c32 zc = c32{zb.x, -zb.y};                     // conj(Zb)
-    const c32 a = za + zc;                               // Za + conj(Zb)
-    const c32 w = cmul(cmul(za - zc, wl), wc);           // W4096^K (Za - conj(Zb))
-    const c32 x = a + c32{w.y, -w.x};                    // 2 X[K] = a - i w
+    const c32 a = cadd_conj(za, zb);                     // Za + conj(Zb)
+    const c32 w = cmul(cmul(csub_conj(za, zb), wl), wc); // W4096^K (Za - conj(Zb))
+    const c32 x = cadd_mi(a, w);                         // 2 X[K] = a - i w
     const c32 x2 = x * x;
     return 0.5f * __builtin_amdgcn_sqrtf(x2.x + x2.y);   // v_sqrt_f32 (1 ulp): 5e-7 dB, saves ~10 VALU per bin
 }
@@ -137,9 +158,11 @@ NQ_DEV void fft512(c32 (&u)[8], const c32 (&z)[8], const mel_twiddles& tw, char*
 
 // NQ = ceil(win / 1024) quarters of the frame carry non-zero window taps (1 for sr <= 51.2 kHz, 2 for 96 kHz, 4 up to the
 // full 4096): z[n] for n >= 512 q folds onto n - 512 q with the radix-4 factor (-i)^(q r) before the 512-point FFTs
-template <int NQ>
+// T = float (samples as lb.load returns them) or int16_t (PCM16 as it sits in the file: the x / 32768 of soundfile is
+// folded into the window taps -- a power of two, so both instantiations produce the same bits)
+template <int NQ, typename T>
 __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
-    const float* __restrict__ pcm, const int64_t* __restrict__ clip_off,
+    const T* __restrict__ pcm, const int64_t* __restrict__ clip_off,
     const int32_t* __restrict__ frame_off, int n_clips, int total_frames, int frames_per_wave,
     nisqa_mel_cfg cfg, int mag_stride, int w_floats,
     const float* __restrict__ window, const float2* __restrict__ twg,
@@ -169,13 +192,15 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
     for (int q = 0; q < 8; ++q) { const float2 w = twg[(64 * (lane & 7) * q) & 4095]; tw.c[q] = cmk(w.x, w.y); }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const float2 w = twg[4 * lane + r]; tw.d[r] = cmk(w.x, w.y); }
+    constexpr bool PCM16 = sizeof(T) == 2;
+    const float scale = PCM16 ? 1.0f / 32768.0f : 1.0f;
     float win[8][2];                                              // NQ == 1: window taps live in registers
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int m = 2 * (lane + 64 * a) + e;
-            win[a][e] = (NQ == 1 && m < cfg.win) ? window[m] : 0.f;
+            win[a][e] = (NQ == 1 && m < cfg.win) ? window[m] * scale : 0.f;
         }
     // band tables of this lane's DPP row: pass ps handles band 4*ps + row
     const int row = lane >> 4, l16 = lane & 15;
@@ -203,12 +228,21 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
     auto load_frame = [&](int f, int bb, int quarter, float (&raw)[8][2]) {
         const int64_t c0 = clip_off[bb];
         const int L = (int)(clip_off[bb + 1] - c0);
-        const float* y = pcm + c0;
+        const T* y = pcm + c0;
         const int s0 = (f - frame_off[bb]) * cfg.hop + start0 + 1024 * quarter;
         if (s0 >= 0 && s0 + 1024 <= L) {              // interior frame (wave-uniform): plain coalesced loads
-            const float* q = y + s0 + 2 * lane;
+            const T* q = y + s0 + 2 * lane;
+            if (PCM16 && ((c0 + s0) & 1) == 0) {      // sample pairs as one aligned dword
 #pragma unroll
-            for (int a = 0; a < 8; ++a) { raw[a][0] = q[128 * a]; raw[a][1] = q[128 * a + 1]; }
+                for (int a = 0; a < 8; ++a) {
+                    const int v = *(const int*)(q + 128 * a);
+                    raw[a][0] = (float)(short)(v & 0xffff);
+                    raw[a][1] = (float)(v >> 16);
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 8; ++a) { raw[a][0] = (float)q[128 * a]; raw[a][1] = (float)q[128 * a + 1]; }
+            }
         } else {
 #pragma unroll
             for (int a = 0; a < 8; ++a)
@@ -218,7 +252,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
                     i = i < 0 ? -i : i;
                     i = i >= L ? 2 * (L - 1) - i : i;
                     i = min(max(i, 0), L - 1);
-                    raw[a][e] = y[i];
+                    raw[a][e] = (float)y[i];
                 }
         }
     };
@@ -242,7 +276,8 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
 #pragma unroll
                 for (int a = 0; a < 8; ++a) {
                     const int m = 1024 * q + 2 * (lane + 64 * a);
-                    zq[q][a] = cmk(m < cfg.win ? raw[a][0] * window[m] : 0.f, m + 1 < cfg.win ? raw[a][1] * window[m + 1] : 0.f);
+                    zq[q][a] = cmk(m < cfg.win ? raw[a][0] * (window[m] * scale) : 0.f,
+                                   m + 1 < cfg.win ? raw[a][1] * (window[m + 1] * scale) : 0.f);
                 }
             }
         }
@@ -255,7 +290,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
                 for (int q = 1; q < NQ; ++q) {
                     const int e = (q * r) & 3;
                     const c32 v = zq[q][a];
-                    acc = e == 0 ? cadd(acc, v) : e == 1 ? cadd(acc, cnegi(v)) : e == 2 ? csub(acc, v) : csub(acc, cnegi(v));
+                    acc = e == 0 ? cadd(acc, v) : e == 1 ? cadd_mi(acc, v) : e == 2 ? csub(acc, v) : csub_mi(acc, v);
                 }
                 o[a] = acc;
             }
@@ -357,11 +392,12 @@ __global__ void pcm16_kernel(const int16_t* __restrict__ in, float* __restrict__
     for (; i < n; i += stride) out[i] = (float)in[i] * (1.0f / 32768.0f);
 }
 
-extern "C" int nisqa_mel_db(const float* pcm, const int64_t* clip_off, const int32_t* frame_off,
-                            int32_t n_clips, int32_t total_frames, const nisqa_mel_cfg* cfg,
-                            const float* window, const float* twiddle, const int32_t* band_start,
-                            const int32_t* band_len, const int32_t* band_woff, const float* band_w,
-                            float* mel_tm, uint32_t* clip_max_enc, void* stream) {
+template <typename T>
+static int mel_db_launch(const T* pcm, const int64_t* clip_off, const int32_t* frame_off,
+                         int32_t n_clips, int32_t total_frames, const nisqa_mel_cfg* cfg,
+                         const float* window, const float* twiddle, const int32_t* band_start,
+                         const int32_t* band_len, const int32_t* band_woff, const float* band_w,
+                         float* mel_tm, uint32_t* clip_max_enc, void* stream) {
     if (!cfg || cfg->n_fft != NISQA_N_FFT || cfg->n_mels != NISQA_N_MELS || cfg->win < 2 || cfg->win > 4096 ||
         cfg->hop < 1 || cfg->n_bins < 1 || cfg->n_bins > 2049 || cfg->w_floats < 1 || cfg->w_floats > 8192 ||
         n_clips <= 0 || total_frames <= 0)
@@ -383,22 +419,34 @@ extern "C" int nisqa_mel_db(const float* pcm, const int64_t* clip_off, const int
     int frames_per_wave = fpw_env ? fpw_env : (total_frames + 2047) / 2048;
     if (!fpw_env) frames_per_wave = frames_per_wave < 4 ? 4 : (frames_per_wave > 32 ? 32 : frames_per_wave);
     const int per_wg = MEL_WAVES * frames_per_wave;
-    if (cfg->win <= 1024)
-        hipLaunchKernelGGL(mel_frame_kernel<1>, dim3((total_frames + per_wg - 1) / per_wg), dim3(64 * MEL_WAVES), lds,
-                       (hipStream_t)stream, pcm, clip_off, frame_off, n_clips, total_frames, frames_per_wave, *cfg,
-                       mag_stride, w_floats, window, (const float2*)twiddle, band_start, band_len, band_woff, band_w,
-                       mel_tm, clip_max_enc);
-    else if (cfg->win <= 2048)
-        hipLaunchKernelGGL(mel_frame_kernel<2>, dim3((total_frames + per_wg - 1) / per_wg), dim3(64 * MEL_WAVES), lds,
-                       (hipStream_t)stream, pcm, clip_off, frame_off, n_clips, total_frames, frames_per_wave, *cfg,
-                       mag_stride, w_floats, window, (const float2*)twiddle, band_start, band_len, band_woff, band_w,
-                       mel_tm, clip_max_enc);
-    else
-        hipLaunchKernelGGL(mel_frame_kernel<4>, dim3((total_frames + per_wg - 1) / per_wg), dim3(64 * MEL_WAVES), lds,
-                       (hipStream_t)stream, pcm, clip_off, frame_off, n_clips, total_frames, frames_per_wave, *cfg,
-                       mag_stride, w_floats, window, (const float2*)twiddle, band_start, band_len, band_woff, band_w,
-                       mel_tm, clip_max_enc);
+    const dim3 grid((total_frames + per_wg - 1) / per_wg), block(64 * MEL_WAVES);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, pcm, clip_off, frame_off, n_clips, total_frames,
+                           frames_per_wave, *cfg, mag_stride, w_floats, window, (const float2*)twiddle, band_start,
+                           band_len, band_woff, band_w, mel_tm, clip_max_enc);
+    };
+    if (cfg->win <= 1024) go(mel_frame_kernel<1, T>);
+    else if (cfg->win <= 2048) go(mel_frame_kernel<2, T>);
+    else go(mel_frame_kernel<4, T>);
     return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_mel_db(const float* pcm, const int64_t* clip_off, const int32_t* frame_off,
+                            int32_t n_clips, int32_t total_frames, const nisqa_mel_cfg* cfg,
+                            const float* window, const float* twiddle, const int32_t* band_start,
+                            const int32_t* band_len, const int32_t* band_woff, const float* band_w,
+                            float* mel_tm, uint32_t* clip_max_enc, void* stream) {
+    return mel_db_launch(pcm, clip_off, frame_off, n_clips, total_frames, cfg, window, twiddle, band_start, band_len,
+                         band_woff, band_w, mel_tm, clip_max_enc, stream);
+}
+
+extern "C" int nisqa_mel_db_pcm16(const int16_t* pcm, const int64_t* clip_off, const int32_t* frame_off,
+                                  int32_t n_clips, int32_t total_frames, const nisqa_mel_cfg* cfg,
+                                  const float* window, const float* twiddle, const int32_t* band_start,
+                                  const int32_t* band_len, const int32_t* band_woff, const float* band_w,
+                                  float* mel_tm, uint32_t* clip_max_enc, void* stream) {
+    return mel_db_launch(pcm, clip_off, frame_off, n_clips, total_frames, cfg, window, twiddle, band_start, band_len,
+                         band_woff, band_w, mel_tm, clip_max_enc, stream);
 }
 
 extern "C" int nisqa_mel_finalize(float* mel_tm, const int32_t* frame_off, int32_t n_clips, int32_t total_frames,

@@ -178,11 +178,12 @@ class HipNisqa(object):
 
     # -- whole forward --------------------------------------------------------------------------
     def forward_pcm(self, pcm, plan, sr, stage_events=None):
-        """pcm: float32 device tensor [plan.total_samples] -> device tensor [B, n_heads].
+        """pcm: device tensor [plan.total_samples], float32 samples or int16 PCM (scaled by 1/32768 inside the mel
+        kernel, as soundfile does for lb.load) -> device tensor [B, n_heads].
 
         stage_events: optional list of 6 recorded-once torch.cuda.Event(enable_timing=True); they are
         re-recorded at the stage boundaries (profiling hook of nisqa_model_dev)."""
-        assert pcm.dtype == torch.float32 and pcm.is_cuda and pcm.numel() == plan.total_samples
+        assert pcm.dtype in (torch.float32, torch.int16) and pcm.is_cuda and pcm.numel() == plan.total_samples
         mt = self.mel_tables(sr)
         d = plan.to(self.device)
         need = self.lib.nisqa_workspace_bytes(plan.n_clips, plan.total_frames, plan.total_tok)
@@ -196,10 +197,11 @@ class HipNisqa(object):
             arr = (ctypes.c_void_p * 6)(*[ctypes.c_void_p(e.cuda_event) for e in stage_events])
             model = _lib.ModelDev.from_buffer_copy(mt['model'])
             model.stage_events = ctypes.cast(arr, ctypes.c_void_p)
-        rc = self.lib.nisqa_predict_batch(_ptr(pcm), _ptr(d['clip_off']), _ptr(d['frame_off']), _ptr(d['tok_off']),
-                                          _ptr(d['n_wins']), plan.n_clips, plan.total_frames, plan.total_tok,
-                                          ctypes.byref(mt['cfg']), ctypes.byref(model), _ptr(ws),
-                                          ws.numel(), _ptr(out), self._stream())
+        entry = self.lib.nisqa_predict_batch_pcm16 if pcm.dtype == torch.int16 else self.lib.nisqa_predict_batch
+        rc = entry(_ptr(pcm), _ptr(d['clip_off']), _ptr(d['frame_off']), _ptr(d['tok_off']),
+                   _ptr(d['n_wins']), plan.n_clips, plan.total_frames, plan.total_tok,
+                   ctypes.byref(mt['cfg']), ctypes.byref(model), _ptr(ws),
+                   ws.numel(), _ptr(out), self._stream())
         _lib.check(rc, 'nisqa_predict_batch')
         return out
 
@@ -216,11 +218,12 @@ class HipNisqa(object):
         mel = torch.empty((plan.total_frames, 48), dtype=torch.float32, device=self.device)
         cmax = torch.zeros(plan.n_clips, dtype=torch.int32, device=self.device)
         floor = torch.empty(plan.n_clips, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.nisqa_mel_db(_ptr(pcm), _ptr(d['clip_off']), _ptr(d['frame_off']), plan.n_clips,
-                                         plan.total_frames, ctypes.byref(mt['cfg']), _ptr(mt['window']),
-                                         _ptr(mt['twiddle']), _ptr(mt['band_start']), _ptr(mt['band_len']),
-                                         _ptr(mt['band_woff']), _ptr(mt['band_w']), _ptr(mel), _ptr(cmax),
-                                         self._stream()), 'nisqa_mel_db')
+        entry = self.lib.nisqa_mel_db_pcm16 if pcm.dtype == torch.int16 else self.lib.nisqa_mel_db
+        _lib.check(entry(_ptr(pcm), _ptr(d['clip_off']), _ptr(d['frame_off']), plan.n_clips,
+                         plan.total_frames, ctypes.byref(mt['cfg']), _ptr(mt['window']),
+                         _ptr(mt['twiddle']), _ptr(mt['band_start']), _ptr(mt['band_len']),
+                         _ptr(mt['band_woff']), _ptr(mt['band_w']), _ptr(mel), _ptr(cmax),
+                         self._stream()), 'nisqa_mel_db')
         _lib.check(self.lib.nisqa_mel_finalize(_ptr(mel), _ptr(d['frame_off']), plan.n_clips, plan.total_frames,
                                                _ptr(cmax), 80.0, _ptr(floor), 1 if clamp else 0, self._stream()),
                    'nisqa_mel_finalize')

@@ -37,6 +37,8 @@ SYMBOLS = {
     'nisqa_abi_version': (ctypes.c_int, []),
     'nisqa_mel_db': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, ctypes.POINTER(MelCfg), c_p, c_p, c_p, c_p, c_p, c_p,
                                     c_p, c_p, c_p]),
+    'nisqa_mel_db_pcm16': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, ctypes.POINTER(MelCfg), c_p, c_p, c_p, c_p, c_p, c_p,
+                                          c_p, c_p, c_p]),
     'nisqa_mel_finalize': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_p, ctypes.c_float, c_p, c_i32, c_p]),
     'nisqa_cnn_adapt': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_cnn_front': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
@@ -56,6 +58,8 @@ SYMBOLS = {
     'nisqa_workspace_bytes': (ctypes.c_size_t, [c_i32, c_i32, c_i32]),
     'nisqa_predict_batch': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, ctypes.POINTER(MelCfg),
                                            ctypes.POINTER(ModelDev), c_p, ctypes.c_size_t, c_p, c_p]),
+    'nisqa_predict_batch_pcm16': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, ctypes.POINTER(MelCfg),
+                                                 ctypes.POINTER(ModelDev), c_p, ctypes.c_size_t, c_p, c_p]),
     'nisqa_pcm16_to_f32': (ctypes.c_int, [c_p, c_p, c_i64, c_p]),
     'nisqa_selftest_mfma': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_p]),
 }

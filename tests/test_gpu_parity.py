@@ -117,6 +117,30 @@ def test_pcm16_conversion(eng_rand):
     np.testing.assert_array_equal(d.cpu().numpy(), p.astype(np.float32) / np.float32(32768.0))
 
 
+@pytest.mark.parametrize('sr', [48000, 16000, 96000, 192000])
+def test_pcm16_input_matches_float_input_bit_for_bit(eng_rand, sr):
+    """The int16 instantiation of the mel kernel (what predict_dir feeds) folds soundfile's x / 32768 into the window
+    taps: a power of two, so spectrogram and outputs carry the same bits as the float path.  Odd clip lengths put the
+    following clips at odd sample offsets (the dword fast path must fall back); the 15-frame clip is the shortest allowed."""
+    rng = np.random.default_rng(sr)
+    lens = [int(sr * 1.3) + 1, 14 * (sr // 100) + 5, int(sr * 0.61), int(sr * 0.8) + 3, int(sr * 0.5)]
+    pcm = [rng.integers(-32768, 32768, n).astype(np.int16) for n in lens]
+    pcm[2][:] = 0
+    pcm[3][::7] = -32768
+    plan = eng_rand.plan(lens, sr)
+    i16 = torch.from_numpy(np.concatenate(pcm)).to(eng_rand.device)
+    f32 = eng_rand.pcm16_to_f32(i16)
+    mel_i, floor_i = eng_rand.mel(i16, plan, sr, clamp=True)
+    mel_f, floor_f = eng_rand.mel(f32, plan, sr, clamp=True)
+    out_i = eng_rand.forward_pcm(i16, plan, sr)
+    out_f = eng_rand.forward_pcm(f32, plan, sr)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(mel_i.cpu().numpy(), mel_f.cpu().numpy())
+    np.testing.assert_array_equal(floor_i.cpu().numpy(), floor_f.cpu().numpy())
+    np.testing.assert_array_equal(out_i.cpu().numpy(), out_f.cpu().numpy())
+    assert np.isfinite(out_i.cpu().numpy()).all()
+
+
 def _stages_vs_oracle(eng, args, sd, pcm_list, tol_feat=2e-4, tol_out=1e-3):
     dev_pcm, plan = _upload(eng, pcm_list)
     mel, floor = eng.mel(dev_pcm, plan, 48000, clamp=False)      # fused path: CNN applies the floor

@@ -402,10 +402,9 @@ class FakeEngine(object):
     def plan(self, lengths, sr, names=None):
         return BatchPlan(lengths, int(sr * 0.01), 4, 1300, names)
 
-    def pcm16_to_f32(self, t):
-        return t.to(torch.float32) / 32768.0
-
     def forward_pcm(self, pcm, plan, sr):
+        if pcm.dtype == torch.int16:
+            pcm = pcm.to(torch.float32) / 32768.0
         rows = []
         for b in range(plan.n_clips):
             seg = pcm[plan.clip_off[b]:plan.clip_off[b + 1]]

@@ -16,7 +16,7 @@ durs = np.random.default_rng(7).uniform(3, 30, 32)
 base = synth.synth_pcm16(5, 30.0)
 pcm = [base[:int(d * 48000)] for d in durs]
 plan = eng.plan([len(p) for p in pcm], 48000)
-x = eng.pcm16_to_f32(torch.from_numpy(np.concatenate(pcm)).to(dev))
+x = torch.from_numpy(np.concatenate(pcm)).to(dev)             # int16 PCM
 for _ in range(2):
     eng.forward_pcm(x, plan, 48000)
 torch.cuda.synchronize()
@@ -60,7 +60,7 @@ streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
 def step(s):
     with torch.cuda.stream(streams[s % 2]):
         d16 = host.to(dev, non_blocking=True)
-        return eng.forward_pcm(eng.pcm16_to_f32(d16), plan, 48000)
+        return eng.forward_pcm(d16, plan, 48000)
 for s in range(4):
     step(s)
 torch.cuda.synchronize()

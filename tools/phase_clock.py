@@ -1,0 +1,35 @@
+"""Per-phase shader-clock profile of cnn_front_bf16_kernel (build: tools/phase_clock.sh -> ab_libs/clock.so).
+
+Run on the GPU box:  NISQA_HIP_LIB=$PWD/ab_libs/clock.so python tools/phase_clock.py
+Prints the mean cycles one wave spends between the layer boundaries (under the real 2-waves-per-SIMD contention)."""
+import os, sys, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from nisqa_amd import synth, lib
+from nisqa_amd.engine import HipNisqa
+
+dev = torch.device('cuda:0')
+eng = HipNisqa(dict(synth.DIM_ARGS), synth.random_state_dict(7, 'NISQA_DIM'), dev)
+L = ctypes.CDLL(lib.LIB_PATH)
+L.nisqa_debug_phase_clock.restype = ctypes.c_int
+L.nisqa_debug_phase_clock.argtypes = [ctypes.c_void_p, ctypes.c_int]
+base = [synth.synth_pcm16(1000 + i, 10.0) for i in range(8)]
+pcm = torch.from_numpy(np.concatenate([base[i % 8] for i in range(64)])).to(dev)
+plan = eng.plan([len(base[0])] * 64, 48000)
+for _ in range(20):
+    eng.forward_pcm(pcm, plan, 48000)
+torch.cuda.synchronize()
+L.nisqa_debug_phase_clock(None, 1)
+for _ in range(50):
+    eng.forward_pcm(pcm, plan, 48000)
+torch.cuda.synchronize()
+out = (ctypes.c_ulonglong * 16)()
+assert L.nisqa_debug_phase_clock(out, 0) == 0
+n = out[12]
+names = ['stage patch', 'conv1+pool', 'conv2 K loop', 'conv2 epilogue', 'conv3 K loop', 'conv3 epilogue', 'conv4 K loop',
+         'barrier+conv4 epilogue+barrier', 'conv5 K loop', 'conv5 epilogue+barrier', 'conv6 K loop', 'conv6 epilogue']
+tot = sum(out[q] for q in range(12)) / n
+print('waves %d, mean clock64 ticks per wave %.0f (+ %.0f before the first stamp); wall clock (100 MHz) per wave %.2f us'
+      % (n, tot, out[14] / n, out[13] / n / 100.0))
+for q, nm in enumerate(names):
+    print('%-32s %9.0f  %5.1f%%' % (nm, out[q] / n, 100.0 * out[q] / n / tot))
