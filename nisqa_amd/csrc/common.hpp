@@ -42,6 +42,18 @@ NQ_DEV int find_segment(const int32_t* __restrict__ off, int n, int p) {
     return lo;
 }
 
+// The same for a wave-uniform p with all 64 lanes active: one vector load and a ballot per 64 entries instead of a
+// chain of log2(n) dependent loads (one-wave workgroups start on cold caches: every link is a trip to L2).
+NQ_DEV int find_segment_wave(const int32_t* __restrict__ off, int n, int p, int lane) {
+    int cnt = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool le = i < n && off[i] <= p;
+        cnt += __popcll(__ballot(le));
+    }
+    return cnt - 1;                // off[0] = 0 <= p
+}
+
 // order-preserving float <-> uint32 (for atomicMax on floats of either sign)
 NQ_DEV uint32_t enc_ordered(float f) {
     uint32_t u = __float_as_uint(f);

@@ -311,7 +311,8 @@ __global__ __launch_bounds__(64) void pool_final_kernel(const int32_t* __restric
                                                         const float* __restrict__ yv, float* __restrict__ out) {
     const int lane = threadIdx.x, b = blockIdx.x;
     const int n = n_wins[b], c0 = tok_off[b];
-    for (int hd = 0; hd < n_heads; ++hd) {
+    {
+        const int hd = blockIdx.y;                           // one wave per (clip, head)
         float mx = -INFINITY;
         for (int t = lane; t < n; t += 64) mx = fmaxf(mx, sc[(size_t)(c0 + t) * 8 + hd]);
         mx = wave_max(mx);
@@ -356,7 +357,7 @@ extern "C" int nisqa_pool_final(const int32_t* tok_off, const int32_t* n_wins, i
                                 int32_t n_heads, const float* ws, float* out, void* stream) {
     if (n_clips <= 0 || total_tok_padded <= 0 || n_heads < 1 || n_heads > 8) return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(pool_final_kernel, dim3(n_clips), dim3(64), 0, (hipStream_t)stream, tok_off, n_wins, n_heads, ws,
+    hipLaunchKernelGGL(pool_final_kernel, dim3(n_clips, n_heads), dim3(64), 0, (hipStream_t)stream, tok_off, n_wins, n_heads, ws,
                        ws + (size_t)total_tok_padded * 8, out);
     return NQ_LAUNCH_STATUS();
 }
@@ -372,7 +373,7 @@ extern "C" int nisqa_pool_att(const float* x, const int32_t* tok_off, const int3
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(pool_score_kernel, dim3(total_tok_padded / 32), dim3(64), 0, st, x, tok_off, n_wins, n_clips,
                        n_heads, pool_w, sc, yv);
-    hipLaunchKernelGGL(pool_final_kernel, dim3(n_clips), dim3(64), 0, st, tok_off, n_wins, n_heads,
+    hipLaunchKernelGGL(pool_final_kernel, dim3(n_clips, n_heads), dim3(64), 0, st, tok_off, n_wins, n_heads,
                        (const float*)sc, (const float*)yv, out);
     return NQ_LAUNCH_STATUS();
 }

@@ -82,36 +82,49 @@ NQ_DEV void store_dtok_split(u16* __restrict__ hi_row, u16* __restrict__ lo_row,
         }
 }
 
-// out[mt] += W * in  (W: chain-order bf16 fragments [4 steps][MT][hl][64][8], in: D layout of a 64 x 32 tile)
+// out[mt] += W * in  (W: chain-order bf16 fragments [4 steps][MTT][hl][64][8], in: D layout of a 64 x 32 tile).
+// One wave runs per SIMD, so every global load is an exposed round trip unless it is requested a phase ahead: the
+// fragments of a whole GEMM (tiles mt0 .. mt0+MT-1 of MTT) are loaded by chain_load -- which the caller issues before
+// the VALU work that precedes the GEMM -- and consumed by chain_mma.
 template <int MT>
-NQ_DEV void chain_gemm_bf(const u16* __restrict__ wb, const f32x16 (&in)[2], f32x16 (&out)[MT], int lane) {
+struct chain_frags { f32x4 h[4][MT], l[4][MT]; };
+
+template <int MT, int MTT>
+NQ_DEV void chain_load(const u16* __restrict__ wb, int mt0, chain_frags<MT>& f, int lane) {
     const f32x4* af = (const f32x4*)wb + lane;
-    f32x4 ah[2][MT], al[2][MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { ah[0][mt] = af[(mt * 2 + 0) * 64]; al[0][mt] = af[(mt * 2 + 1) * 64]; }
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f.h[s][mt] = af[((s * MTT + mt0 + mt) * 2 + 0) * 64];
+            f.l[s][mt] = af[((s * MTT + mt0 + mt) * 2 + 1) * 64];
+        }
+}
+
+template <int MT>
+NQ_DEV void chain_mma(const chain_frags<MT>& f, const f32x16 (&in)[2], f32x16 (&out)[MT]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        if (s + 1 < 4) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                ah[(s + 1) & 1][mt] = af[(((s + 1) * MT + mt) * 2 + 0) * 64];
-                al[(s + 1) & 1][mt] = af[(((s + 1) * MT + mt) * 2 + 1) * 64];
-            }
-        }
         f32x4 bh, bl;
         split8(in[s >> 1], 8 * (s & 1), bh, bl);
-        __builtin_amdgcn_sched_barrier(0);     // keep next step's fragment requests ahead of this step's MFMAs
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) out[mt] = mfma_bf(ah[s & 1][mt], bl, out[mt]);   // product-major: consecutive
+        for (int mt = 0; mt < MT; ++mt) out[mt] = mfma_bf(f.h[s][mt], bl, out[mt]);   // product-major: consecutive
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) out[mt] = mfma_bf(al[s & 1][mt], bh, out[mt]);   // MFMAs on different
+        for (int mt = 0; mt < MT; ++mt) out[mt] = mfma_bf(f.l[s][mt], bh, out[mt]);   // MFMAs on different
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) out[mt] = mfma_bf(ah[s & 1][mt], bh, out[mt]);   // accumulators
-        __builtin_amdgcn_sched_barrier(0);
+        for (int mt = 0; mt < MT; ++mt) out[mt] = mfma_bf(f.h[s][mt], bh, out[mt]);   // accumulators
     }
 }
 
-NQ_DEV void layernorm64(f32x16 (&x)[2], const float* __restrict__ gamma, const float* __restrict__ beta, int hf) {
+template <int MT>
+NQ_DEV void chain_gemm_bf(const u16* __restrict__ wb, const f32x16 (&in)[2], f32x16 (&out)[MT], int lane) {
+    chain_frags<MT> f;
+    chain_load<MT, MT>(wb, 0, f, lane);
+    chain_mma<MT>(f, in, out);
+}
+
+// LayerNorm over the 64 features of each token (gamma / beta preloaded in D layout)
+NQ_DEV void layernorm64(f32x16 (&x)[2], const f32x16 (&g)[2], const f32x16 (&bt)[2]) {
     float s = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -129,15 +142,11 @@ NQ_DEV void layernorm64(f32x16 (&x)[2], const float* __restrict__ gamma, const f
         }
     q += __shfl_xor(q, 32);
     const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + LN_EPS);
-    f32x16 g[2], bt[2];
-    load_dvec<2>(gamma, g, hf);
-    load_dvec<2>(beta, bt, hf);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) x[mt][r] = (x[mt][r] - mean) * rstd * g[mt][r] + bt[mt][r];
 }
-
 struct qkv_planes { u16 *qh, *ql, *kh, *kl, *vh, *vl; };   // q,k: [NP][64]; v: [64][NP]
 NQ_DEV qkv_planes planes_of(float* base, size_t np64) {
     u16* p = (u16*)base;                                    // 6 planes of np*64 bf16 = 3 * np64 floats
@@ -146,23 +155,33 @@ NQ_DEV qkv_planes planes_of(float* base, size_t np64) {
     return r;
 }
 
+// Q, K, V of a layer as three 64-wide chain GEMMs: the fragments and biases of the next one are in flight while the
+// previous one's results are split and stored.  qkv_prefetch (the q fragments) is issued by the caller a phase ahead.
+struct qkv_pre { chain_frags<2> f; f32x16 bias[2]; };
+NQ_DEV void qkv_prefetch(const float* __restrict__ lw, const u16* __restrict__ lwb, qkv_pre& p, int lane) {
+    chain_load<2, 6>(lwb + TDBL_QKV, 0, p.f, lane);
+    load_dvec<2>(lw + TDL_QKV_B, p.bias, lane >> 5);
+}
 NQ_DEV void qkv_store_bf(const float* __restrict__ lw, const u16* __restrict__ lwb, const f32x16 (&x)[2],
-                         const qkv_planes& P, int tok, int np, int lane) {
+                         const qkv_planes& P, int tok, int np, int lane, qkv_pre& q) {
     const int hf = lane >> 5;
-    f32x16 acc[6];
-    load_dvec<6>(lw + TDL_QKV_B, acc, hf);
-    chain_gemm_bf<6>(lwb + TDBL_QKV, x, acc, lane);
-    f32x16 t2[2];
-    t2[0] = acc[0]; t2[1] = acc[1];
-    store_dtok_split(P.qh + (size_t)tok * 64, P.ql + (size_t)tok * 64, t2, hf, 0.125f);
-    t2[0] = acc[2]; t2[1] = acc[3];
-    store_dtok_split(P.kh + (size_t)tok * 64, P.kl + (size_t)tok * 64, t2, hf, 1.0f);
+    qkv_pre k;
+    chain_load<2, 6>(lwb + TDBL_QKV, 2, k.f, lane);
+    load_dvec<2>(lw + TDL_QKV_B + 64, k.bias, hf);
+    chain_mma<2>(q.f, x, q.bias);
+    qkv_pre v;
+    chain_load<2, 6>(lwb + TDBL_QKV, 4, v.f, lane);
+    load_dvec<2>(lw + TDL_QKV_B + 128, v.bias, hf);
+    store_dtok_split(P.qh + (size_t)tok * 64, P.ql + (size_t)tok * 64, q.bias, hf, 0.125f);
+    chain_mma<2>(k.f, x, k.bias);
+    store_dtok_split(P.kh + (size_t)tok * 64, P.kl + (size_t)tok * 64, k.bias, hf, 1.0f);
+    chain_mma<2>(v.f, x, v.bias);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             unsigned h_, l_;
-            split2(acc[4 + mt][r], acc[4 + mt][r + 1], h_, l_);
+            split2(v.bias[mt][r], v.bias[mt][r + 1], h_, l_);
             const size_t f0 = (size_t)(32 * mt + NQ_DROW(r, hf)) * np + tok, f1 = f0 + np;   // rows r, r+1 are adjacent features
             P.vh[f0] = (u16)h_; P.vh[f1] = (u16)(h_ >> 16);
             P.vl[f0] = (u16)l_; P.vl[f1] = (u16)(l_ >> 16);
@@ -176,36 +195,54 @@ __global__ __launch_bounds__(64) void td_proj_bf16_kernel(const float* __restric
                                                           float* __restrict__ x, float* __restrict__ qkv) {
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     const int tile0 = blockIdx.x * 32;
-    const int b = find_segment(tok_off, n_clips, tile0);
+    const int b = find_segment_wave(tok_off, n_clips, tile0, lane);
     const int n = n_wins[b], k0 = tile0 - tok_off[b];
     if (k0 >= n) return;
     const int tok = tile0 + j;
     const bool valid = k0 + j < n;
     const f32x4* frow = (const f32x4*)(feat + (size_t)tok * 384);
     const f32x4* af = (const f32x4*)(twb + TDB_PROJ) + lane;
-    f32x16 acc[2];
+    f32x16 acc[2], g0[2], b0[2];
     load_dvec<2>(tw + TD_PROJ_B, acc, h);
-    f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 f0 = valid ? frow[2 * h] : z4, f1 = valid ? frow[2 * h + 1] : z4;
-#pragma unroll 2
+    load_dvec<2>(tw + TD_LN0_G, g0, h);
+    load_dvec<2>(tw + TD_LN0_B, b0, h);
+    // One wave per tile and nothing else on its SIMD: the 24 K-steps are a pure latency chain unless the feature rows
+    // (ring of 8 steps) and the weight fragments (ring of 4 steps) are requested far ahead of their MFMAs.
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 fr[8][2], wr[4][4];
+    auto load_f = [&](int s) {
+        fr[s & 7][0] = valid ? frow[4 * s + 2 * h] : z4;
+        fr[s & 7][1] = valid ? frow[4 * s + 2 * h + 1] : z4;
+    };
+    auto load_w = [&](int s) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wr[s & 3][q] = af[(s * 4 + q) * 64];       // (mt 0 hi, mt 0 lo, mt 1 hi, mt 1 lo)
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) load_w(s);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) load_f(s);
+#pragma unroll
     for (int s = 0; s < 24; ++s) {
-        f32x4 n0 = z4, n1 = z4;
-        if (s + 1 < 24 && valid) { n0 = frow[4 * (s + 1) + 2 * h]; n1 = frow[4 * (s + 1) + 2 * h + 1]; }
-        const f32x4 ah0 = af[((s * 2 + 0) * 2 + 0) * 64], al0 = af[((s * 2 + 0) * 2 + 1) * 64];
-        const f32x4 ah1 = af[((s * 2 + 1) * 2 + 0) * 64], al1 = af[((s * 2 + 1) * 2 + 1) * 64];
+        const f32x4 f0 = fr[s & 7][0], f1 = fr[s & 7][1];
+        const f32x4 ah0 = wr[s & 3][0], al0 = wr[s & 3][1], ah1 = wr[s & 3][2], al1 = wr[s & 3][3];
         f32x4 bh, bl;
         unsigned hh, ll;
         split2(f0[0], f0[1], hh, ll); bh[0] = __uint_as_float(hh); bl[0] = __uint_as_float(ll);
         split2(f0[2], f0[3], hh, ll); bh[1] = __uint_as_float(hh); bl[1] = __uint_as_float(ll);
         split2(f1[0], f1[1], hh, ll); bh[2] = __uint_as_float(hh); bl[2] = __uint_as_float(ll);
         split2(f1[2], f1[3], hh, ll); bh[3] = __uint_as_float(hh); bl[3] = __uint_as_float(ll);
-        acc[0] = mfma_bf(ah0, bl, acc[0]); acc[0] = mfma_bf(al0, bh, acc[0]); acc[0] = mfma_bf(ah0, bh, acc[0]);
-        acc[1] = mfma_bf(ah1, bl, acc[1]); acc[1] = mfma_bf(al1, bh, acc[1]); acc[1] = mfma_bf(ah1, bh, acc[1]);
-        f0 = n0; f1 = n1;
+        acc[0] = mfma_bf(ah0, bl, acc[0]); acc[1] = mfma_bf(ah1, bl, acc[1]);
+        acc[0] = mfma_bf(al0, bh, acc[0]); acc[1] = mfma_bf(al1, bh, acc[1]);
+        acc[0] = mfma_bf(ah0, bh, acc[0]); acc[1] = mfma_bf(ah1, bh, acc[1]);
+        if (s + 4 < 24) load_w(s + 4);
+        if (s + 8 < 24) load_f(s + 8);
     }
-    layernorm64(acc, tw + TD_LN0_G, tw + TD_LN0_B, h);
+    qkv_pre qp;
+    qkv_prefetch(tw + TD_LAYER0, twb + TDB_LAYER0, qp, lane);
+    layernorm64(acc, g0, b0);
     store_dtok(x + (size_t)tok * 64, acc, h);
-    qkv_store_bf(tw + TD_LAYER0, twb + TDB_LAYER0, acc, planes_of(qkv, (size_t)np * 64), tok, np, lane);
+    qkv_store_bf(tw + TD_LAYER0, twb + TDB_LAYER0, acc, planes_of(qkv, (size_t)np * 64), tok, np, lane, qp);
 }
 
 __global__ __launch_bounds__(64) void td_layer_bf16_kernel(const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
@@ -215,7 +252,7 @@ __global__ __launch_bounds__(64) void td_layer_bf16_kernel(const int32_t* __rest
                                                            float* x_out, float* qkv_next) {
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     const int tile0 = blockIdx.x * 32;
-    const int b = find_segment(tok_off, n_clips, tile0);
+    const int b = find_segment_wave(tok_off, n_clips, tile0, lane);
     const int n = n_wins[b], c0 = tok_off[b];
     if (tile0 - c0 >= n) return;
     const int tok = tile0 + j;
@@ -276,11 +313,13 @@ __global__ __launch_bounds__(64) void td_layer_bf16_kernel(const int32_t* __rest
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m, mx);
-        const float alpha = expf(m - m_new);
+        // exp(x) = 2^(x log2 e) on v_exp_f32: x <= 0 here, |x log2 e| < 150, so the argument's rounding moves the
+        // result by < 2e-5 relative at the underflow edge and ~1e-7 where the weights matter
+        const float alpha = __builtin_amdgcn_exp2f((m - m_new) * 1.44269504088896341f);
         float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sacc[r] = expf(sacc[r] - m_new);
+            sacc[r] = __builtin_amdgcn_exp2f((sacc[r] - m_new) * 1.44269504088896341f);
             rs += sacc[r];
         }
         rs += __shfl_xor(rs, 32);
@@ -301,29 +340,39 @@ __global__ __launch_bounds__(64) void td_layer_bf16_kernel(const int32_t* __rest
         tile(kt, kAh, kAl, kBh, kBl);
         if (kt + 1 < nkt) tile(kt + 1, kBh, kBl, kAh, kAl);
     }
+    // ---- out-projection, residual + LN1, feed-forward, residual + LN2, next layer's QKV: every parameter block is
+    //      requested one phase before its use
+    chain_frags<2> fa, fb;
+    f32x16 y[2], xr[2], g[2], bt[2], h1[2], h2[2];
+    chain_load<2, 2>(lwb + TDBL_OUT, 0, fa, lane);
+    load_dvec<2>(lw + TDL_OUT_B, y, h);
+    load_dvec<2>(x_in + (size_t)tok * 64, xr, h);
     const float inv_l = 1.0f / l;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] *= inv_l; o[1][r] *= inv_l; }
-
-    f32x16 y[2], xr[2];
-    load_dvec<2>(lw + TDL_OUT_B, y, h);
-    chain_gemm_bf<2>(lwb + TDBL_OUT, o, y, lane);
-    load_dvec<2>(x_in + (size_t)tok * 64, xr, h);
+    chain_mma<2>(fa, o, y);
+    chain_load<2, 2>(lwb + TDBL_FF1, 0, fb, lane);
+    load_dvec<2>(lw + TDL_LN1_G, g, h);
+    load_dvec<2>(lw + TDL_LN1_B, bt, h);
+    load_dvec<2>(lw + TDL_FF1_B, h1, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { y[0][r] += xr[0][r]; y[1][r] += xr[1][r]; }
-    layernorm64(y, lw + TDL_LN1_G, lw + TDL_LN1_B, h);
-    f32x16 h1[2], h2[2];
-    load_dvec<2>(lw + TDL_FF1_B, h1, h);
-    chain_gemm_bf<2>(lwb + TDBL_FF1, y, h1, lane);
+    layernorm64(y, g, bt);
+    chain_mma<2>(fb, y, h1);
+    chain_load<2, 2>(lwb + TDBL_FF2, 0, fa, lane);
+    load_dvec<2>(lw + TDL_FF2_B, h2, h);
+    load_dvec<2>(lw + TDL_LN2_G, g, h);
+    load_dvec<2>(lw + TDL_LN2_B, bt, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { h1[0][r] = fmaxf(h1[0][r], 0.f); h1[1][r] = fmaxf(h1[1][r], 0.f); }
-    load_dvec<2>(lw + TDL_FF2_B, h2, h);
-    chain_gemm_bf<2>(lwb + TDBL_FF2, h1, h2, lane);
+    chain_mma<2>(fa, h1, h2);
+    qkv_pre qp;
+    if (lw_next) qkv_prefetch(lw_next, lwb_next, qp, lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) { y[0][r] += h2[0][r]; y[1][r] += h2[1][r]; }
-    layernorm64(y, lw + TDL_LN2_G, lw + TDL_LN2_B, h);
+    layernorm64(y, g, bt);
     store_dtok(x_out + (size_t)tok * 64, y, h);
-    if (lw_next) qkv_store_bf(lw_next, lwb_next, y, planes_of(qkv_next, (size_t)np * 64), tok, np, lane);
+    if (lw_next) qkv_store_bf(lw_next, lwb_next, y, planes_of(qkv_next, (size_t)np * 64), tok, np, lane, qp);
 }
 
 __global__ __launch_bounds__(64) void pool_score_bf16_kernel(const float* __restrict__ x, const int32_t* __restrict__ tok_off,
@@ -332,18 +381,21 @@ __global__ __launch_bounds__(64) void pool_score_bf16_kernel(const float* __rest
                                                              float* __restrict__ sc, float* __restrict__ yv) {
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
     const int tile0 = blockIdx.x * 32;
-    const int b = find_segment(tok_off, n_clips, tile0);
+    const int b = find_segment_wave(tok_off, n_clips, tile0, lane);
     if (tile0 - tok_off[b] >= n_wins[b]) return;
     const int tok = tile0 + j;
     f32x16 xr[2];
     load_dvec<2>(x + (size_t)tok * 64, xr, h);
-    for (int hd = 0; hd < n_heads; ++hd) {
+    {
+        const int hd = blockIdx.y;                           // one wave per (tile, head): the heads are independent
         const float* w = pw + (size_t)hd * PL_FLOATS;
         f32x16 hid[4], w2[4], w3[2];
+        chain_frags<4> f;
+        chain_load<4, 4>(pwb + (size_t)hd * PLB_U16S, 0, f, lane);
         load_dvec<4>(w + PL_B1, hid, h);
-        chain_gemm_bf<4>(pwb + (size_t)hd * PLB_U16S, xr, hid, lane);
         load_dvec<4>(w + PL_W2, w2, h);
         load_dvec<2>(w + PL_W3, w3, h);
+        chain_mma<4>(f, xr, hid);
         float s = 0.f, v = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
@@ -391,7 +443,7 @@ extern "C" int nisqa_pool_score_bf16(const float* x, const int32_t* tok_off, con
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || n_heads < 1 || n_heads > 8 || !pool_wb)
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(pool_score_bf16_kernel, dim3(total_tok_padded / 32), dim3(64), 0, (hipStream_t)stream, x, tok_off,
+    hipLaunchKernelGGL(pool_score_bf16_kernel, dim3(total_tok_padded / 32, n_heads), dim3(64), 0, (hipStream_t)stream, x, tok_off,
                        n_wins, n_clips, n_heads, pool_w, pool_wb, ws, ws + (size_t)total_tok_padded * 8);
     return NQ_LAUNCH_STATUS();
 }
