@@ -126,38 +126,35 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const int i = lane & 31, hfi = (i >> 2) & 1, qi = (i & 3) + 4 * (i >> 3);
     const int n = lane & 31, hf = lane >> 5, h = lane >> 5;
 
-    // ---- conv1 1->16 + pool 48x15 -> 24x7 on the matrix pipe.  K = 16 holds the 9 taps (lane half 0: taps
-    //      0..7, half 1: tap 8); N = 32 holds the 16 channels.  Each lane half owns 12 pooled rows; a pooled
-    //      row = 2 x 15 conv pixels = local index u = 15*yy + x in two 16-row tiles.
+    // ---- conv1 1->16 + pool 48x15 -> 24x7 on the matrix pipe, two output pixels per row.  A row = the mel pair
+    //      (m0, m0 + 1) of one frame x; N = 32 = (channel c, pair member dm); K = 12 of 16 = (frame tap kx, mel m0 - 1 +
+    //      dmm), dmm = 0..3: the four mels of one kx are CONTIGUOUS in the bordered patch, so the 8 k-slots of a lane are
+    //      two pairs of dwords per plane and no packing.  B[k][n] = w[c][dmm - dm][kx] (zero outside the kernel), packed
+    //      by weights.py.  Each lane half owns 12 pooled rows gl = mel pairs; the 16 rows of its tile are the frames.
     {
         const char* pb = act + FB_PATCH;
         f32x4 w1[2];                                      // weights hi and the first residual term (16 mantissa bits)
 #pragma unroll
         for (int t = 0; t < 2; ++t) w1[t] = *(const f32x4*)(wb + CNNB_W1 + t * 512 + lane * 8);
         const float tn = tn1;
-        char* a1 = act;                                   // A1 planes: 168 px x 16 ch
-        // byte offset of tap 8h + e relative to the pixel's (dy, dx) = (0, 0) corner in the bordered patch; lane half
-        // 1 only needs tap 8 (its taps 9..15 meet zero weights, any finite value will do)
-        int toff[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) toff[e] = h ? 2 * (2 * 50 + 2) : 2 * ((e % 3) * 50 + e / 3);
-        for (int gl = 0; gl < 12; ++gl) {
+        char* a1w = act + (n < 16 ? 0 : FB_P1) + (n & 15) * 2;   // A1 planes: 168 px x 16 ch; this lane's plane and channel
+        // lane half 0: k-slots 0..7 = (kx 0, kx 1); half 1: k-slots 8..11 = kx 2 (12..15 meet zero weights: kx 2 again)
+        const int xq = min(qi, 14);                       // row 15 of a tile is padding (result unused)
+        const int off_a = ((xq + (h ? 2 : 0)) * 50 + 24 * hfi) * 2, off_b = ((xq + (h ? 2 : 1)) * 50 + 24 * hfi) * 2;
+        for (int g2 = 0; g2 < 6; ++g2) {
             f32x16 acc[2];
             f32x4 xa[2][2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const int u = min(16 * tt + qi, 29);      // rows 30, 31 of the pair are padding (results unused)
-                const int yy = u >= 15 ? 1 : 0, x = u - 15 * yy;
-                const int y = 2 * (12 * hfi + gl) + yy;
-                const char* base = pb + (x * 50 + y) * 2;
+                const char* base = pb + 4 * (2 * g2 + tt);          // mel m0 = 2 gl, gl = 12 hfi + 2 g2 + tt
+                // dword reads (ds_read2_b32): the pairs are only 4-byte aligned, and a misaligned ds_read_b64 is several
+                // times slower on gfx950 (it cost 8 % of the whole kernel here)
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned lo16 = *(const unsigned short*)(base + t * FB_PPLANE + toff[2 * q]);
-                        const unsigned hi16 = *(const unsigned short*)(base + t * FB_PPLANE + toff[2 * q + 1]);
-                        xa[tt][t][q] = __uint_as_float(lo16 | (hi16 << 16));
-                    }
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned* pa = (const unsigned*)(base + t * FB_PPLANE + off_a);
+                    const unsigned* pq = (const unsigned*)(base + t * FB_PPLANE + off_b);
+                    xa[tt][t] = f32x4{__uint_as_float(pa[0]), __uint_as_float(pa[1]), __uint_as_float(pq[0]), __uint_as_float(pq[1])};
+                }
             }
             acc[0] = zero16();
             acc[1] = zero16();
@@ -167,19 +164,23 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             acc[0] = mfma_bf(xa[0][0], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[1], acc[1]);
             acc[0] = mfma_bf(xa[0][0], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[0], acc[1]);
 #pragma unroll
-            for (int bb = 0; bb < 7; ++bb) {
-                float mx = -3.0e38f;
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                    for (int x = 2 * bb; x < 2 * bb + 3; ++x) {
-                        const int u = 15 * yy + x;
-                        mx = fmaxf(mx, acc[u >> 4][u & 15]);
-                    }
-                const int pp = (12 * hf + gl) * 7 + bb;
-                if (n < 16)
-                    store_split(a1, FB_P1, pp * FB_RS1 + n * 2, fmaxf(mx + tn, 0.f));
-            }
+                for (int bb = 0; bb < 7; ++bb) {
+                    const float mx = fmaxf(fmaxf(acc[tt][2 * bb], acc[tt][2 * bb + 1]), acc[tt][2 * bb + 2]);   // frames
+                    // The other member of the mel pair sits 16 lanes away (columns n and n ^ 16).  ReLU(. + shift) is
+                    // monotone, so it is applied first and the pair maximum is taken on non-negative floats -- as
+                    // unsigned integers.  Both lanes end up with the pooled value: lane n < 16 stores its bf16 hi part,
+                    // lane n + 16 the lo part (no divergent branch, one 16-bit store per lane).
+                    const unsigned r = __float_as_uint(fmaxf(mx + tn, 0.f));
+                    // (lanes ^ 16 on the LDS pipe; v_permlane16_swap costs ~20 VALU cycles on gfx950)
+                    const unsigned ro = (unsigned)__builtin_amdgcn_ds_swizzle((int)r, 0x401F);
+                    const float v = __uint_as_float(max(r, ro));
+                    const unsigned hi = cvt_pk_bf16(v, 0.f);
+                    const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
+                    const int pp = (12 * hf + 2 * g2 + tt) * 7 + bb;
+                    *(unsigned short*)(a1w + pp * FB_RS1) = (unsigned short)(n < 16 ? hi : lo);
+                }
         }
     }
 

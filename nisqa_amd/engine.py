@@ -142,7 +142,7 @@ class HipNisqa(object):
         self.n_heads = len(heads)
         self.cnn_w = up(_w.pack_adapt_cnn(state_dict))
         bf = self.precision == 'bf16x3'
-        self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict).view(np.int16)) if bf else None
+        self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict, conv1_pairs=True).view(np.int16)) if bf else None
         self.td_w = up(_w.pack_self_att(state_dict, self.n_layers))
         self.pool_w = up(_w.pack_pool_att(state_dict, heads))
         self.td_wb = up(_w.pack_self_att_bf16(state_dict, self.n_layers).view(np.int16)) if bf else None

@@ -251,8 +251,12 @@ def conv_b_fragments_bf16_nsplit(wf):
     return np.stack([hi, lo], 2).reshape(-1)
 
 
-def pack_adapt_cnn_bf16(sd, pfx='cnn.model.'):
-    """bf16 hi/lo weight fragments for cnn_front_bf16_kernel -> uint16 [CNNB_U16S] (biases: pack_adapt_cnn)."""
+def pack_adapt_cnn_bf16(sd, pfx='cnn.model.', conv1_pairs=False):
+    """bf16 hi/lo weight fragments for cnn_front_bf16_kernel -> uint16 [CNNB_U16S] (biases: pack_adapt_cnn).
+
+    conv1 B operand [k][n], lane (n = lane & 31, h = lane >> 5) holds k-slots 8h .. 8h+7.  Plain layout (StandardCNN
+    kernel): k = tap ky*3 + kx, n = channel.  conv1_pairs (AdaptCNN kernel): a row is a pair of mel-adjacent output
+    pixels, n = c + 16*dm, k = 4*kx + dmm over the 4 mels the pair touches: w[c][ky = dmm - dm][kx]."""
     blob = np.zeros(CNNB_U16S, np.uint16)
     w, _ = fold_bn(sd, pfx, 1)
     w1 = w.reshape(16, 9).astype(np.float32)
@@ -261,7 +265,11 @@ def pack_adapt_cnn_bf16(sd, pfx='cnn.model.'):
         j, h = lane & 31, lane >> 5
         for e in range(8):
             k = 8 * h + e
-            if j < 16 and k < 9:
+            if conv1_pairs:
+                c, dm, kx, dmm = j & 15, j >> 4, k >> 2, k & 3
+                if k < 12 and 0 <= dmm - dm <= 2:
+                    full[lane, e] = w1[c, (dmm - dm) * 3 + kx]
+            elif j < 16 and k < 9:
                 full[lane, e] = w1[j, k]
     for t, part in enumerate(bf16_split(full, 3)):
         blob[CNNB_W1 + t * 512: CNNB_W1 + (t + 1) * 512] = part.reshape(-1)
