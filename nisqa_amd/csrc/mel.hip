@@ -101,14 +101,14 @@ NQ_DEV float row16_sum(float v) {
 
 NQ_DEV c32 shfl_c(c32 v, int src) { return cmk(__shfl((float)v.x, src), __shfl((float)v.y, src)); }
 
-// |X[K]| for K = 4k + r from za = Z[K], zb = Z[2048-K], W4096^K = wl * wc (per-lane x constant part;
+// |2 X[K]| for K = 4k + r from za = Z[K], zb = Z[2048-K], W4096^K = wl * wc (per-lane x constant part;
 // applied one after the other so that nothing loop-invariant can be hoisted into 64 extra registers)
 NQ_DEV float xmag(c32 za, c32 zb, c32 wl, c32 wc) {
     const c32 a = cadd_conj(za, zb);                     // Za + conj(Zb)
     const c32 w = cmul(cmul(csub_conj(za, zb), wl), wc); // W4096^K (Za - conj(Zb))
     const c32 x = cadd_mi(a, w);                         // 2 X[K] = a - i w
     const c32 x2 = x * x;
-    return 0.5f * __builtin_amdgcn_sqrtf(x2.x + x2.y);   // v_sqrt_f32 (1 ulp): 5e-7 dB, saves ~10 VALU per bin
+    return __builtin_amdgcn_sqrtf(x2.x + x2.y);          // |2 X[K]|; v_sqrt_f32 (1 ulp): 5e-7 dB, saves ~10 VALU per bin
 }
 
 struct mel_twiddles {
@@ -177,7 +177,8 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
     const int per_wave = MEL_EXCH_BYTES + mag_stride * 16 + 512;   // exchange + 4 magnitude planes + slack
     char* exch = smem + w_bytes + wave * per_wave;
     float* mag = (float*)(exch + MEL_EXCH_BYTES);                 // |X[K]| at (K&3)*mag_stride + (K>>2)
-    for (int i = tid; i < w_floats; i += 64 * MEL_WAVES) wlds[i] = band_w[i];
+    // the 1/2 of |X[K]| = |2 X[K]| / 2 rides on the band weights (a power of two: same bits), not on every bin
+    for (int i = tid; i < w_floats; i += 64 * MEL_WAVES) wlds[i] = 0.5f * band_w[i];
     for (int i = lane; i < 4 * mag_stride + 128; i += 64) mag[i] = 0.f;       // planes + slack start finite
     __syncthreads();
 
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
                 if (lane + 64 * q2 < mag_stride)
                     mag[0 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tw.d[0], cmk(W16C[q2], W16S[q2]));
             }
-            if (lane == 0 && 512 < mag_stride) mag[512] = fabsf(u[0].x - u[0].y);   // Nyquist bin X[2048] = Re Z0 - Im Z0
+            if (lane == 0 && 512 < mag_stride) mag[512] = 2.0f * fabsf(u[0].x - u[0].y);   // Nyquist bin: 2 X[2048] = 2 (Re Z0 - Im Z0)
 
         }
         // r = 2: partner Z_2[511 - k] = lane 63 - l, register 7 - q2
