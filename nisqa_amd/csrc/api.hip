@@ -1,6 +1,7 @@
 // libnisqa_hip.so: ABI glue -- version, workspace carving, the whole-batch forward and the MFMA
 // fragment-map self-test.  See include/nisqa_hip.h for the contract.
 #include "common.hpp"
+#include "internal.hpp"
 #include "../../include/nisqa_hip.h"
 
 extern "C" int nisqa_abi_version(void) { return NISQA_ABI_VERSION; }
@@ -58,8 +59,12 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
                                   model->twiddle, model->band_start, model->band_len, model->band_woff, model->band_w,
                                   mel, cmax, stream);
     if (rc) return rc;
-    rc = nisqa_mel_finalize(mel, frame_off, n_clips, total_frames, cmax, cfg->top_db, cfloor, 0, stream);
-    if (rc) return rc;
+    // the split-bf16 AdaptCNN kernel derives the top_db floor from cmax itself; the other CNN kernels take clip_floor
+    const bool floor_in_cnn = model->arch == 0 && model->cnn_mode == 1;
+    if (!floor_in_cnn) {
+        rc = nisqa_mel_finalize(mel, frame_off, n_clips, total_frames, cmax, cfg->top_db, cfloor, 0, stream);
+        if (rc) return rc;
+    }
     NQ_STAGE(1);
     if (model->arch == 1) {
         // StandardCNN + BiLSTM + last-step pooling; scratch: p3 region holds [NP][12][64], feat region [NP][20],
@@ -79,8 +84,8 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
         return NISQA_OK;
     }
     if (model->cnn_mode == 1) {
-        rc = nisqa_cnn_adapt_bf16(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
-                                  model->cnn_w, model->cnn_wb, nullptr, feat, stream);
+        rc = nq_cnn_adapt_bf16_from_max(mel, frame_off, tok_off, n_wins, cmax, cfg->top_db, n_clips, total_tok_padded,
+                                        model->seg_hop, model->cnn_w, model->cnn_wb, feat, stream);
         if (rc) return rc;
         NQ_STAGE(2);
     } else {

@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "layout.hpp"
 #include "conv_bf16.hpp"
+#include "internal.hpp"
 #include "../../include/nisqa_hip.h"
 
 // Activation planes: pixel rows of C bf16 padded by 16 bytes (row stride C*2 + 16, NOT swizzled): consecutive pixels land
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
     const float* __restrict__ clip_floor, int n_clips, int seg_hop,
     const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ p3,
-    float* __restrict__ feat, const float* __restrict__ seg_x, int seg_L) {
+    float* __restrict__ feat, const float* __restrict__ seg_x, int seg_L,
+    const uint32_t* __restrict__ clip_max_enc, float top_db) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef NQ_PHASE_CLOCK
     const long long clk_top = clock64(), wall_top = wall_clock64();
@@ -87,7 +89,9 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     //      the 3x3 taps of any output pixel are then at constant offsets from it, no bounds checks.
     //      All 12 global loads of the window (and the per-channel shifts of every layer) are requested up front: one
     //      memory latency instead of twelve.
-    const float fl = seg_x ? -3.0e38f : clip_floor[b];
+    // top_db floor of the clip: precomputed (nisqa_mel_finalize), or taken here from the encoded running maximum the mel
+    // kernel published (whole-forward path: one tiny kernel launch less)
+    const float fl = seg_x ? -3.0e38f : clip_max_enc ? dec_ordered(clip_max_enc[b]) - top_db : clip_floor[b];
     const float* src = seg_x ? seg_x + ((size_t)b * seg_L + k) * 720
                              : mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
     float vraw[12];
@@ -486,7 +490,21 @@ extern "C" int nisqa_cnn_adapt_bf16(const float* mel_tm, const int32_t* frame_of
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
                        mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat,
-                       (const float*)nullptr, 0);
+                       (const float*)nullptr, 0, (const uint32_t*)nullptr, 0.f);
+    return NQ_LAUNCH_STATUS();
+}
+
+// nisqa_cnn_adapt_bf16 with the per-clip floor derived in the kernel from the mel kernel's clip_max_enc (internal.hpp)
+int nq_cnn_adapt_bf16_from_max(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                               const int32_t* n_wins, const uint32_t* clip_max_enc, float top_db, int32_t n_clips,
+                               int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w, const uint16_t* cnn_wb,
+                               float* feat, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat || !clip_max_enc)
+        return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
+                       mel_tm, frame_off, tok_off, n_wins, (const float*)nullptr, n_clips, seg_hop, cnn_w, cnn_wb,
+                       (float*)nullptr, feat, (const float*)nullptr, 0, clip_max_enc, top_db);
     return NQ_LAUNCH_STATUS();
 }
 
@@ -498,6 +516,6 @@ extern "C" int nisqa_cnn_adapt_segments_bf16(const float* x, int32_t seg_len_pad
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
                        (const float*)nullptr, (const int32_t*)nullptr, tok_off, n_wins, (const float*)nullptr, n_clips, 1,
-                       cnn_w, cnn_wb, (float*)nullptr, feat, x, seg_len_padded);
+                       cnn_w, cnn_wb, (float*)nullptr, feat, x, seg_len_padded, (const uint32_t*)nullptr, 0.f);
     return NQ_LAUNCH_STATUS();
 }
