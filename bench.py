@@ -6,7 +6,7 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE pass of the whole hot path (PCM -> mel -> AdaptCNN -> self-attention -> pooling
-heads -> [B,5] rows) over one batch of synthetic input already resident in HBM.  Workload at every N:
+heads -> [B,5] rows) over one batch of synthetic input (int16 PCM, as in the WAV files) already resident in HBM.  Workload at every N:
 BASELINE.json configs[1] per GPU -- nisqa.tar architecture (NISQA_DIM, random-init weights: there
 are no checkpoints on the GPU box), bs = 64 clips of 10 s / 48 kHz synthetic audio (SURVEY.md
 section 8d generator).  Weak scaling: each rank owns its own 64-clip batch (clips shard with no
@@ -51,7 +51,7 @@ PEAK_F32_MFMA = 157.3                                        # TFLOP/s, MI355X_M
 PEAK_BF16_MFMA = 2500.0                                      # TFLOP/s dense, MI355X_MICROARCH.md
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, KB units, the
 # gfx950 x2 correction for wide reads): profiles/r01_pmc_bench_bf16x3.txt, profiles/r01_pmc_f32_cnn.txt
-PMC_TRAFFIC_BYTES = {'bf16x3': 2 * 13055.9e3 * 1.024 + 23724.1e3 * 1.024, 'f32': 2 * 23916.2e3 * 1.024 + 71136.0e3 * 1.024}
+PMC_TRAFFIC_BYTES = {'bf16x3': 2 * 12657.2e3 * 1.024 + 23712.0e3 * 1.024, 'f32': 2 * 23916.2e3 * 1.024 + 71136.0e3 * 1.024}
 
 
 def cpu_baseline(n_distinct=6, min_seconds=12.0):
@@ -193,7 +193,7 @@ def main():
                      if eng.precision == 'bf16x3' else 'f32',
             'data': 'synthetic 48 kHz / 10 s PCM16 clips (SURVEY 8d generator), random-init nisqa.tar architecture',
             'config': {'workload': 'predict_dir nisqa.tar (NISQA_DIM CNN-SA-AP) bs=64 per GPU, 10 s synthetic 48 kHz '
-                                   'clips, PCM resident in HBM', 'batch_clips_per_gpu': BATCH, 'streams': len(streams),
+                                   'clips, int16 PCM resident in HBM', 'batch_clips_per_gpu': BATCH, 'streams': len(streams),
                        'precision': eng.precision,
                        'segments_per_batch': int(plan.n_wins.sum()), 'frames_per_batch': plan.total_frames,
                        'parallelism': 'clip-sharded x%d, final all_gather of MOS rows' % world},

@@ -33,4 +33,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_train -o ks -- p
 cp /tmp/ks_train/ks_kernel_stats.csv $O/${R}_train_kernel_stats.csv
 python tools/bench_extra.py 2>/dev/null | tail -1 > $O/${R}_side_tts_pcie.json
 python tools/bench_ingest.py 1024 8,32 2>/dev/null | tail -1 > $O/${R}_side_ingest.json
+# optional extras, when built beforehand (tools/phase_clock.sh; hipcc -o ab_libs/issue tools/micro/issue.hip)
+[ -f ab_libs/clock.so ] && NISQA_HIP_LIB=$PWD/ab_libs/clock.so python tools/phase_clock.py 2>/dev/null | grep -v amdgpu.ids > $O/${R}_cnn_phase_clock.txt
+[ -x ab_libs/issue ] && ./ab_libs/issue > $O/${R}_micro_issue.txt
 ls -la $O
