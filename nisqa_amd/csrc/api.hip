@@ -49,7 +49,11 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
     float* x = (float*)(w + p.x);
     float* pool = (float*)(w + p.pool);
     void* const* ev = model->stage_events;
+#define NQ_SECTION_DONE() do { if (model->conv_section_done && hipEventRecord((hipEvent_t)model->conv_section_done, (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH; } while (0)
 #define NQ_STAGE(i) do { if (ev && hipEventRecord((hipEvent_t)ev[i], (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH; } while (0)
+    if (model->conv_section_wait &&
+        hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)model->conv_section_wait, 0) != hipSuccess)
+        return NISQA_ERR_LAUNCH;
     if (hipMemsetAsync(cmax, 0, (size_t)n_clips * 4, (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH;
     NQ_STAGE(0);
     int rc = pcm16 ? nisqa_mel_db_pcm16((const int16_t*)pcm, clip_off, frame_off, n_clips, total_frames, cfg, model->window,
@@ -75,6 +79,7 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
                  : nisqa_cnn_standard(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded,
                                       model->seg_hop, model->cnn_w, p3, feat, stream);
         if (rc) return rc;
+        NQ_SECTION_DONE();
         NQ_STAGE(2);
         NQ_STAGE(3);
         rc = nisqa_lstm_laststep(feat, tok_off, n_wins, n_clips, model->td_w, td, nullptr, out, stream);
@@ -87,6 +92,7 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
         rc = nq_cnn_adapt_bf16_from_max(mel, frame_off, tok_off, n_wins, cmax, cfg->top_db, n_clips, total_tok_padded,
                                         model->seg_hop, model->cnn_w, model->cnn_wb, feat, stream);
         if (rc) return rc;
+        NQ_SECTION_DONE();
         NQ_STAGE(2);
     } else {
         rc = nisqa_cnn_front(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
@@ -95,6 +101,7 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
         NQ_STAGE(2);
         rc = nisqa_cnn_back(p3, tok_off, n_wins, n_clips, total_tok_padded, model->cnn_w, feat, stream);
         if (rc) return rc;
+        NQ_SECTION_DONE();
     }
     NQ_STAGE(3);
     const bool bf = model->cnn_mode == 1 && model->td_wb && model->pool_wb;

@@ -29,7 +29,8 @@ class ModelDev(ctypes.Structure):
     _fields_ = [('window', c_p), ('twiddle', c_p), ('band_start', c_p), ('band_len', c_p), ('band_woff', c_p),
                 ('band_w', c_p), ('cnn_w', c_p), ('td_w', c_p), ('pool_w', c_p),
                 ('n_layers', c_i32), ('n_heads', c_i32), ('seg_hop', c_i32), ('stage_events', c_p),
-                ('cnn_wb', c_p), ('cnn_mode', c_i32), ('td_wb', c_p), ('pool_wb', c_p), ('arch', c_i32)]
+                ('cnn_wb', c_p), ('cnn_mode', c_i32), ('td_wb', c_p), ('pool_wb', c_p), ('arch', c_i32),
+                ('conv_section_wait', c_p), ('conv_section_done', c_p)]
 
 
 # name -> (restype, argtypes); every symbol include/nisqa_hip.h declares

@@ -141,6 +141,32 @@ def test_pcm16_input_matches_float_input_bit_for_bit(eng_rand, sr):
     assert np.isfinite(out_i.cpu().numpy()).all()
 
 
+@pytest.mark.parametrize('arch', ['NISQA_DIM', 'NISQA_TTS'])
+def test_two_streams_are_bit_identical_to_serial(arch):
+    """Batches in flight on two HIP streams (the predict loop): the engine keeps their mel + CNN sections apart
+    (nisqa_model_dev.conv_section_*; tools/probe_concurrency.py shows what happens otherwise), so outputs must carry the
+    same bits as when the batches run one after the other."""
+    from nisqa_amd.engine import HipNisqa
+    args = dict(synth.DIM_ARGS) if arch == 'NISQA_DIM' else dict(synth.TTS_ARGS)
+    eng = HipNisqa(args, synth.random_state_dict(7 if arch == 'NISQA_DIM' else 9, arch), 'cuda:0')
+    dev = eng.device
+    base = [synth.synth_pcm16(300 + i, 6.0) for i in range(4)]
+    n = 24
+    pcm = [torch.from_numpy(np.concatenate([base[(i + k) % 4] for i in range(n)])).to(dev) for k in range(2)]
+    plans = [eng.plan([len(base[0])] * n, 48000) for _ in range(2)]
+    ref = [eng.forward_pcm(pcm[k], plans[k], 48000).clone() for k in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    for rep in range(12):
+        outs = []
+        for k in (rep & 1, 1 - (rep & 1)):
+            with torch.cuda.stream(streams[k]):
+                outs.append((k, eng.forward_pcm(pcm[k], plans[k], 48000)))
+        torch.cuda.synchronize()
+        for k, o in outs:
+            np.testing.assert_array_equal(o.cpu().numpy(), ref[k].cpu().numpy())
+
+
 def _stages_vs_oracle(eng, args, sd, pcm_list, tol_feat=2e-4, tol_out=1e-3):
     dev_pcm, plan = _upload(eng, pcm_list)
     mel, floor = eng.mel(dev_pcm, plan, 48000, clamp=False)      # fused path: CNN applies the floor

@@ -1,0 +1,71 @@
+// Does a wave's arithmetic change when bf16 MFMA waves run on the same SIMD?  (gfx950; follow-up of exp_split.py)
+// Even waves of each workgroup spam v_mfma_f32_32x32x16_bf16 / 16x16x32; odd waves run deterministic chains of packed-f32
+// VALU ops, DPP adds, ds_bpermute, v_sqrt / v_log and LDS round trips and write their results.  Run twice -- with the even
+// waves idle and busy -- and compare the odd waves' outputs bit for bit.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float c32 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(512) void k(float* out, int iters, int busy) {
+    __shared__ float ex[8][64 * 2 + 16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((wave & 1) == 0) {
+        if (!busy) return;
+        bf16x8 a, b;
+        for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(lane * 0.001f + i); b[i] = (__bf16)(lane * 0.002f - i); }
+        f32x16 c0 = {}, c1 = {};
+        f32x4 d0 = {}, d1 = {};
+        for (int it = 0; it < iters; ++it) {
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, d1, 0, 0, 0);
+        }
+        float s = d0[0] + d1[1];
+        for (int i = 0; i < 16; ++i) s += c0[i] + c1[i];
+        if (s == 12345.f) out[0] = s;
+        return;
+    }
+    c32 z = {1.0f + lane * 0.01f, 0.5f - lane * 0.003f}, w = {0.9995f, 0.0301f};
+    float acc = 0.f, tr = 1.5f + lane;
+    for (int it = 0; it < iters; ++it) {
+        // packed complex multiply-add (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32)
+        const c32 t = __builtin_elementwise_fma(c32{z.y, z.y}, c32{-w.y, w.x}, c32{z.x, z.x} * w);
+        z = t + c32{1e-3f, -1e-3f};
+        // DPP row sum + bpermute mirror + LDS round trip
+        float v = z.x;
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+        v += __shfl(z.y, 63 - lane);
+        ex[wave][lane * 2] = v;
+        ex[wave][lane * 2 + 1] = z.y;
+        __builtin_amdgcn_wave_barrier();
+        const float u = ex[wave][((lane + 7) & 63) * 2] + ex[wave][((lane + 13) & 63) * 2 + 1];
+        __builtin_amdgcn_wave_barrier();
+        tr = __builtin_amdgcn_sqrtf(tr * tr + 1.0f) * 0.999f + __log2f(2.0f + fabsf(u)) * 1e-3f;
+        acc = fmaf(u, 1e-3f, acc * 0.999f);
+    }
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = acc + z.x + z.y + tr;
+}
+
+int main() {
+    const int blocks = 512, n = blocks * 512;
+    float* d; hipMalloc(&d, n * 4);
+    std::vector<float> r0(n), r1(n), r2(n);
+    auto run = [&](int busy, std::vector<float>& r) {
+        hipMemset(d, 0, n * 4);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(512), 0, 0, d, 4000, busy);
+        hipDeviceSynchronize();
+        hipMemcpy(r.data(), d, n * 4, hipMemcpyDeviceToHost);
+    };
+    run(0, r0); run(0, r1); run(1, r2);
+    long same01 = 0, diff02 = 0;
+    for (int i = 0; i < n; ++i) { if (((i >> 6) & 1) == 0) continue; same01 += memcmp(&r0[i], &r1[i], 4) != 0; diff02 += memcmp(&r0[i], &r2[i], 4) != 0; }
+    printf("odd-wave results: idle vs idle differing %ld, idle vs MFMA-busy differing %ld of %d\n", same01, diff02, n / 2);
+    return 0;
+}
