@@ -51,7 +51,7 @@ PEAK_F32_MFMA = 157.3                                        # TFLOP/s, MI355X_M
 PEAK_BF16_MFMA = 2500.0                                      # TFLOP/s dense, MI355X_MICROARCH.md
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (2 x FETCH_SIZE + WRITE_SIZE, KB units, the
 # gfx950 x2 correction for wide reads): profiles/r01_pmc_bench_bf16x3.txt, profiles/r01_pmc_f32_cnn.txt
-PMC_TRAFFIC_BYTES = {'bf16x3': 2 * 12657.2e3 * 1.024 + 23712.0e3 * 1.024, 'f32': 2 * 23916.2e3 * 1.024 + 71136.0e3 * 1.024}
+PMC_TRAFFIC_BYTES = {'bf16x3': 2 * 12665.2e3 * 1.024 + 23712.0e3 * 1.024, 'f32': 2 * 23916.2e3 * 1.024 + 71136.0e3 * 1.024}
 
 
 def cpu_baseline(n_distinct=6, min_seconds=12.0):

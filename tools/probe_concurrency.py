@@ -58,6 +58,8 @@ torch.cuda.synchronize()
 print(prec)
 cross('mel | mel', f_mel, (pcmA, plA), f_mel, (pcmB, plB))
 cross('mel | cnn', f_mel, (pcmA, plA), f_cnn, (melB, flB, plB))
+pcmAf = eng.pcm16_to_f32(pcmA)
+cross('mel (float samples) | cnn', f_mel, (pcmAf, plA), f_cnn, (melB, flB, plB))
 cross('mel | self-attention', f_mel, (pcmA, plA), f_td, (fB, plB))
 cross('mel | pooling', f_mel, (pcmA, plA), f_pool, (xB, plB))
 cross('cnn | cnn', f_cnn, (melA, flA, plA), f_cnn, (melB, flB, plB))
