@@ -1,5 +1,5 @@
 // Does a wave's arithmetic change when bf16 MFMA waves run on the same SIMD?  (gfx950; follow-up of exp_split.py)
-// Even waves of each workgroup spam v_mfma_f32_32x32x16_bf16 / 16x16x32; odd waves run deterministic chains of packed-f32
+// Waves 0-3 of each workgroup (one per SIMD) spam v_mfma_f32_32x32x16_bf16 / 16x16x32; waves 4-7 (sharing those SIMDs) run deterministic chains of packed-f32
 // VALU ops, DPP adds, ds_bpermute, v_sqrt / v_log and LDS round trips and write their results.  Run twice -- with the even
 // waves idle and busy -- and compare the odd waves' outputs bit for bit.
 #include <hip/hip_runtime.h>
@@ -14,7 +14,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __global__ __launch_bounds__(512) void k(float* out, int iters, int busy) {
     __shared__ float ex[8][64 * 2 + 16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if ((wave & 1) == 0) {
+    // waves w and w + 4 of a workgroup share a SIMD: role = bit 2 of the wave id, so every SIMD holds one wave of each
+    if (((wave >> 2) & 1) == 0) {
         if (!busy) return;
         bf16x8 a, b;
         for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(lane * 0.001f + i); b[i] = (__bf16)(lane * 0.002f - i); }
@@ -65,7 +66,7 @@ int main() {
     };
     run(0, r0); run(0, r1); run(1, r2);
     long same01 = 0, diff02 = 0;
-    for (int i = 0; i < n; ++i) { if (((i >> 6) & 1) == 0) continue; same01 += memcmp(&r0[i], &r1[i], 4) != 0; diff02 += memcmp(&r0[i], &r2[i], 4) != 0; }
-    printf("odd-wave results: idle vs idle differing %ld, idle vs MFMA-busy differing %ld of %d\n", same01, diff02, n / 2);
+    for (int i = 0; i < n; ++i) { if ((((i & 511) >> 8) & 1) == 0) continue; same01 += memcmp(&r0[i], &r1[i], 4) != 0; diff02 += memcmp(&r0[i], &r2[i], 4) != 0; }
+    printf("VALU-wave results: idle vs idle differing %ld, idle vs MFMA-busy differing %ld of %d\n", same01, diff02, n / 2);
     return 0;
 }

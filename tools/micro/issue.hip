@@ -17,9 +17,11 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
     f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
     float v0 = lane, v1 = lane + 1, v2 = lane + 2, v3 = lane + 3, v4 = lane + 4, v5 = lane + 5, v6 = lane + 6, v7 = lane + 7;
     unsigned p0 = lane, p1 = lane * 3;
-    const bool do_m = MODE == 0 || MODE == 2 || (MODE == 3 && (wave & 1) == 0);
-    const bool do_v = MODE == 1 || MODE == 2 || ((MODE == 3 || MODE == 5 || MODE == 7 || MODE == 8) && (wave & 1) == 1);
-    const bool do_mn = (MODE == 5 || MODE == 7 || MODE == 8) && (wave & 1) == 0;
+    // waves are placed round-robin on the CU's four SIMDs (wave w and w + 4 share one): the role is bit 2 of the wave id
+    const int role = (wave >> 2) & 1;
+    const bool do_m = MODE == 0 || MODE == 2 || (MODE == 3 && role == 0);
+    const bool do_v = MODE == 1 || MODE == 2 || ((MODE == 3 || MODE == 5 || MODE == 7 || MODE == 8) && role == 1);
+    const bool do_mn = (MODE == 5 || MODE == 7 || MODE == 8) && role == 0;
     for (int it = 0; it < iters; ++it) {
         if (do_m) { MFMA(c0); MFMA(c1); MFMA(c2); MFMA(c3); }                       // 4 x 32 cycles
         if (do_v) {                                                                  // 32 x 4 cycles
@@ -73,11 +75,11 @@ int main() {
     run<1>("VALU only", 2, out);
     run<2>("MFMA + VALU in the same wave", 1, out);
     run<2>("MFMA + VALU in the same wave", 2, out);
-    run<3>("even waves MFMA, odd waves VALU", 2, out);
+    run<3>("one MFMA wave + one VALU wave per SIMD", 2, out);
     run<4>("16 x permlane16_swap (dependent)", 1, out);
-    run<5>("even waves MFMA + s_nop 26, odd waves VALU", 2, out);
-    run<8>("even waves MFMA + s_nop 36, odd waves VALU", 2, out);
-    run<7>("even waves MFMA + s_sleep 1, odd waves VALU", 2, out);
+    run<5>("MFMA wave (+ s_nop 26) + VALU wave per SIMD", 2, out);
+    run<8>("MFMA wave (+ s_nop 36) + VALU wave per SIMD", 2, out);
+    run<7>("MFMA wave (+ s_sleep 1) + VALU wave per SIMD", 2, out);
     run<6>("one wave: MFMA, 8 VALU, MFMA, 8 VALU ...", 1, out);
     run<6>("same, two waves", 2, out);
     return 0;
