@@ -214,11 +214,13 @@ typedef struct {
     const uint16_t* pool_wb; /* split-bf16 pooling fragments, or NULL */
     int32_t arch;            /* 0 = CNN-SA-AP (nisqa.tar, nisqa_mos_only.tar); 1 = StandardCNN + BiLSTM + last-step
                               * pooling (nisqa_tts.tar): cnn_w = cnn_std_w blob, td_w = lstm_w blob, pool_w unused */
-    /* Callers that run batches on SEVERAL streams must keep the mel + CNN sections of different batches apart (on
-     * gfx950 a mel workgroup that shares a CU with a split-bf16 conv workgroup of another batch computes wrong
-     * frames -- tools/probe_concurrency.py; self-attention, pooling and the LSTM overlap freely with everything):
-     * conv_section_wait: NULL or a hipEvent_t the stream waits for before the mel kernel (the previous batch's
-     * conv_section_done); conv_section_done: NULL or a caller-created hipEvent_t recorded after the CNN kernel. */
+    /* Callers that run batches on SEVERAL streams must keep the sections of different batches that could share a SIMD
+     * with split-bf16 MFMA waves apart: on gfx950 fp32 VALU arithmetic of one kernel goes wrong next to bf16-MFMA
+     * waves of ANOTHER kernel (tools/micro/corun2.hip; in this library: mel frames next to the conv kernels,
+     * tools/probe_concurrency.py).  conv_section_wait: NULL or a hipEvent_t the stream waits for before the mel
+     * kernel (the previous batch's conv_section_done); conv_section_done: NULL or a caller-created hipEvent_t,
+     * recorded at the end of the forward on the split-bf16 CNN-SA-AP path, after the CNN kernel otherwise (the LSTM
+     * workgroups fill their SIMDs' registers, the fp32-MFMA kernels are harmless neighbours). */
     void* conv_section_wait;
     void* conv_section_done;
 } nisqa_model_dev;

@@ -92,7 +92,6 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
         rc = nq_cnn_adapt_bf16_from_max(mel, frame_off, tok_off, n_wins, cmax, cfg->top_db, n_clips, total_tok_padded,
                                         model->seg_hop, model->cnn_w, model->cnn_wb, feat, stream);
         if (rc) return rc;
-        NQ_SECTION_DONE();
         NQ_STAGE(2);
     } else {
         rc = nisqa_cnn_front(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
@@ -114,6 +113,10 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
                                   model->pool_wb, pool, out, stream)
             : nisqa_pool_att(x, tok_off, n_wins, n_clips, total_tok_padded, model->n_heads, model->pool_w, pool, out, stream);
     if (rc) return rc;
+    // split-bf16 CNN-SA-AP path: the section ends HERE, not after the CNN -- fp32 VALU work of another kernel is not safe
+    // next to bf16-MFMA waves on gfx950 (tools/micro/corun2.hip), and the small pooling kernels could share a SIMD with
+    // the next batch's conv waves
+    if (model->cnn_mode == 1) NQ_SECTION_DONE();
     NQ_STAGE(5);
     return NISQA_OK;
 }

@@ -87,6 +87,12 @@ __device__ constexpr float W32S[32] = {-0.000000000e+00f, -1.950903220e-01f, -3.
 __device__ constexpr float W16C[16] = {1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f, 6.123233996e-17f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f, -1.000000000e+00f, -9.238795325e-01f, -7.071067812e-01f, -3.826834324e-01f, -1.836970199e-16f, 3.826834324e-01f, 7.071067812e-01f, 9.238795325e-01f};
 __device__ constexpr float W16S[16] = {-0.000000000e+00f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f, -1.000000000e+00f, -9.238795325e-01f, -7.071067812e-01f, -3.826834324e-01f, -1.224646799e-16f, 3.826834324e-01f, 7.071067812e-01f, 9.238795325e-01f, 1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f};
 
+// wave-private LDS round trips: a compiler barrier, plus (NQ_MEL_LDS_WAIT) a wait for the wave's outstanding LDS operations
+#ifdef NQ_MEL_LDS_WAIT
+#define MEL_WBAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define MEL_WBAR() __builtin_amdgcn_wave_barrier()
+#endif
 #define MEL_WAVES 4
 #define MEL_EXCH_BYTES 5120            /* exchange 1 [8][72] complex (4608 B) and exchange 2 64 x 80 B alias */
 
@@ -135,24 +141,24 @@ NQ_DEV void fft512(c32 (&u)[8], const c32 (&z)[8], const mel_twiddles& tw, char*
     c32* b1 = (c32*)exch;
 #pragma unroll
     for (int p = 0; p < 8; ++p) b1[p * 72 + lane] = u[p];
-    __builtin_amdgcn_wave_barrier();
+    MEL_WBAR();
     const int pq = lane >> 3, j1 = lane & 7;
 #pragma unroll
     for (int j2 = 0; j2 < 8; ++j2) u[j2] = b1[pq * 72 + j1 + 8 * j2];
-    __builtin_amdgcn_wave_barrier();
+    MEL_WBAR();
     dft8(u);                                                // over j2 -> q1
 #pragma unroll
     for (int q1 = 1; q1 < 8; ++q1) u[q1] = cmul(u[q1], tw.c[q1]);
 #pragma unroll
     for (int q1 = 0; q1 < 8; ++q1) *(c32*)(exch + (pq + 8 * q1) * 80 + j1 * 8) = u[q1];
-    __builtin_amdgcn_wave_barrier();
+    MEL_WBAR();
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 t4 = *(const f32x4*)(exch + lane * 80 + q * 16);
         u[2 * q] = cmk(t4[0], t4[1]);
         u[2 * q + 1] = cmk(t4[2], t4[3]);
     }
-    __builtin_amdgcn_wave_barrier();
+    MEL_WBAR();
     dft8(u);                                                // over j1 -> q2 ; k = lane + 64 q2
 }
 
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
                 mag[3 * mag_stride + lane + 64 * q2] = xmag(u[q2], z1m, tw.d[3], w16);
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        MEL_WBAR();
 
         // ---- sparse slaney filterbank: 4 bands per pass (one per 16-lane row)
         float mine = 0.f;
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
             part = row16_sum(part);
             if (l16 == ps) mine = part;                 // lane 16*row + ps holds band 4*ps + row
         }
-        __builtin_amdgcn_wave_barrier();
+        MEL_WBAR();
         // ---- amplitude_to_db(ref=1, amin=1e-4): 10*log10(max(amin^2, S^2)); running per-clip max
         if (l16 < 12) {
             const float db = 10.0f * log10f(fmaxf(cfg.amin_sq, mine * mine));
