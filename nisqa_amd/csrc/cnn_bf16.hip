@@ -12,12 +12,15 @@
 // Structure (differences from the fp32 kernels are consequences of the 5x faster matrix pipe):
 //   * a workgroup is FOUR waves = four segments; conv1..conv4 are wave-private and barrier-free: each wave
 //     streams its weight fragments from L2 into a 3-deep register ring (conv_bf16.hpp) and keeps its
-//     activations in its own LDS region as two bf16 planes (hi, lo), pixel-major, XOR-swizzled 16-byte
-//     chunks, with the same row->pixel maps as the fp32 kernel so the adaptive max-pools stay in-lane;
-//   * conv1 runs on the matrix pipe too (im2col gather of the 9 taps from two zero-bordered bf16 planes of
-//     the input patch), because at this speed the VALU version would cost as much as conv2-4;
+//     activations in its own LDS region as two bf16 planes (hi, lo), pixel-major with pixel rows padded by
+//     16 bytes, with the same row->pixel maps as the fp32 kernel so the adaptive max-pools stay in-lane;
+//   * conv1 runs on the matrix pipe too, two mel-adjacent output pixels per MFMA row (operands are dword reads
+//     from two zero-bordered bf16 planes of the input patch, no packing), because at this speed the VALU
+//     version would cost as much as conv2-4;
 //   * conv5/conv6 (18 / 6 output pixels per segment) are batched over the workgroup's four segments with the
 //     output channels split over the waves (16x16x32 MFMA tiles), so no tile is mostly padding.
+// On gfx950 MFMA and VALU instructions of a SIMD do not overlap (tools/micro/issue.hip): the kernel's time is its MFMA
+// cycles plus its VALU cycles plus stalls, so every VALU instruction removed counts.
 #include "common.hpp"
 #include "layout.hpp"
 #include "conv_bf16.hpp"
