@@ -345,6 +345,38 @@ def test_staging_iterator_surfaces_load_errors_in_order(tmp_path):
 
 
 # ---- C ABI ------------------------------------------------------------------------------------------------
+def test_struct_layouts_match_the_c_headers(tmp_path):
+    """The ctypes mirrors in nisqa_amd/lib.py against the structs a C compiler sees in include/*.h: size and every
+    field offset (a maintainer binding the C ABI from another language gets the same numbers from the header)."""
+    import subprocess
+    from nisqa_amd import lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {'nisqa_mel_cfg': lib.MelCfg, 'nisqa_model_dev': lib.ModelDev, 'nisqa_wav_info': lib.WavInfo}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "nisqa_hip.h"', '#include "nisqa_ingest.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        lines.append('  printf("%s size %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-std=c99', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split('\n')
+    seen = 0
+    for line in out:
+        if not line.strip():
+            continue
+        cname, fname, val = line.split()
+        cls = structs[cname]
+        if fname == 'size':
+            assert ctypes.sizeof(cls) == int(val), (cname, ctypes.sizeof(cls), val)
+        else:
+            assert getattr(cls, fname).offset == int(val), (cname, fname, getattr(cls, fname).offset, val)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in structs.values())
+
+
 def test_library_exports_every_declared_symbol():
     from nisqa_amd import lib
     hdr = open(os.path.join(ROOT, 'include', 'nisqa_hip.h')).read()
