@@ -284,7 +284,14 @@ class SpeechQualityDataset(object):
             pad = np.zeros((self.max_length,) + x.shape[1:], np.float32)
             pad[:n_wins] = x
             x = pad
-        return torch.from_numpy(np.ascontiguousarray(x)), self.labels(1)[0], (index, np.array(n_wins))
+        return torch.from_numpy(np.ascontiguousarray(x)), self.label(index), (index, np.array(n_wins))
+
+    def label(self, index):
+        """y of item ``index`` like NL:2217-2231: NaN in predict_only mode, else row ``index`` of the MOS column(s)."""
+        if self.mos_column == 'predict_only':
+            return np.full(5 if self.dim else 1, np.nan, dtype=np.float32)
+        cols = ['mos', 'noi', 'dis', 'col', 'loud'] if self.dim else [self.mos_column]
+        return np.array([self.df[c].iloc[index] for c in cols], dtype=np.float32)
 
     def labels(self, n):
         """Labels of the first n items like NL:2217-2231: NaN rows in predict_only mode, else the csv columns."""

@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     long long clk[13];
 #endif
     NQ_CLK(0);
+    if (NQ_EXP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+    if (NQ_EXP_PRIO == 3 && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u)) __builtin_amdgcn_s_setprio(1);   // HW_ID[3:0] = wave slot
 
     // ---- stage the 15-frame window as two zero-bordered bf16 planes (hi, lo) [frame j + 1][mel m + 1]:
     //      the 3x3 taps of any output pixel are then at constant offsets from it, no bounds checks.
@@ -362,6 +364,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             }
         };
         load_a5(0);
+        NQ_PRIO_KLOOP_BEGIN();
 #pragma unroll
         for (int g = 0; g < 18; ++g) {
             if (g + 3 < 18) { b5[(g + 3) & 3][0] = w5[(g + 3) * 128]; b5[(g + 3) & 3][1] = w5[(g + 3) * 128 + 64]; }
@@ -373,6 +376,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 #pragma unroll
             for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(a5[g & 1][t][0], b5[g & 3][0], acc5[t]);
         }
+        NQ_PRIO_KLOOP_END();
         NQ_CLK(9);
 #pragma unroll
         for (int g = 0; g < 7; ++g) { b6[g][0] = w6[g * 128]; b6[g][1] = w6[g * 128 + 64]; }
@@ -430,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             }
         };
         load_a6(0);
+        NQ_PRIO_KLOOP_BEGIN();
 #pragma unroll
         for (int g = 0; g < 18; ++g) {
             if (g + 7 < 18) { b6[(g + 7) & 7][0] = w6[(g + 7) * 128]; b6[(g + 7) & 7][1] = w6[(g + 7) * 128 + 64]; }
@@ -450,6 +455,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                 for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(a6[0][t][0], b6[g & 7][0], acc6[t]);
             }
         }
+        NQ_PRIO_KLOOP_END();
         NQ_CLK(11);
         // this wave's 4 x 96 outputs (slot, channel * 6 + y) go through S4 (dead since the barrier above) so that the
         // feature rows leave as 16-byte stores: 384 contiguous bytes per slot

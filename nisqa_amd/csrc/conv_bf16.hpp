@@ -5,6 +5,14 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// experiment hook (tools/ab_build.sh): wave priority around the MFMA K loops.  1: K loops at priority 1, epilogues 0;
+// 2: the reverse; 3: static, by the parity of the hardware wave slot (the two waves of a SIMD differ in it)
+#ifndef NQ_EXP_PRIO
+#define NQ_EXP_PRIO 0
+#endif
+#define NQ_PRIO_KLOOP_BEGIN() do { if (NQ_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(1); if (NQ_EXP_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
+#define NQ_PRIO_KLOOP_END() do { if (NQ_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(0); if (NQ_EXP_PRIO == 2) __builtin_amdgcn_s_setprio(1); } while (0)
+
 NQ_DEV f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -96,6 +104,7 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
     load_b(0, 0);
     load_b(1, 1);
     if (APF) load_a(0, 0);
+    NQ_PRIO_KLOOP_BEGIN();
 #pragma unroll
     for (int g = 0; g < TOTAL; ++g) {
         if (g + 2 < TOTAL) load_b(g + 2, (g + 2) % 3);
@@ -116,5 +125,6 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
             for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bh[sb][nt], acc[t][nt]);
 
     }
+    NQ_PRIO_KLOOP_END();
 }
 

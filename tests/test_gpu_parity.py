@@ -3,7 +3,7 @@ golden fixtures, stage by stage and end to end, through the C ABI (ctypes -> lib
 
 Both precision paths of the engine are run: 'f32' (every GEMM on exact fp32 MFMA) and 'bf16x3' (default: AdaptCNN
 on split-bf16 MFMA).  Tolerances (floating point; the bar of BASELINE.json is |dMOS| <= 1e-3 end to end):
-  mel dB        2e-3 dB   (f32 FFT vs librosa's f64 FFT; worst near the amin floor; measured <= 2.6e-4)
+  mel dB        1e-3 dB   (f32 FFT vs librosa's f64 FFT; worst near the amin floor; measured <= 2.6e-4)
   CNN features  f32 2e-4 (measured 1.3e-5)   bf16x3 1e-3 (measured 1.5e-4, features reach |8|)
   td output     same bounds (measured 2e-6 / 1.6e-5)
   final outputs f32 1e-4 (measured 2.2e-6)   bf16x3 2e-4 (measured 2.7e-5)   -- north-star bar 1e-3
@@ -30,6 +30,7 @@ def clip_pcm(i):
 
 
 PRECISIONS = ['f32', 'bf16x3']
+MEL_TOL = 1e-3          # dB
 # stage tolerances per precision path: (CNN features / td output, final outputs)
 TOL = {'f32': (2e-4, 1e-4), 'bf16x3': (1e-3, 2e-4)}
 
@@ -86,9 +87,9 @@ def test_mel_matches_oracle(eng_rand, batch):
         assert got.shape == ref.shape
         err = np.abs(got - ref).max()
         print('mel clip', i, 'T', ref.shape[1], 'max|d|', err)
-        assert err < 2e-3, (i, err)
+        assert err < MEL_TOL, (i, err)
         if 'mel_%d' % i in g.files:
-            assert np.abs(got - g['mel_%d' % i]).max() < 2e-3
+            assert np.abs(got - g['mel_%d' % i]).max() < MEL_TOL
 
 
 @pytest.mark.parametrize('sr', [16000, 44100, 8000, 22050, 96000, 192000, 51300])
@@ -107,7 +108,7 @@ def test_mel_other_sample_rates(eng_rand, sr):
         assert got.shape == ref.shape
         err = np.abs(got - ref).max()
         print('sr', sr, 'clip', n, 'max|d|', err)
-        assert err < 2e-3
+        assert err < MEL_TOL
 
 
 def test_pcm16_conversion(eng_rand):
@@ -388,7 +389,7 @@ def test_tts_architecture_stages_and_fixture(name, precision):
         worst['out'] = max(worst['out'], np.abs(out_h[n] - ref_out).max(), np.abs(outs_h[n] - ref_out).max())
     err_fix = np.abs(out_h - g['out']).max()
     print(name, precision, 'stage max|d|', worst, 'vs reference fixture', err_fix)
-    assert worst['mel'] < 2e-3 and worst['feat'] < TOL[precision][0] and worst['td'] < TOL[precision][0]
+    assert worst['mel'] < MEL_TOL and worst['feat'] < TOL[precision][0] and worst['td'] < TOL[precision][0]
     assert worst['out'] < 1e-3 and err_fix < 1e-3
 
 
@@ -415,3 +416,109 @@ def test_tts_drop_in_surface(tmp_path):
         spec = omel.get_melspec(str(d / row['deg']), None, 4096, 0.01, 0.02, 48, 8000)
         ref = onet.predict_from_melspec(sd, m.args, spec)
         assert abs(row['mos_pred'] - ref[0]) < 1e-3
+
+
+# ---- BASELINE configurations at their own sizes vs fixtures of the reference's modules (make_golden_configs.py) ----
+def _dim_set(name):
+    if name == 'dim_real':
+        path = helpers.find_weights('nisqa.tar')
+        if path is None:
+            pytest.skip('real checkpoint not on this machine')
+        return helpers.load_checkpoint(path)
+    return dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM')
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+@pytest.mark.parametrize('name', ['dim_real', 'dim_rand'])
+def test_config2_bs64_of_64_distinct_clips_matches_reference_fixture(name, precision):
+    """configs[1] at full size: ONE bs = 64 call of 64 different 10 s clips, every row against the reference."""
+    g = helpers.golden('net_cfg2_%s.npz' % name)
+    args, sd = _dim_set(name)
+    eng = _engine(args, sd, precision)
+    pcm = [synth.synth_pcm16(int(s), 10.0) for s in g['seeds']]
+    dev_pcm, plan = _upload(eng, pcm)
+    assert plan.n_clips == 64 and list(plan.n_wins) == list(g['n_wins'])
+    out = eng.forward_pcm(dev_pcm, plan, 48000)
+    out16 = eng.forward_pcm(torch.from_numpy(np.concatenate(pcm)).to(eng.device), plan, 48000)   # what predict_dir feeds
+    torch.cuda.synchronize()
+    err = np.abs(out.cpu().numpy() - g['out']).max(axis=1)
+    print(name, precision, 'bs64 per-clip max|d| (max %.3g):' % err.max(), np.array2string(err, precision=2))
+    assert err.max() < TOL[precision][1]
+    np.testing.assert_array_equal(out16.cpu().numpy(), out.cpu().numpy())
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+@pytest.mark.parametrize('name', ['dim_real', 'dim_rand'])
+def test_config3_bs256_sampled_rows_match_reference_fixture(name, precision):
+    """configs[2]: ONE bs = 256 call; 16 sampled rows carry distinct clips with reference results, the other 240 rows
+    are filler clips (four distinct ones, checked against each other only)."""
+    g = helpers.golden('net_cfg3_%s.npz' % name)
+    args, sd = _dim_set(name)
+    eng = _engine(args, sd, precision)
+    rows = [int(r) for r in g['rows']]
+    filler = [synth.synth_pcm16(300 + i, 10.0) for i in range(4)]
+    pcm = [filler[r % 4] for r in range(256)]
+    for r in rows:
+        pcm[r] = synth.synth_pcm16(int(g['seed0']) + r, 10.0)
+    plan = eng.plan([len(p) for p in pcm], 48000)
+    out = eng.forward_pcm(torch.from_numpy(np.concatenate(pcm)).to(eng.device), plan, 48000).cpu().numpy()
+    assert out.shape == (256, 5) and np.isfinite(out).all()
+    err = np.abs(out[rows] - g['out']).max(axis=1)
+    print(name, precision, 'bs256 sampled rows max|d| (max %.3g):' % err.max(), np.array2string(err, precision=2))
+    assert err.max() < TOL[precision][1]
+    rest = [r for r in range(256) if r not in rows]
+    ref4 = {}
+    for r in rest:
+        ref4.setdefault(r % 4, out[r])
+        assert np.abs(out[r] - ref4[r % 4]).max() < 1e-5
+
+
+@pytest.mark.parametrize('precision', PRECISIONS)
+@pytest.mark.parametrize('name', ['tts_real', 'tts_rand'])
+def test_config4_tts_long_clips_match_reference_fixture(name, precision):
+    """configs[3] lengths on the nisqa_tts.tar architecture: 30 s (2 987 sequential LSTM steps, NL:925-943), 17.3 s and
+    3 s in one mixed batch; CNN features / LSTM outputs at the sampled steps and the final MOS vs the reference."""
+    g = helpers.golden('net_cfg4_%s.npz' % name)
+    if name == 'tts_real':
+        path = helpers.find_weights('nisqa_tts.tar')
+        if path is None:
+            pytest.skip('real checkpoint not on this machine')
+        args, sd = helpers.load_checkpoint(path)
+    else:
+        args, sd = dict(helpers.TTS_ARGS), helpers.random_state_dict(9, 'NISQA_TTS')
+    eng = _engine(args, sd, precision)
+    pcm = [synth.synth_pcm16(int(s), float(d)) for s, d in zip(g['seeds'], g['seconds'])]
+    dev_pcm, plan = _upload(eng, pcm)
+    assert list(plan.n_wins) == list(g['n_wins']) == [2987, 1717, 287]
+    mel, floor = eng.mel(dev_pcm, plan, 48000, clamp=False)
+    feat = eng.cnn_std(mel, floor, plan)
+    out_st, seq = eng.lstm(feat, plan, want_seq=True)
+    out = eng.forward_pcm(dev_pcm, plan, 48000)
+    torch.cuda.synchronize()
+    feat_h, seq_h, out_h = feat.cpu().numpy(), seq.cpu().numpy(), out.cpu().numpy()
+    worst = {'feat': 0.0, 'td': 0.0}
+    for n in range(3):
+        idx, t0 = g['stage_idx_%d' % n], int(plan.tok_off[n])
+        worst['feat'] = max(worst['feat'], np.abs(feat_h[t0 + idx] - g['feat_%d' % n]).max())
+        worst['td'] = max(worst['td'], np.abs(seq_h[t0 + idx] - g['td_%d' % n]).max())
+    err = np.abs(out_h - g['out']).max(axis=1)
+    print(name, precision, 'tts long clips: stage max|d|', worst, 'per-clip output max|d|', err)
+    assert worst['feat'] < TOL[precision][0] and worst['td'] < TOL[precision][0]
+    assert err.max() < 1e-3 and np.abs(out_st.cpu().numpy() - g['out']).max() < 1e-3
+
+
+def test_mel_against_librosa_fixture_or_report_unpinned(eng_rand):
+    """GPU mel vs librosa 0.8.1's own output (tests/golden/mel_librosa.npz, make_golden_librosa.py).  XFAIL 'parity
+    unpinned' while that file is absent -- see tests/test_oracle.py."""
+    path = os.path.join(helpers.GOLDEN, 'mel_librosa.npz')
+    if not os.path.isfile(path):
+        pytest.xfail('PARITY UNPINNED: tests/golden/mel_librosa.npz (librosa==0.8.1 output) is not committed')
+    g = np.load(path, allow_pickle=False)
+    ids = list(range(len(CLIPS)))
+    pcm = [clip_pcm(i) for i in ids]
+    dev_pcm, plan = _upload(eng_rand, pcm)
+    mel, _ = eng_rand.mel(dev_pcm, plan, 48000, clamp=True)
+    mel = mel.cpu().numpy()
+    for n, i in enumerate(ids):
+        got = mel[plan.frame_off[n]:plan.frame_off[n + 1]].T
+        assert np.abs(got - g['mel_%d' % i]).max() < MEL_TOL

@@ -661,3 +661,31 @@ def test_predict_loop_sharded_over_two_gloo_ranks(tmp_path, wav_dir):
     np.testing.assert_allclose(np.array(r0['y']), y, rtol=0, atol=1e-6)
     assert np.isnan(ynan).all() and ynan.shape == (5, 5)
     assert r0['cols'] == ['deg', 'mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred']
+
+
+def test_dataset_item_label_follows_the_index(tmp_path):
+    """SpeechQualityDataset.__getitem__(k) returns the label of row k (NL:2217-2231), not of row 0."""
+    from nisqa_amd import NISQA_lib as NL
+    d = tmp_path / 'w'
+    d.mkdir()
+    for i in range(3):
+        synth.write_wav(str(d / ('c%d.wav' % i)), synth.synth_pcm16(i, 0.3), 48000)
+    df = pd.DataFrame({'deg': ['c0.wav', 'c1.wav', 'c2.wav'], 'mos': [1.5, 2.5, 3.5], 'noi': [1.0, 2.0, 3.0],
+                       'dis': [4.0, 4.1, 4.2], 'col': [2.2, 2.3, 2.4], 'loud': [3.0, 3.1, np.nan]})
+
+    class MelEngine(FakeEngine):
+        def mel(self, pcm, plan, sr, clamp=True):
+            return torch.zeros((int(plan.total_frames), 48)), None
+
+    for dim, col in ((True, 'mos'), (False, 'mos')):
+        ds = NL.SpeechQualityDataset(df, data_dir=str(d), filename_column='deg', mos_column=col, seg_length=15,
+                                     max_length=40, seg_hop_length=4, ms_n_fft=4096, ms_hop_length=0.01,
+                                     ms_win_length=0.02, ms_n_mels=48, ms_sr=None, ms_fmax=20000, dim=dim)
+        ds.bind_engine(lambda: MelEngine(5 if dim else 1))
+        for k in range(3):
+            x, y, (idx, n_wins) = ds[k]
+            want = df[['mos', 'noi', 'dis', 'col', 'loud']].iloc[k].to_numpy(np.float32) if dim else np.float32([df['mos'].iloc[k]])
+            assert idx == k and y.dtype == np.float32 and y.shape == want.shape
+            np.testing.assert_array_equal(y, want)
+            assert tuple(x.shape) == (40, 1, 48, 15)
+        np.testing.assert_array_equal(ds.labels(3)[:, 0], np.float32([1.5, 2.5, 3.5]))

@@ -182,3 +182,119 @@ def test_mel_oracle_against_independent_librosa_compatible_implementation(sr):
     assert got.shape == want.shape
     # float32 (librosa's dtype discipline, oracle) against float64 (transformers): measured 1.2e-5 dB
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)
+
+
+# ---- fixtures for the BASELINE configurations (tests/golden/make_golden_configs.py) ------------------------------
+def _dim_set(name):
+    if name == 'dim_real':
+        path = helpers.find_weights('nisqa.tar')
+        if path is None:
+            pytest.skip('real checkpoint not on this machine')
+        return helpers.load_checkpoint(path)
+    return dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM')
+
+
+@pytest.mark.parametrize('name', ['dim_real', 'dim_rand'])
+def test_net_oracle_matches_config2_and_config3_fixtures(name):
+    """A sample of the 64 distinct bs = 64 clips and of the bs = 256 rows (reference modules, batched) vs the oracle
+    (clip by clip): also shows that the reference's rows do not depend on the batch they were computed in."""
+    args, sd = _dim_set(name)
+    g2, g3 = helpers.golden('net_cfg2_%s.npz' % name), helpers.golden('net_cfg3_%s.npz' % name)
+    for k in (0, 21, 63):
+        pcm = synth.synth_pcm16(int(g2['seeds'][k]), 10.0)
+        assert zlib.crc32(pcm.tobytes()) == int(g2['pcm_crc32'][k])
+        out = onet.predict_from_melspec(sd, args, omel.melspec_db_from_audio(pcm.astype(np.float32) / np.float32(32768.0), 48000))
+        np.testing.assert_allclose(out, g2['out'][k], rtol=0, atol=2e-5)
+    for k in (2, 15):
+        pcm = synth.synth_pcm16(int(g3['seed0']) + int(g3['rows'][k]), 10.0)
+        assert zlib.crc32(pcm.tobytes()) == int(g3['pcm_crc32'][k])
+        out = onet.predict_from_melspec(sd, args, omel.melspec_db_from_audio(pcm.astype(np.float32) / np.float32(32768.0), 48000))
+        np.testing.assert_allclose(out, g3['out'][k], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', ['tts_real', 'tts_rand'])
+def test_net_oracle_matches_config4_long_clip_fixture(name):
+    """nisqa_tts.tar architecture at BASELINE configs[3] lengths: 30 s = 2 987 sequential LSTM steps (NL:925-943)."""
+    g = helpers.golden('net_cfg4_%s.npz' % name)
+    if name == 'tts_real':
+        path = helpers.find_weights('nisqa_tts.tar')
+        if path is None:
+            pytest.skip('real checkpoint not on this machine')
+        args, sd = helpers.load_checkpoint(path)
+    else:
+        args, sd = dict(helpers.TTS_ARGS), helpers.random_state_dict(9, 'NISQA_TTS')
+    assert list(g['n_wins']) == [2987, 1717, 287]
+    for n in (0, 2):
+        pcm = synth.synth_pcm16(int(g['seeds'][n]), float(g['seconds'][n]))
+        assert zlib.crc32(pcm.tobytes()) == int(g['pcm_crc32'][n])
+        spec = omel.melspec_db_from_audio(pcm.astype(np.float32) / np.float32(32768.0), 48000, fmax=8000.0)
+        out, st = onet.predict_from_melspec(sd, args, spec, return_stages=True)
+        idx = g['stage_idx_%d' % n]
+        np.testing.assert_allclose(out, g['out'][n], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(st['feat'][idx], g['feat_%d' % n], rtol=0, atol=5e-5)
+        np.testing.assert_allclose(st['td'][idx], g['td_%d' % n], rtol=0, atol=5e-5)
+
+
+# ---- the mel stage: what can and cannot be pinned here ------------------------------------------------------------
+def _scipy_melspec_db(y, sr, fmax):
+    """THIRD restatement of the mel front end, sharing no code with oracle/mel.py or transformers.audio_utils:
+    framing + FFT by scipy.signal.stft (its own segmenting / detrend / scaling code), the slaney triangles by
+    numpy.interp over the band edges, dB by the textbook formula in float64."""
+    from scipy import signal
+    n_fft, hop, win = 4096, int(sr * 0.01), int(sr * 0.02)
+    ypad = np.pad(np.asarray(y, np.float64), n_fft // 2, mode='reflect')
+    lead = (n_fft - win) // 2                      # librosa centres the window inside the n_fft frame
+    w = signal.get_window('hann', win, fftbins=True)
+    _, _, Z = signal.stft(ypad[lead:], fs=sr, window=w, nperseg=win, noverlap=win - hop, nfft=n_fft, detrend=False,
+                          return_onesided=True, boundary=None, padded=False, scaling='spectrum')
+    n_frames = 1 + len(y) // hop
+    S = np.abs(Z[:, :n_frames]) * w.sum()          # undo scipy's 1 / sum(window)
+    f_sp, min_log_hz, logstep = 200.0 / 3, 1000.0, np.log(6.4) / 27.0
+
+    def to_mel(f):
+        return f / f_sp if f < min_log_hz else min_log_hz / f_sp + np.log(f / min_log_hz) / logstep
+
+    def to_hz(m):
+        return f_sp * m if m < min_log_hz / f_sp else min_log_hz * np.exp(logstep * (m - min_log_hz / f_sp))
+
+    edges = np.array([to_hz(m) for m in np.linspace(to_mel(0.0), to_mel(fmax), 48 + 2)])
+    freqs = np.arange(1 + n_fft // 2) * (sr / float(n_fft))
+    fb = np.stack([np.interp(freqs, edges[i:i + 3], [0.0, 1.0, 0.0], left=0.0, right=0.0) * 2.0 / (edges[i + 2] - edges[i])
+                   for i in range(48)])
+    M = fb @ S
+    db = 20.0 * np.log10(np.maximum(1e-4, M))
+    return np.maximum(db, db.max() - 80.0)
+
+
+@pytest.mark.parametrize('sr,fmax', [(48000, 20000.0), (48000, 8000.0), (16000, 8000.0)])
+def test_mel_oracle_against_scipy_stft_restatement(sr, fmax):
+    pcm = synth.synth_pcm16(12, 2.3, sr=sr)
+    y = pcm.astype(np.float32) / np.float32(32768.0)
+    got = omel.melspec_db_from_audio(y, sr, fmax=fmax)
+    want = _scipy_melspec_db(y, sr, fmax)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-4)       # float32 oracle vs float64: measured ~1e-5 dB
+
+
+LIBROSA_FIXTURE = 'mel_librosa.npz'
+
+
+def test_mel_oracle_against_librosa_fixture_or_report_unpinned():
+    """The ONLY test that can pin the mel stage: tests/golden/mel_librosa.npz, written by librosa 0.8.1 itself
+    (tests/golden/make_golden_librosa.py, to be run on a machine that has the reference's env.yml).  While that file
+    is absent this test reports XFAIL 'parity unpinned' -- nothing else in the suite may be read as a librosa pin."""
+    import os
+    path = os.path.join(helpers.GOLDEN, LIBROSA_FIXTURE)
+    if not os.path.isfile(path):
+        pytest.xfail('PARITY UNPINNED: tests/golden/mel_librosa.npz (librosa==0.8.1 output) is not committed; '
+                     'the mel stage is checked against restatements only')
+    g = np.load(path, allow_pickle=False)
+    assert str(g['librosa_version']) == '0.8.1'
+    for i in range(len(CLIPS)):
+        pcm = clip_pcm(i)
+        assert zlib.crc32(pcm.tobytes()) == int(g['pcm_crc32'][i])
+        for tag, fmax in (('mel', 20000.0), ('mel8k', 8000.0)):
+            if '%s_%d' % (tag, i) not in g.files:
+                continue
+            got = omel.melspec_db_from_audio(pcm.astype(np.float32) / np.float32(32768.0), 48000, fmax=fmax)
+            np.testing.assert_allclose(got, g['%s_%d' % (tag, i)], rtol=0, atol=1e-3)
