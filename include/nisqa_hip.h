@@ -36,7 +36,7 @@ extern "C" {
 #define NISQA_ERR_LAUNCH 2     /* a kernel launch failed */
 #define NISQA_ERR_WORKSPACE 3  /* workspace too small */
 
-#define NISQA_ABI_VERSION 1
+#define NISQA_ABI_VERSION 2
 #define NISQA_N_MELS 48
 #define NISQA_SEG_LEN 15
 #define NISQA_N_FFT 4096
@@ -214,15 +214,10 @@ typedef struct {
     const uint16_t* pool_wb; /* split-bf16 pooling fragments, or NULL */
     int32_t arch;            /* 0 = CNN-SA-AP (nisqa.tar, nisqa_mos_only.tar); 1 = StandardCNN + BiLSTM + last-step
                               * pooling (nisqa_tts.tar): cnn_w = cnn_std_w blob, td_w = lstm_w blob, pool_w unused */
-    /* Callers that run batches on SEVERAL streams must keep the sections of different batches that could share a SIMD
-     * with split-bf16 MFMA waves apart: on gfx950 fp32 VALU arithmetic of one kernel goes wrong next to bf16-MFMA
-     * waves of ANOTHER kernel (tools/micro/corun2.hip; in this library: mel frames next to the conv kernels,
-     * tools/probe_concurrency.py).  conv_section_wait: NULL or a hipEvent_t the stream waits for before the mel
-     * kernel (the previous batch's conv_section_done); conv_section_done: NULL or a caller-created hipEvent_t,
-     * recorded at the end of the forward on the split-bf16 CNN-SA-AP path, after the CNN kernel otherwise (the LSTM
-     * workgroups fill their SIMDs' registers, the fp32-MFMA kernels are harmless neighbours). */
-    void* conv_section_wait;
-    void* conv_section_done;
+    /* Batches may be in flight on SEVERAL streams at once (the predict loop keeps two): every kernel pair of this library
+     * is bit-exact under overlap.  (Round 1 kept the mel + CNN sections of different streams apart with two event
+     * fields here; the cause -- a gfx950 packed-f32 op_sel form that misreads next to another kernel's bf16 MFMA waves,
+     * tools/micro/corun6.hip -- is avoided in the kernels now and tests/test_host.py lints the ISA for it.) */
 } nisqa_model_dev;
 
 size_t nisqa_workspace_bytes(int32_t n_clips, int32_t total_frames, int32_t total_tok_padded);

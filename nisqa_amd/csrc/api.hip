@@ -49,11 +49,7 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
     float* x = (float*)(w + p.x);
     float* pool = (float*)(w + p.pool);
     void* const* ev = model->stage_events;
-#define NQ_SECTION_DONE() do { if (model->conv_section_done && hipEventRecord((hipEvent_t)model->conv_section_done, (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH; } while (0)
 #define NQ_STAGE(i) do { if (ev && hipEventRecord((hipEvent_t)ev[i], (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH; } while (0)
-    if (model->conv_section_wait &&
-        hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)model->conv_section_wait, 0) != hipSuccess)
-        return NISQA_ERR_LAUNCH;
     if (hipMemsetAsync(cmax, 0, (size_t)n_clips * 4, (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH;
     NQ_STAGE(0);
     int rc = pcm16 ? nisqa_mel_db_pcm16((const int16_t*)pcm, clip_off, frame_off, n_clips, total_frames, cfg, model->window,
@@ -79,7 +75,6 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
                  : nisqa_cnn_standard(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded,
                                       model->seg_hop, model->cnn_w, p3, feat, stream);
         if (rc) return rc;
-        NQ_SECTION_DONE();
         NQ_STAGE(2);
         NQ_STAGE(3);
         rc = nisqa_lstm_laststep(feat, tok_off, n_wins, n_clips, model->td_w, td, nullptr, out, stream);
@@ -100,7 +95,6 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
         NQ_STAGE(2);
         rc = nisqa_cnn_back(p3, tok_off, n_wins, n_clips, total_tok_padded, model->cnn_w, feat, stream);
         if (rc) return rc;
-        NQ_SECTION_DONE();
     }
     NQ_STAGE(3);
     const bool bf = model->cnn_mode == 1 && model->td_wb && model->pool_wb;
@@ -113,10 +107,6 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
                                   model->pool_wb, pool, out, stream)
             : nisqa_pool_att(x, tok_off, n_wins, n_clips, total_tok_padded, model->n_heads, model->pool_w, pool, out, stream);
     if (rc) return rc;
-    // split-bf16 CNN-SA-AP path: the section ends HERE, not after the CNN -- fp32 VALU work of another kernel is not safe
-    // next to bf16-MFMA waves on gfx950 (tools/micro/corun2.hip), and the small pooling kernels could share a SIMD with
-    // the next batch's conv waves
-    if (model->cnn_mode == 1) NQ_SECTION_DONE();
     NQ_STAGE(5);
     return NISQA_OK;
 }

@@ -136,7 +136,6 @@ class HipNisqa(object):
             self.td_wb = self.pool_wb = None
             self._mel = {}
             self._ws = {}
-            self._init_sections()
             return
         self.n_layers = int(a['td_sa_num_layers'])
         heads = ['pool_layers.%d.model.' % h for h in range(5)] if self.dim else ['pool.model.']
@@ -150,7 +149,6 @@ class HipNisqa(object):
         self.pool_wb = up(_w.pack_pool_att_bf16(state_dict, heads).view(np.int16)) if bf else None
         self._mel = {}
         self._ws = {}                      # one workspace per stream (batches may be in flight on several)
-        self._init_sections()
 
     # -- tables -----------------------------------------------------------------------------
     def mel_tables(self, sr):
@@ -175,15 +173,6 @@ class HipNisqa(object):
     def plan(self, lengths, sr, names=None):
         return BatchPlan(lengths, self.mel_tables(sr)['host'].hop, self.seg_hop, self.max_segments, names)
 
-    def _init_sections(self):
-        """Events that keep the mel + CNN sections of batches on different streams apart (forward_pcm)."""
-        self._section, self._section_i, self._section_events = None, 0, []
-        if self.device.type == 'cuda':
-            for _ in range(8):
-                e = torch.cuda.Event()
-                e.record(torch.cuda.current_stream(self.device))      # forces handle creation; re-recorded by the library
-                self._section_events.append(e)
-
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -207,15 +196,6 @@ class HipNisqa(object):
         if stage_events is not None:
             arr = (ctypes.c_void_p * 6)(*[ctypes.c_void_p(e.cuda_event) for e in stage_events])
             model.stage_events = ctypes.cast(arr, ctypes.c_void_p)
-        # mel + CNN sections of batches on DIFFERENT streams must not overlap (nisqa_model_dev.conv_section_*): wait for
-        # the previous call's section if it ran on another stream, and publish this one's
-        prev = self._section
-        if prev is not None and prev[1] != skey:
-            model.conv_section_wait = ctypes.c_void_p(prev[0].cuda_event)
-        ev = self._section_events[self._section_i % len(self._section_events)]
-        self._section_i += 1
-        model.conv_section_done = ctypes.c_void_p(ev.cuda_event)
-        self._section = (ev, skey)
         entry = self.lib.nisqa_predict_batch_pcm16 if pcm.dtype == torch.int16 else self.lib.nisqa_predict_batch
         rc = entry(_ptr(pcm), _ptr(d['clip_off']), _ptr(d['frame_off']), _ptr(d['tok_off']),
                    _ptr(d['n_wins']), plan.n_clips, plan.total_frames, plan.total_tok,

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('NISQA_HIP_LIB') or os.path.join(_HERE, 'libnisqa_hip.so')     # override: A/B of two builds
 
 NISQA_OK, NISQA_ERR_ARG, NISQA_ERR_LAUNCH, NISQA_ERR_WORKSPACE = 0, 1, 2, 3
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_p = ctypes.c_void_p
 c_i32 = ctypes.c_int32
@@ -29,8 +29,7 @@ class ModelDev(ctypes.Structure):
     _fields_ = [('window', c_p), ('twiddle', c_p), ('band_start', c_p), ('band_len', c_p), ('band_woff', c_p),
                 ('band_w', c_p), ('cnn_w', c_p), ('td_w', c_p), ('pool_w', c_p),
                 ('n_layers', c_i32), ('n_heads', c_i32), ('seg_hop', c_i32), ('stage_events', c_p),
-                ('cnn_wb', c_p), ('cnn_mode', c_i32), ('td_wb', c_p), ('pool_wb', c_p), ('arch', c_i32),
-                ('conv_section_wait', c_p), ('conv_section_done', c_p)]
+                ('cnn_wb', c_p), ('cnn_mode', c_i32), ('td_wb', c_p), ('pool_wb', c_p), ('arch', c_i32)]
 
 
 # name -> (restype, argtypes); every symbol include/nisqa_hip.h declares

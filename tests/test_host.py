@@ -386,7 +386,7 @@ def test_library_exports_every_declared_symbol():
         import __graft_entry__
         __graft_entry__.build()
     L = lib.load()                                           # loads, binds every symbol, checks the ABI version
-    assert L.nisqa_abi_version() == 1
+    assert L.nisqa_abi_version() == 2
     assert L.nisqa_workspace_bytes(64, 64064, 16384) > 64064 * 48 * 4
     assert L.nisqa_workspace_bytes(0, 1, 1) == 0
     out = subprocess.check_output(['nm', '-D', '--defined-only', lib.LIB_PATH]).decode()
@@ -689,3 +689,38 @@ def test_dataset_item_label_follows_the_index(tmp_path):
             np.testing.assert_array_equal(y, want)
             assert tuple(x.shape) == (40, 1, 48, 15)
         np.testing.assert_array_equal(ds.labels(3)[:, 0], np.float32([1.5, 2.5, 3.5]))
+
+
+def test_no_kernel_contains_the_packed_f32_op_sel_form_gfx950_misreads():
+    """ISA lint.  On gfx950 (MI355X, ROCm 7.2) a v_pk_{add,mul,fma}_f32 whose LOW result reads the HIGH half of a VGPR
+    src1 (op_sel:[x,1,...]) returns wrong values in lanes 48..63 while bf16 / f16 MFMA waves of ANOTHER kernel share
+    the SIMD (tools/micro/corun6.hip; round 1 saw it as wrong mel frames next to the conv kernels of another stream).
+    The same swap on src0 / src2 is exact, so kernels put swapped operands there; this test compiles every HIP source
+    to gfx950 assembly and fails if the compiler or an asm helper produced the bad form anywhere."""
+    import concurrent.futures
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.isfile(hipcc):
+        pytest.skip('hipcc not on this machine')
+    csrc = os.path.join(ROOT, 'nisqa_amd', 'csrc')
+    srcs = sorted(f for f in os.listdir(csrc) if f.endswith('.hip'))
+    bad_form = re.compile(r'v_pk_(add|mul|fma)_f32\b.*\bop_sel:\[[01],1')
+
+    def scan(f):
+        r = subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fno-strict-aliasing', '-w',
+                            '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only', '-o', '-', f],
+                           cwd=csrc, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = r.stdout.split('\n')
+        return f, sum(1 for l in lines if 'v_pk_' in l and '_f32' in l), [l.strip() for l in lines if bad_form.search(l)]
+
+    with concurrent.futures.ThreadPoolExecutor(8) as ex:
+        res = list(ex.map(scan, srcs))
+    assert any(n > 0 for _, n, _ in res), 'no packed f32 instruction found at all: the scan itself is broken'
+    for f, n, bad in res:
+        assert not bad, '%s: %d packed-f32 instruction(s) with op_sel on the low half of src1, e.g. %s' % (f, len(bad), bad[0])
+    # the pattern does match the form the probe found
+    assert bad_form.search('v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]')
+    assert not bad_form.search('v_pk_add_f32 v[0:1], v[4:5], v[2:3] op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]')

@@ -36,9 +36,10 @@ __global__ __launch_bounds__(256, 2) void kern_f(float* out, wave_rec* rec, int 
     wave_rec* r = rec + (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     stamp(r, true);
     float f[16];
+    float acc = 0.f;
+#ifndef F_VARIANT
 #pragma unroll
     for (int a = 0; a < 16; ++a) f[a] = 0.001f * (lane + 64 * a) - 0.03f * a;
-    float acc = 0.f;
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int rr = 0; rr < 6; ++rr)
@@ -47,14 +48,33 @@ __global__ __launch_bounds__(256, 2) void kern_f(float* out, wave_rec* rec, int 
 #pragma unroll
         for (int a = 0; a < 16; ++a) acc += f[a];
     }
+#else
+    // -DF_VARIANT: the arithmetic of tools/micro/corun2.hip kern_f<4> (constants from v_cos_f32 at kernel start, state
+    // re-seeded through z every iteration)
+    float zx[8], zy[8], tb[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) { zx[a] = 0.001f * (lane + 64 * a); zy[a] = 0.5f - 0.002f * lane; tb[a] = F_VARIANT == 2 ? 1.f - 0.0002f * lane * a : __cosf(0.02f * lane * a); }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) { f[2 * a] = zx[a]; f[2 * a + 1] = zy[a]; }
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+            for (int a = 0; a < 16; ++a) f[a] = fmaf(f[(a + 5) & 15], 0.37f, f[a] * 0.61f) + 0.01f * tb[a & 7];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) { acc += f[2 * a] - f[2 * a + 1]; zx[a] = f[2 * a] * 0.5f + 1e-3f * a; zy[a] = f[2 * a + 1] * 0.5f + 1e-4f; }
+    }
+#endif
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = acc;
     stamp(r, false);
 }
 
 // M variants: 0 bf16 32x32x16 back to back, 1 the same at ~half duty (s_nop padding), 2 bf16 16x16x32, 3 f16 32x32x16,
-// 4 fp32 32x32x2, 5 VALU only (no matrix instruction)
+// 4 fp32 32x32x2, 5 VALU only (no matrix instruction); with wsrc != nullptr the B operands stream from GLOBAL memory
+// (like the conv kernels' weight fragments: VMEM returns land between the MFMAs); 6 = 0 with the loads waited for
+// (s_waitcnt vmcnt(0)) before the MFMAs issue
 template <int V>
-__global__ __launch_bounds__(256, 2) void kern_m(float* out, wave_rec* rec, int iters) {
+__global__ __launch_bounds__(256, 2) void kern_m(float* out, wave_rec* rec, int iters, const f32x4* __restrict__ wsrc) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63;
     wave_rec* r = rec + (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -68,10 +88,15 @@ __global__ __launch_bounds__(256, 2) void kern_m(float* out, wave_rec* rec, int 
     float v[8];
     for (int q = 0; q < 8; ++q) v[q] = lane + q;
     for (int it = 0; it < iters; ++it) {
-        const f32x4 a = src[(lane + it) & 1023], b = src[(lane * 3 + it) & 1023];
+        const f32x4 a = src[(lane + it) & 1023];
+        f32x4 bq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[q] = wsrc ? wsrc[((size_t)(it * 4 + q) * 64 + lane) & 65535] : src[(lane * 3 + it + q) & 1023];
+        if (V == 6) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            if (V == 0 || V == 1) c[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, a), __builtin_bit_cast(bfx8, b), c[q], 0, 0, 0);
+            const f32x4 b = bq[q & 3];
+            if (V == 0 || V == 1 || V == 6) c[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, a), __builtin_bit_cast(bfx8, b), c[q], 0, 0, 0);
             if (V == 1) { asm volatile("s_nop 15"); asm volatile("s_nop 15"); }
             if (V == 2) c4[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfx8, a), __builtin_bit_cast(bfx8, b), c4[q], 0, 0, 0);
             if (V == 3) c[q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hfx8, a), __builtin_bit_cast(hfx8, b), c[q], 0, 0, 0);
@@ -110,22 +135,25 @@ int main(int argc, char** argv) {
     hipFuncGetAttributes(&fa, (const void*)kern_f); printf("kern_f: %d regs, %zu B scratch\n", fa.numRegs, fa.localSizeBytes);
     hipFuncGetAttributes(&fa, (const void*)kern_m<0>); printf("kern_m<0>: %d regs, %zu B scratch\n", fa.numRegs, fa.localSizeBytes);
 
-    auto run = [&](int variant, int mblocks, int miters, const char* name) {
+    f32x4* dw; hipMalloc(&dw, 65536 * 16); hipMemset(dw, 0x3c, 65536 * 16);
+    auto run = [&](int variant, int mblocks, int miters, const char* name, bool gl = false, int flds = 0) {
+        const f32x4* ws = gl ? dw : nullptr;
         for (int rep = 0; rep < 2; ++rep) {
             hipMemsetAsync(df, 0, n * 4, s1);
             hipMemsetAsync(rm, 0, (size_t)mblocks_max * 4 * sizeof(wave_rec), s1);
             hipDeviceSynchronize();
             if (mblocks > 0) {
                 switch (variant) {
-                    case 0: hipLaunchKernelGGL(kern_m<0>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters); break;
-                    case 1: hipLaunchKernelGGL(kern_m<1>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters / 2); break;
-                    case 2: hipLaunchKernelGGL(kern_m<2>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters * 2); break;
-                    case 3: hipLaunchKernelGGL(kern_m<3>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters); break;
-                    case 4: hipLaunchKernelGGL(kern_m<4>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters / 2); break;
-                    case 5: hipLaunchKernelGGL(kern_m<5>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters / 2); break;
+                    case 0: hipLaunchKernelGGL(kern_m<0>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters, ws); break;
+                    case 1: hipLaunchKernelGGL(kern_m<1>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters / 2, ws); break;
+                    case 2: hipLaunchKernelGGL(kern_m<2>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters * 2, ws); break;
+                    case 3: hipLaunchKernelGGL(kern_m<3>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters, ws); break;
+                    case 4: hipLaunchKernelGGL(kern_m<4>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters / 2, ws); break;
+                    case 6: hipLaunchKernelGGL(kern_m<6>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters, ws); break;
+                    case 5: hipLaunchKernelGGL(kern_m<5>, dim3(mblocks), dim3(256), 78848, s2, dm, rm, miters / 2, ws); break;
                 }
             }
-            hipLaunchKernelGGL(kern_f, dim3(fblocks), dim3(256), 0, s1, df, rf, fiters);
+            hipLaunchKernelGGL(kern_f, dim3(fblocks), dim3(256), flds, s1, df, rf, fiters);
             hipDeviceSynchronize();
             hipMemcpy(r1.data(), df, n * 4, hipMemcpyDeviceToHost);
             hipMemcpy(wf.data(), rf, wf.size() * sizeof(wave_rec), hipMemcpyDeviceToHost);
@@ -171,5 +199,15 @@ int main(int argc, char** argv) {
     run(3, 4096, 3000, "f16 32x32x16 MFMA");
     run(4, 4096, 3000, "fp32 32x32x2 MFMA");
     run(5, 4096, 3000, "VALU only");
+    printf("-- B operands of M streamed from global memory (L2-resident 1 MiB), as in tools/micro/corun2.hip\n");
+    run(0, 4096, 3000, "bf16 32x32x16 + global B loads", true);
+    run(0, 128, 60000, "bf16 + global loads, 128 blocks", true);
+    run(6, 4096, 3000, "bf16 + global loads, vmcnt(0)", true);
+    run(4, 4096, 3000, "fp32 MFMA + global B loads", true);
+    run(5, 4096, 3000, "VALU only + global loads", true);
+    run(2, 4096, 3000, "bf16 16x16x32 + global loads", true);
+    printf("-- F with 67840 B of (unused) dynamic LDS: one F and one M workgroup per CU\n");
+    run(0, 4096, 3000, "bf16 32x32x16, F with LDS", false, 67840);
+    run(0, 4096, 3000, "bf16 + global loads, F with LDS", true, 67840);
     return 0;
 }

@@ -1,13 +1,11 @@
 """Concurrency probe (GPU): does running work on two HIP streams at the same time change any result?
 
-Finding on gfx950 (MI355X, ROCm 7.2): a mel_frame_kernel workgroup that shares a CU with a split-bf16 conv workgroup
-(cnn_front_bf16_kernel / cnn_std_bf16_kernel) of ANOTHER stream computes a few hundred to a few thousand wrong
-spectrogram values per launch (errors up to ~10 dB in ~1 % of the frames; the conv kernel's own output stays exact).
-Every other pair of kernels is bit-exact under overlap, and so is the pair when the two cannot share a CU (LDS request
-of the conv kernel inflated to 96 KB).  Synthetic LDS / MFMA / VALU stress kernels (tools/micro/lds_fill.hip,
-corun.hip) do not reproduce it; the cause is not found yet.  The engine therefore keeps the mel + CNN sections of
-batches on different streams apart (nisqa_model_dev.conv_section_wait / conv_section_done); the last lines below check
-that whole forwards on two streams are bit-identical to serial ones.
+Round 1 found that a mel_frame_kernel workgroup sharing a CU with a split-bf16 conv workgroup of ANOTHER stream computed
+wrong spectrogram frames.  Round 2 traced it (tools/micro/corun3..6.hip) to one instruction form: a v_pk_{add,mul,fma}_f32
+whose low result reads the high half of a VGPR src1 (op_sel:[x,1]) misreads in lanes 48..63 while bf16 / f16 MFMA waves of
+another kernel share the SIMD.  The mel kernel's half-swapped operands now sit in src0 (exact), tests/test_host.py lints
+every kernel's ISA for the form, and this probe -- all kernel pairs on two streams, compared bit for bit with their
+serial results -- prints zeros (profiles/r02_probe_concurrency_no_guard.txt).
 
     python tools/probe_concurrency.py [bf16x3|f32]
 """
