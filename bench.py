@@ -238,6 +238,7 @@ def bench_predict_csv(a):
 
 
 def main():
+    global BATCH
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     # a step is ~1 ms: 50 + 400 steps are under half a second of GPU time and let the clocks settle (20 steps after 3
@@ -254,7 +255,9 @@ def main():
     ap.add_argument('--distinct', type=int, default=256, help='predict_csv: distinct WAV files written')
     ap.add_argument('--workers', type=int, default=16, help='predict_csv: native ingest threads per rank')
     ap.add_argument('--tmp-dir', default=None)
+    ap.add_argument('--batch', type=int, default=BATCH, help='clips per step (experiments; the contract line is 64)')
     a = ap.parse_args()
+    BATCH = a.batch
     if a.workload == 'predict_csv':
         return bench_predict_csv(a)
 
@@ -352,7 +355,7 @@ def main():
                      if eng.precision == 'bf16x3' else 'f32',
             'data': 'synthetic 48 kHz / 10 s PCM16 clips (SURVEY 8d generator); ' + wdesc,
             'config': {'workload': 'predict_dir nisqa.tar (NISQA_DIM CNN-SA-AP) bs=64 per GPU, 10 s synthetic 48 kHz '
-                                   'clips, int16 PCM resident in HBM', 'batch_clips_per_gpu': BATCH, 'streams': len(streams),
+                                   'clips, int16 PCM resident in HBM' + ('' if BATCH == 64 else ' [EXPERIMENT: bs=%d]' % BATCH), 'batch_clips_per_gpu': BATCH, 'streams': len(streams),
                        'precision': eng.precision,
                        'segments_per_batch': int(plan.n_wins.sum()), 'frames_per_batch': plan.total_frames,
                        'parallelism': 'clip-sharded x%d, final all_gather of MOS rows' % world,

@@ -7,28 +7,33 @@
 // accumulation: 3 MFMAs at 16x the fp32-MFMA rate = 5.3x the exact-fp32 throughput.  Dropped term:
 // lo*lo ~ 2^-18.  conv1 sees dB values up to |80|: two terms resolve them to 6e-4 dB, the size of the mel
 // stage's own deviation from the oracle.  Measured effect on the outputs with the real nisqa.tar
-// weights: |dMOS| <= 4e-5 (pure bf16: 4.5e-3, pure f16: 5e-4; bar 1e-3) -- DESIGN.md 4.5.
+// weights: |dMOS| <= 5e-5 (pure bf16: 4.5e-3, pure f16: 5e-4; bar 1e-3) -- DESIGN.md 4.5.
 //
-// Structure (differences from the fp32 kernels are consequences of the 5x faster matrix pipe):
-//   * a workgroup is FOUR waves = four segments; conv1..conv4 are wave-private and barrier-free: each wave
-//     streams its weight fragments from L2 into a 3-deep register ring (conv_bf16.hpp) and keeps its
-//     activations in its own LDS region as two bf16 planes (hi, lo), pixel-major with pixel rows padded by
-//     16 bytes, with the same row->pixel maps as the fp32 kernel so the adaptive max-pools stay in-lane;
-//   * conv1 runs on the matrix pipe too, two mel-adjacent output pixels per MFMA row (operands are dword reads
-//     from two zero-bordered bf16 planes of the input patch, no packing), because at this speed the VALU
-//     version would cost as much as conv2-4;
-//   * conv5/conv6 (18 / 6 output pixels per segment) are batched over the workgroup's four segments with the
-//     output channels split over the waves (16x16x32 MFMA tiles), so no tile is mostly padding.
-// On gfx950 MFMA and VALU instructions of a SIMD do not overlap (tools/micro/issue.hip): the kernel's time is its MFMA
-// cycles plus its VALU cycles plus stalls, so every VALU instruction removed counts.
+// Structure:
+//   * a workgroup is FOUR waves = four consecutive segments of one clip; conv1..conv4 are wave-private and barrier-free:
+//     each wave streams its weight fragments from L2 into a 3-deep register ring (conv_k_bf16) and keeps its
+//     activations in its own LDS region as two bf16 planes (hi, lo), pixel-major with pixel rows padded by 16 bytes, with
+//     row -> pixel maps chosen so that every adaptive-max-pool window is in-lane;
+//   * conv1 runs on the matrix pipe too, two mel-adjacent output pixels per MFMA row (operands are dword reads from two
+//     zero-bordered bf16 planes of the input patch, no packing);
+//   * conv5/conv6 (18 / 6 output pixels per segment) are batched over the workgroup's four segments with the output
+//     channels split over the waves (16x16x32 MFMA tiles), so no tile is mostly padding.
+// What bounds it (tools/micro/issue2.hip): a wave hides <= 5 other instructions behind a 32x32x16 MFMA
+// (<= 2 behind a 16x16x32) and a VALU-only stream issues one instruction per ~5 cycles, so every instruction outside the
+// MFMA shadows counts.  Hence: LDS by 32-bit addresses (no 64-bit pointer arithmetic), lane-static tap masks instead of
+// per-tap bounds arithmetic, weight fragments through a buffer descriptor (no per-load address VALU), epilogue addresses
+// as lane base + immediates, and the conv1 epilogue finalises each pooled value in ONE lane of the mel pair, not both.
 #include "common.hpp"
 #include "layout.hpp"
 #include "conv_bf16.hpp"
 #include "internal.hpp"
 #include "../../include/nisqa_hip.h"
 
-// Activation planes: pixel rows of C bf16 padded by 16 bytes (row stride C*2 + 16, NOT swizzled): consecutive pixels land
-// 4 banks apart like with an XOR swizzle, and every LDS address is lane base + compile-time offset.
+// LDS plan (byte addresses; the kernel has no static LDS, so the dynamic segment starts at 0 and addresses are used as
+// plain 32-bit numbers): one 128-byte zero block shared by the four waves ABOVE the largest tap offset (so "zero block
+// address - tap offset" never goes negative), then one region per wave.
+//   activation planes: pixel rows of C bf16 padded by 16 bytes (row stride 2 C + 16, NOT swizzled): consecutive pixels
+//   land 4 banks apart, and every LDS address is lane base + compile-time offset.
 #define FB_RS1 48                          /* A1: 168 px x 16 ch */
 #define FB_P1 (168 * FB_RS1)
 #define FB_RS2 80                          /* A2: 60 px x 32 ch */
@@ -38,10 +43,12 @@
 #define FB_PS (72 * FB_RS3)
 #define FB_PATCH (2 * FB_P1)               /* conv1 input: two zero-bordered bf16 planes [17][50] behind the A1 planes */
 #define FB_PPLANE 1700                     /* bytes per patch plane (850 bf16) */
-#define FB_ZERO 19584                      /* 128 B of zeros per wave (128-byte aligned) */
-#define FB_WAVE (FB_ZERO + 128)
-#define FB_LDS (4 * FB_WAVE)               /* 78848 B -> two workgroups (8 waves) per CU */
-static_assert(FB_PATCH + 2 * FB_PPLANE <= FB_ZERO && 2 * FB_P3 <= FB_ZERO && 2 * FB_PS <= 2 * FB_WAVE, "LDS plan");
+#define FB_ZADDR 2048u                     /* the shared zero block */
+#define FB_BASE 2176u                      /* first wave region */
+#define FB_WAVE 19584u
+#define FB_LDS (FB_BASE + 4 * FB_WAVE)     /* 80512 B -> two workgroups (8 waves) per CU */
+static_assert(FB_PATCH + 2 * FB_PPLANE <= FB_WAVE && 2 * FB_P3 <= FB_WAVE && 2 * FB_PS <= 2 * FB_WAVE, "LDS plan");
+static_assert(2 * FB_LDS <= 160 * 1024, "two workgroups per CU");
 
 __device__ constexpr int bwin75_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 2 : b == 3 ? 4 : 5; }
 __device__ constexpr int bwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b == 2 ? 5 : b == 3 ? 6 : 7; }
@@ -61,6 +68,8 @@ extern "C" int nisqa_debug_phase_clock(unsigned long long* out16, int reset) {
 #define NQ_CLK(i)
 #endif
 
+// SEGX: the input is the reference's segment tensor x[B][L][1][48][15] (inner-operator mode) instead of the spectrogram
+template <bool SEGX>
 __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
@@ -71,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef NQ_PHASE_CLOCK
     const long long clk_top = clock64(), wall_top = wall_clock64();
+    long long clk[13];
 #endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -81,14 +91,10 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     if (nvalid <= 0) return;                             // whole workgroup is padding
     const bool valid = wave < nvalid;                    // padding waves still walk the barriers (on zeros)
     const int p = p0 + wave, k = k0 + wave;
-    char* act = smem + wave * FB_WAVE;
-    char* zero = act + FB_ZERO;
-#ifdef NQ_PHASE_CLOCK
-    long long clk[13];
-#endif
+    const unsigned R = FB_BASE + wave * FB_WAVE;         // this wave's LDS region
+    const unsigned lane16 = lane * 16;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
     NQ_CLK(0);
-    if (NQ_EXP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
-    if (NQ_EXP_PRIO == 3 && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u)) __builtin_amdgcn_s_setprio(1);   // HW_ID[3:0] = wave slot
 
     // ---- stage the 15-frame window as two zero-bordered bf16 planes (hi, lo) [frame j + 1][mel m + 1]:
     //      the 3x3 taps of any output pixel are then at constant offsets from it, no bounds checks.
@@ -96,36 +102,63 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     //      memory latency instead of twelve.
     // top_db floor of the clip: precomputed (nisqa_mel_finalize), or taken here from the encoded running maximum the mel
     // kernel published (whole-forward path: one tiny kernel launch less)
-    const float fl = seg_x ? -3.0e38f : clip_max_enc ? dec_ordered(clip_max_enc[b]) - top_db : clip_floor[b];
-    const float* src = seg_x ? seg_x + ((size_t)b * seg_L + k) * 720
-                             : mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
+    const float fl = SEGX ? -3.0e38f : clip_max_enc ? dec_ordered(clip_max_enc[b]) - top_db : clip_floor[b];
+    const float* src = SEGX ? seg_x + ((size_t)b * seg_L + k) * 720
+                            : mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
     float vraw[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
         const int i0 = lane + 64 * q;
-        vraw[q] = (valid && i0 < 720) ? src[i0] : 0.f;
+        vraw[q] = (valid && (q < 11 || lane < 16)) ? src[i0] : 0.f;
     }
     const float tn1 = cw[CNN_T1 + (lane & 15)], tn2 = cw[CNN_T2 + (lane & 31)];
     const float tn3[2] = {cw[CNN_T3 + (lane & 31)], cw[CNN_T3 + 32 + (lane & 31)]};
     const float tn4[2] = {cw[CNN_T4 + (lane & 31)], cw[CNN_T4 + 32 + (lane & 31)]};
     const float tn5 = cw[CNN_T5 + 16 * wave + (lane & 15)], tn6 = cw[CNN_T6 + 16 * wave + (lane & 15)];
     {
-        char* pb = act + FB_PATCH;
-        for (int q = lane; q < (2 * FB_PPLANE + 15) / 16; q += 64) *(f32x4*)(pb + q * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (lane < 32) ((float*)zero)[lane] = 0.f;
-        __builtin_amdgcn_wave_barrier();
+        const unsigned pb = R + FB_PATCH;
+        // zero the patch planes (213 x 16 bytes) and the shared zero block (every wave writes the same zeros)
 #pragma unroll
-        for (int q = 0; q < 12; ++q) {
-            const int i0 = lane + 64 * q;
-            int j, m;
-            if (seg_x) { m = i0 / 15; j = i0 - 15 * m; } else { j = i0 / 48; m = i0 - 48 * j; }
-            const float v = valid ? fmaxf(vraw[q], fl) : 0.f;
-            const unsigned hi = cvt_pk_bf16(v, 0.f);
-            const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
-            const int o = ((j + 1) * 50 + (m + 1)) * 2;
-            if (i0 < 720) {
-                *(unsigned short*)(pb + o) = (unsigned short)hi;
-                *(unsigned short*)(pb + FB_PPLANE + o) = (unsigned short)lo;
+        for (int it = 0; it < 4; ++it)
+            if (it < 3 || lane < (2 * FB_PPLANE + 15) / 16 - 192) lds_st128(pb + (lane + 64 * it) * 16, f32x4{0.f, 0.f, 0.f, 0.f});
+        // (this store goes through the dynamic-LDS symbol on purpose: a kernel that only touches LDS through integer
+        // addresses is compiled as one that uses no LDS at all, and then computes garbage)
+        if (lane < 32) ((unsigned*)(smem + FB_ZADDR))[lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (!SEGX) {
+            // element i0 = lane + 64 q of the [15][48] window is (frame j, mel m) = divmod(i0, 48); with q = 3 t + u that
+            // is j = q + t + (lane + 16 u) / 48, m = (lane + 16 u) % 48: three lane-dependent store bases, the rest are
+            // immediates
+            unsigned ob[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int e = lane + 16 * u, j0 = e >= 48 ? 1 : 0, m = e - 48 * j0;
+                ob[u] = pb + ((j0 + 1) * 50 + m + 1) * 2;
+            }
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const float v = valid ? fmaxf(vraw[q], fl) : 0.f;
+                const unsigned hi = cvt_pk_bf16(v, 0.f);
+                const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
+                const unsigned a = ob[q % 3] + (q + q / 3) * 100;
+                if (q < 11 || lane < 16) {
+                    lds_st16(a, hi);
+                    lds_st16(a + FB_PPLANE, lo);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const int i0 = lane + 64 * q;
+                const int m = i0 / 15, j = i0 - 15 * m;
+                const float v = valid ? vraw[q] : 0.f;
+                const unsigned hi = cvt_pk_bf16(v, 0.f);
+                const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
+                const unsigned a = pb + ((j + 1) * 50 + (m + 1)) * 2;
+                if (i0 < 720) {
+                    lds_st16(a, hi);
+                    lds_st16(a + FB_PPLANE, lo);
+                }
             }
         }
     }
@@ -141,30 +174,32 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     //      two pairs of dwords per plane and no packing.  B[k][n] = w[c][dmm - dm][kx] (zero outside the kernel), packed
     //      by weights.py.  Each lane half owns 12 pooled rows gl = mel pairs; the 16 rows of its tile are the frames.
     {
-        const char* pb = act + FB_PATCH;
         f32x4 w1[2];                                      // weights hi and the first residual term (16 mantissa bits)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) w1[t] = *(const f32x4*)(wb + CNNB_W1 + t * 512 + lane * 8);
+        for (int t = 0; t < 2; ++t) w1[t] = wfrag_load(wrs, lane16, (CNNB_W1 + t * 512) * 2);
         const float tn = tn1;
-        char* a1w = act + (n < 16 ? 0 : FB_P1) + (n & 15) * 2;   // A1 planes: 168 px x 16 ch; this lane's plane and channel
         // lane half 0: k-slots 0..7 = (kx 0, kx 1); half 1: k-slots 8..11 = kx 2 (12..15 meet zero weights: kx 2 again)
         const int xq = min(qi, 14);                       // row 15 of a tile is padding (result unused)
-        const int off_a = ((xq + (h ? 2 : 0)) * 50 + 24 * hfi) * 2, off_b = ((xq + (h ? 2 : 1)) * 50 + 24 * hfi) * 2;
+        unsigned rd_a = R + FB_PATCH + ((xq + (h ? 2 : 0)) * 50 + 24 * hfi) * 2;
+        unsigned rd_b = R + FB_PATCH + ((xq + (h ? 2 : 1)) * 50 + 24 * hfi) * 2;
+        // The pooled value of a mel pair needs both pair members, which sit 16 lanes apart (columns n and n ^ 16).  Of the
+        // 14 pooled values of an iteration (2 mel pairs x 7 frame windows, consecutive pixels v = 7 tt + bb of A1), lane
+        // group dm = 0 finalises the even ones and dm = 1 the odd ones: each sends the partner the values it does not own
+        // (ONE ds_swizzle per value pair), takes the maximum, splits it into hi + lo and stores both planes.
+        const bool is_b = (n & 16) != 0;
+        const unsigned mb = is_b ? ~0u : 0u;             // bit select (v_bfi_b32): a ternary on r[] becomes an indexed stack array
+        unsigned wr = R + (12 * hf * 7) * FB_RS1 + (n & 15) * 2 + (is_b ? FB_RS1 : 0);
         for (int g2 = 0; g2 < 6; ++g2) {
             f32x16 acc[2];
             f32x4 xa[2][2];
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const char* base = pb + 4 * (2 * g2 + tt);          // mel m0 = 2 gl, gl = 12 hfi + 2 g2 + tt
-                // dword reads (ds_read2_b32): the pairs are only 4-byte aligned, and a misaligned ds_read_b64 is several
-                // times slower on gfx950 (it cost 8 % of the whole kernel here)
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const unsigned* pa = (const unsigned*)(base + t * FB_PPLANE + off_a);
-                    const unsigned* pq = (const unsigned*)(base + t * FB_PPLANE + off_b);
-                    xa[tt][t] = f32x4{__uint_as_float(pa[0]), __uint_as_float(pa[1]), __uint_as_float(pq[0]), __uint_as_float(pq[1])};
+                for (int t = 0; t < 2; ++t) {              // dword reads (ds_read2_b32): the pairs are only 4-byte aligned
+                    const unsigned pa = rd_a + 4 * tt + t * FB_PPLANE, pq = rd_b + 4 * tt + t * FB_PPLANE;
+                    xa[tt][t] = f32x4{__uint_as_float(lds_ld32(pa)), __uint_as_float(lds_ld32(pa + 4)),
+                                      __uint_as_float(lds_ld32(pq)), __uint_as_float(lds_ld32(pq + 4))};
                 }
-            }
             acc[0] = zero16();
             acc[1] = zero16();
             // x = hi + lo carries 16 mantissa bits: 6e-4 dB at |80| dB, the size of the mel stage's own deviation from
@@ -172,24 +207,26 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             acc[0] = mfma_bf(xa[0][1], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[0], acc[1]);
             acc[0] = mfma_bf(xa[0][0], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[1], acc[1]);
             acc[0] = mfma_bf(xa[0][0], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[0], acc[1]);
+            // ReLU(. + shift) is monotone, so it is applied before the pair maximum, which is then taken on non-negative
+            // floats -- as unsigned integers
+            unsigned r[14];
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+            for (int v = 0; v < 14; ++v) {
+                const int tt = v / 7, bb = v - 7 * tt;
+                const float mx = fmaxf(fmaxf(acc[tt][2 * bb], acc[tt][2 * bb + 1]), acc[tt][2 * bb + 2]);   // frames
+                r[v] = __float_as_uint(fmaxf(mx + tn, 0.f));
+            }
+            unsigned got[7];
 #pragma unroll
-                for (int bb = 0; bb < 7; ++bb) {
-                    const float mx = fmaxf(fmaxf(acc[tt][2 * bb], acc[tt][2 * bb + 1]), acc[tt][2 * bb + 2]);   // frames
-                    // The other member of the mel pair sits 16 lanes away (columns n and n ^ 16).  ReLU(. + shift) is
-                    // monotone, so it is applied first and the pair maximum is taken on non-negative floats -- as
-                    // unsigned integers.  Both lanes end up with the pooled value: lane n < 16 stores its bf16 hi part,
-                    // lane n + 16 the lo part (no divergent branch, one 16-bit store per lane).
-                    const unsigned r = __float_as_uint(fmaxf(mx + tn, 0.f));
-                    // (lanes ^ 16 on the LDS pipe; v_permlane16_swap costs ~20 VALU cycles on gfx950)
-                    const unsigned ro = (unsigned)__builtin_amdgcn_ds_swizzle((int)r, 0x401F);
-                    const float v = __uint_as_float(max(r, ro));
-                    const unsigned hi = cvt_pk_bf16(v, 0.f);
-                    const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
-                    const int pp = (12 * hf + 2 * g2 + tt) * 7 + bb;
-                    *(unsigned short*)(a1w + pp * FB_RS1) = (unsigned short)(n < 16 ? hi : lo);
-                }
+            for (int kk = 0; kk < 7; ++kk)                 // (lanes ^ 16 on the LDS pipe; v_permlane16_swap costs ~20 VALU cycles)
+                got[kk] = (unsigned)__builtin_amdgcn_ds_swizzle((int)((r[2 * kk] & mb) | (r[2 * kk + 1] & ~mb)), 0x401F);
+#pragma unroll
+            for (int kk = 0; kk < 7; ++kk) {
+                const unsigned own = (r[2 * kk + 1] & mb) | (r[2 * kk] & ~mb);
+                lds_store_split(wr + 2 * kk * FB_RS1, FB_P1, __uint_as_float(max(own, got[kk])));
+            }
+            rd_a += 8; rd_b += 8;                          // mel m0 = 2 gl, gl = 12 hfi + 2 g2 + tt
+            wr += 14 * FB_RS1;
         }
     }
 
@@ -197,21 +234,20 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     // ---- conv2 16->32 on 24x7, pool -> 12x5 (row maps as in cnn.hip)
     {
         f32x16 acc[6][1];
-#pragma unroll
-        for (int t = 0; t < 6; ++t) acc[t][0] = zero16();
-        int py[6], px[6];
-        bool pv[6];
+        unsigned base[6], m9[6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
+            acc[t][0] = zero16();
             const int u = 16 * t + qi;
-            pv[t] = u < 84;
             const int gl = u / 14, w = u % 14, yy = w / 7;
-            py[t] = 2 * (6 * hfi + gl) + yy;
-            px[t] = w - 7 * yy;
+            const int py = 2 * (6 * hfi + gl) + yy, px = w - 7 * yy;
+            m9[t] = tap_mask(u < 84, py, px, 24, 7);
+            base[t] = R + ((py - 1) * 7 + (px - 1)) * FB_RS1 + (h << 4);
         }
-        conv3x3_bf16<16, 6, 1, 24, 7, false, true>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane);
+        conv_k_bf16<16, 6, 1, 7, FB_RS1, FB_P1, FB_ZADDR, false>(acc, wrs, CNNB_W2 * 2, lane16, base, m9);
         NQ_CLK(3);
         const float tn = tn2;
+        const unsigned wr = R + (6 * hf * 5) * FB_RS2 + n * 2;
 #pragma unroll
         for (int gl = 0; gl < 6; ++gl)
 #pragma unroll
@@ -224,35 +260,36 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                         const int u = 14 * gl + 7 * yy + x;
                         mx = fmaxf(mx, acc[u >> 4][0][u & 15]);
                     }
-                const int pp = (6 * hf + gl) * 5 + bb;
-                store_split(act, FB_P2, pp * FB_RS2 + n * 2, fmaxf(mx + tn, 0.f));
+                lds_store_split(wr + (gl * 5 + bb) * FB_RS2, FB_P2, fmaxf(mx + tn, 0.f));
             }
     }
 
     NQ_CLK(4);
-    int py[2], px[2];
-    bool pv[2];
+    unsigned base34[2], m34[2];                           // conv3 and conv4 share the 12 x 5 geometry
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int u = 16 * t + qi;
-        pv[t] = u < 30;
         const int gl = u / 10, w = u % 10, yy = w / 5;
-        py[t] = 2 * (3 * hfi + gl) + yy;
-        px[t] = w - 5 * yy;
+        const int py = 2 * (3 * hfi + gl) + yy, px = w - 5 * yy;
+        m34[t] = tap_mask(u < 30, py, px, 12, 5);
+        base34[t] = (py - 1) * 5 + (px - 1);              // pixel index of tap (-1, -1)
     }
 
     // ---- conv3 32->64 on 12x5
     {
         f32x16 acc[2][2];
+        unsigned base[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<32, 2, 2, 12, 5, true, true>(acc, act, zero, wb + CNNB_W3, py, px, pv, lane);
+            base[t] = R + base34[t] * FB_RS2 + (h << 4);
+        }
+        conv_k_bf16<32, 2, 2, 5, FB_RS2, FB_P2, FB_ZADDR, true>(acc, wrs, CNNB_W3 * 2, lane16, base, m34);
         NQ_CLK(5);
+        const unsigned wr = R + (6 * hf * 5) * FB_RS3 + n * 2;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int c = n + 32 * nt;
             const float tn = tn3[nt];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -261,8 +298,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                     const int u = 16 * t + r;
                     if (u < 30) {
                         const int gl = u / 10, w = u % 10, yy = w / 5, x = w - 5 * yy;
-                        const int pp = (2 * (3 * hf + gl) + yy) * 5 + x;
-                        store_split(act, FB_P3, pp * FB_RS3 + c * 2, fmaxf(acc[t][nt][r] + tn, 0.f));
+                        lds_store_split(wr + ((2 * gl + yy) * 5 + x) * FB_RS3 + 64 * nt, FB_P3, fmaxf(acc[t][nt][r] + tn, 0.f));
                     }
                 }
         }
@@ -271,29 +307,32 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     // ---- conv4 64->64 on 12x5, pool -> 6x3.  The pooled outputs of the workgroup's four segments go to a
     //      SHARED pair of bf16 planes S4[72 px][64 ch] (row = 18 * wave + pixel) for the N-split conv5/conv6.
     NQ_CLK(6);
-    char* s4 = smem;                       // 2 planes x FB_PS (wave 0/1 regions; their A3 is dead by then)
-    char* s5 = smem + 2 * FB_WAVE;         // conv5 output, same shape (wave 2/3 regions)
+    const unsigned S4 = FB_BASE;                          // 2 planes x FB_PS (wave 0/1 regions; their A3 is dead by then)
+    const unsigned S5 = FB_BASE + 2 * FB_WAVE;            // conv5 output, same shape (wave 2/3 regions)
     // conv5 / conv6 weight fragments of this wave (its 16 output channels), [step][hi,lo][lane][8]: rings of 4 / 8
     // K-steps, requested 3 / 7 steps ahead -- a step of conv5 (conv6) is only 15 (6) short MFMAs, an L2 round trip
     // several steps long.  The first requests go out before the previous layer's epilogue.
-    const f32x4* w5 = (const f32x4*)(wb + CNNB_W5) + (size_t)wave * (18 * 2 * 64) + lane;
-    const f32x4* w6 = (const f32x4*)(wb + CNNB_W6) + (size_t)wave * (18 * 2 * 64) + lane;
+    const int w5b = __builtin_amdgcn_readfirstlane((CNNB_W5 + wave * (18 * 2 * 512)) * 2);
+    const int w6b = __builtin_amdgcn_readfirstlane((CNNB_W6 + wave * (18 * 2 * 512)) * 2);
     f32x4 b5[4][2], b6[8][2];
     {
         f32x16 acc[2][2];
+        unsigned base[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<64, 2, 2, 12, 5, true, true>(acc, act, zero, wb + CNNB_W4, py, px, pv, lane);
+            base[t] = R + base34[t] * FB_RS3 + (h << 4);
+        }
+        conv_k_bf16<64, 2, 2, 5, FB_RS3, FB_P3, FB_ZADDR, true>(acc, wrs, CNNB_W4 * 2, lane16, base, m34);
         NQ_CLK(7);
 #pragma unroll
-        for (int g = 0; g < 3; ++g) { b5[g][0] = w5[g * 128]; b5[g][1] = w5[g * 128 + 64]; }
+        for (int g = 0; g < 3; ++g) { b5[g][0] = wfrag_load(wrs, lane16, w5b + g * 2048); b5[g][1] = wfrag_load(wrs, lane16, w5b + g * 2048 + 1024); }
         __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
+        const unsigned wr = S4 + (18 * wave + 9 * hf) * FB_RS3 + n * 2;
         float* dst = p3 ? p3 + (size_t)p * (18 * 64) : nullptr;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int c = n + 32 * nt;
             const float tn = tn4[nt];
 #pragma unroll
             for (int gl = 0; gl < 3; ++gl)
@@ -308,10 +347,8 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                             mx = fmaxf(mx, acc[u >> 4][nt][u & 15]);
                         }
                     const float v = fmaxf(mx + tn, 0.f);
-                    const int pl = (3 * hf + gl) * 3 + bb;
-                    if (dst && valid) dst[pl * 64 + c] = v;                  // optional fp32 copy (debug / parity)
-                    const int pp = 18 * wave + pl;
-                    store_split(s4, FB_PS, pp * FB_RS3 + c * 2, v);
+                    if (dst && valid) dst[((3 * hf + gl) * 3 + bb) * 64 + n + 32 * nt] = v;   // optional fp32 copy (debug / parity)
+                    lds_store_split(wr + (gl * 3 + bb) * FB_RS3 + 64 * nt, FB_PS, v);
                 }
         }
     }
@@ -324,50 +361,40 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     {
         const int i16 = lane & 15, kg = lane >> 4;
         const int ch = 16 * wave + i16;                    // D-fragment column = output channel
-        const char* zero = smem + 3 * FB_WAVE + FB_ZERO;   // wave 3's zero block: the only one S4 / S5 do not cover
         // conv5: rows rho = 16 t + i16 <-> (slot = rho / 18, pixel = rho % 18), 6 x 3 image per slot
         f32x4 acc5[5];
-#pragma unroll
-        for (int t = 0; t < 5; ++t) acc5[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int ry[5], rx[5], rb[5];
-        bool rv[5];
+        unsigned base5[5], m5[5];
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
+            acc5[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int rho = 16 * t + i16;
-            rv[t] = rho < 72;
-            const int slot = rho / 18, pix = rho - 18 * slot;
-            ry[t] = pix / 3;
-            rx[t] = pix - 3 * ry[t];
-            rb[t] = slot * 18;
+            const int slot = rho / 18, pix = rho - 18 * slot, ry = pix / 3, rx = pix - 3 * ry;
+            m5[t] = tap_mask(rho < 72, ry, rx, 6, 3);
+            base5[t] = S4 + (slot * 18 + (ry - 1) * 3 + (rx - 1)) * FB_RS3 + (kg << 4);
         }
-        const int zoff = (int)(zero - s4);                  // per tap: row + 16 kg, per K-step: + 64 s (an immediate offset)
-        int a5h[5], a5l[5];
+        unsigned a5h[5], a5l[5];
         f32x4 a5[2][5][2];                                  // A rows one step ahead: [buffer][tile][hi, lo]
         auto load_a5 = [&](int g) {
             const int tap = g >> 1, s = g & 1;
+            const int tapoff = ((tap / 3) * 3 + tap % 3) * FB_RS3;
             if (s == 0) {
-                const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
 #pragma unroll
                 for (int t = 0; t < 5; ++t) {
-                    const int y = ry[t] + dy, x = rx[t] + dx;
-                    const bool ok = rv[t] && (unsigned)y < 6u && (unsigned)x < 3u;
-                    const int pix = rb[t] + y * 3 + x;
-                    const int row = pix * FB_RS3 + (kg << 4);
-                    a5h[t] = ok ? row : zoff;
-                    a5l[t] = ok ? row + FB_PS : zoff;
+                    const bool ok = (m5[t] >> tap) & 1u;
+                    a5h[t] = ok ? base5[t] : FB_ZADDR - tapoff;
+                    a5l[t] = ok ? base5[t] + FB_PS : FB_ZADDR - tapoff;
                 }
             }
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
-                a5[g & 1][t][0] = *(const f32x4*)(s4 + a5h[t] + 64 * s);
-                a5[g & 1][t][1] = *(const f32x4*)(s4 + a5l[t] + 64 * s);
+                a5[g & 1][t][0] = lds_ld128(a5h[t] + tapoff + 64 * s);
+                a5[g & 1][t][1] = lds_ld128(a5l[t] + tapoff + 64 * s);
             }
         };
         load_a5(0);
-        NQ_PRIO_KLOOP_BEGIN();
 #pragma unroll
         for (int g = 0; g < 18; ++g) {
-            if (g + 3 < 18) { b5[(g + 3) & 3][0] = w5[(g + 3) * 128]; b5[(g + 3) & 3][1] = w5[(g + 3) * 128 + 64]; }
+            if (g + 3 < 18) { b5[(g + 3) & 3][0] = wfrag_load(wrs, lane16, w5b + (g + 3) * 2048); b5[(g + 3) & 3][1] = wfrag_load(wrs, lane16, w5b + (g + 3) * 2048 + 1024); }
             if (g + 1 < 18) load_a5(g + 1);
 #pragma unroll
             for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(a5[g & 1][t][0], b5[g & 3][1], acc5[t]);
@@ -376,68 +403,57 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 #pragma unroll
             for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(a5[g & 1][t][0], b5[g & 3][0], acc5[t]);
         }
-        NQ_PRIO_KLOOP_END();
         NQ_CLK(9);
 #pragma unroll
-        for (int g = 0; g < 7; ++g) { b6[g][0] = w6[g * 128]; b6[g][1] = w6[g * 128 + 64]; }
+        for (int g = 0; g < 7; ++g) { b6[g][0] = wfrag_load(wrs, lane16, w6b + g * 2048); b6[g][1] = wfrag_load(wrs, lane16, w6b + g * 2048 + 1024); }
         {
             const float tn = tn5;
+            const unsigned wr = S5 + (4 * kg) * FB_RS3 + ch * 2;
 #pragma unroll
             for (int t = 0; t < 5; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rho = 16 * t + 4 * kg + r;
-                    if (rho < 72)
-                        store_split(s5, FB_PS, rho * FB_RS3 + ch * 2, fmaxf(acc5[t][r] + tn, 0.f));
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (t < 4 || kg * 4 + r < 8)               // rho = 16 t + 4 kg + r < 72
+                        lds_store_split(wr + (16 * t + r) * FB_RS3, FB_PS, fmaxf(acc5[t][r] + tn, 0.f));
         }
         __syncthreads();
         NQ_CLK(10);
 
         // conv6 (3 x 3 kernel, padding (1,0)) = padding-1 conv at the centre column: rows (slot, y), 24 of 32
         f32x4 acc6[2], acc6b[2];            // even / odd K-steps accumulate separately: four independent chains
-        acc6[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc6[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc6b[0] = acc6[0];
-        acc6b[1] = acc6[0];
-        int sy[2], sb[2];
-        bool sv[2];
+        unsigned base6[2], m6[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            acc6[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc6b[t] = acc6[t];
             const int rho = 16 * t + i16;
-            sv[t] = rho < 24;
-            const int slot = rho / 6;
-            sy[t] = rho - 6 * slot;
-            sb[t] = slot * 18;
+            const int slot = rho / 6, y = rho - 6 * slot;
+            m6[t] = tap_mask(rho < 24, y, 1, 6, 3);          // output column x = 1: input columns 0..2 are all inside
+            base6[t] = S5 + (slot * 18 + (y - 1) * 3) * FB_RS3 + (kg << 4);
         }
-        const int zoff6 = (int)(zero - s5);
-        int a6h[2], a6l[2];
+        unsigned a6h[2], a6l[2];
         f32x4 a6[2][2][2];
         auto load_a6 = [&](int g) {
             const int tap = g >> 1, s = g & 1;
+            const int tapoff = ((tap / 3) * 3 + tap % 3) * FB_RS3;
             if (s == 0) {
-                const int dy = tap / 3 - 1, xin = tap - 3 * (tap / 3);       // input column = dx (output at x = 1)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int y = sy[t] + dy;
-                    const bool ok = sv[t] && (unsigned)y < 6u;
-                    const int pix = sb[t] + y * 3 + xin;
-                    const int row = pix * FB_RS3 + (kg << 4);
-                    a6h[t] = ok ? row : zoff6;
-                    a6l[t] = ok ? row + FB_PS : zoff6;
+                    const bool ok = (m6[t] >> tap) & 1u;
+                    a6h[t] = ok ? base6[t] : FB_ZADDR - tapoff;
+                    a6l[t] = ok ? base6[t] + FB_PS : FB_ZADDR - tapoff;
                 }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                a6[g & 1][t][0] = *(const f32x4*)(s5 + a6h[t] + 64 * s);
-                a6[g & 1][t][1] = *(const f32x4*)(s5 + a6l[t] + 64 * s);
+                a6[g & 1][t][0] = lds_ld128(a6h[t] + tapoff + 64 * s);
+                a6[g & 1][t][1] = lds_ld128(a6l[t] + tapoff + 64 * s);
             }
         };
         load_a6(0);
-        NQ_PRIO_KLOOP_BEGIN();
 #pragma unroll
         for (int g = 0; g < 18; ++g) {
-            if (g + 7 < 18) { b6[(g + 7) & 7][0] = w6[(g + 7) * 128]; b6[(g + 7) & 7][1] = w6[(g + 7) * 128 + 64]; }
+            if (g + 7 < 18) { b6[(g + 7) & 7][0] = wfrag_load(wrs, lane16, w6b + (g + 7) * 2048); b6[(g + 7) & 7][1] = wfrag_load(wrs, lane16, w6b + (g + 7) * 2048 + 1024); }
             if (g + 1 < 18) load_a6(g + 1);
             if (g & 1) {
 #pragma unroll
@@ -455,11 +471,10 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                 for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(a6[0][t][0], b6[g & 7][0], acc6[t]);
             }
         }
-        NQ_PRIO_KLOOP_END();
         NQ_CLK(11);
         // this wave's 4 x 96 outputs (slot, channel * 6 + y) go through S4 (dead since the barrier above) so that the
         // feature rows leave as 16-byte stores: 384 contiguous bytes per slot
-        float* fo = (float*)(s4 + wave * 2048);
+        const unsigned fo = S4 + wave * 2048;
         const float tn = tn6;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -467,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             for (int r = 0; r < 4; ++r) {
                 const int rho = 16 * t + 4 * kg + r;
                 const int slot = rho / 6, y = rho - 6 * slot;
-                if (rho < 24) fo[slot * 96 + i16 * 6 + y] = fmaxf(acc6[t][r] + acc6b[t][r] + tn, 0.f);
+                if (rho < 24) lds_st32(fo + (slot * 96 + i16 * 6 + y) * 4, __float_as_uint(fmaxf(acc6[t][r] + acc6b[t][r] + tn, 0.f)));
             }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -475,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             const int q = q0 + lane;                                         // float4 index: slot = q / 24
             const int slot = q / 24;
             if (q < 96 && slot < nvalid)
-                *(f32x4*)(feat + (size_t)(p0 + slot) * 384 + 96 * wave + 4 * (q - 24 * slot)) = *(const f32x4*)(fo + 4 * q);
+                *(f32x4*)(feat + (size_t)(p0 + slot) * 384 + 96 * wave + 4 * (q - 24 * slot)) = lds_ld128(fo + 16 * q);
         }
     }
 #ifdef NQ_PHASE_CLOCK
@@ -497,7 +512,7 @@ extern "C" int nisqa_cnn_adapt_bf16(const float* mel_tm, const int32_t* frame_of
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat)
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL(cnn_front_bf16_kernel<false>, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
                        mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat,
                        (const float*)nullptr, 0, (const uint32_t*)nullptr, 0.f);
     return NQ_LAUNCH_STATUS();
@@ -511,7 +526,7 @@ int nq_cnn_adapt_bf16_from_max(const float* mel_tm, const int32_t* frame_off, co
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat || !clip_max_enc)
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL(cnn_front_bf16_kernel<false>, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
                        mel_tm, frame_off, tok_off, n_wins, (const float*)nullptr, n_clips, seg_hop, cnn_w, cnn_wb,
                        (float*)nullptr, feat, (const float*)nullptr, 0, clip_max_enc, top_db);
     return NQ_LAUNCH_STATUS();
@@ -523,7 +538,7 @@ extern "C" int nisqa_cnn_adapt_segments_bf16(const float* x, int32_t seg_len_pad
     if (!x || seg_len_padded <= 0 || n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || !cnn_wb || !feat)
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(cnn_front_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL(cnn_front_bf16_kernel<true>, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
                        (const float*)nullptr, (const int32_t*)nullptr, tok_off, n_wins, (const float*)nullptr, n_clips, 1,
                        cnn_w, cnn_wb, (float*)nullptr, feat, x, seg_len_padded, (const uint32_t*)nullptr, 0.f);
     return NQ_LAUNCH_STATUS();

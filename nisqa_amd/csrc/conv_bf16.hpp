@@ -128,3 +128,99 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
     NQ_PRIO_KLOOP_END();
 }
 
+
+
+// ======================================================================================================================
+// Second-generation K loop (AdaptCNN kernel): LDS addressed by 32-bit byte addresses in address space 3 (no 64-bit
+// pointer arithmetic), tap validity as one precomputed 9-bit mask per M tile (lane-static: the row -> pixel maps do not
+// depend on the data), out-of-image taps redirected to a zero block with ONE select per tap and tile, weight fragments
+// through a buffer resource (address = SGPR descriptor + constant lane offset + immediate).  DESIGN.md 4.5.
+// ======================================================================================================================
+#define NQ_AS3 __attribute__((address_space(3)))
+NQ_DEV f32x4 lds_ld128(unsigned a) { return *(NQ_AS3 const f32x4*)(a); }
+NQ_DEV unsigned lds_ld32(unsigned a) { return *(NQ_AS3 const unsigned*)(a); }
+NQ_DEV void lds_st16(unsigned a, unsigned v) { *(NQ_AS3 unsigned short*)(a) = (unsigned short)v; }
+NQ_DEV void lds_st32(unsigned a, unsigned v) { *(NQ_AS3 unsigned*)(a) = v; }
+NQ_DEV void lds_st128(unsigned a, f32x4 v) { *(NQ_AS3 f32x4*)(a) = v; }
+// v = hi + lo into the two bf16 planes (lo plane `plane` bytes behind the hi plane)
+NQ_DEV void lds_store_split(unsigned a, int plane, float v) {
+    const unsigned hi = cvt_pk_bf16(v, 0.f);
+    const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
+    lds_st16(a, hi);
+    lds_st16(a + plane, lo);
+}
+typedef int nq_i32x4 __attribute__((ext_vector_type(4)));
+NQ_DEV f32x4 wfrag_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane16, int byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, byte_off, 0));
+}
+// 9-bit tap mask of output pixel (y, x) of an H x W image: bit dy * 3 + dx set iff (y + dy - 1, x + dx - 1) is inside
+NQ_DEV unsigned tap_mask(bool valid, int y, int x, int H, int W) {
+    unsigned m = 0;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        m |= (valid && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? (1u << tap) : 0u;
+    }
+    return m;
+}
+
+// acc[t][nt] += conv over K = 9 taps x CIN channels for this wave's MT row tiles.
+//   base[t] : LDS address of the 16-byte chunk (K half h of channel step 0) of the pixel at tap (-1, -1) of tile t's row,
+//             hi plane; the lo plane is PLANE bytes behind.  Tap (dy, dx) sits TAPOFF = (dy * W + dx) * RS bytes further
+//             (dy, dx = 0..2), channel step s 32 s bytes further: both ride on the ds_read offset field.
+//   m9[t]   : tap_mask of the row; a cleared bit sends both reads to the zero block at ZADDR (a kernel-wide constant).
+//   wbyte   : byte offset of the layer's fragments [step][NT][hi, lo][64 lanes][8 bf16] in the weight blob
+template <int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZADDR, bool APF>
+NQ_DEV void conv_k_bf16(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
+                        const unsigned (&base)[MT], const unsigned (&m9)[MT]) {
+    constexpr int S16 = CIN / 16, TOTAL = 9 * S16, AB = APF ? 2 : 1;
+    static_assert(ZADDR >= (2 * W + 2) * RS + 32 * S16, "zero block must sit above the largest tap offset");
+    f32x4 bh[3][NT], bl[3][NT], ah[AB][MT], al[AB][MT];
+    unsigned a_hi[MT], a_lo[MT];
+    auto load_b = [&](int g, int slot) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            bh[slot][nt] = wfrag_load(rsrc, lane16, wbyte + ((g * NT + nt) * 2 + 0) * 1024);
+            bl[slot][nt] = wfrag_load(rsrc, lane16, wbyte + ((g * NT + nt) * 2 + 1) * 1024);
+        }
+    };
+    auto load_a = [&](int g, int slot) {
+        const int tap = g / S16, s = g - tap * S16;
+        const int tapoff = ((tap / 3) * W + tap % 3) * RS;
+        if (s == 0) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const bool ok = (m9[t] >> tap) & 1u;
+                a_hi[t] = ok ? base[t] : ZADDR - tapoff;
+                a_lo[t] = ok ? base[t] + PLANE : ZADDR - tapoff;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            ah[slot][t] = lds_ld128(a_hi[t] + tapoff + 32 * s);
+            al[slot][t] = lds_ld128(a_lo[t] + tapoff + 32 * s);
+        }
+    };
+    load_b(0, 0);
+    load_b(1, 1);
+    if (APF) load_a(0, 0);
+#pragma unroll
+    for (int g = 0; g < TOTAL; ++g) {
+        if (g + 2 < TOTAL) load_b(g + 2, (g + 2) % 3);
+        if (APF) { if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1); } else load_a(g, 0);
+        const int sa = APF ? (g & 1) : 0, sb = g % 3;
+        // product-major: consecutive MFMAs go to DIFFERENT accumulators (no dependent-accumulate bubbles)
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bl[sb][nt], acc[t][nt]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(al[sa][t], bh[sb][nt], acc[t][nt]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bh[sb][nt], acc[t][nt]);
+    }
+}

@@ -1,0 +1,40 @@
+"""rocprofv3 --pmc counter_collection CSVs -> one JSON with the mean counter value per kernel and launch.
+
+    python tools/pmc_to_json.py OUT.json DIR [DIR ...]      (each DIR = the -d directory of one rocprofv3 --pmc pass)
+
+bench.py reads the newest profiles/rNN_pmc_kernels.json for roofline.traffic / mfma_util (Measurement)."""
+import glob
+import json
+import sys
+
+import pandas as pd
+
+
+def main():
+    out, dirs = sys.argv[1], sys.argv[2:]
+    frames = []
+    for d in dirs:
+        for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+            frames.append(pd.read_csv(f))
+    if not frames:
+        raise SystemExit('no counter_collection.csv under ' + ' '.join(dirs))
+    t = pd.concat(frames)
+    t = t[~t.Kernel_Name.str.contains('at::|rocclr|Cijk|elementwise')]
+    t['k'] = t.Kernel_Name.str.split('(').str[0].str.replace(r'^void ', '', regex=True).str.replace(r'<.*', '', regex=True)
+    g = t.groupby(['k', 'Counter_Name'])['Counter_Value'].mean()
+    n = t.groupby(['k', 'Counter_Name'])['Counter_Value'].count()
+    kernels = {}
+    for (k, c), v in g.items():
+        kernels.setdefault(k, {})[c] = float(v)
+        kernels[k].setdefault('_launches_sampled', int(n[(k, c)]))
+    for k, reg in t.groupby('k')[['VGPR_Count', 'LDS_Block_Size', 'Scratch_Size']].max().iterrows() if 'VGPR_Count' in t.columns else []:
+        kernels[k]['_vgpr'] = int(reg['VGPR_Count']); kernels[k]['_lds'] = int(reg['LDS_Block_Size']); kernels[k]['_scratch'] = int(reg['Scratch_Size'])
+    with open(out, 'w') as f:
+        json.dump({'units': 'mean per launch; FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE counts half the bytes of wide reads on gfx950)',
+                   'kernels': kernels}, f, indent=1, sort_keys=True)
+    for k in sorted(kernels):
+        print(k, {c: round(v, 1) for c, v in kernels[k].items()})
+
+
+if __name__ == '__main__':
+    main()
