@@ -315,7 +315,8 @@ def main():
         dt = float(tmax.item())
 
     if rank == 0:
-        assert torch.isfinite(outs[-1]).all()
+        if os.environ.get('NISQA_BENCH_KO') != '1':           # knock-out builds (tools/ab_build.sh -DNQ_KO=..) compute garbage
+            assert torch.isfinite(outs[-1]).all()
         names = ['mel', 'cnn_front', 'cnn_back', 'selfatt', 'pool']
         stage_ms = {n: float(np.mean([evs[s][i].elapsed_time(evs[s][i + 1]) for s in range(a.steps)]))
                     for i, n in enumerate(names)}
