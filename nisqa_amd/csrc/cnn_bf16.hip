@@ -35,9 +35,6 @@
 #ifndef NQ_RING34
 #define NQ_RING34 3
 #endif
-#ifndef NQ_SHARED_W
-#define NQ_SHARED_W 1                      /* conv2..4 weight fragments shared by the workgroup through LDS (conv_ks_bf16) */
-#endif
 
 // LDS plan (byte addresses; the kernel has no static LDS, so the dynamic segment starts at 0 and addresses are used as
 // plain 32-bit numbers): one 128-byte zero block shared by the four waves ABOVE the largest tap offset (so "zero block
@@ -56,11 +53,9 @@
 #define FB_ZADDR 2048u                     /* the shared zero block */
 #define FB_BASE 2176u                      /* first wave region */
 #define FB_WAVE 19584u
-#define FB_RING 17280u                     /* per wave: two 1 KiB slots of the shared weight ring, above the A3 planes */
 #define FB_LDS (FB_BASE + 4 * FB_WAVE)     /* 80512 B -> two workgroups (8 waves) per CU */
 static_assert(FB_PATCH + 2 * FB_PPLANE <= FB_WAVE && 2 * FB_P3 <= FB_WAVE && 2 * FB_PS <= 2 * FB_WAVE, "LDS plan");
 static_assert(2 * FB_LDS <= 160 * 1024, "two workgroups per CU");
-static_assert(FB_RING >= 2 * FB_P3 && FB_RING >= 2 * FB_P1 && FB_RING + 2048 <= FB_WAVE, "weight ring above the planes a K loop reads");
 
 __device__ constexpr int bwin75_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 2 : b == 3 ? 4 : 5; }
 __device__ constexpr int bwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b == 2 ? 5 : b == 3 ? 6 : 7; }
@@ -106,7 +101,6 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const unsigned R = FB_BASE + wave * FB_WAVE;         // this wave's LDS region
     const unsigned lane16 = lane * 16;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
-    const nq_i32x4 wrs4 = buffer_words(wb, CNNB_U16S * 2);
     NQ_CLK(0);
 
     // ---- stage the 15-frame window as two zero-bordered bf16 planes (hi, lo) [frame j + 1][mel m + 1]:
@@ -257,12 +251,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             m9[t] = tap_mask(u < 84, py, px, 24, 7);
             base[t] = R + ((py - 1) * 7 + (px - 1)) * FB_RS1 + (h << 4);
         }
-#if NQ_SHARED_W
-        NQ_SYNC();                         // every wave is done with its input patch: the weight ring lives there
-        conv_ks_bf16<16, 6, 1, 7, FB_RS1, FB_P1, FB_ZADDR, false, FB_BASE + FB_RING, FB_WAVE>(acc, wrs4, CNNB_W2 * 2, lane16, wave, base, m9);
-#else
         conv_k_bf16<16, 6, 1, 7, FB_RS1, FB_P1, FB_ZADDR, false, NQ_RING2>(acc, wrs, CNNB_W2 * 2, lane16, base, m9);
-#endif
         NQ_CLK(3);
         const float tn = tn2;
         const unsigned wr = R + (6 * hf * 5) * FB_RS2 + n * 2;
@@ -303,11 +292,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
             base[t] = R + base34[t] * FB_RS2 + (h << 4);
         }
-#if NQ_SHARED_W
-        conv_ks_bf16<32, 2, 2, 5, FB_RS2, FB_P2, FB_ZADDR, true, FB_BASE + FB_RING, FB_WAVE>(acc, wrs4, CNNB_W3 * 2, lane16, wave, base, m34);
-#else
         conv_k_bf16<32, 2, 2, 5, FB_RS2, FB_P2, FB_ZADDR, true, NQ_RING34>(acc, wrs, CNNB_W3 * 2, lane16, base, m34);
-#endif
         NQ_CLK(5);
         const unsigned wr = R + (6 * hf * 5) * FB_RS3 + n * 2;
 #pragma unroll
@@ -346,11 +331,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
             base[t] = R + base34[t] * FB_RS3 + (h << 4);
         }
-#if NQ_SHARED_W
-        conv_ks_bf16<64, 2, 2, 5, FB_RS3, FB_P3, FB_ZADDR, true, FB_BASE + FB_RING, FB_WAVE>(acc, wrs4, CNNB_W4 * 2, lane16, wave, base, m34);
-#else
         conv_k_bf16<64, 2, 2, 5, FB_RS3, FB_P3, FB_ZADDR, true, NQ_RING34>(acc, wrs, CNNB_W4 * 2, lane16, base, m34);
-#endif
         NQ_CLK(7);
 #pragma unroll
         for (int g = 0; g < 3; ++g) { b5[g][0] = wfrag_load(wrs, lane16, w5b + g * 2048); b5[g][1] = wfrag_load(wrs, lane16, w5b + g * 2048 + 1024); }

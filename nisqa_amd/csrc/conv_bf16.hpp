@@ -174,12 +174,6 @@ typedef int nq_i32x4 __attribute__((ext_vector_type(4)));
 #ifndef NQ_KO
 #define NQ_KO 0
 #endif
-// the four descriptor words of make_buffer_rsrc(ptr, stride 0, bytes, 0x00020000) as SGPR values (for asm operands)
-NQ_DEV nq_i32x4 buffer_words(const void* ptr, int bytes) {
-    const unsigned long long a = (unsigned long long)ptr;
-    return nq_i32x4{__builtin_amdgcn_readfirstlane((int)(unsigned)a), __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu)),
-                    bytes, 0x00020000};
-}
 NQ_DEV f32x4 wfrag_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane16, int byte_off) {
     if (NQ_KO & 1) return f32x4{__uint_as_float(lane16 + byte_off), 1.f, 2.f, 3.f};
     if (NQ_KO & 32) return *(NQ_AS3 const f32x4*)(2176u + 16128u + lane16 + (byte_off & 2048));   // weights "from LDS": 1 KiB conflict-free reads
@@ -257,89 +251,3 @@ NQ_DEV void conv_k_bf16(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int 
     }
 }
 
-
-// The same K loop with the weight fragments SHARED by the four waves of the workgroup through a two-slot LDS ring
-// (tools/ab_build.sh -DNQ_KO=.. knock-outs: fetching every fragment into every wave's registers costs 23 % of the
-// AdaptCNN kernel, the same reads from LDS 6 %).  The layer's fragments form one linear list of 1 KiB blocks
-// ([step][nt][hi, lo]); ring round J holds blocks 4 J .. 4 J + 3, block i in wave i's region at RING + 1024 * (J & 1);
-// wave w fetches block 4 J + w with ONE LDS-DMA instruction (buffer_load_dwordx4 ... lds: no VGPRs), two rounds ahead
-// of its use.  Protocol at the top of round J (all four waves, one s_barrier per round):
-//     wait for the own DMA of round J + 1 and for the register copy of round J  ->  barrier  ->
-//     DMA of round J + 2 into the slot round J just vacated  ->  read round J + 1 into the other register buffer.
-// The caller guarantees that nobody still uses the ring area when this function starts (a barrier after conv1, whose
-// input patch lives there; between layers the last barrier of the previous call is enough).
-//   RINGBASE(i) = LDS address of wave i's ring (FB_BASE + i * FB_WAVE + FB_RING in the AdaptCNN kernel)
-template <int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZADDR, bool APF, unsigned RING0, unsigned RSTRIDE>
-NQ_DEV void conv_ks_bf16(f32x16 (&acc)[MT][NT], nq_i32x4 rs4, int wbyte, unsigned lane16, int wave,
-                         const unsigned (&base)[MT], const unsigned (&m9)[MT]) {
-    constexpr int S16 = CIN / 16, TOTAL = 9 * S16, AB = APF ? 2 : 1;
-    constexpr int FPS = NT * 2, SPR = 4 / FPS, ROUNDS = (TOTAL + SPR - 1) / SPR;
-    static_assert(FPS == 2 || FPS == 4, "one or two N tiles");
-    static_assert(ZADDR >= (2 * W + 2) * RS + 32 * S16, "zero block must sit above the largest tap offset");
-    f32x4 breg[2][4], ah[AB][MT], al[AB][MT];             // breg[buffer][block of the round]
-    unsigned a_hi[MT], a_lo[MT];
-    const unsigned my_ring = RING0 + wave * RSTRIDE;      // wave-uniform
-    // (inline asm on purpose: hipcc orders every later LDS read behind a builtin LDS-DMA with s_waitcnt vmcnt(0), which
-    // would serialise the two-rounds-ahead prefetch; this form has no VGPR destination, and the waits are counted below)
-    auto dma = [&](int J) {                               // block 4 J + wave -> my ring, slot J & 1
-        const unsigned dst = my_ring + (J & 1) * 1024;
-        const int soff = wbyte + (4 * J + wave) * 1024;
-        if (NQ_KO & 64) return;
-        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                     :: "v"(lane16), "s"(rs4), "s"(soff), "s"(dst) : "memory");
-    };
-    auto read_b = [&](int J) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) breg[J & 1][i] = lds_ld128(RING0 + i * RSTRIDE + (J & 1) * 1024 + lane16);
-    };
-    auto load_a = [&](int g, int slot) {
-        const int tap = g / S16, s = g - tap * S16;
-        const int tapoff = ((tap / 3) * W + tap % 3) * RS;
-        if (s == 0) {
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const bool ok = (m9[t] >> tap) & 1u;
-                a_hi[t] = ok ? base[t] : ZADDR - tapoff;
-                a_lo[t] = ok ? base[t] + PLANE : ZADDR - tapoff;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            ah[slot][t] = lds_ld128_a(a_hi[t] + tapoff + 32 * s);
-            al[slot][t] = lds_ld128_a(a_lo[t] + tapoff + 32 * s);
-        }
-    };
-    dma(0);
-    if (ROUNDS > 1) dma(1);
-    if (APF) load_a(0, 0);
-    if (ROUNDS > 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    NQ_SYNC();
-    read_b(0);
-#pragma unroll
-    for (int g = 0; g < TOTAL; ++g) {
-        const int J = g / SPR, sr = g - J * SPR;
-        if (sr == 0) {                                    // top of a ring round
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            NQ_SYNC();
-            if (J + 2 < ROUNDS) dma(J + 2);
-            if (J + 1 < ROUNDS) read_b(J + 1);
-        }
-        if (APF) { if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1); } else load_a(g, 0);
-        __builtin_amdgcn_sched_barrier(0);                // the register copies of the next round / step are requested HERE,
-                                                          // ahead of this step's MFMAs, not just before the next wait
-        const int sa = APF ? (g & 1) : 0;
-        // blocks of this K-step inside the round: (sr * FPS + nt * 2 + hl)
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], breg[J & 1][sr * FPS + nt * 2 + 1], acc[t][nt]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(al[sa][t], breg[J & 1][sr * FPS + nt * 2 + 0], acc[t][nt]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], breg[J & 1][sr * FPS + nt * 2 + 0], acc[t][nt]);
-    }
-}
