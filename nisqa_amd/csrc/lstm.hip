@@ -2,20 +2,20 @@
 // architecture -- replaces LSTM.forward (pack / nn.LSTM / pad, reference nisqa/NISQA_lib.py:925-943) and
 // PoolLastStepBi.forward (NL:1107-1115).
 //
-// The recurrence is sequential in time (up to 5,986 steps), so what matters is the LATENCY of one step, and
-// parallelism comes from clips x directions x gate rows: one 512-thread workgroup per (clip, direction); thread
-// i owns gate row i (PyTorch order i,f,g,o) and keeps its W_hh row (128 floats) and W_ih row (20 floats) in
-// REGISTERS for the whole clip.  A step is then a 512 x 128 matrix-vector product = 1024 VALU cycles on one
-// CU; everything else is arranged so that nothing but those FMAs sits on the critical path:
-//   * h never travels through LDS for the product (eight waves reading 512 B each per step is ~2000 LDS
-//     cycles, twice the FMA time): every wave keeps the WHOLE h in 8 registers, lane l holding h[16k + (l & 15)]
-//     in register k, and feeds it to the FMAs through the DPP row_share broadcast (v_fmac_f32_dpp, no extra
-//     instruction);
-//   * the gate non-linearity is applied by the row's own thread before the exchange; after the single
-//     workgroup barrier of the step every wave redundantly updates (c, h) for all 128 units (two per lane), so
-//     h needs no second barrier -- it is re-laid out through a wave-private LDS strip;
-//   * x_{t+1} is requested (vector loads, vmcnt) before the product of step t and W_ih x_{t+1} + b is formed right
-//     after it, so no memory latency is left on the step's critical path.
+// The recurrence is sequential in time (2 987 steps for a 30 s clip), so what matters is the LATENCY of one step;
+// parallelism comes from clips x directions x gate rows: one 512-thread workgroup per (clip, direction).  A step is a
+// 512 x 128 matrix-vector product (64 v_pk_fma_f32 per thread, ~500 cycles of VALU issue on the CU's four SIMDs) and
+// everything else is latency on the critical path, so the step is organised around ONE LDS round trip and ONE barrier:
+//   * thread (u, q) = (hidden unit, quarter of the K dimension) holds the weights of ALL FOUR gates (i, f, g, o) of
+//     unit u for h[32 q .. 32 q + 31] in 128 registers; the four quarters of a unit are the four lanes of a DPP quad, so
+//     the gate pre-activations are completed with two quad_perm adds per gate -- the gates of a unit never travel
+//     through LDS (round 1: one thread per gate ROW, gates exchanged through LDS + barrier, state re-laid out through a
+//     second LDS hop: 0.97 us per step);
+//   * every lane of the quad then holds i, f, g, o of its unit and updates (c, h) itself; lane q = 0 publishes h[u]
+//     in a double-buffered LDS vector, one workgroup barrier, and every lane reads the 32 h values of its quarter
+//     (8 ds_read_b128, four distinct addresses per wave: conflict-free) straight into the FMA operands;
+//   * the input projection W_ih x_t is split the same way (5 of the 20 inputs per quarter); x_{t+1} is requested one
+//     step ahead with vector loads (vmcnt, not the lgkmcnt the LDS waits use).
 // Only what the pooling needs leaves the kernel: the forward direction's last state and the backward
 // direction's state at position 0 (hfin[clip][2][128]); the full [n,256] sequence is written only when a
 // caller asks for it (parity tests).
@@ -27,117 +27,101 @@
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // 1 / (1 + e^-x) and tanh on v_exp_f32 / v_rcp_f32 (absolute error ~1e-7; the states are bounded by 1)
-NQ_DEV float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 NQ_DEV float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
-// value of lane (row base + N) for every lane of the 16-lane row; folds into the consuming v_fmac as a DPP operand
-template <int N>
-NQ_DEV float row_share(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + N, 0xf, 0xf, true));
-}
-template <int N>
-NQ_DEV void fma16(f32x2 (&a)[2], const float* w, float hk) {          // two FMAs per v_pk_fma_f32
-    const f32x2 hv = {row_share<N>(hk), row_share<N + 1>(hk)}, wv = {w[N], w[N + 1]};
-    a[(N >> 1) & 1] = __builtin_elementwise_fma(hv, wv, a[(N >> 1) & 1]);
-    if constexpr (N < 14) fma16<N + 2>(a, w, hk);
+// sum over the four lanes of a DPP quad, result in every lane
+NQ_DEV float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return v;
 }
 
-template <int KD>
+// lane N of the quad, in every lane of the quad
+template <int N>
+NQ_DEV float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), N * 0x55, 0xF, 0xF, true));   // quad_perm [N,N,N,N]
+}
+
 __global__ __launch_bounds__(512, 1) void lstm_dir_kernel(
     const float* __restrict__ feat20, const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
     const float* __restrict__ lw, float* __restrict__ hfin, float* __restrict__ seq) {
-    __shared__ __attribute__((aligned(16))) float gact[2][512];       // activated gates, double-buffered over steps
-    __shared__ __attribute__((aligned(16))) float hstrip[8][128];     // wave-private h re-layout
+    __shared__ __attribute__((aligned(16))) float hbuf[2][128];       // h_t, double-buffered over steps
     const int i = threadIdx.x, b = blockIdx.x, dir = blockIdx.y;
     const int lane = i & 63, wave = __builtin_amdgcn_readfirstlane(i >> 6);
+    const int u = 16 * wave + (lane >> 2), q = lane & 3;               // hidden unit, K quarter
     const int n = n_wins[b], c0 = tok_off[b];
     const float* w = lw + (size_t)dir * LSTM_DIR_FLOATS;
-    float whh[128];
+    // weights of the four gate rows of unit u (PyTorch order i, f, g, o: rows g * 128 + u), columns 32 q .. 32 q + 31
+    f32x2 whh[4][16], wih[4][3];
+    float bias[4];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) {
-        const f32x4 v = *(const f32x4*)(w + LSTM_WHH + (size_t)i * 128 + 4 * q);
-        whh[4 * q] = v[0]; whh[4 * q + 1] = v[1]; whh[4 * q + 2] = v[2]; whh[4 * q + 3] = v[3];
+    for (int g = 0; g < 4; ++g) {
+        const int row = g * 128 + u;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const f32x4 v = *(const f32x4*)(w + LSTM_WHH + (size_t)row * 128 + 32 * q + 4 * kk);
+            whh[g][2 * kk] = f32x2{v[0], v[1]};
+            whh[g][2 * kk + 1] = f32x2{v[2], v[3]};
+        }
+        const float* wi = w + LSTM_WIH + row * 20 + 5 * q;             // inputs 5 q .. 5 q + 4 (the sixth slot is zero)
+        wih[g][0] = f32x2{wi[0], wi[1]};
+        wih[g][1] = f32x2{wi[2], wi[3]};
+        wih[g][2] = f32x2{wi[4], 0.f};
+        bias[g] = q == 0 ? w[LSTM_B + row] : 0.f;                      // added once per quad
     }
-    f32x2 wih[10];
-#pragma unroll
-    for (int j = 0; j < 10; ++j) wih[j] = f32x2{w[LSTM_WIH + i * 20 + 2 * j], w[LSTM_WIH + i * 20 + 2 * j + 1]};
-    const float bias = w[LSTM_B + i];
-    const bool is_g = (wave >> 1) == 2;                                // rows 256..383: the cell candidate (tanh)
-    float hk[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) hk[k] = 0.f;
-    float c2[2] = {0.f, 0.f}, h2[2] = {0.f, 0.f};
-    float* hs = hstrip[wave];
-    hs[lane] = 0.f;
-    hs[lane + 64] = 0.f;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+    const float gk = q == 2 ? 2.0f : 1.0f, gb = q == 2 ? -1.0f : 0.0f;
+    float c = 0.f, h = 0.f;
+    if (i < 256) ((float*)hbuf)[i] = 0.f;
+    __syncthreads();
 
-    // x_t by VECTOR loads (every lane the same address): they are counted by vmcnt, so a request issued one
-    // step ahead stays in flight across the LDS waits of the step (scalar loads share lgkmcnt with LDS and would
-    // be waited for at the first of them)
-    const int vzero = __builtin_amdgcn_mbcnt_lo(0u, 0u);               // 0, opaque to the compiler: keeps the loads VMEM
-    auto xload = [&](int t, f32x4 (&xv)[5]) {
+    // x_t: this lane's five inputs, requested one step ahead
+    auto xload = [&](int t, float (&xv)[5]) {
         const int tok = c0 + (dir == 0 ? t : n - 1 - t);
-        const f32x4* x = (const f32x4*)(feat20 + (size_t)tok * 20) + vzero;
+        const float* x = feat20 + (size_t)tok * 20 + 5 * q;
 #pragma unroll
-        for (int q = 0; q < 5; ++q) xv[q] = x[q];
+        for (int j = 0; j < 5; ++j) xv[j] = x[j];
     };
-    auto xproj = [&](const f32x4 (&xv)[5]) {
-        f32x2 a = {bias, 0.f};
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            a = __builtin_elementwise_fma(wih[2 * q], f32x2{xv[q][0], xv[q][1]}, a);
-            a = __builtin_elementwise_fma(wih[2 * q + 1], f32x2{xv[q][2], xv[q][3]}, a);
-        }
-        return a[0] + a[1];
-    };
-    f32x4 xv[5];
-    float xin = 0.f;
-    if (n > 0) { xload(0, xv); xin = xproj(xv); }
+    float xv[5];
+    if (n > 0) xload(0, xv);
     for (int t = 0; t < n; ++t) {
-        if (t + 1 < n) xload(t + 1, xv);                               // consumed after the matrix-vector product
-        f32x2 a[2] = {{xin, 0.f}, {0.f, 0.f}};
-        // units 0 .. 16 KD - 1 through the DPP broadcast, the rest as LDS broadcast reads: the VALU (one v_mov_dpp per
-        // unit) and the LDS pipe (8 waves x 16 B per 4 units) share the cost of distributing h
+        // h_{t-1}: the 32 values of this lane's quarter
+        const f32x4* hp = (const f32x4*)(hbuf[t & 1] + 32 * q);
+        f32x4 hv[8];
 #pragma unroll
-        for (int k = 0; k < KD; ++k) fma16<0>(a, whh + 16 * k, hk[k]);
-        {
-            const f32x4* hp = (const f32x4*)(hs + 16 * KD);
+        for (int kk = 0; kk < 8; ++kk) hv[kk] = hp[kk];
+        f32x2 a[4];
 #pragma unroll
-            for (int q = 0; q < 32 - 4 * KD; ++q) {
-                const f32x4 hv = hp[q];
-                const float* wq = whh + 16 * KD + 4 * q;
-                a[0] = __builtin_elementwise_fma(f32x2{hv[0], hv[1]}, f32x2{wq[0], wq[1]}, a[0]);
-                a[1] = __builtin_elementwise_fma(f32x2{hv[2], hv[3]}, f32x2{wq[2], wq[3]}, a[1]);
+        for (int g = 0; g < 4; ++g) {
+            a[g] = f32x2{bias[g], 0.f};
+            a[g] = __builtin_elementwise_fma(wih[g][0], f32x2{xv[0], xv[1]}, a[g]);
+            a[g] = __builtin_elementwise_fma(wih[g][1], f32x2{xv[2], xv[3]}, a[g]);
+            a[g] = __builtin_elementwise_fma(wih[g][2], f32x2{xv[4], 0.f}, a[g]);
+        }
+        if (t + 1 < n) xload(t + 1, xv);                               // in flight across the product and the barrier
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                a[g] = __builtin_elementwise_fma(whh[g][2 * kk], f32x2{hv[kk][0], hv[kk][1]}, a[g]);
+                a[g] = __builtin_elementwise_fma(whh[g][2 * kk + 1], f32x2{hv[kk][2], hv[kk][3]}, a[g]);
             }
+        // lane q of the quad finishes gate q: the pre-activation sum over the quad, then the non-linearity -- sigmoid for
+        // i, f, o and tanh(x) = 2 sigmoid(2 x) - 1 for g share one formula with per-lane constants (ONE v_exp / v_rcp per
+        // lane instead of four); the four results come back through quad broadcasts
+        const float p0 = quad_sum(a[0][0] + a[0][1]), p1 = quad_sum(a[1][0] + a[1][1]);
+        const float p2 = quad_sum(a[2][0] + a[2][1]), p3 = quad_sum(a[3][0] + a[3][1]);
+        const float pre = q == 0 ? p0 : q == 1 ? p1 : q == 2 ? p2 : p3;
+        const float act = fmaf(gk, __builtin_amdgcn_rcpf(1.0f + __expf(-gk * pre)), gb);      // gk = 1 or 2, gb = 0 or -1
+        const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act), gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
+        c = fmaf(fg, c, ig * gg);
+        h = og * tanh_fast(c);
+        if (q == 0) {
+            hbuf[(t + 1) & 1][u] = h;
+            if (seq) seq[(size_t)(c0 + (dir == 0 ? t : n - 1 - t)) * 256 + dir * 128 + u] = h;
         }
-        const float pre = (a[0][0] + a[0][1]) + (a[1][0] + a[1][1]);
-        gact[t & 1][i] = is_g ? tanh_fast(pre) : sigmoid_fast(pre);
-        if (t + 1 < n) xin = xproj(xv);
         __syncthreads();
-        // every wave: units 2*lane, 2*lane + 1
-        const float* g = gact[t & 1];
-        const f32x2 ig = *(const f32x2*)(g + 2 * lane), fg = *(const f32x2*)(g + 128 + 2 * lane);
-        const f32x2 gg = *(const f32x2*)(g + 256 + 2 * lane), og = *(const f32x2*)(g + 384 + 2 * lane);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            c2[e] = fmaf(fg[e], c2[e], ig[e] * gg[e]);
-            h2[e] = og[e] * tanh_fast(c2[e]);
-        }
-        *(f32x2*)(hs + 2 * lane) = f32x2{h2[0], h2[1]};
-        if (seq && wave == 0) {
-            const int tok = c0 + (dir == 0 ? t : n - 1 - t);
-            *(f32x2*)(seq + (size_t)tok * 256 + dir * 128 + 2 * lane) = f32x2{h2[0], h2[1]};
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int k = 0; k < KD; ++k) hk[k] = hs[16 * k + (lane & 15)];
-        __builtin_amdgcn_wave_barrier();
     }
-    if (wave == 0) *(f32x2*)(hfin + ((size_t)b * 2 + dir) * 128 + 2 * lane) = f32x2{h2[0], h2[1]};
+    if (q == 0) hfin[((size_t)b * 2 + dir) * 128 + u] = h;
 }
 
 __global__ __launch_bounds__(64) void pool_last_kernel(const float* __restrict__ hfin, const float* __restrict__ lw,
@@ -157,17 +141,8 @@ extern "C" int nisqa_lstm_laststep(const float* feat20, const int32_t* tok_off, 
                                    float* out, void* stream) {
     if (n_clips <= 0) return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    static const int kd = getenv("NISQA_LSTM_KD") ? atoi(getenv("NISQA_LSTM_KD")) : 3;
-#define NQ_LSTM(K) hipLaunchKernelGGL(lstm_dir_kernel<K>, dim3(n_clips, 2), dim3(512), 0, (hipStream_t)stream, feat20, \
-                                      tok_off, n_wins, lstm_w, hfin_ws, seq_opt)
-    switch (kd) {
-        case 0: NQ_LSTM(0); break;
-        case 2: NQ_LSTM(2); break;
-        case 4: NQ_LSTM(4); break;
-        case 8: NQ_LSTM(8); break;
-        default: NQ_LSTM(3); break;
-    }
-#undef NQ_LSTM
+    hipLaunchKernelGGL(lstm_dir_kernel, dim3(n_clips, 2), dim3(512), 0, (hipStream_t)stream, feat20, tok_off, n_wins, lstm_w,
+                       hfin_ws, seq_opt);
     hipLaunchKernelGGL(pool_last_kernel, dim3(n_clips), dim3(64), 0, (hipStream_t)stream, (const float*)hfin_ws, lstm_w,
                        out);
     return NQ_LAUNCH_STATUS();
