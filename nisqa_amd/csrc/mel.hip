@@ -98,6 +98,19 @@ __device__ constexpr float W16S[16] = {-0.000000000e+00f, -3.826834324e-01f, -7.
 #define MEL_WBAR() __builtin_amdgcn_wave_barrier()
 #endif
 #define MEL_WAVES 4
+// -DNQ_MEL_CLOCK (tools/ab_build.sh melclk mel -DNQ_MEL_CLOCK; tools/mel_clock.py): shader-clock stamps at the phase
+// boundaries of a frame, summed over all frames
+#ifdef NQ_MEL_CLOCK
+__device__ unsigned long long g_mel_clk[16];
+#define MEL_CLK(i) do { const long long t_ = clock64(); mclk[i] += t_ - tprev; tprev = t_; } while (0)
+extern "C" int nisqa_debug_mel_clock(unsigned long long* out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mel_clk), sizeof(g_mel_clk)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mel_clk), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define MEL_CLK(i)
+#endif
 #define MEL_EXCH_BYTES 5120            /* exchange 1 [8][72] complex (4608 B) and exchange 2 64 x 80 B alias */
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
@@ -270,6 +283,9 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
 
     float raw[8][2];
     if (NQ == 1) load_frame(f_begin, b, 0, raw);
+#ifdef NQ_MEL_CLOCK
+    long long mclk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
     for (int f = f_begin; f < f_end; ++f) {
         c32 zq[NQ][8];
         const int fn = f + 1;
@@ -310,6 +326,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
 
         c32 u[8], u1[8];
         const int mir = 63 - lane;
+        MEL_CLK(0);                                   // window + prefetch
         // r = 0: partner Z_0[512 - k] = lane (64 - l) & 63, register 7 - q2 (lane 0: register (8 - q2) & 7)
         fold(0, z);
         fft512<0>(u, z, tw, exch, lane);
@@ -325,6 +342,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
             if (lane == 0 && 512 < mag_stride) mag[512] = 2.0f * fabsf(u[0].x - u[0].y);   // Nyquist bin: 2 X[2048] = 2 (Re Z0 - Im Z0)
 
         }
+        MEL_CLK(1);                                   // FFT r = 0 + magnitudes
         // r = 2: partner Z_2[511 - k] = lane 63 - l, register 7 - q2
         fold(2, z);
         fft512<2>(u, z, tw, exch, lane);
@@ -334,11 +352,13 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
             if (lane + 64 * q2 < mag_stride)
                 mag[2 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tw.d[2], cmk(W16C[q2], W16S[q2]));
         }
+        MEL_CLK(2);                                   // FFT r = 2 + magnitudes
         // r = 1 and r = 3 are each other's partners
         fold(1, z);
         fft512<1>(u1, z, tw, exch, lane);
         fold(3, z);
         fft512<3>(u, z, tw, exch, lane);
+        MEL_CLK(3);                                   // FFTs r = 1, 3
 #pragma unroll
         for (int q2 = 0; q2 < 8; ++q2) {
             const c32 z3m = shfl_c(u[7 - q2], mir), z1m = shfl_c(u1[7 - q2], mir);
@@ -349,6 +369,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
             }
         }
         MEL_WBAR();
+        MEL_CLK(4);                                   // magnitudes r = 1, 3
 
         // ---- sparse slaney filterbank: 4 bands per pass (one per 16-lane row)
         float mine = 0.f;
@@ -365,6 +386,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
             if (l16 == ps) mine = part;                 // lane 16*row + ps holds band 4*ps + row
         }
         MEL_WBAR();
+        MEL_CLK(5);                                   // filterbank
         // ---- amplitude_to_db(ref=1, amin=1e-4): 10*log10(max(amin^2, S^2)); running per-clip max
         if (l16 < 12) {
             const float db = 10.0f * log10f(fmaxf(cfg.amin_sq, mine * mine));
@@ -377,7 +399,15 @@ __global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
             runmax = -3.0e38f;
             b = bn;
         }
+        MEL_CLK(6);                                   // dB, store, clip maximum
     }
+#ifdef NQ_MEL_CLOCK
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) atomicAdd(&g_mel_clk[q], (unsigned long long)mclk[q]);
+        atomicAdd(&g_mel_clk[8], (unsigned long long)(f_end - f_begin));
+    }
+#endif
 }
 
 __global__ void mel_floor_kernel(const uint32_t* __restrict__ clip_max_enc, float top_db, int n_clips,
