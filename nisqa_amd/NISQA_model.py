@@ -17,6 +17,20 @@ import yaml
 from . import NISQA_lib as NL
 
 
+def _load_checkpoint(path):
+    """torch.load(path) like the reference (NISQA_model.py:933-939), but through torch's restricted unpickler first: the
+    shipped checkpoints hold tensors, plain containers and one datetime in ``args`` -- allow-listed here.  Only when that
+    fails (a checkpoint with other pickled objects) does it fall back to the full unpickle, with a warning: a .tar from an
+    untrusted source can then run arbitrary code, exactly as with the reference."""
+    import datetime
+    try:
+        with torch.serialization.safe_globals([datetime.datetime]):
+            return torch.load(path, map_location='cpu', weights_only=True)
+    except Exception as e:                                      # noqa: BLE001 -- any unpickling refusal
+        print('nisqa_amd: {} needs the full (unsafe) unpickler: {}'.format(os.path.basename(path), str(e).split('\n')[0][:120]))
+        return torch.load(path, map_location='cpu', weights_only=False)
+
+
 class nisqaModel(object):
     """Loads the checkpoint and the dataset table; ``predict()`` returns the frame the reference returns."""
 
@@ -182,7 +196,7 @@ class nisqaModel(object):
                 model_path = os.path.join(self.args['pretrained_model'])
             else:
                 model_path = os.path.join(os.getcwd(), self.args['pretrained_model'])
-            checkpoint = torch.load(model_path, map_location='cpu', weights_only=False)   # full unpickle like the reference (args hold a datetime)
+            checkpoint = _load_checkpoint(model_path)
             checkpoint['args'].update(self.args)                      # caller keys win (NISQA_model.py:941)
             self.args = checkpoint['args']
         else:
