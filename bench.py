@@ -105,6 +105,37 @@ def pmc_derived(k):
     return tr, mu
 
 
+def mfma_sustained(dev):
+    """Dense bf16 MFMA rate and shader clock this GPU SUSTAINS on random operands (nisqa_probe_mfma_sustained: two waves
+    per SIMD of back-to-back v_mfma_f32_32x32x16_bf16 on registers, ~50 ms).  On MI355X the clock drops from ~2.38 GHz
+    (zero operands: the data-sheet 2.5 PFLOP/s) to ~1.8 GHz under random data -- the ceiling a bf16 kernel on real data has."""
+    import ctypes
+    from nisqa_amd import lib as _lib
+    L = _lib.load()
+    blocks, iters = 4096, 12000
+    g = torch.Generator().manual_seed(5)
+    bits = torch.randint(0, 1 << 16, (65536 * 8,), generator=g, dtype=torch.int32)
+    bits = ((bits & 0x807f) | 0x3f00 | ((bits >> 3) & 0x0080)).to(torch.int16)        # sign, 7 mantissa bits, exponent 126/127
+    res = {}
+    for name, ops in (('zeros', torch.zeros_like(bits)), ('random', bits)):
+        d_ops = ops.to(dev)
+        out = torch.empty(blocks * 256, dtype=torch.float32, device=dev)
+        clk = torch.zeros(blocks * 4 * 2, dtype=torch.int64, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for rep in range(2):                                                             # the first launch ramps the clock
+            e0.record()
+            _lib.check(L.nisqa_probe_mfma_sustained(d_ops.data_ptr(), out.data_ptr(), clk.data_ptr(), blocks, iters, st),
+                       'nisqa_probe_mfma_sustained')
+            e1.record()
+            torch.cuda.synchronize(dev)
+        ms = e0.elapsed_time(e1)
+        c = clk.view(-1, 2).double().sum(0)
+        res[name] = {'tflops': round(blocks * 4 * iters * 16 * 32768.0 / (ms * 1e-3) / 1e12, 1),
+                     'shader_clock_mhz': round(float(c[0] / c[1]) * 100.0, 0)}
+    return res
+
+
 def cpu_baseline(args, sd, bs=BATCH):
     """Oracle (CPU port of the reference path) on ONE bs = 64 batch of 10 s clips: mel per clip as the reference's
     dataset does (librosa is serial at num_workers = 0; here numpy's single-threaded pocketfft), then the network on the
@@ -337,6 +368,14 @@ def main():
         clips = BATCH * a.steps * world
         roof = roofline_of(eng.precision, stage_ms['cnn_front'])
         roof['whole_path_tflops'] = round(FLOP_TOTAL * clips / dt / 1e12 / world, 2)
+        k = pmc.get('cnn_front_bf16_kernel' if eng.precision == 'bf16x3' else 'cnn_front_kernel') or {}
+        if k.get('GRBM_GUI_ACTIVE') and k.get('_ms'):
+            roof['shader_clock_mhz_profiled'] = round(k['GRBM_GUI_ACTIVE'] / 8.0 / (k['_ms'] * 1e-3) / 1e6, 0)
+        if world == 1 and not a.no_extras and eng.precision == 'bf16x3':
+            sus = mfma_sustained(dev)
+            roof['peak_sustained'] = {'what': 'dense v_mfma_f32_32x32x16_bf16 on register operands, measured on this GPU just now: '
+                                              'zero operands reach the data-sheet peak, random operands are power-limited',
+                                      **sus, 'frac_of_sustained_random': round(roof['achieved'] / sus['random']['tflops'], 4)}
         mel_flop = FLOP_MEL_FRAME * plan.total_frames
         mel_ach = mel_flop / (stage_ms['mel'] * 1e-3) / 1e12
         mtr, _ = pmc_derived(pmc.get('mel_frame_kernel'))

@@ -243,6 +243,12 @@ int nisqa_pcm16_to_f32(const int16_t* pcm16, float* pcm, int64_t n, void* stream
  * v_mfma_f32_32x32x2_f32, a/b/d [dev] row-major.  Used by tests only. */
 int nisqa_selftest_mfma(const float* a, const float* b, float* d, int32_t k, void* stream);
 
+/* Measurement probe (not on the predict path): dense v_mfma_f32_32x32x16_bf16 on register operands, two waves per SIMD.
+ * operands [dev] 65536 x 16 bytes of bf16 bit patterns; out [dev] blocks * 256 floats; clk [dev] blocks * 4 pairs
+ * (shader-clock ticks, 100 MHz ticks) per wave; every wave issues 16 * iters MFMAs (32768 flop each).  bench.py uses it to
+ * report the bf16 rate and shader clock THIS GPU sustains on random operands next to the data-sheet peak. */
+int nisqa_probe_mfma_sustained(const void* operands, float* out, uint64_t* clk, int32_t blocks, int32_t iters, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

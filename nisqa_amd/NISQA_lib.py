@@ -12,6 +12,7 @@ Out of scope here (raise NotImplementedError): training, NISQA_DE,
 alternative blocks no shipped checkpoint uses.
 """
 import os
+import time
 from contextlib import nullcontext as _nullcontext
 
 import numpy as np
@@ -256,6 +257,15 @@ class SpeechQualityDataset(object):
     def file_path(self, index):
         return os.path.join(self.data_dir, self.df[self.filename_column].iloc[index])   # NL:2132
 
+    def file_paths(self, indices):
+        """Paths of many items at once: the filename column is read out once (a pandas scalar lookup per item costs
+        more host time than staging the item's samples)."""
+        cache = getattr(self, '_path_cache', None)
+        if cache is None or cache[0] is not self.df or len(cache[1]) != len(self.df):
+            cache = self._path_cache = (self.df, self.df[self.filename_column].tolist())
+        names, d = cache[1], self.data_dir
+        return [os.path.join(d, names[i]) for i in indices]
+
     def load_audio(self, index):
         """(samples, sr) of item ``index``; raises ValueError('Could not load file ...') like NL:2305-2306."""
         return read_wav(self.file_path(index), self.ms_channel)
@@ -304,6 +314,25 @@ class SpeechQualityDataset(object):
 # ---------------------------------------------------------------------------------------------
 # Batching loop
 # ---------------------------------------------------------------------------------------------
+_STREAMS = {}
+
+
+def _loop_streams(device):
+    """(copy stream, [kernel stream, kernel stream]) of the predict loop on ``device``, created once per process.
+    The copy stream has high priority = a hardware queue of its own: streams of one priority share a small pool of
+    hardware queues round-robin, and a copy stream that lands on the queue of a kernel stream is serialised behind its
+    kernels."""
+    key = str(device)
+    if key not in _STREAMS:
+        nk = int(os.environ.get('NISQA_LOOP_KERNEL_STREAMS', '2'))
+        ks = [torch.cuda.Stream(device=device) for _ in range(max(1, min(nk, 2)))]
+        _STREAMS[key] = (torch.cuda.Stream(device=device, priority=-1), [ks[0], ks[-1]])
+    return _STREAMS[key]
+
+
+LOOP_STATS = {}                 # host seconds of the last _predict call by phase (tools/probe_loop.py)
+
+
 def _predict(model, ds, bs, dev, num_workers):
     """Shared body of predict_mos / predict_dim: returns y_hat [N, heads] float32 for ALL items of ds
     (clip-sharded over ranks when torch.distributed is initialised, then gathered)."""
@@ -320,41 +349,75 @@ def _predict(model, ds, bs, dev, num_workers):
     y_local = np.zeros((hi - lo, heads), dtype=np.float32)
     batches = [list(range(s, min(s + bs, hi))) for s in range(lo, hi, bs)]
     # host side (ingest.py): a producer thread + num_workers readers stage batches two ahead in page-locked buffers;
-    # device side: two HIP streams, the H2D copy + forward of batch i+1 are enqueued while batch i is still running,
-    # and the D2H of batch i's [B, heads] rows is waited for one batch late (no device-wide sync in the loop)
+    # device side: ONE stream carries nothing but the H2D copies (a stream that also carries kernels gets its copies done
+    # by a shader blit that competes with them instead of the SDMA engine: copy and kernels of neighbouring batches then
+    # do not overlap at all, tools/probe_overlap.py: 7.5 ms per 256-clip batch against 4.5), two streams take the
+    # kernels of alternate batches behind an event, a staging slot is recycled as soon as ITS copy is done, and the D2H
+    # of batch i's [B, heads] rows is waited for one batch late (no device-wide sync in the loop)
     ing = _ingest.Ingest(ds, batches, pin=on_gpu, num_workers=num_workers)
-    streams = [torch.cuda.Stream(device=eng.device) for _ in range(2)] if on_gpu else [None, None]
-    inflight = []                                                   # (ids, out tensor, stream)
+    copy_stream, streams = _loop_streams(eng.device) if on_gpu else (None, [None, None])
+    inflight = []                                                   # (ids, host rows, event behind them)
+
+    T = {'queue_wait': 0.0, 'enqueue': 0.0, 'result_wait': 0.0}
+    clock = time.perf_counter
 
     def drain(keep):
+        # waits on the EVENT behind a batch's rows, never on its stream: hipStreamSynchronize also waits for whatever was
+        # queued on the stream (or on another stream that shares its hardware queue) after that batch, i.e. for the batch
+        # just enqueued -- the loop then runs copy and kernels strictly one after the other (8.2 instead of 4.6 ms per
+        # 256 clips; which it was depended on the order streams were created in)
+        t0 = clock()
         while len(inflight) > keep:
-            ids, out, st = inflight.pop(0)
-            if st is not None:
-                st.synchronize()
-            y_local[np.asarray(ids) - lo] = out.cpu().numpy()
+            ids, rows, done = inflight.pop(0)
+            if done is not None:
+                done.synchronize()
+            y_local[np.asarray(ids) - lo] = rows.numpy()
+        T['result_wait'] += clock() - t0
 
     try:
+        t_it = clock()
         for bi, staged in enumerate(ing):
+            t_got = clock()
+            T['queue_wait'] += t_got - t_it
             st = streams[bi % 2]
             raw = ing.ring.buf[staged.slot]
-            ctx = torch.cuda.stream(st) if st is not None else _nullcontext()
+            sent, ev = [], None
             try:
-                with ctx:
+                with (torch.cuda.stream(copy_stream) if on_gpu else _nullcontext()):
                     for g in staged.groups:                          # files of one rate share the mel tables
-                        plan = eng.plan(g.lengths, g.sr, names=[ds.file_path(i) for i in g.ids])
+                        plan = eng.plan(g.lengths, g.sr, names=g.names)
+                        tables = plan.to(eng.device)
                         host = raw[g.offset:g.offset + g.nbytes].view(torch.int16 if g.is_i16 else torch.float32)
                         pcm = host.to(eng.device, non_blocking=True)     # PCM16 stays int16: 2 bytes/sample over PCIe
-                        inflight.append((g.ids, eng.forward_pcm(pcm, plan, g.sr), st))
+                        sent.append((g, plan, tables, pcm))
+                    if on_gpu:
+                        ev = torch.cuda.Event()
+                        ev.record(copy_stream)
             finally:
-                ev = None
-                if st is not None:
-                    ev = torch.cuda.Event()
-                    ev.record(st)
                 ing.ring.release_after(staged.slot, ev)
+            if on_gpu:
+                st.wait_event(ev)
+            with (torch.cuda.stream(st) if on_gpu else _nullcontext()):
+                for g, plan, tables, pcm in sent:
+                    out = eng.forward_pcm(pcm, plan, g.sr)
+                    if on_gpu:
+                        pcm.record_stream(st)                        # allocated on the copy stream, consumed on this one
+                        tables['_buf'].record_stream(st)
+                        rows = torch.empty(out.shape, dtype=out.dtype, pin_memory=True)
+                        rows.copy_(out, non_blocking=True)           # [B, heads] floats, behind the kernels
+                        done = torch.cuda.Event()
+                        done.record(st)
+                        inflight.append((g.ids, rows, done))
+                    else:
+                        inflight.append((g.ids, out, None))
+            T['enqueue'] += clock() - t_got
             drain(keep=len(staged.groups))                           # results of the previous batch
+            t_it = clock()
         drain(keep=0)
     finally:
         ing.close()
+        LOOP_STATS.clear()
+        LOOP_STATS.update(T)
     return _dist.gather_rows(y_local, n, lo, hi, dev)
 
 

@@ -25,6 +25,7 @@
 // as lane base + immediates, and the conv1 epilogue finalises each pooled value in ONE lane of the mel pair, not both.
 #include "common.hpp"
 #include "layout.hpp"
+#include <stdlib.h>
 #include "conv_bf16.hpp"
 #include "internal.hpp"
 #include "../../include/nisqa_hip.h"
@@ -62,13 +63,26 @@ __device__ constexpr int bwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b =
 __device__ constexpr int bwin53_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : 3; }
 __device__ constexpr int bwin53_hi(int b) { return b == 0 ? 2 : b == 1 ? 4 : 5; }
 
-// -DNQ_PHASE_CLOCK (tools/phase_clock.sh): shader-clock stamps at the layer boundaries, summed per phase over all waves
+// -DNQ_PHASE_CLOCK (tools/phase_clock.sh): shader-clock stamps at the layer boundaries.  Every wave of a launch writes
+// its 16 numbers to its OWN slot with plain stores (a first version added them to 16 shared counters: 250 k atomics on
+// one cache line per launch made the kernel 4x slower and its phase profile meaningless); the host adds the slots up.
 #ifdef NQ_PHASE_CLOCK
-__device__ unsigned long long g_phase_clk[16];
+#define NQ_CLK_SLOTS 32768
+__device__ unsigned long long g_phase_clk[NQ_CLK_SLOTS * 16];
 #define NQ_CLK(i) clk[i] = clock64()
 extern "C" int nisqa_debug_phase_clock(unsigned long long* out16, int reset) {
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_phase_clk), sizeof(g_phase_clk)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clk), z, sizeof(z)) != hipSuccess) return -1; }
+    if (out16) {
+        unsigned long long* h = (unsigned long long*)malloc(sizeof(g_phase_clk));
+        if (!h || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk), sizeof(g_phase_clk)) != hipSuccess) { free(h); return -1; }
+        for (int q = 0; q < 16; ++q) out16[q] = 0;
+        for (int w = 0; w < NQ_CLK_SLOTS; ++w)
+            for (int q = 0; q < 16; ++q) out16[q] += h[(size_t)w * 16 + q];
+        free(h);
+    }
+    if (reset) {
+        void* d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_phase_clk)) != hipSuccess || hipMemset(d, 0, sizeof(g_phase_clk)) != hipSuccess) return -1;
+    }
     return 0;
 }
 #else
@@ -502,12 +516,13 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     }
 #ifdef NQ_PHASE_CLOCK
     clk[12] = clock64();
-    if (lane == 0) {
+    if (lane == 0) {                                      // the LAST launch's numbers stay (slots are overwritten)
+        unsigned long long* slot = g_phase_clk + (size_t)((((blockIdx.y * gridDim.x + blockIdx.x) << 2) + wave) & (NQ_CLK_SLOTS - 1)) * 16;
 #pragma unroll
-        for (int q = 0; q < 12; ++q) atomicAdd(&g_phase_clk[q], (unsigned long long)(clk[q + 1] - clk[q]));
-        atomicAdd(&g_phase_clk[12], 1ull);
-        atomicAdd(&g_phase_clk[13], (unsigned long long)(wall_clock64() - wall_top));
-        atomicAdd(&g_phase_clk[14], (unsigned long long)(clk[0] - clk_top));
+        for (int q = 0; q < 12; ++q) slot[q] = (unsigned long long)(clk[q + 1] - clk[q]);
+        slot[12] = 1ull;
+        slot[13] = (unsigned long long)(wall_clock64() - wall_top);
+        slot[14] = (unsigned long long)(clk[0] - clk_top);
     }
 #endif
 }

@@ -68,14 +68,24 @@ class BatchPlan(object):
         return self
 
     def to(self, device):
+        """The four index tables on ``device``: packed into ONE page-locked buffer and sent with one asynchronous copy.
+        (Four pageable ``.to(device)`` calls each block the host until everything queued before them on the stream has
+        run -- behind a batch's 245 MB PCM copy that is 4 ms of the predict loop.)"""
         if self.dev is None or self.dev['device'] != device:
-            self.dev = {
-                'device': device,
-                'clip_off': torch.from_numpy(self.clip_off).to(device),
-                'frame_off': torch.from_numpy(self.frame_off).to(device),
-                'tok_off': torch.from_numpy(self.tok_off).to(device),
-                'n_wins': torch.from_numpy(self.n_wins).to(device),
-            }
+            parts = (('clip_off', self.clip_off), ('frame_off', self.frame_off), ('tok_off', self.tok_off), ('n_wins', self.n_wins))
+            offs, total = [], 0
+            for _, a in parts:
+                offs.append(total)
+                total += (a.nbytes + 15) // 16 * 16
+            pin = torch.device(device).type == 'cuda'
+            host = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=pin)
+            hv = host.numpy()
+            for (_, a), o in zip(parts, offs):
+                hv[o:o + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+            buf = host.to(device, non_blocking=pin)
+            self.dev = {'device': device, '_buf': buf, '_host': host}
+            for (k, a), o in zip(parts, offs):
+                self.dev[k] = buf[o:o + a.nbytes].view(torch.from_numpy(a[:0]).dtype)
         return self.dev
 
     def token_index(self):

@@ -16,6 +16,7 @@ import ctypes
 import os
 import queue
 import threading
+import time
 
 import numpy as np
 import torch
@@ -24,6 +25,29 @@ from . import lib as _lib
 from . import wavio
 
 _ALIGN = 64
+
+
+def cpu_budget():
+    """CPUs this process may actually burn: the affinity mask, cut down to the cgroup's CPU quota (cpu.max of cgroup v2,
+    cpu.cfs_quota_us of v1).  A container with 256 visible cores and a 16-CPU quota that starts 32 reader threads spends
+    its quota in half of every 100 ms period and is then frozen for the other half -- consumer thread included."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+                quota = int(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 class StagingRing(object):
@@ -61,13 +85,45 @@ class StagingRing(object):
         for e in self.back:
             e.set()
 
+    def reset(self):
+        """Ready for a new loop: every slot free (after the copies still reading from it), buffers kept."""
+        for k in range(len(self.buf)):
+            if self.busy[k] is not None:
+                self.busy[k].synchronize()
+                self.busy[k] = None
+            self.back[k].set()
+        self.k = 0
+        return self
+
+
+# Page-locking a few hundred MB costs tens of milliseconds per buffer: the rings of finished loops are kept for the next
+# one (one predict() call per process is the common case, repeated calls and the train/validate alternation the other).
+_spare_rings = {}
+_spare_lock = threading.Lock()
+
+
+def _take_ring(n_slots, pin):
+    with _spare_lock:
+        lst = _spare_rings.get((n_slots, pin))
+        if lst:
+            return lst.pop().reset()
+    return StagingRing(n_slots, pin)
+
+
+def _give_ring(ring):
+    with _spare_lock:
+        lst = _spare_rings.setdefault((len(ring.buf), ring.pin), [])
+        if len(lst) < 2:
+            lst.append(ring)
+
 
 class Group(object):
     """Clips of one sample rate inside a staged batch."""
-    __slots__ = ('ids', 'lengths', 'sr', 'offset', 'nbytes', 'is_i16')
+    __slots__ = ('ids', 'lengths', 'sr', 'offset', 'nbytes', 'is_i16', 'names')
 
-    def __init__(self, ids, lengths, sr, offset, nbytes, is_i16):
+    def __init__(self, ids, lengths, sr, offset, nbytes, is_i16, names=None):
         self.ids, self.lengths, self.sr, self.offset, self.nbytes, self.is_i16 = ids, lengths, sr, offset, nbytes, is_i16
+        self.names = names
 
 
 class Staged(object):
@@ -84,21 +140,30 @@ class Ingest(object):
 
     def __init__(self, ds, batches, pin, num_workers, depth=2):
         self.ds, self.batches = ds, batches
-        self.ring = StagingRing(depth + 1, pin)
-        self.workers = max(1, int(num_workers or 0))
+        self.ring = _take_ring(depth + 1, pin)
+        # reader threads: what the caller asked for, but never more than the CPU budget leaves next to the producer and
+        # consumer threads (over-subscribing a quota-limited container stalls the whole loop, see cpu_budget)
+        self.workers = max(1, min(int(num_workers or 0), cpu_budget() - 3))
         self.lib = _lib.load_ingest()
         self.q = queue.Queue(maxsize=depth)
         self.stop = threading.Event()
+        self.stats = {'paths': 0.0, 'probe': 0.0, 'layout': 0.0, 'slot_wait': 0.0, 'read': 0.0, 'queue_wait': 0.0, 'batches': 0}
         self.thread = threading.Thread(target=self._produce, name='nisqa-ingest', daemon=True)
         self.thread.start()
 
     # -- producer side ---------------------------------------------------------------------------------
     def _stage(self, idx):
         ds, L, n = self.ds, self.lib, len(idx)
-        names = [ds.file_path(i) for i in idx]
+        T, t0 = self.stats, time.perf_counter()
+        names = ds.file_paths(idx) if hasattr(ds, 'file_paths') else [ds.file_path(i) for i in idx]
         paths = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in names])
         infos = (_lib.WavInfo * n)()
-        if L.nisqa_ingest_probe(paths, n, infos, self.workers):
+        t1 = time.perf_counter()
+        T['paths'] += t1 - t0
+        rc = L.nisqa_ingest_probe(paths, n, infos, self.workers)
+        t2 = time.perf_counter()
+        T['probe'] += t2 - t1
+        if rc:
             bad = next(k for k in range(n) if infos[k].status != _lib.WAV_OK)
             raise ValueError('Could not load file {}'.format(names[bad]))      # NISQA_lib.py:2305-2306
         info = np.ctypeslib.as_array(infos)                        # structured view of the nisqa_wav_info records
@@ -117,10 +182,17 @@ class Ingest(object):
                 dst_off[sel] = off
             layout.append((int(sr), sel, is_i16, off, nbytes))
             total = (total + nbytes + _ALIGN - 1) // _ALIGN * _ALIGN
+        t3 = time.perf_counter()
+        T['layout'] += t3 - t2
         slot = self.ring.acquire(max(total, _ALIGN))
         buf = self.ring.buf[slot]
-        if L.nisqa_ingest_read(paths, n, infos, ctypes.c_void_p(buf.data_ptr()),
-                               dst_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), self.workers):
+        t4 = time.perf_counter()
+        T['slot_wait'] += t4 - t3
+        rc = L.nisqa_ingest_read(paths, n, infos, ctypes.c_void_p(buf.data_ptr()),
+                                 dst_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), self.workers)
+        T['read'] += time.perf_counter() - t4
+        T['batches'] += 1
+        if rc:
             bad = next(k for k in range(n) if infos[k].status != _lib.WAV_OK)
             self.ring.release_after(slot, None)
             raise ValueError('Could not load file {}'.format(names[bad]))
@@ -135,7 +207,7 @@ class Ingest(object):
                         y = y.astype(np.float32) / np.float32(32768.0)
                     raw[o:o + 4 * len(y)].view(np.float32)[:] = y
             groups.append(Group([idx[k] for k in sel.tolist()], frames[sel].tolist(), sr, int(off[0]) if len(off) else 0,
-                                nbytes, is_i16))
+                                nbytes, is_i16, [names[k] for k in sel.tolist()]))
         return Staged(slot, groups)
 
     def _produce(self):
@@ -143,7 +215,10 @@ class Ingest(object):
             for idx in self.batches:
                 if self.stop.is_set():
                     return
-                self.q.put(('ok', self._stage(idx)))
+                st = self._stage(idx)
+                t0 = time.perf_counter()
+                self.q.put(('ok', st))
+                self.stats['queue_wait'] += time.perf_counter() - t0
             self.q.put(('end', None))
         except BaseException as e:             # surfaces in the consumer, like a DataLoader worker error
             self.q.put(('err', e))
@@ -159,6 +234,8 @@ class Ingest(object):
             yield val
 
     def close(self):
+        if self.ring is None:                      # already closed
+            return
         self.stop.set()
         self.ring.abandon()
         try:
@@ -167,3 +244,6 @@ class Ingest(object):
         except queue.Empty:
             pass
         self.thread.join(timeout=30)
+        if not self.thread.is_alive():
+            _give_ring(self.ring)                  # the consumer's release events are still attached: reset() waits for them
+        self.ring = None

@@ -62,6 +62,7 @@ SYMBOLS = {
                                                  ctypes.POINTER(ModelDev), c_p, ctypes.c_size_t, c_p, c_p]),
     'nisqa_pcm16_to_f32': (ctypes.c_int, [c_p, c_p, c_i64, c_p]),
     'nisqa_selftest_mfma': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_p]),
+    'nisqa_probe_mfma_sustained': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p]),
 }
 
 # include/nisqa_train.h: operators of the training step (same shared library)

@@ -182,7 +182,7 @@ def train(nm):
                     raise NotImplementedError('a training batch mixes sample rates {}: BatchNorm statistics span the batch, '
                                               'so it cannot be split'.format([g.sr for g in staged.groups]))
                 g = staged.groups[0]
-                plan = tr.eng.plan(g.lengths, g.sr, names=[nm.ds_train.file_path(i) for i in g.ids])
+                plan = tr.eng.plan(g.lengths, g.sr, names=g.names)
                 raw = ing.ring.buf[staged.slot]
                 host = raw[g.offset:g.offset + g.nbytes].view(torch.int16 if g.is_i16 else torch.float32)
                 pcm = host.to(tr.device, non_blocking=True)

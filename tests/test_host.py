@@ -724,3 +724,39 @@ def test_no_kernel_contains_the_packed_f32_op_sel_form_gfx950_misreads():
     # the pattern does match the form the probe found
     assert bad_form.search('v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]')
     assert not bad_form.search('v_pk_add_f32 v[0:1], v[4:5], v[2:3] op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]')
+
+
+def test_frame_to_string_equals_pandas_to_string():
+    """predict() prints df.to_string(index=False) like the reference (NISQA_model.py:79); the fast formatter must give
+    the same text, character for character, and must fall back to pandas for frames it does not cover."""
+    import pandas as pd
+    from nisqa_amd.NISQA_model import frame_to_string, _fast_frame_lines
+    rng = np.random.default_rng(3)
+    frames = []
+    for n in (1, 2, 7, 300, 5000):
+        df = pd.DataFrame({'deg': ['clip_%d.wav' % int(x) for x in rng.integers(0, 10 ** int(rng.integers(1, 7)), n)]})
+        for c in ('mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred'):
+            df[c] = rng.uniform(1, 5, n).astype(np.float32).astype(float)
+        df['model'] = 'NISQA_DIM'
+        frames.append(df)
+        g = df.copy()
+        g['mos'] = np.where(rng.random(n) < 0.3, np.nan, np.round(rng.uniform(1, 5, n), 1))
+        g['neg'] = rng.uniform(-3, 3, n)
+        g['votes'] = rng.integers(-5, 2000, n)
+        g['con'] = ['c%d' % i for i in range(n)]
+        g['half'] = np.round(rng.uniform(0, 9, n)) / 2
+        g['whole'] = np.round(rng.uniform(0, 9, n))
+        frames.append(g)
+        frames.append(g[['whole']])
+        frames.append(pd.DataFrame({'x': np.full(n, np.nan)}))
+    for df in frames:
+        assert _fast_frame_lines(df) is not None
+        assert frame_to_string(df) == df.to_string(index=False)
+        assert '\n'.join(_fast_frame_lines(df)) == df.to_string(index=False)
+    # frames the fast path must hand to pandas
+    odd = [pd.DataFrame({'a': [1e-9, 2.0]}), pd.DataFrame({'a': [1e7, 2.0]}), pd.DataFrame({'a': [True, False]}),
+           pd.DataFrame({'a': ['x', None]}), pd.DataFrame({'a': [np.inf, 1.0]}), pd.DataFrame({'a': []}),
+           pd.DataFrame({'a': ['two\nlines', 'x']}), pd.DataFrame({'t': pd.to_datetime(['2020-01-01', '2021-05-05'])})]
+    for df in odd:
+        assert _fast_frame_lines(df) is None
+        assert frame_to_string(df) == df.to_string(index=False)

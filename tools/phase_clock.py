@@ -20,7 +20,7 @@ for _ in range(20):
     eng.forward_pcm(pcm, plan, 48000)
 torch.cuda.synchronize()
 L.nisqa_debug_phase_clock(None, 1)
-for _ in range(50):
+for _ in range(50):                      # every wave overwrites its own slot: the last launch's numbers are read
     eng.forward_pcm(pcm, plan, 48000)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 16)()
@@ -30,6 +30,6 @@ names = ['stage patch', 'conv1+pool', 'conv2 K loop', 'conv2 epilogue', 'conv3 K
          'barrier+conv4 epilogue+barrier', 'conv5 K loop', 'conv5 epilogue+barrier', 'conv6 K loop', 'conv6 epilogue']
 tot = sum(out[q] for q in range(12)) / n
 print('waves %d, mean clock64 ticks per wave %.0f (+ %.0f before the first stamp); wall clock (100 MHz) per wave %.2f us'
-      % (n, tot, out[14] / n, out[13] / n / 100.0))
+      ' -> shader clock %.0f MHz' % (n, tot, out[14] / n, out[13] / n / 100.0, (tot + out[14] / n) / (out[13] / n / 100.0)))
 for q, nm in enumerate(names):
     print('%-32s %9.0f  %5.1f%%' % (nm, out[q] / n, 100.0 * out[q] / n / tot))

@@ -29,6 +29,15 @@ def main():
         kernels[k].setdefault('_launches_sampled', int(n[(k, c)]))
     for k, reg in t.groupby('k')[['VGPR_Count', 'LDS_Block_Size', 'Scratch_Size']].max().iterrows() if 'VGPR_Count' in t.columns else []:
         kernels[k]['_vgpr'] = int(reg['VGPR_Count']); kernels[k]['_lds'] = int(reg['LDS_Block_Size']); kernels[k]['_scratch'] = int(reg['Scratch_Size'])
+    if 'Accum_VGPR_Count' in t.columns:
+        for k, v in t.groupby('k')['Accum_VGPR_Count'].max().items():
+            kernels[k]['_agpr'] = int(v)
+    if 'Start_Timestamp' in t.columns and 'End_Timestamp' in t.columns:
+        # launch duration UNDER the pass that sampled GRBM_GUI_ACTIVE: cycles / duration = the shader clock of that launch
+        tt = t[t.Counter_Name == 'GRBM_GUI_ACTIVE']
+        for k, v in ((tt.End_Timestamp - tt.Start_Timestamp) * 1e-6).groupby(tt.k).mean().items():
+            kernels[k]['_ms'] = float(v)
+            kernels[k]['_shader_clock_mhz'] = round(kernels[k]['GRBM_GUI_ACTIVE'] / 8.0 / (v * 1e-3) / 1e6, 1)
     with open(out, 'w') as f:
         json.dump({'units': 'mean per launch; FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE counts half the bytes of wide reads on gfx950)',
                    'kernels': kernels}, f, indent=1, sort_keys=True)
