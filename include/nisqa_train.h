@@ -57,6 +57,10 @@ int nisqa_im2col3x3(const float* x, int32_t n_segments, int32_t h, int32_t w, in
  * ci, co powers of two >= 4; padding (1, pad_w) as in nisqa_im2col3x3. */
 int nisqa_conv3x3_gemm(int32_t mode, const float* x_or_dz, const float* w_or_dz, float* out, int32_t n_segments, int32_t h,
                        int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, int32_t ksplit, void* stream);
+/* The same on split-bf16 MFMA (operands as bf16 hi + lo, three products per term, fp32 accumulation: 16 operand bits, the
+ * arithmetic of the inference path's default precision; 5.3x the fp32-MFMA rate).  Same arguments. */
+int nisqa_conv3x3_gemm_bf16(int32_t mode, const float* x_or_dz, const float* w_or_dz, float* out, int32_t n_segments, int32_t h,
+                            int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, int32_t ksplit, void* stream);
 /* adjoint of nisqa_im2col3x3 (gather form, no atomics): dx[S][H*W][C] = sum of the patch entries that read it */
 int nisqa_col2im3x3(const float* dcol, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w, float* dx,
                     void* stream);

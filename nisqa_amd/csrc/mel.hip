@@ -184,7 +184,7 @@ NQ_DEV void fft512(c32 (&u)[8], const c32 (&z)[8], const mel_twiddles& tw, char*
 // T = float (samples as lb.load returns them) or int16_t (PCM16 as it sits in the file: the x / 32768 of soundfile is
 // folded into the window taps -- a power of two, so both instantiations produce the same bits)
 template <int NQ, typename T>
-__global__ __launch_bounds__(64 * MEL_WAVES, 2) void mel_frame_kernel(
+__global__ __launch_bounds__(64 * MEL_WAVES, NQ >= 4 ? 1 : 2) void mel_frame_kernel(
     const T* __restrict__ pcm, const int64_t* __restrict__ clip_off,
     const int32_t* __restrict__ frame_off, int n_clips, int total_frames, int frames_per_wave,
     nisqa_mel_cfg cfg, int mag_stride, int w_floats,

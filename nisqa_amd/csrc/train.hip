@@ -10,6 +10,7 @@
 // products (ragged, one group per clip) and all their gradients (transposed operands; split-K with atomics where K
 // is the row count of the batch).
 #include "common.hpp"
+#include "conv_bf16.hpp"
 #include "../../include/nisqa_hip.h"
 #include "../../include/nisqa_train.h"
 
@@ -400,12 +401,206 @@ __global__ __launch_bounds__((BM / (32 * MT)) * (BN / (32 * NT)) * 64) void conv
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same three products on split-bf16 MFMA (v_mfma_f32_32x32x16_bf16; hi * hi + hi * lo + lo * hi, fp32 accumulate:
+// 16 operand bits like the inference path, 5.3x the fp32-MFMA rate).  Loaders and tiling as above; what changes is
+// the LDS image and how fragments come out of it.  A tile is two bf16 planes (hi, lo) written by the loader threads, which
+// split their four fp32 values on the way (v_cvt_pk_bf16_f32):
+//   * operand whose CONTIGUOUS index in memory is k (forward / dgrad patches, forward weights): image [row][32 k] with
+//     80-byte rows; a lane's fragment (row lane & 31, k = 8 * (lane >> 5) .. + 7) is one ds_read_b128;
+//   * operand whose contiguous index is the row (dgrad weights; dz and the patches of wgrad, where k is the pixel row of
+//     the batch): image [32 k][rows] as loaded (row stride 2 * rows + 64 bytes: the four k-rows of a transpose read land
+//     in different bank quarters), and the fragment comes out of ds_read_b64_tr_b16, gfx950's transposing LDS read:
+//     within a 16-lane group lane s points at row (s >> 2), columns 4 * (s & 3) .. + 3 of a [4 k][16 rows] block and
+//     lane i receives column i of that block (tools/micro/trread.hip prints the mapping from the hardware).
+// ---------------------------------------------------------------------------------------------------------
+typedef short nq_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned nq_u32x2 __attribute__((ext_vector_type(2)));
+
+template <int R, bool KC>
+struct bf_tile {
+    static constexpr int RS = KC ? 80 : 2 * R + ((R / 32) % 2 ? 128 : 64);   // row stride in bytes: an odd multiple of 64
+    static constexpr int PLANE = KC ? R * 80 : GB_K * RS;     // one bf16 plane
+    static constexpr int BYTES = 2 * PLANE;
+    // the loader thread's groups of four values -> both planes
+    template <int NV, int NTH>
+    static __device__ __forceinline__ void store(const f32x4 (&v)[NV], unsigned base, int tid) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = tid + NTH * j;
+            unsigned a;
+            if (KC) a = base + (i / (GB_K / 4)) * RS + 8 * (i % (GB_K / 4));
+            else a = base + (i / (R / 4)) * RS + 8 * (i % (R / 4));
+            const unsigned h0 = cvt_pk_bf16(v[j][0], v[j][1]), h1 = cvt_pk_bf16(v[j][2], v[j][3]);
+            const unsigned l0 = cvt_pk_bf16(v[j][0] - __uint_as_float(h0 << 16), v[j][1] - __uint_as_float(h0 & 0xffff0000u));
+            const unsigned l1 = cvt_pk_bf16(v[j][2] - __uint_as_float(h1 << 16), v[j][3] - __uint_as_float(h1 & 0xffff0000u));
+            *(NQ_AS3 nq_u32x2*)(a) = nq_u32x2{h0, h1};
+            *(NQ_AS3 nq_u32x2*)(a + PLANE) = nq_u32x2{l0, l1};
+        }
+    }
+    // lane-dependent part of a fragment address for the 32 rows starting at row0
+    static __device__ __forceinline__ unsigned lane_base(unsigned base, int row0, int lane) {
+        if (KC) return base + (row0 + (lane & 31)) * RS + 16 * (lane >> 5);
+        return base + (8 * (lane >> 5) + ((lane & 15) >> 2)) * RS + 2 * (row0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
+    }
+    // fragment of k-substep s (k = 16 s .. 16 s + 15) of one plane
+    static __device__ __forceinline__ f32x4 frag(unsigned lb, int s) {
+        if (KC) return lds_ld128(lb + 32 * s);
+        const unsigned a = lb + 16 * s * RS;
+        const nq_s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((NQ_AS3 nq_s16x4*)(a));
+        const nq_s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((NQ_AS3 nq_s16x4*)(a + 4 * RS));
+        struct { nq_s16x4 a, b; } both = {x0, x1};
+        return __builtin_bit_cast(f32x4, both);
+    }
+};
+
+template <int BM, int BN, int MT, int NT, int MODE>
+__global__ __launch_bounds__((BM / (32 * MT)) * (BN / (32 * NT)) * 64) void conv_gemm_bf16_kernel(
+    const float* __restrict__ G, const float* __restrict__ O, float* __restrict__ C, conv_geom g, int M, int N, int K, int ksplit,
+    const float* __restrict__ bias) {
+    typedef bf_tile<BM, MODE != 2> TA;
+    typedef bf_tile<BN, MODE == 0> TB;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TA::BYTES + TB::BYTES];
+    constexpr int WN = BN / (32 * NT);
+    constexpr int NTH = (BM / (32 * MT)) * WN * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int m0 = ((int)blockIdx.x / tiles_n) * BM, n0 = ((int)blockIdx.x % tiles_n) * BN;
+    int kc = (K + ksplit - 1) / ksplit;
+    kc = (kc + GB_K - 1) / GB_K * GB_K;
+    const int k_begin = blockIdx.y * kc, k_end = min(K, k_begin + kc);
+    if (k_begin >= k_end) return;
+    const int wm = (wave / WN) * 32 * MT, wn = (wave % WN) * 32 * NT;
+    tile_loader<BM, MODE != 2, NTH> la;
+    tile_loader<BN, MODE == 0, NTH> lb;
+    const int csm = (1 << g.lcs) - 1;
+    const unsigned sa = (unsigned)(size_t)(NQ_AS3 unsigned char*)smem, sb = sa + TA::BYTES;
+    smem[TA::BYTES + TB::BYTES - 1] = 0;                    // a pad byte: the kernel must be seen to use its LDS through the symbol
+
+    int a_s[la.NV], a_y[la.NV], a_x[la.NV];
+    if (MODE != 2) {
+#pragma unroll
+        for (int j = 0; j < la.NV; ++j) {
+            const int row = m0 + (tid + NTH * j) / (GB_K / 4);
+            const uint32_t s = fdiv_q((uint32_t)row, g.d_img);
+            const uint32_t rem = (uint32_t)row - s * (uint32_t)(g.hr * g.wr);
+            const uint32_t y = fdiv_q(rem, g.d_row);
+            a_s[j] = row < M ? (int)s : -1;
+            a_y[j] = (int)y;
+            a_x[j] = (int)(rem - y * (uint32_t)g.wr);
+        }
+    }
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < la.NV; ++j) {
+            const int i = tid + NTH * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (MODE != 2) {
+                const int kk = k0 + 4 * (i % (GB_K / 4));
+                if (a_s[j] >= 0 && kk < k_end) v = conv_gather(G, g, a_s[j], a_y[j], a_x[j], kk >> g.lcs, kk & csm);
+            } else {
+                const int kk = k0 + i / (BM / 4), m = m0 + 4 * (i % (BM / 4));
+                if (kk < k_end && m < M) v = *(const f32x4*)(O + (int64_t)kk * g.co + m);
+            }
+            la.v[j] = v;
+        }
+    };
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < lb.NV; ++j) {
+            const int i = tid + NTH * j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (MODE == 0) {
+                const int n = n0 + i / (GB_K / 4), kk = k0 + 4 * (i % (GB_K / 4));
+                if (n < N && kk < k_end) v = *(const f32x4*)(O + (int64_t)n * K + kk);
+            } else if (MODE == 1) {
+                const int kk = k0 + i / (BN / 4), n = n0 + 4 * (i % (BN / 4));
+                if (kk < k_end && n < N) {
+                    const int tap = kk >> g.lcs, co = kk & csm;
+                    v = *(const f32x4*)(O + (int64_t)co * (9 * g.ci) + tap * g.ci + n);
+                }
+            } else {
+                const int kk = k0 + i / (BN / 4), n = n0 + 4 * (i % (BN / 4));
+                if (kk < k_end && n < N) {
+                    const uint32_t s = fdiv_q((uint32_t)kk, g.d_img);
+                    const uint32_t rem = (uint32_t)kk - s * (uint32_t)(g.hr * g.wr);
+                    const uint32_t y = fdiv_q(rem, g.d_row);
+                    v = conv_gather(G, g, (int)s, (int)y, (int)(rem - y * (uint32_t)g.wr), n >> g.lcs, n & csm);
+                }
+            }
+            lb.v[j] = v;
+        }
+    };
+
+    unsigned fa[MT], fb[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[i] = TA::lane_base(sa, wm + 32 * i, lane);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[j] = TB::lane_base(sb, wn + 32 * j, lane);
+
+    load_a(k_begin);
+    load_b(k_begin);
+    TA::template store<la.NV, NTH>(la.v, sa, tid);
+    TB::template store<lb.NV, NTH>(lb.v, sb, tid);
+    __syncthreads();
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = zero16();
+    for (int k0 = k_begin; k0 < k_end; k0 += GB_K) {
+        const bool more = k0 + GB_K < k_end;
+        if (more) {
+            load_a(k0 + GB_K);
+            load_b(k0 + GB_K);
+        }
+#pragma unroll
+        for (int s = 0; s < GB_K / 16; ++s) {
+            f32x4 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) { ah[i] = TA::frag(fa[i], s); al[i] = TA::frag(fa[i] + TA::PLANE, s); }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) { bh[j] = TB::frag(fb[j], s); bl[j] = TB::frag(fb[j] + TB::PLANE, s); }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = mfma_bf(ah[i], bh[j], acc[i][j]);
+                    acc[i][j] = mfma_bf(ah[i], bl[j], acc[i][j]);
+                    acc[i][j] = mfma_bf(al[i], bh[j], acc[i][j]);
+                }
+        }
+        __syncthreads();
+        if (more) {
+            TA::template store<la.NV, NTH>(la.v, sa, tid);
+            TB::template store<lb.NV, NTH>(lb.v, sb, tid);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn + 32 * j + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + NQ_DROW(r, lane >> 5);
+                if (row < M && col < N) {
+                    const float v = acc[i][j][r];
+                    if (MODE == 2) atomicAdd(C + (int64_t)row * N + col, v);
+                    else C[(int64_t)row * N + col] = bias ? v + bias[col] : v;
+                }
+            }
+        }
+}
+
 template <int BM, int BN, int MT, int NT, int MODE>
 static void conv_launch(hipStream_t st, const float* gsrc, const float* other, float* c, const conv_geom& g, int M, int N, int K,
-                        int ksplit, const float* bias) {
+                        int ksplit, const float* bias, bool bf16) {
     const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, MT, NT, MODE>), dim3((unsigned)tiles, ksplit),
-                       dim3((BM / (32 * MT)) * (BN / (32 * NT)) * 64), 0, st, gsrc, other, c, g, M, N, K, ksplit, bias);
+    const dim3 grid((unsigned)tiles, ksplit), block((BM / (32 * MT)) * (BN / (32 * NT)) * 64);
+    if (bf16) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BM, BN, MT, NT, MODE>), grid, block, 0, st, gsrc, other, c, g, M, N, K, ksplit, bias);
+    else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, MT, NT, MODE>), grid, block, 0, st, gsrc, other, c, g, M, N, K, ksplit, bias);
 }
 
 static int ilog2_exact(int v) {
@@ -415,9 +610,9 @@ static int ilog2_exact(int v) {
 }
 
 // mode 0: x -> z (bias may be NULL); mode 1: dz -> dx; mode 2: (x, dz) -> dw += (dw zeroed by the caller), ksplit chunks
-extern "C" int nisqa_conv3x3_gemm(int32_t mode, const float* x_or_dz, const float* w_or_dz, float* out, int32_t n_segments,
-                                  int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias,
-                                  int32_t ksplit, void* stream) {
+static int conv3x3_gemm(bool bf16, int32_t mode, const float* x_or_dz, const float* w_or_dz, float* out, int32_t n_segments,
+                        int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias,
+                        int32_t ksplit, void* stream) {
     const int wo = w + 2 * pad_w - 2;
     if (mode < 0 || mode > 2 || !x_or_dz || !w_or_dz || !out || n_segments <= 0 || h <= 0 || w <= 0 || wo <= 0 || pad_w < 0 ||
         pad_w > 1 || ilog2_exact(ci) < 2 || ilog2_exact(co) < 2 || ksplit < 1 || ksplit > 65535 || (mode != 2 && ksplit != 1) ||
@@ -435,22 +630,33 @@ extern "C" int nisqa_conv3x3_gemm(int32_t mode, const float* x_or_dz, const floa
         g.hr = h; g.wr = w; g.hs = h; g.ws = wo; g.lcs = ilog2_exact(co); g.sgn = -1;
         g.d_img = fdiv_make((uint32_t)(h * w)); g.d_row = fdiv_make((uint32_t)w);
         const int M = (int)rows_in, N = ci, K = 9 * co;
-        if (N > 32) conv_launch<256, 64, 2, 1, 1>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, nullptr);
-        else conv_launch<128, 32, 1, 1, 1>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, nullptr);
+        if (N > 32) conv_launch<256, 64, 2, 1, 1>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, nullptr, bf16);
+        else conv_launch<128, 32, 1, 1, 1>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, nullptr, bf16);
     } else {                                                // rows = output pixels, gather x [H][W][ci]
         g.hr = h; g.wr = wo; g.hs = h; g.ws = w; g.lcs = ilog2_exact(ci); g.sgn = 1;
         g.d_img = fdiv_make((uint32_t)(h * wo)); g.d_row = fdiv_make((uint32_t)wo);
         if (mode == 0) {
             const int M = (int)rows_out, N = co, K = 9 * ci;
-            if (N > 32) conv_launch<256, 64, 2, 1, 0>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, bias);
-            else conv_launch<128, 32, 1, 1, 0>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, bias);
+            if (N > 32) conv_launch<256, 64, 2, 1, 0>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, bias, bf16);
+            else conv_launch<128, 32, 1, 1, 0>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, bias, bf16);
         } else {
             const int M = co, N = 9 * ci, K = (int)rows_out;
-            if (N >= 256) conv_launch<64, 256, 2, 1, 2>(st, x_or_dz, w_or_dz, out, g, M, N, K, ksplit, nullptr);
-            else conv_launch<64, 64, 1, 1, 2>(st, x_or_dz, w_or_dz, out, g, M, N, K, ksplit, nullptr);
+            if (N >= 256) conv_launch<64, 256, 2, 1, 2>(st, x_or_dz, w_or_dz, out, g, M, N, K, ksplit, nullptr, bf16);
+            else conv_launch<64, 64, 1, 1, 2>(st, x_or_dz, w_or_dz, out, g, M, N, K, ksplit, nullptr, bf16);
         }
     }
     return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_conv3x3_gemm(int32_t mode, const float* x_or_dz, const float* w_or_dz, float* out, int32_t n_segments,
+                                  int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias,
+                                  int32_t ksplit, void* stream) {
+    return conv3x3_gemm(false, mode, x_or_dz, w_or_dz, out, n_segments, h, w, ci, co, pad_w, bias, ksplit, stream);
+}
+extern "C" int nisqa_conv3x3_gemm_bf16(int32_t mode, const float* x_or_dz, const float* w_or_dz, float* out, int32_t n_segments,
+                                       int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias,
+                                       int32_t ksplit, void* stream) {
+    return conv3x3_gemm(true, mode, x_or_dz, w_or_dz, out, n_segments, h, w, ci, co, pad_w, bias, ksplit, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -19,6 +19,7 @@ the first Linear in [y][c] order); ``state_dict()`` / ``load_state_dict()`` conv
 and shapes, so checkpoints interoperate with the reference and with the inference engine.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -36,14 +37,29 @@ def _ptr(t, off=0):
 
 
 class HipTrainer(object):
-    def __init__(self, args, state_dict, device=None, lr=1e-3):
+    def __init__(self, args, state_dict, device=None, lr=1e-3, precision=None):
+        """precision of conv2..6 (everything else is fp32 in every mode); NISQA_HIP_TRAIN_PRECISION sets the default:
+          'f32'    forward, dgrad and wgrad on exact fp32 MFMA: the reference's arithmetic;
+          'mixed'  (default) forward on fp32 MFMA, dgrad and wgrad on split-bf16 MFMA (bf16 hi + lo operands, three products per term,
+                   fp32 accumulation): loss, y_hat and BatchNorm buffers are those of 'f32' bit for bit, every gradient
+                   stays within the same 1e-3 bound of the reference fixture (measured 7e-5);
+          'bf16x3' the forward convolutions on split-bf16 MFMA as well (the arithmetic of the inference path's default):
+                   y_hat moves by <= 1e-4.  On the random-weight fixtures that is enough to move individual gradient
+                   tensors by per cent (the network's Jacobian at a random initialisation is that sensitive to its
+                   activations; the backward kernels themselves agree with fp32 to 1e-5, tests/test_gpu_train.py)."""
         a = args
+        self.precision = precision or os.environ.get('NISQA_HIP_TRAIN_PRECISION', 'mixed')
+        if self.precision not in ('f32', 'mixed', 'bf16x3'):
+            raise ValueError('precision must be f32, mixed or bf16x3, got {}'.format(self.precision))
         if not (a.get('cnn_model') == 'adapt' and a.get('td') == 'self_att' and a.get('pool') == 'att') \
                 or a.get('td_2') not in (None, 'skip') or a['model'] not in ('NISQA', 'NISQA_DIM'):
             raise NotImplementedError('HIP training step covers NISQA / NISQA_DIM with cnn_model=adapt, td=self_att, '
                                       'pool=att (config/train_nisqa_cnn_sa_ap.yaml)')
         self.eng = HipNisqa(args, state_dict, device, precision='f32')       # mel front end + geometry checks
         self.lib, self.device, self.args = self.eng.lib, self.eng.device, args
+        fast, exact = self.lib.nisqa_conv3x3_gemm_bf16, self.lib.nisqa_conv3x3_gemm
+        self._conv_fwd = fast if self.precision == 'bf16x3' else exact
+        self._conv_bwd = exact if self.precision == 'f32' else fast
         self.lr = float(lr)
         self.n_layers = int(a['td_sa_num_layers'])
         self.heads = ['pool_layers.%d.model.' % h for h in range(5)] if a['model'] == 'NISQA_DIM' else ['pool.model.']
@@ -319,7 +335,7 @@ class HipTrainer(object):
                                             _ptr(self.P[wk]), _ptr(self.P[bk]), _ptr(z), st), 'nisqa_conv1_fwd')
             else:                                                              # implicit GEMM: patches gathered by the loaders
                 hi, wi = geo[i - 2][2]
-                self._ck(L_.nisqa_conv3x3_gemm(0, _ptr(act), _ptr(self.P[wk]), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
+                self._ck(self._conv_fwd(0, _ptr(act), _ptr(self.P[wk]), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
                                                _ptr(self.P[bk]), 1, st), 'nisqa_conv3x3_gemm fwd')
             sums = self._coldot(z, z, rows, co)
             drop = self._mask(masks, _DROP_AFTER.get(i), (S, co), self.p_cnn) if i in _DROP_AFTER else None
@@ -477,10 +493,10 @@ class HipTrainer(object):
             else:
                 hi, wi = geo[i - 2][2]
                 pad = 0 if i == 6 else 1
-                self._ck(L_.nisqa_conv3x3_gemm(2, _ptr(c['x']), _ptr(dz), _ptr(self.G[wk]), S, hi, wi, ci, co, pad, None,
+                self._ck(self._conv_bwd(2, _ptr(c['x']), _ptr(dz), _ptr(self.G[wk]), S, hi, wi, ci, co, pad, None,
                                                self._ksplit(rows, co, 9 * ci), st), 'nisqa_conv3x3_gemm wgrad')
                 da = self._new(S, hi * wi, ci)
-                self._ck(L_.nisqa_conv3x3_gemm(1, _ptr(dz), _ptr(self.P[wk]), _ptr(da), S, hi, wi, ci, co, pad, None, 1, st),
+                self._ck(self._conv_bwd(1, _ptr(dz), _ptr(self.P[wk]), _ptr(da), S, hi, wi, ci, co, pad, None, 1, st),
                          'nisqa_conv3x3_gemm dgrad')
             c['x'] = None
 

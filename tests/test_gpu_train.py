@@ -141,9 +141,11 @@ def test_im2col_col2im_against_unfold_and_adjointness(h, w, c, pad_w):
     assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))                # <im2col(x), d> == <x, col2im(d)>
 
 
+@pytest.mark.parametrize('entry', ['nisqa_conv3x3_gemm', 'nisqa_conv3x3_gemm_bf16'])
 @pytest.mark.parametrize('h,w,ci,co,pad_w', [(24, 7, 16, 32, 1), (12, 5, 32, 64, 1), (12, 5, 64, 64, 1), (6, 3, 64, 64, 1), (6, 3, 64, 64, 0)])
-def test_implicit_gemm_convolution_forward_dgrad_wgrad(h, w, ci, co, pad_w):
+def test_implicit_gemm_convolution_forward_dgrad_wgrad(h, w, ci, co, pad_w, entry):
     lib, L = _L()
+    conv = getattr(L, entry)                                          # exact fp32 MFMA / split-bf16 MFMA (same tolerances)
     S = 37                                                            # rows not a multiple of any tile
     wo = w + 2 * pad_w - 2
     x = _r(S, h * w, ci, seed=50).requires_grad_(True)
@@ -154,13 +156,16 @@ def test_implicit_gemm_convolution_forward_dgrad_wgrad(h, w, ci, co, pad_w):
     (z_t.permute(0, 2, 3, 1).reshape(S, h * wo, co) * dz).sum().backward()
     wk = wt.detach().permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
     z = torch.empty(S * h * wo, co, device=DEV)
-    lib.check(L.nisqa_conv3x3_gemm(0, _p(x.detach()), _p(wk), _p(z), S, h, w, ci, co, pad_w, _p(b), 1, _st()), 'conv fwd')
+    lib.check(conv(0, _p(x.detach()), _p(wk), _p(z), S, h, w, ci, co, pad_w, _p(b), 1, _st()), 'conv fwd')
     dx = torch.empty(S, h * w, ci, device=DEV)
-    lib.check(L.nisqa_conv3x3_gemm(1, _p(dz), _p(wk), _p(dx), S, h, w, ci, co, pad_w, None, 1, _st()), 'conv dgrad')
+    lib.check(conv(1, _p(dz), _p(wk), _p(dx), S, h, w, ci, co, pad_w, None, 1, _st()), 'conv dgrad')
     dw = torch.zeros(co, 9 * ci, device=DEV)
-    lib.check(L.nisqa_conv3x3_gemm(2, _p(x.detach()), _p(dz), _p(dw), S, h, w, ci, co, pad_w, None, 5, _st()), 'conv wgrad')
+    lib.check(conv(2, _p(x.detach()), _p(dz), _p(dw), S, h, w, ci, co, pad_w, None, 5, _st()), 'conv wgrad')
     torch.cuda.synchronize()
     want_z = z_t.detach().permute(0, 2, 3, 1).reshape(S * h * wo, co)
+    print(entry, 'max|d| z %.2e of %.1f, dx %.2e of %.1f, dw %.2e of %.1f' % (
+        float((z - want_z).abs().max()), float(want_z.abs().max()), float((dx - x.grad).abs().max()), float(x.grad.abs().max()),
+        float((dw - wt.grad.permute(0, 2, 3, 1).reshape(co, 9 * ci)).abs().max()), float(wt.grad.abs().max())))
     assert (z - want_z).abs().max() < 2e-5 * max(1.0, float(want_z.abs().max())) * 3
     assert (dx - x.grad).abs().max() < 2e-5 * max(1.0, float(x.grad.abs().max())) * 3
     want_dw = wt.grad.permute(0, 2, 3, 1).reshape(co, 9 * ci)
@@ -357,11 +362,12 @@ def _case(name):
     return g, args, sd, specs, y
 
 
+@pytest.mark.parametrize('precision', ['f32', 'mixed'])
 @pytest.mark.parametrize('name', ['mos', 'dim'])
-def test_training_step_matches_reference_fixture(name):
+def test_training_step_matches_reference_fixture(name, precision):
     from nisqa_amd.train import HipTrainer
     g, args, sd, specs, y = _case(name)
-    tr = HipTrainer(args, sd, DEV, lr=float(g['lr']))
+    tr = HipTrainer(args, sd, DEV, lr=float(g['lr']), precision=precision)
     loss = tr.step_spec(specs, y)
     torch.cuda.synchronize()
     assert float(loss) == pytest.approx(float(g['loss1']), rel=1e-4)
@@ -377,7 +383,7 @@ def test_training_step_matches_reference_fixture(name):
         e = float(np.abs(gr.numpy() - want).max()) / max(1e-3, float(np.abs(want).max()))
         if e > worst:
             worst, wk = e, k
-    print(name, 'worst relative gradient error', worst, wk)
+    print(name, precision, 'worst relative gradient error', worst, wk)
     assert worst < 1e-3, (worst, wk)
     lr = float(g['lr'])
     new = tr.state_dict()
@@ -402,6 +408,37 @@ def test_training_step_matches_reference_fixture(name):
     # the trained weights load into the inference engine
     from nisqa_amd.engine import HipNisqa
     HipNisqa(args, tr.state_dict(), DEV)
+
+
+@pytest.mark.parametrize('name', ['mos', 'dim'])
+def test_training_step_with_split_bf16_forward_convolutions(name):
+    """precision='bf16x3' also runs the FORWARD convolutions on split-bf16 MFMA.  Loss, y_hat and BatchNorm buffers stay
+    within 2e-4 of the reference fixture.  Gradients are held to a loose bound only: at the random initialisation of these
+    fixtures a 5e-6 relative change of the activations moves some gradient tensors by per cent (5.6 % in
+    pool_layers.1.linear1 of the 'dim' case, also with the fixture's residuals restored), while the same kernels used for
+    the backward pass only ('mixed', test above) leave every gradient within 7e-5 of the reference."""
+    from nisqa_amd.train import HipTrainer
+    g, args, sd, specs, y = _case(name)
+    tr = HipTrainer(args, sd, DEV, lr=float(g['lr']), precision='bf16x3')
+    loss = tr.step_spec(specs, y)
+    torch.cuda.synchronize()
+    dev_y = float(np.abs(tr.last['y_hat'].cpu().numpy() - g['y_hat1']).max())
+    worst, wk = 0.0, None
+    for k, gr in tr.grads().items():
+        if _conv_bias(k):
+            continue
+        want = g['grad/' + k]
+        e = float(np.abs(gr.numpy() - want).max()) / max(1e-3, float(np.abs(want).max()))
+        if e > worst:
+            worst, wk = e, k
+    print(name, 'bf16x3: loss', float(loss), 'fixture', float(g['loss1']), 'max|d y_hat|', dev_y, 'worst relative gradient error', worst, wk)
+    assert float(loss) == pytest.approx(float(g['loss1']), rel=2e-4)
+    assert dev_y < 2e-4
+    assert worst < 0.1, (worst, wk)
+    for k, v in tr.state_dict().items():
+        if 'running' in k:
+            want = g['sd1/' + k]
+            assert np.abs(v.numpy() - want).max() < 2e-4 * max(1.0, np.abs(want).max()), k
 
 
 def test_training_step_with_dropout_masks_and_bias_loss_matches_oracle():

@@ -31,6 +31,6 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 if world == 1 or torch.distributed.get_rank() == 0:
     print(json.dumps({'config': 'train_nisqa_cnn_sa_ap bs=%d x 10 s per GPU' % bs, 'n_gpus': world,
-                      'segments': int(plan.n_wins.sum()), 'ms_per_step': round(dt * 1e3, 2),
+                      'precision': tr.precision, 'segments': int(plan.n_wins.sum()), 'ms_per_step': round(dt * 1e3, 2),
                       'clips_per_s': round(world * bs / dt, 1), 'loss': float(loss),
                       'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
