@@ -46,6 +46,29 @@ int nisqa_conv1_fwd(const float* mel_tm, const int32_t* frame_off, const int32_t
                     void* stream);
 int nisqa_conv1_wgrad(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
                       int32_t n_clips, int32_t n_segments, int32_t seg_hop, const float* dz, float* dw, void* stream);
+/* Layer 1 of the training step without its 720-pixel activations (conv1 -> train-mode BatchNorm -> ReLU -> 24 x 7 adaptive
+ * max-pool -> per-channel dropout scale; NISQA_lib.py:688-697 in train mode).  z1 is affine in the nine patch values, so
+ * the batch statistics, the reductions of the BatchNorm backward and the dense part of the weight gradient follow from the
+ * first and second patch moments; pooled values and their gradients are recomputed from the spectrogram.
+ *   nisqa_conv1_moments: mom54 [dev, zeroed by the caller] += P1[t] = sum patch[t] (9), then the upper triangle of
+ *                        P2[t][u] = sum patch[t] patch[u] (45), over all pixels of all valid segments;
+ *   ..._fwd: sums32 [dev] (sum z, sum z^2 per channel, as nisqa_col_dot(z, z) would give), running statistics and
+ *            mean_rstd [dev, 32] updated like nisqa_bn_act_pool_fwd, y [S][168][16] pooled activations (x drop[s][c] if
+ *            drop != NULL), arg = pixel (band * 15 + frame) of each maximum;
+ *   ..._bwd: dy [S][168][16] -> dgamma, dbeta [16], dw [16][9] (overwritten; the conv bias gradient is exactly zero);
+ *            acc176 [dev, zeroed by the caller] is scratch for the float64 reductions. */
+int nisqa_conv1_moments(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
+                        int32_t n_clips, int32_t n_segments, int32_t seg_hop, double* mom54, void* stream);
+int nisqa_conv1_bn_act_pool_fwd(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
+                                int32_t n_clips, int32_t n_segments, int32_t seg_hop, const float* w, const float* bias,
+                                const double* mom54, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, double* sums32, float* mean_rstd, const float* drop, float* y,
+                                int32_t* arg, void* stream);
+int nisqa_conv1_bn_act_pool_bwd(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
+                                int32_t n_clips, int32_t n_segments, int32_t seg_hop, const float* w, const float* bias,
+                                const double* mom54, const float* gamma, const float* beta, const float* mean_rstd,
+                                const float* drop, const float* dy, const int32_t* arg, double* acc176, float* dgamma,
+                                float* dbeta, float* dw, void* stream);
 /* 3x3 patches, padding (1, pad_w): x[S][H*W][C] -> col[S*H*Wo][9*C], Wo = W + 2*pad_w - 2, k = (dy*3+dx)*C + c
  * (C % 4 == 0, 16-byte aligned buffers) */
 int nisqa_im2col3x3(const float* x, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w, float* col,

@@ -787,6 +787,257 @@ extern "C" int nisqa_conv1_wgrad(const float* mel_tm, const int32_t* frame_off, 
     return NQ_LAUNCH_STATUS();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Layer 1 without its activations.  z1 = conv1(patch) has S x 720 x 16 entries (364 MB at 32 x 10 s clips) and the
+// unfused step makes nine passes over tensors of that size (z, dyb, dz).  But z is AFFINE in nine numbers per pixel, so
+//   * the BatchNorm statistics follow from the first and second moments of the patches, P1[t] = sum patch[t] and
+//     P2[t][u] = sum patch[t] patch[u] over all pixels of all valid segments (54 float64 numbers, one pass over the
+//     spectrogram): sum z_c = w_c . P1 + N b_c, sum z_c^2 = w_c' P2 w_c + 2 b_c w_c . P1 + N b_c^2;
+//   * forward = recompute the six pixels of every pooling window from the LDS copy of the segment, normalise, ReLU, max;
+//   * the gradient arriving from the pool is non-zero at ONE pixel per pooled value: the reductions of the BatchNorm
+//     backward and the data-dependent part of the weight gradient are sums over the 168 x 16 pooled values of a segment
+//     (z at the argmax pixel is recomputed), and the dense parts of dz = gamma rstd (dyb - mean(dyb) - xhat mean(dyb xhat))
+//     contribute -mean(dyb) P1[t] - mean(dyb xhat) sum xhat patch[t], again moments.  The bias gradient is exactly zero.
+// No tensor of 720 pixels per segment is ever written.
+// ---------------------------------------------------------------------------------------------------------
+#define C1_MOM 54                                            /* P1[9], then P2 upper triangle [t <= u] */
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+NQ_DEV int win_lo(int i, int n_in, int n_out);
+NQ_DEV int win_hi(int i, int n_in, int n_out);
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int c, int64_t m_rows, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ mean_rstd);
+NQ_DEV int c1_p2(int t, int u) { return t <= u ? 9 + t * 9 - t * (t - 1) / 2 + (u - t) : 9 + u * 9 - u * (u - 1) / 2 + (t - u); }
+
+__global__ __launch_bounds__(256) void conv1_moments_kernel(const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
+                                                            const int32_t* __restrict__ seg_off, const float* __restrict__ clip_floor,
+                                                            int n_clips, int n_segments, int seg_hop, double* __restrict__ mom) {
+    __shared__ float patch[17][50];
+    __shared__ double red[C1_MOM];
+    const int tid = threadIdx.x;
+    double acc[C1_MOM];
+#pragma unroll
+    for (int i = 0; i < C1_MOM; ++i) acc[i] = 0.0;
+    if (tid < C1_MOM) red[tid] = 0.0;
+    for (int s = blockIdx.x; s < n_segments; s += gridDim.x) {
+        const int b = find_segment(seg_off, n_clips, s);
+        __syncthreads();
+        stage_patch(patch, mel_tm + (int64_t)(frame_off[b] + (s - seg_off[b]) * seg_hop) * 48, clip_floor[b], tid);
+        __syncthreads();
+        for (int p = tid; p < 720; p += 256) {
+            const int m = p / 15, j = p % 15;
+            double x[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) x[t] = (double)patch[j + t % 3][m + t / 3];
+            int q = 9;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                acc[t] += x[t];
+#pragma unroll
+                for (int u = t; u < 9; ++u) acc[q++] += x[t] * x[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < C1_MOM; ++i) {
+        double v = acc[i];
+        for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+        if ((tid & 63) == 0) atomicAdd(&red[i], v);
+    }
+    __syncthreads();
+    if (tid < C1_MOM) atomicAdd(mom + tid, red[tid]);
+}
+
+// sums[c] = sum z_c, sums[16 + c] = sum z_c^2 from the moments (the layout col_dot(z, z) produces)
+__global__ void conv1_sums_kernel(const double* __restrict__ mom, const float* __restrict__ w, const float* __restrict__ bias,
+                                  int64_t n_rows, double* __restrict__ sums) {
+    const int c = threadIdx.x;
+    if (c >= 16) return;
+    double wp = 0.0, wpw = 0.0;
+    for (int t = 0; t < 9; ++t) {
+        wp += (double)w[c * 9 + t] * mom[t];
+        for (int u = 0; u < 9; ++u) wpw += (double)w[c * 9 + t] * (double)w[c * 9 + u] * mom[c1_p2(t, u)];
+    }
+    const double b = bias[c], n = (double)n_rows;
+    sums[c] = wp + n * b;
+    sums[16 + c] = wpw + 2.0 * b * wp + n * b * b;
+}
+
+// one thread = four channels of one pooled value: y[s][oy * 7 + ox][c], arg = pixel index (band * 15 + frame) of the maximum
+__global__ __launch_bounds__(256) void conv1_bn_act_pool_fwd_kernel(
+    const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off, const int32_t* __restrict__ seg_off,
+    const float* __restrict__ clip_floor, int n_clips, int seg_hop, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean_rstd,
+    const float* __restrict__ drop, float* __restrict__ y, int32_t* __restrict__ arg) {
+    __shared__ float patch[17][50];
+    __shared__ float ws[16 * 9 + 16 + 32];
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int b = find_segment(seg_off, n_clips, s);
+    stage_patch(patch, mel_tm + (int64_t)(frame_off[b] + (s - seg_off[b]) * seg_hop) * 48, clip_floor[b], tid);
+    if (tid < 144) ws[tid] = w[tid];
+    else if (tid < 160) ws[tid] = bias[tid - 144];
+    else if (tid < 176) {                                   // the affine form of the normalisation: y = z * g + sh
+        const int c = tid - 160;
+        const float g = gamma[c] * mean_rstd[16 + c];
+        ws[160 + c] = g;
+        ws[176 + c] = beta[c] - mean_rstd[c] * g;
+    }
+    __syncthreads();
+    for (int i = tid; i < 168 * 4; i += 256) {
+        const int o = i >> 2, ch = 4 * (i & 3);
+        const int oy = o / 7, ox = o % 7;
+        f32x4 best = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+        i32x4 bp = {0, 0, 0, 0};
+        for (int m = win_lo(oy, 48, 24); m < win_hi(oy, 48, 24); ++m)
+            for (int j = win_lo(ox, 15, 7); j < win_hi(ox, 15, 7); ++j) {
+                float x[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) x[t] = patch[j + t % 3][m + t / 3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float acc = ws[144 + ch + e];
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc = fmaf(x[t], ws[(ch + e) * 9 + t], acc);
+                    const float r = fmaxf(acc * ws[160 + ch + e] + ws[176 + ch + e], 0.f);
+                    if (r > best[e]) { best[e] = r; bp[e] = m * 15 + j; }
+                }
+            }
+        if (drop) best *= *(const f32x4*)(drop + (int64_t)s * 16 + ch);
+        *(f32x4*)(y + ((int64_t)s * 168 + o) * 16 + ch) = best;
+        *(i32x4*)(arg + ((int64_t)s * 168 + o) * 16 + ch) = bp;
+    }
+}
+
+// acc[c][0] = sum dyb, [1] = sum dyb * z, [2 + t] = sum dyb * patch[t] over all pooled values whose ReLU is open
+__global__ __launch_bounds__(256) void conv1_bn_act_pool_bwd_kernel(
+    const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off, const int32_t* __restrict__ seg_off,
+    const float* __restrict__ clip_floor, int n_clips, int n_segments, int seg_hop, const float* __restrict__ w,
+    const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ mean_rstd, const float* __restrict__ drop, const float* __restrict__ dy,
+    const int32_t* __restrict__ arg, double* __restrict__ out) {
+    __shared__ float patch[17][50];
+    __shared__ float ws[16 * 9 + 16 + 32];
+    __shared__ double red[16 * 11];
+    const int tid = threadIdx.x, ch = 4 * (tid & 3);        // items stride by 256: a thread always meets the same four channels
+    if (tid < 144) ws[tid] = w[tid];
+    else if (tid < 160) ws[tid] = bias[tid - 144];
+    else if (tid < 176) {
+        const int c = tid - 160;
+        const float g = gamma[c] * mean_rstd[16 + c];
+        ws[160 + c] = g;
+        ws[176 + c] = beta[c] - mean_rstd[c] * g;
+    }
+    if (tid < 176) red[tid] = 0.0;
+    double a[4][11];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < 11; ++q) a[e][q] = 0.0;
+    for (int s = blockIdx.x; s < n_segments; s += gridDim.x) {
+        const int b = find_segment(seg_off, n_clips, s);
+        __syncthreads();
+        stage_patch(patch, mel_tm + (int64_t)(frame_off[b] + (s - seg_off[b]) * seg_hop) * 48, clip_floor[b], tid);
+        __syncthreads();
+        f32x4 dr = {1.f, 1.f, 1.f, 1.f};
+        if (drop) dr = *(const f32x4*)(drop + (int64_t)s * 16 + ch);
+        for (int i = tid; i < 168 * 4; i += 256) {
+            const int64_t at = ((int64_t)s * 168 + (i >> 2)) * 16 + ch;
+            const f32x4 g = *(const f32x4*)(dy + at) * dr;
+            const i32x4 ap = *(const i32x4*)(arg + at);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = ap[e] / 15, j = ap[e] % 15;
+                float x[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) x[t] = patch[j + t % 3][m + t / 3];
+                float z = ws[144 + ch + e];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) z = fmaf(x[t], ws[(ch + e) * 9 + t], z);
+                if (z * ws[160 + ch + e] + ws[176 + ch + e] > 0.f) {                  // ReLU gate
+                    const double gd = (double)g[e];
+                    a[e][0] += gd;
+                    a[e][1] += gd * (double)z;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) a[e][2 + t] += gd * (double)x[t];
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int q = 0; q < 11; ++q) {
+            double v = a[e][q];                             // lanes with equal (lane & 3) hold the same channels
+            for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o);
+            if ((tid & 63) < 4) atomicAdd(&red[(ch + e) * 11 + q], v);
+        }
+    __syncthreads();
+    if (tid < 176) atomicAdd(out + tid, red[tid]);
+}
+
+// dgamma, dbeta, dw[16][9] of layer 1 from the sparse sums and the patch moments (one thread per (channel, tap))
+__global__ void conv1_bwd_finalize_kernel(const double* __restrict__ acc, const double* __restrict__ mom, const float* __restrict__ w,
+                                          const float* __restrict__ bias, const float* __restrict__ gamma,
+                                          const float* __restrict__ mean_rstd, int64_t n_rows, float* __restrict__ dgamma,
+                                          float* __restrict__ dbeta, float* __restrict__ dw) {
+    const int c = threadIdx.x / 9, t = threadIdx.x % 9;
+    if (c >= 16) return;
+    const double mean = mean_rstd[c], rstd = mean_rstd[16 + c], n = (double)n_rows;
+    const double m1 = acc[c * 11], m2 = rstd * (acc[c * 11 + 1] - mean * acc[c * 11]);      // sum dyb, sum dyb * xhat
+    if (t == 0) {
+        dbeta[c] = (float)m1;
+        dgamma[c] = (float)m2;
+    }
+    double zp = (double)bias[c] * mom[t];                                              // sum z * patch[t]
+    for (int u = 0; u < 9; ++u) zp += (double)w[c * 9 + u] * mom[c1_p2(u, t)];
+    const double xp = rstd * (zp - mean * mom[t]);                                      // sum xhat * patch[t]
+    dw[c * 9 + t] = (float)((double)gamma[c] * rstd * (acc[c * 11 + 2 + t] - m1 / n * mom[t] - m2 / n * xp));
+}
+
+extern "C" int nisqa_conv1_moments(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
+                                   int32_t n_clips, int32_t n_segments, int32_t seg_hop, double* mom54, void* stream) {
+    if (!mel_tm || !frame_off || !seg_off || !clip_floor || !mom54 || n_clips <= 0 || n_segments <= 0 || seg_hop <= 0) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(conv1_moments_kernel, dim3(n_segments < 1024 ? n_segments : 1024), dim3(256), 0, (hipStream_t)stream, mel_tm,
+                       frame_off, seg_off, clip_floor, n_clips, n_segments, seg_hop, mom54);
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_conv1_bn_act_pool_fwd(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
+                                           int32_t n_clips, int32_t n_segments, int32_t seg_hop, const float* w, const float* bias,
+                                           const double* mom54, const float* gamma, const float* beta, float* running_mean,
+                                           float* running_var, double* sums32, float* mean_rstd, const float* drop, float* y,
+                                           int32_t* arg, void* stream) {
+    if (!mel_tm || !frame_off || !seg_off || !clip_floor || !w || !bias || !mom54 || !gamma || !beta || !running_mean || !running_var ||
+        !sums32 || !mean_rstd || !y || !arg || n_clips <= 0 || n_segments <= 0 || seg_hop <= 0)
+        return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t rows = (int64_t)n_segments * 720;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(conv1_sums_kernel, dim3(1), dim3(64), 0, st, mom54, w, bias, rows, sums32);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, st, (const double*)sums32, 16, rows, running_mean, running_var, mean_rstd);
+    hipLaunchKernelGGL(conv1_bn_act_pool_fwd_kernel, dim3(n_segments), dim3(256), 0, st, mel_tm, frame_off, seg_off, clip_floor, n_clips,
+                       seg_hop, w, bias, gamma, beta, (const float*)mean_rstd, drop, y, arg);
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_conv1_bn_act_pool_bwd(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off, const float* clip_floor,
+                                           int32_t n_clips, int32_t n_segments, int32_t seg_hop, const float* w, const float* bias,
+                                           const double* mom54, const float* gamma, const float* beta, const float* mean_rstd,
+                                           const float* drop, const float* dy, const int32_t* arg, double* acc176, float* dgamma,
+                                           float* dbeta, float* dw, void* stream) {
+    if (!mel_tm || !frame_off || !seg_off || !clip_floor || !w || !bias || !mom54 || !gamma || !beta || !mean_rstd || !dy || !arg ||
+        !acc176 || !dgamma || !dbeta || !dw || n_clips <= 0 || n_segments <= 0 || seg_hop <= 0)
+        return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(conv1_bn_act_pool_bwd_kernel, dim3(n_segments < 1024 ? n_segments : 1024), dim3(256), 0, st, mel_tm, frame_off,
+                       seg_off, clip_floor, n_clips, n_segments, seg_hop, w, bias, gamma, beta, mean_rstd, drop, dy, arg, acc176);
+    hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(144), 0, st, (const double*)acc176, mom54, w, bias, gamma, mean_rstd,
+                       (int64_t)n_segments * 720, dgamma, dbeta, dw);
+    return NQ_LAUNCH_STATUS();
+}
+
 extern "C" int nisqa_im2col_mel(const float* mel_tm, const int32_t* frame_off, const int32_t* seg_off,
                                 const float* clip_floor, int32_t n_clips, int32_t n_segments, int32_t seg_hop,
                                 float* col, void* stream) {

@@ -73,6 +73,9 @@ TRAIN_SYMBOLS = {
                                           c_f, c_p, c_i32, c_p]),
     'nisqa_conv1_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_conv1_wgrad': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
+    'nisqa_conv1_moments': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p]),
+    'nisqa_conv1_bn_act_pool_fwd': (ctypes.c_int, [c_p] * 4 + [c_i32] * 3 + [c_p] * 13),
+    'nisqa_conv1_bn_act_pool_bwd': (ctypes.c_int, [c_p] * 4 + [c_i32] * 3 + [c_p] * 14),
     'nisqa_im2col_mel': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p]),
     'nisqa_im2col3x3': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     'nisqa_conv3x3_gemm': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p]),

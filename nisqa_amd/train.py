@@ -58,6 +58,7 @@ class HipTrainer(object):
         self.eng = HipNisqa(args, state_dict, device, precision='f32')       # mel front end + geometry checks
         self.lib, self.device, self.args = self.eng.lib, self.eng.device, args
         fast, exact = self.lib.nisqa_conv3x3_gemm_bf16, self.lib.nisqa_conv3x3_gemm
+        self.fused_l1 = os.environ.get('NISQA_HIP_TRAIN_FUSED_L1', '1') != '0'
         self._conv_fwd = fast if self.precision == 'bf16x3' else exact
         self._conv_bwd = exact if self.precision == 'f32' else fast
         self.lr = float(lr)
@@ -328,20 +329,38 @@ class HipTrainer(object):
             ci, co = _CONV[i - 1]
             h, w, (ho, wo) = geo[i - 1]
             rows = S * h * w
-            z = self._new(rows, co)
             wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
+            drop = self._mask(masks, _DROP_AFTER.get(i), (S, co), self.p_cnn) if i in _DROP_AFTER else None
+            out = self._new(S, ho * wo, co)
+            arg = self._new(S, ho * wo, co, dtype=torch.int32)
+            mr = self._new(2 * co)
+            if i == 1 and self.fused_l1:
+                # layer 1 straight from the spectrogram: its 720-pixel activations are never written (csrc/train.hip,
+                # "Layer 1 without its activations"): patch moments -> batch statistics -> recomputed pooling windows
+                mom = self._sums[self._sum_i][:54]
+                sums = self._sums[self._sum_i + 1][:32]
+                self._sum_i += 2
+                self._ck(L_.nisqa_conv1_moments(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
+                                                mom.data_ptr(), st), 'nisqa_conv1_moments')
+                self._ck(L_.nisqa_conv1_bn_act_pool_fwd(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
+                                                        _ptr(self.P[wk]), _ptr(self.P[bk]), mom.data_ptr(),
+                                                        _ptr(self.P['cnn.model.bn1.weight']), _ptr(self.P['cnn.model.bn1.bias']),
+                                                        _ptr(self.bn[1]['mean']), _ptr(self.bn[1]['var']), sums.data_ptr(), _ptr(mr),
+                                                        _ptr(drop) if drop is not None else None, _ptr(out), arg.data_ptr(), st),
+                         'nisqa_conv1_bn_act_pool_fwd')
+                self.bn[i]['n'] += 1
+                cnn.append(dict(x=None, z=None, arg=arg, mr=mr, drop=drop, h=h, w=w, ho=ho, wo=wo, ci=ci, co=co, rows=rows, mom=mom))
+                act = out
+                continue
+            z = self._new(rows, co)
             if i == 1:                                                         # straight from the spectrogram, no patches
                 self._ck(L_.nisqa_conv1_fwd(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
                                             _ptr(self.P[wk]), _ptr(self.P[bk]), _ptr(z), st), 'nisqa_conv1_fwd')
             else:                                                              # implicit GEMM: patches gathered by the loaders
                 hi, wi = geo[i - 2][2]
                 self._ck(self._conv_fwd(0, _ptr(act), _ptr(self.P[wk]), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
-                                               _ptr(self.P[bk]), 1, st), 'nisqa_conv3x3_gemm fwd')
+                                        _ptr(self.P[bk]), 1, st), 'nisqa_conv3x3_gemm fwd')
             sums = self._coldot(z, z, rows, co)
-            drop = self._mask(masks, _DROP_AFTER.get(i), (S, co), self.p_cnn) if i in _DROP_AFTER else None
-            out = self._new(S, ho * wo, co)
-            arg = self._new(S, ho * wo, co, dtype=torch.int32)
-            mr = self._new(2 * co)
             self._ck(L_.nisqa_bn_act_pool_fwd(_ptr(z), sums.data_ptr(), _ptr(self.P['cnn.model.bn%d.weight' % i]),
                                               _ptr(self.P['cnn.model.bn%d.bias' % i]), _ptr(self.bn[i]['mean']),
                                               _ptr(self.bn[i]['var']), _ptr(mr), S, h, w, co, ho, wo,
@@ -474,8 +493,19 @@ class HipTrainer(object):
         for i in range(6, 0, -1):
             c = cnn[i - 1]
             rows, co, ci = c['rows'], c['co'], c['ci']
-            dz = self._new(rows, co)
             g, b_ = self.P['cnn.model.bn%d.weight' % i], self.P['cnn.model.bn%d.bias' % i]
+            if i == 1 and c['z'] is None:                                      # fused layer 1: sparse sums + patch moments
+                acc = self._sums[self._sum_i][:176]
+                self._sum_i += 1
+                self._ck(L_.nisqa_conv1_bn_act_pool_bwd(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
+                                                        _ptr(self.P['cnn.model.conv1.weight']), _ptr(self.P['cnn.model.conv1.bias']),
+                                                        c['mom'].data_ptr(), _ptr(g), _ptr(b_), _ptr(c['mr']),
+                                                        _ptr(c['drop']) if c['drop'] is not None else None, _ptr(da),
+                                                        c['arg'].data_ptr(), acc.data_ptr(), _ptr(self.G['cnn.model.bn1.weight']),
+                                                        _ptr(self.G['cnn.model.bn1.bias']), _ptr(self.G['cnn.model.conv1.weight']),
+                                                        st), 'nisqa_conv1_bn_act_pool_bwd')
+                continue                                                       # conv1.bias: exactly zero (gflat was cleared)
+            dz = self._new(rows, co)
             s2 = self._sums[self._sum_i]
             sb = self._sums[self._sum_i + 1]
             self._sum_i += 2

@@ -192,6 +192,74 @@ def test_im2col_mel_segments_and_floor():
     assert torch.equal(col, want)
 
 
+@pytest.mark.parametrize('use_drop', [False, True])
+def test_layer1_without_its_activations_matches_autograd(use_drop):
+    """conv1 -> train-mode BatchNorm -> ReLU -> adaptive max-pool (24, 7) -> per-channel dropout scale, forward and
+    backward from the patch moments and recomputed pooling windows (nisqa_conv1_moments / _bn_act_pool_fwd / _bwd), against
+    torch autograd on the materialised segments (NISQA_lib.py:688-697 in train mode)."""
+    lib, L = _L()
+    T = [40, 15, 23]
+    n_wins = [7, 1, 3]
+    mel = _r(sum(T), 48, seed=60, scale=20.0)
+    frame_off = torch.tensor(np.concatenate(([0], np.cumsum(T))), dtype=torch.int32, device=DEV)
+    seg_off = torch.tensor(np.concatenate(([0], np.cumsum(n_wins))), dtype=torch.int32, device=DEV)
+    floor = torch.tensor([-10.0, -3.0e38, -25.0], device=DEV)
+    S = sum(n_wins)
+    segs = []
+    for b, n in enumerate(n_wins):
+        sp = torch.maximum(mel[int(frame_off[b]):int(frame_off[b + 1])], floor[b]).t()
+        segs += [sp[:, 4 * k:4 * k + 15] for k in range(n)]
+    x = torch.stack(segs)[:, None]                                                     # [S,1,48,15]
+    w = (_r(16, 1, 3, 3, seed=61) * 0.3).requires_grad_(True)
+    b_ = _r(16, seed=62).requires_grad_(True)
+    gamma, beta = (_r(16, seed=63) * 0.5 + 1).requires_grad_(True), (_r(16, seed=64) * 0.3).requires_grad_(True)
+    drop = ((torch.rand(S, 16, device=DEV) > 0.3).float() / 0.7) if use_drop else None
+    rm, rv = _r(16, seed=65), _r(16, seed=66).abs() + 0.5
+    rm_t, rv_t = rm.clone(), rv.clone()
+    z = F.conv2d(x, w, b_, padding=1)
+    yb = F.batch_norm(z, rm_t, rv_t, gamma, beta, True, 0.1, 1e-5)
+    pooled = F.adaptive_max_pool2d(F.relu(yb), (24, 7))                                 # [S,16,24,7]
+    if drop is not None:
+        pooled = pooled * drop[:, :, None, None]
+    dy = _r(S, 168, 16, seed=67)
+    (pooled.permute(0, 2, 3, 1).reshape(S, 168, 16) * dy).sum().backward()
+    # the HIP path
+    wk = w.detach().reshape(16, 9).contiguous()
+    mom = torch.zeros(54, dtype=torch.float64, device=DEV)
+    sums = torch.zeros(32, dtype=torch.float64, device=DEV)
+    acc = torch.zeros(176, dtype=torch.float64, device=DEV)
+    mr = torch.empty(32, device=DEV)
+    y = torch.empty(S, 168, 16, device=DEV)
+    arg = torch.empty(S, 168, 16, dtype=torch.int32, device=DEV)
+    dg, db, dw = torch.empty(16, device=DEV), torch.empty(16, device=DEV), torch.empty(16, 9, device=DEV)
+    common = (_p(mel), frame_off.data_ptr(), seg_off.data_ptr(), _p(floor), 3, S, 4)
+    lib.check(L.nisqa_conv1_moments(*common, mom.data_ptr(), _st()), 'moments')
+    lib.check(L.nisqa_conv1_bn_act_pool_fwd(*common, _p(wk), _p(b_.detach()), mom.data_ptr(), _p(gamma.detach()), _p(beta.detach()),
+                                            _p(rm), _p(rv), sums.data_ptr(), _p(mr), _p(drop) if drop is not None else None,
+                                            _p(y), arg.data_ptr(), _st()), 'fwd')
+    lib.check(L.nisqa_conv1_bn_act_pool_bwd(*common, _p(wk), _p(b_.detach()), mom.data_ptr(), _p(gamma.detach()), _p(beta.detach()),
+                                            _p(mr), _p(drop) if drop is not None else None, _p(dy), arg.data_ptr(),
+                                            acc.data_ptr(), _p(dg), _p(db), _p(dw), _st()), 'bwd')
+    torch.cuda.synchronize()
+    col = F.unfold(x, 3, padding=1).permute(0, 2, 1).reshape(S * 720, 9).double()
+    assert (mom[:9] - col.sum(0)).abs().max() < 1e-6 * S * 720
+    want_z = z.detach().permute(0, 2, 3, 1).reshape(-1, 16).double()
+    # analytic float64 sums against float64 sums of torch's float32 z: the difference is z's own rounding
+    assert ((sums[:16] - want_z.sum(0)).abs() < 1e-6 * want_z.abs().sum(0)).all()
+    assert ((sums[16:] - (want_z ** 2).sum(0)).abs() < 1e-6 * (want_z ** 2).sum(0)).all()
+    want_y = pooled.detach().permute(0, 2, 3, 1).reshape(S, 168, 16)
+    print('layer 1 fused: max|d y| %.2e, running mean/var %.2e %.2e; dgamma %.2e dbeta %.2e dw %.2e (of %.1f), db(ref) %.1e' % (
+        float((y - want_y).abs().max()), float((rm - rm_t).abs().max()), float((rv - rv_t).abs().max()),
+        float((dg - gamma.grad).abs().max()), float((db - beta.grad).abs().max()),
+        float((dw - w.grad.reshape(16, 9)).abs().max()), float(w.grad.abs().max()), float(b_.grad.abs().max())))
+    assert (y - want_y).abs().max() < 1e-4
+    assert (rm - rm_t).abs().max() < 1e-5 and (rv - rv_t).abs().max() < 1e-4
+    assert (dg - gamma.grad).abs().max() < 2e-4 * max(1.0, float(gamma.grad.abs().max()))
+    assert (db - beta.grad).abs().max() < 2e-4 * max(1.0, float(beta.grad.abs().max()))
+    assert (dw - w.grad.reshape(16, 9)).abs().max() < 2e-4 * max(1.0, float(w.grad.abs().max()))
+    assert b_.grad.abs().max() < 1e-3                                                  # analytically zero
+
+
 def test_col_dot_float64_accumulation():
     lib, L = _L()
     rows, c = 100003, 48
