@@ -109,6 +109,11 @@ int nisqa_bn_act_pool_bwd1(const float* dy, const int32_t* arg, const float* dro
                            const float* mean_rstd, const float* gamma, const float* beta, int32_t n_segments,
                            int32_t h, int32_t w, int32_t c, int32_t ho, int32_t wo, float* dyb, double* sums2_opt,
                            void* stream);
+/* The two passes above in a form that reads z and writes dz ONCE: the reductions only see pixels that won a pooling
+ * window, so they are taken over the pooled values first (sums2 [2c] float64, zeroed by the caller; 1024 % c == 0). */
+int nisqa_bn_act_pool_bwd(const float* dy, const int32_t* arg, const float* drop, const float* z, const float* mean_rstd,
+                          const float* gamma, const float* beta, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t ho,
+                          int32_t wo, double* sums2, float* dz, float* dgamma, float* dbeta, void* stream);
 int nisqa_bn_bwd2(float* dyb_to_dz, const float* z, const double* sums2, const float* mean_rstd, const float* gamma,
                   int64_t rows, int32_t c, float* dgamma, float* dbeta, double* sum_dz_opt, void* stream);
 

@@ -1392,6 +1392,121 @@ extern "C" int nisqa_bn_act_pool_bwd1(const float* dy, const int32_t* arg, const
     return NQ_LAUNCH_STATUS();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same backward in two launches that touch the dense tensors ONCE (read z, write dz) instead of twice each way:
+// the reductions of the BatchNorm backward only see pixels that won a pooling window, so they are sums over the POOLED
+// values (one z gather per value); with them known, dz follows from dy / arg / z in a single dense pass.
+// ---------------------------------------------------------------------------------------------------------
+template <int H, int W, int C, int HO, int WO>
+__global__ __launch_bounds__(256) void pool_bwd_sums_kernel(
+    const float* __restrict__ dy, const int32_t* __restrict__ arg, const float* __restrict__ drop, const float* __restrict__ z,
+    const float* __restrict__ mean_rstd, const float* __restrict__ gamma, const float* __restrict__ beta, int64_t total4,
+    int h_, int w_, int c_, int ho_, int wo_, double* __restrict__ sums2) {
+    const int h = H ? H : h_, w = H ? W : w_, c = H ? C : c_, ho = H ? HO : ho_, wo = H ? WO : wo_;
+    const int c4 = c / 4;
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int ch = 4 * (int)(i % c4);
+        const int64_t s = (i / c4) / (ho * wo);
+        f32x4 g, bsh;
+        bn_affine4(gamma, beta, mean_rstd, c, ch, g, bsh);
+        f32x4 d = ((const f32x4*)dy)[i];
+        if (drop) d *= *(const f32x4*)(drop + s * c + ch);
+        f32x4 zw;
+        if (h == ho && w == wo) zw = ((const f32x4*)z)[i];  // identity pooling: the winning pixel is the cell itself
+        else {
+            const i32x4 ap = ((const i32x4*)arg)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) zw[e] = z[(s * (h * w) + ap[e]) * c + ch + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float zv = zw[e];
+            if (zv * g[e] + bsh[e] > 0.f) {                 // ReLU gate at the winning pixel
+                a1[e] += (double)d[e];
+                a2[e] += (double)d[e] * (double)zv;
+            }
+        }
+    }
+    block_channel_sums4(a1, a2, c, sums2);
+}
+
+template <int H, int W, int C, int HO, int WO>
+__global__ __launch_bounds__(256) void bn_act_pool_bwd_dense_kernel(
+    const float* __restrict__ dy, const int32_t* __restrict__ arg, const float* __restrict__ drop, const float* __restrict__ z,
+    const float* __restrict__ mean_rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const double* __restrict__ sums2, int64_t total4, int h_, int w_, int c_, int ho_, int wo_, float* __restrict__ dz,
+    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int h = H ? H : h_, w = H ? W : w_, c = H ? C : c_, ho = H ? HO : ho_, wo = H ? WO : wo_;
+    const int c4 = c / 4;
+    const double inv = 1.0 / ((double)(total4 / c4));
+    if (blockIdx.x == 0 && (int)threadIdx.x < c) {
+        const int ch = threadIdx.x;
+        const double mean = mean_rstd[ch], rstd = mean_rstd[c + ch];
+        dbeta[ch] = (float)sums2[ch];
+        dgamma[ch] = (float)(rstd * (sums2[c + ch] - mean * sums2[ch]));
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int ch = 4 * (int)(i % c4);
+        const int64_t pix = i / c4;
+        const int64_t s = pix / (h * w);
+        const int p = (int)(pix - s * (h * w));
+        const int yy = p / w, xx = p % w;
+        f32x4 g, bsh, mean, rstd, m1, m2;
+        bn_affine4(gamma, beta, mean_rstd, c, ch, g, bsh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mean[e] = mean_rstd[ch + e];
+            rstd[e] = mean_rstd[c + ch + e];
+            m1[e] = (float)(sums2[ch + e] * inv);
+            m2[e] = (float)((double)rstd[e] * (sums2[c + ch + e] - (double)mean[e] * sums2[ch + e]) * inv);
+        }
+        const f32x4 zi = ((const f32x4*)z)[i];
+        const f32x4 yb = zi * g + bsh;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const bool live = yb[0] > 0.f || yb[1] > 0.f || yb[2] > 0.f || yb[3] > 0.f;
+        if (h == ho && w == wo) {
+            acc = *(const f32x4*)(dy + (s * (ho * wo) + p) * c + ch);
+        } else if (live) {
+            const int oy0 = max(0, (yy * ho) / h - 1), oy1 = min(ho - 1, ((yy + 1) * ho) / h + 1);
+            const int ox0 = max(0, (xx * wo) / w - 1), ox1 = min(wo - 1, ((xx + 1) * wo) / w + 1);
+            for (int oy = oy0; oy <= oy1; ++oy) {
+                if (yy < win_lo(oy, h, ho) || yy >= win_hi(oy, h, ho)) continue;
+                for (int ox = ox0; ox <= ox1; ++ox) {
+                    if (xx < win_lo(ox, w, wo) || xx >= win_hi(ox, w, wo)) continue;
+                    const int64_t o = (s * (ho * wo) + oy * wo + ox) * c + ch;
+                    const i32x4 ag = *(const i32x4*)(arg + o);
+                    const f32x4 d = *(const f32x4*)(dy + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (ag[e] == p) acc[e] += d[e];
+                }
+            }
+        }
+        if (drop) acc *= *(const f32x4*)(drop + s * c + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (!(yb[e] > 0.f)) acc[e] = 0.f;
+        const f32x4 xh = (zi - mean) * rstd;
+        ((f32x4*)dz)[i] = (g) * (acc - m1 - xh * m2);        // g = gamma * rstd
+    }
+}
+
+// dy [S][HO*WO][C] -> dz [S][H*W][C], dgamma, dbeta; sums2 [2c] float64 scratch zeroed by the caller
+extern "C" int nisqa_bn_act_pool_bwd(const float* dy, const int32_t* arg, const float* drop, const float* z, const float* mean_rstd,
+                                     const float* gamma, const float* beta, int32_t n_segments, int32_t h, int32_t w, int32_t c,
+                                     int32_t ho, int32_t wo, double* sums2, float* dz, float* dgamma, float* dbeta, void* stream) {
+    if (!dy || !arg || !z || !mean_rstd || !gamma || !beta || !sums2 || !dz || !dgamma || !dbeta || n_segments <= 0 || h <= 0 ||
+        w <= 0 || c <= 0 || ho <= 0 || wo <= 0 || ho > h || wo > w || (c & 3) || (1024 % c) != 0)
+        return NISQA_ERR_ARG;
+    const int64_t cells = (int64_t)n_segments * ho * wo * c / 4, total = (int64_t)n_segments * h * w * c / 4;
+    hipStream_t st = (hipStream_t)stream;
+    NQ_LAUNCH_BEGIN();
+    const int g1 = grid_for(cells) < 2048 ? grid_for(cells) : 2048;
+    NQ_POOL_DISPATCH(pool_bwd_sums_kernel, dim3(g1), st, dy, arg, drop, z, mean_rstd, gamma, beta, cells, h, w, c, ho, wo, sums2);
+    NQ_POOL_DISPATCH(bn_act_pool_bwd_dense_kernel, dim3(grid_for(total)), st, dy, arg, drop, z, mean_rstd, gamma, beta,
+                     (const double*)sums2, total, h, w, c, ho, wo, dz, dgamma, dbeta);
+    return NQ_LAUNCH_STATUS();
+}
+
 __global__ __launch_bounds__(256) void bn_bwd2_kernel(float* __restrict__ d, const float* __restrict__ z,
                                                       const double* __restrict__ sums2, const float* __restrict__ mean_rstd,
                                                       const float* __restrict__ gamma, int64_t rows, int c,

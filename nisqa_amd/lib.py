@@ -86,6 +86,7 @@ TRAIN_SYMBOLS = {
                                              c_p, c_p, c_p, c_p]),
     'nisqa_bn_act_pool_bwd1': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                               c_p, c_p, c_p]),
+    'nisqa_bn_act_pool_bwd': (ctypes.c_int, [c_p] * 7 + [c_i32] * 6 + [c_p] * 5),
     'nisqa_bn_bwd2': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_layernorm_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
     'nisqa_layernorm_bwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),

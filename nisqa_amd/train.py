@@ -59,6 +59,8 @@ class HipTrainer(object):
         self.lib, self.device, self.args = self.eng.lib, self.eng.device, args
         fast, exact = self.lib.nisqa_conv3x3_gemm_bf16, self.lib.nisqa_conv3x3_gemm
         self.fused_l1 = os.environ.get('NISQA_HIP_TRAIN_FUSED_L1', '1') != '0'
+        self._kchunk = int(os.environ.get('NISQA_HIP_TRAIN_KCHUNK', '128'))
+        self.fused_bn_bwd = os.environ.get('NISQA_HIP_TRAIN_FUSED_BN_BWD', '1') != '0'
         self._conv_fwd = fast if self.precision == 'bf16x3' else exact
         self._conv_bwd = exact if self.precision == 'f32' else fast
         self.lr = float(lr)
@@ -177,9 +179,10 @@ class HipTrainer(object):
 
     def _ksplit(self, rows, m=64, n=64):
         """K-chunks of a weight-gradient GEMM (K = rows of the batch): enough workgroups to fill 256 CUs a few times
-        over (tiles x chunks ~ 2048), chunks of at least 512 rows."""
+        over (tiles x chunks ~ 2048), chunks of at least NISQA_HIP_TRAIN_KCHUNK rows (a K-tile of 32 rows takes a workgroup
+        ~1 us with its single-buffered loads: a 512-row chunk is a 16 us kernel however small the product)."""
         tiles = ((m + 63) // 64) * ((n + 63) // 64)
-        return int(max(1, min(2048 // tiles, rows // 512, 4096)))
+        return int(max(1, min(2048 // tiles, rows // self._kchunk, 4096)))
 
     def _linear_fwd(self, X, wk, bk, rows, n_in, n_out, relu=False):
         Y = self._new(rows, n_out)
@@ -506,17 +509,29 @@ class HipTrainer(object):
                                                         st), 'nisqa_conv1_bn_act_pool_bwd')
                 continue                                                       # conv1.bias: exactly zero (gflat was cleared)
             dz = self._new(rows, co)
-            s2 = self._sums[self._sum_i]
-            sb = self._sums[self._sum_i + 1]
-            self._sum_i += 2
-            self._ck(L_.nisqa_bn_act_pool_bwd1(_ptr(da), c['arg'].data_ptr(), _ptr(c['drop']) if c['drop'] is not None else None,
-                                               _ptr(c['z']), _ptr(c['mr']), _ptr(g), _ptr(b_), S, c['h'], c['w'], co, c['ho'],
-                                               c['wo'], _ptr(dz), s2.data_ptr(), st), 'nisqa_bn_act_pool_bwd1')
-            self._ck(L_.nisqa_bn_bwd2(_ptr(dz), _ptr(c['z']), s2.data_ptr(), _ptr(c['mr']), _ptr(g), rows, co,
-                                      _ptr(self.G['cnn.model.bn%d.weight' % i]), _ptr(self.G['cnn.model.bn%d.bias' % i]),
-                                      sb.data_ptr(), st), 'nisqa_bn_bwd2')
+            if self.fused_bn_bwd:
+                # reductions over the pooled values first, then ONE dense pass z -> dz (csrc/train.hip); the conv bias
+                # gradient (column sums of dz) is exactly zero under train-mode BatchNorm and stays at the cleared value
+                s2 = self._sums[self._sum_i]
+                self._sum_i += 1
+                self._ck(L_.nisqa_bn_act_pool_bwd(_ptr(da), c['arg'].data_ptr(), _ptr(c['drop']) if c['drop'] is not None else None,
+                                                  _ptr(c['z']), _ptr(c['mr']), _ptr(g), _ptr(b_), S, c['h'], c['w'], co, c['ho'],
+                                                  c['wo'], s2.data_ptr(), _ptr(dz), _ptr(self.G['cnn.model.bn%d.weight' % i]),
+                                                  _ptr(self.G['cnn.model.bn%d.bias' % i]), st), 'nisqa_bn_act_pool_bwd')
+                sb = None
+            else:
+                s2 = self._sums[self._sum_i]
+                sb = self._sums[self._sum_i + 1]
+                self._sum_i += 2
+                self._ck(L_.nisqa_bn_act_pool_bwd1(_ptr(da), c['arg'].data_ptr(), _ptr(c['drop']) if c['drop'] is not None else None,
+                                                   _ptr(c['z']), _ptr(c['mr']), _ptr(g), _ptr(b_), S, c['h'], c['w'], co, c['ho'],
+                                                   c['wo'], _ptr(dz), s2.data_ptr(), st), 'nisqa_bn_act_pool_bwd1')
+                self._ck(L_.nisqa_bn_bwd2(_ptr(dz), _ptr(c['z']), s2.data_ptr(), _ptr(c['mr']), _ptr(g), rows, co,
+                                          _ptr(self.G['cnn.model.bn%d.weight' % i]), _ptr(self.G['cnn.model.bn%d.bias' % i]),
+                                          sb.data_ptr(), st), 'nisqa_bn_bwd2')
             wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
-            self._defer_cast(sb, 0, co, self.G[bk])
+            if sb is not None:
+                self._defer_cast(sb, 0, co, self.G[bk])
             if i == 1:
                 self._ck(L_.nisqa_conv1_wgrad(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop, _ptr(dz),
                                               _ptr(self.G[wk]), st), 'nisqa_conv1_wgrad')

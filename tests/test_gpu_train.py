@@ -318,6 +318,18 @@ def test_batchnorm_relu_pool_dropout_forward_and_backward(h, w, c, ho, wo, use_d
     assert (dyb - z.grad).abs().max() < 2e-4 * max(1.0, float(z.grad.abs().max()))
     assert (dg - gamma.grad).abs().max() < 2e-4 * max(1.0, float(gamma.grad.abs().max()))
     assert (db - beta.grad).abs().max() < 2e-4 * max(1.0, float(beta.grad.abs().max()))
+    # the two-launch form (sums over the pooled values, then one dense pass z -> dz) gives the same numbers
+    if 1024 % c == 0:
+        s3 = torch.zeros(2 * c, dtype=torch.float64, device=DEV)
+        dz2, dg2, db2 = torch.empty(S, h * w, c, device=DEV), torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+        lib.check(L.nisqa_bn_act_pool_bwd(_p(dy), arg.data_ptr(), dp, _p(zd), _p(mr), _p(gamma), _p(beta), S, h, w, c, ho, wo,
+                                          s3.data_ptr(), _p(dz2), _p(dg2), _p(db2), _st()), 'bn bwd fused')
+        torch.cuda.synchronize()
+        # (pass 1 adds the <= 4 window gradients of a pixel in float32 before they enter the float64 sums, this form adds
+        # every pooled value on its own: float32 rounding apart)
+        assert (s3 - s2).abs().max() < 1e-6 * max(1.0, float(s2.abs().max()))
+        assert (dz2 - dyb).abs().max() < 2e-6 * max(1.0, float(dyb.abs().max()))      # dyb holds dz after pass 2
+        assert (dg2 - dg).abs().max() < 1e-5 * max(1.0, float(dg.abs().max())) and (db2 - db).abs().max() < 1e-5 * max(1.0, float(db.abs().max()))
 
 
 def test_layernorm_softmax_elementwise_loss_adam():
