@@ -84,6 +84,11 @@ int nisqa_conv3x3_gemm(int32_t mode, const float* x_or_dz, const float* w_or_dz,
  * arithmetic of the inference path's default precision; 5.3x the fp32-MFMA rate).  Same arguments. */
 int nisqa_conv3x3_gemm_bf16(int32_t mode, const float* x_or_dz, const float* w_or_dz, float* out, int32_t n_segments, int32_t h,
                             int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, int32_t ksplit, void* stream);
+/* Mode 0 with the BatchNorm batch statistics riding along: stats2c [dev, float64, zeroed by the caller] += sum z, sum z^2
+ * per output channel over all rows (what nisqa_col_dot(z, z) would add in a second pass over z); split_bf16 selects the
+ * arithmetic of nisqa_conv3x3_gemm_bf16. */
+int nisqa_conv3x3_fwd_stats(int32_t split_bf16, const float* x, const float* w_, float* z, int32_t n_segments, int32_t h,
+                            int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c, void* stream);
 /* adjoint of nisqa_im2col3x3 (gather form, no atomics): dx[S][H*W][C] = sum of the patch entries that read it */
 int nisqa_col2im3x3(const float* dcol, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w, float* dx,
                     void* stream);

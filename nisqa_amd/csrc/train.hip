@@ -209,8 +209,9 @@ extern "C" int nisqa_gemm_f32_one(const float* a, const float* b, float* c, int6
     int cfg = 0;
     int64_t bm = 64, bn = 64;
     if (n <= 32 && m > 64) { cfg = 1; bm = 128; bn = 32; }
-    else if (m >= 256 && n >= 128) { cfg = 2; bm = 128; bn = 128; }
-    else if (m >= 512 && n > 32) { cfg = 3; bm = 256; bn = 64; }
+    // (the big tiles only where they still give every CU a workgroup: a 7 904 x 64 product is 31 tiles of 256 x 64)
+    else if (m >= 256 && n >= 128 && ((m + 127) / 128) * ((n + 127) / 128) >= 192) { cfg = 2; bm = 128; bn = 128; }
+    else if (m >= 512 && n > 32 && ((m + 255) / 256) * ((n + 63) / 64) >= 192) { cfg = 3; bm = 256; bn = 64; }
     else if (m <= 64 && n >= 256) { cfg = 4; bm = 64; bn = 256; }
     const int64_t tiles = ((m + bm - 1) / bm) * ((n + bn - 1) / bn);
     if (tiles == 0) return NISQA_OK;
@@ -275,7 +276,7 @@ NQ_DEV f32x4 conv_gather(const float* __restrict__ src, const conv_geom& g, int 
 template <int BM, int BN, int MT, int NT, int MODE>
 __global__ __launch_bounds__((BM / (32 * MT)) * (BN / (32 * NT)) * 64) void conv_gemm_kernel(
     const float* __restrict__ G, const float* __restrict__ O, float* __restrict__ C, conv_geom g, int M, int N, int K, int ksplit,
-    const float* __restrict__ bias) {
+    const float* __restrict__ bias, double* __restrict__ stats) {
     // G: the gathered tensor (x for forward / wgrad, dz for dgrad); O: the other operand (weights, or dz for wgrad)
     __shared__ __attribute__((aligned(16))) float As[GB_K][BM + 4];
     __shared__ __attribute__((aligned(16))) float Bs[GB_K][BN + 4];
@@ -384,21 +385,50 @@ __global__ __launch_bounds__((BM / (32 * MT)) * (BN / (32 * NT)) * 64) void conv
             __syncthreads();
         }
     }
+    // forward with stats != NULL: the per-channel sums of z and z^2 over all rows (the BatchNorm batch statistics) ride
+    // along in float64 -- lane pairs, then the workgroup's waves through LDS, then one atomic per channel and workgroup
+    __shared__ double red[MODE == 0 ? 2 * BN : 1];
+    const bool with_stats = MODE == 0 && stats != nullptr;
+    if (with_stats) {
+        for (int q = tid; q < 2 * BN; q += NTH) red[q] = 0.0;
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = n0 + wn + 32 * j + (lane & 31);
+            double s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + 32 * i + NQ_DROW(r, lane >> 5);
                 if (row < M && col < N) {
                     const float v = acc[i][j][r];
                     if (MODE == 2) atomicAdd(C + (int64_t)row * N + col, v);
-                    else C[(int64_t)row * N + col] = bias ? v + bias[col] : v;
+                    else {
+                        const float zv = bias ? v + bias[col] : v;
+                        C[(int64_t)row * N + col] = zv;
+                        if (MODE == 0) { s1 += (double)zv; s2 += (double)zv * (double)zv; }
+                    }
+                }
+            }
+            if (with_stats) {
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (lane < 32 && col < N) {
+                    atomicAdd(&red[wn + 32 * j + lane], s1);
+                    atomicAdd(&red[BN + wn + 32 * j + lane], s2);
                 }
             }
         }
+    if (with_stats) {
+        __syncthreads();
+        for (int q = tid; q < BN; q += NTH)
+            if (n0 + q < N) {
+                atomicAdd(stats + n0 + q, red[q]);
+                atomicAdd(stats + N + n0 + q, red[BN + q]);
+            }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -457,7 +487,7 @@ struct bf_tile {
 template <int BM, int BN, int MT, int NT, int MODE>
 __global__ __launch_bounds__((BM / (32 * MT)) * (BN / (32 * NT)) * 64) void conv_gemm_bf16_kernel(
     const float* __restrict__ G, const float* __restrict__ O, float* __restrict__ C, conv_geom g, int M, int N, int K, int ksplit,
-    const float* __restrict__ bias) {
+    const float* __restrict__ bias, double* __restrict__ stats) {
     typedef bf_tile<BM, MODE != 2> TA;
     typedef bf_tile<BN, MODE == 0> TB;
     __shared__ __attribute__((aligned(16))) unsigned char smem[TA::BYTES + TB::BYTES];
@@ -577,30 +607,59 @@ __global__ __launch_bounds__((BM / (32 * MT)) * (BN / (32 * NT)) * 64) void conv
             __syncthreads();
         }
     }
+    // forward with stats != NULL: the per-channel sums of z and z^2 over all rows (the BatchNorm batch statistics) ride
+    // along in float64 -- lane pairs, then the workgroup's waves through LDS, then one atomic per channel and workgroup
+    __shared__ double red[MODE == 0 ? 2 * BN : 1];
+    const bool with_stats = MODE == 0 && stats != nullptr;
+    if (with_stats) {
+        for (int q = tid; q < 2 * BN; q += NTH) red[q] = 0.0;
+        __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = n0 + wn + 32 * j + (lane & 31);
+            double s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + 32 * i + NQ_DROW(r, lane >> 5);
                 if (row < M && col < N) {
                     const float v = acc[i][j][r];
                     if (MODE == 2) atomicAdd(C + (int64_t)row * N + col, v);
-                    else C[(int64_t)row * N + col] = bias ? v + bias[col] : v;
+                    else {
+                        const float zv = bias ? v + bias[col] : v;
+                        C[(int64_t)row * N + col] = zv;
+                        if (MODE == 0) { s1 += (double)zv; s2 += (double)zv * (double)zv; }
+                    }
+                }
+            }
+            if (with_stats) {
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (lane < 32 && col < N) {
+                    atomicAdd(&red[wn + 32 * j + lane], s1);
+                    atomicAdd(&red[BN + wn + 32 * j + lane], s2);
                 }
             }
         }
+    if (with_stats) {
+        __syncthreads();
+        for (int q = tid; q < BN; q += NTH)
+            if (n0 + q < N) {
+                atomicAdd(stats + n0 + q, red[q]);
+                atomicAdd(stats + N + n0 + q, red[BN + q]);
+            }
+    }
 }
 
 template <int BM, int BN, int MT, int NT, int MODE>
 static void conv_launch(hipStream_t st, const float* gsrc, const float* other, float* c, const conv_geom& g, int M, int N, int K,
-                        int ksplit, const float* bias, bool bf16) {
+                        int ksplit, const float* bias, bool bf16, double* stats = nullptr) {
     const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const dim3 grid((unsigned)tiles, ksplit), block((BM / (32 * MT)) * (BN / (32 * NT)) * 64);
-    if (bf16) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BM, BN, MT, NT, MODE>), grid, block, 0, st, gsrc, other, c, g, M, N, K, ksplit, bias);
-    else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, MT, NT, MODE>), grid, block, 0, st, gsrc, other, c, g, M, N, K, ksplit, bias);
+    if (bf16) hipLaunchKernelGGL((conv_gemm_bf16_kernel<BM, BN, MT, NT, MODE>), grid, block, 0, st, gsrc, other, c, g, M, N, K, ksplit, bias, stats);
+    else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, MT, NT, MODE>), grid, block, 0, st, gsrc, other, c, g, M, N, K, ksplit, bias, stats);
 }
 
 static int ilog2_exact(int v) {
@@ -612,7 +671,7 @@ static int ilog2_exact(int v) {
 // mode 0: x -> z (bias may be NULL); mode 1: dz -> dx; mode 2: (x, dz) -> dw += (dw zeroed by the caller), ksplit chunks
 static int conv3x3_gemm(bool bf16, int32_t mode, const float* x_or_dz, const float* w_or_dz, float* out, int32_t n_segments,
                         int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias,
-                        int32_t ksplit, void* stream) {
+                        int32_t ksplit, void* stream, double* stats = nullptr) {
     const int wo = w + 2 * pad_w - 2;
     if (mode < 0 || mode > 2 || !x_or_dz || !w_or_dz || !out || n_segments <= 0 || h <= 0 || w <= 0 || wo <= 0 || pad_w < 0 ||
         pad_w > 1 || ilog2_exact(ci) < 2 || ilog2_exact(co) < 2 || ksplit < 1 || ksplit > 65535 || (mode != 2 && ksplit != 1) ||
@@ -637,8 +696,8 @@ static int conv3x3_gemm(bool bf16, int32_t mode, const float* x_or_dz, const flo
         g.d_img = fdiv_make((uint32_t)(h * wo)); g.d_row = fdiv_make((uint32_t)wo);
         if (mode == 0) {
             const int M = (int)rows_out, N = co, K = 9 * ci;
-            if (N > 32) conv_launch<256, 64, 2, 1, 0>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, bias, bf16);
-            else conv_launch<128, 32, 1, 1, 0>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, bias, bf16);
+            if (N > 32) conv_launch<256, 64, 2, 1, 0>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, bias, bf16, stats);
+            else conv_launch<128, 32, 1, 1, 0>(st, x_or_dz, w_or_dz, out, g, M, N, K, 1, bias, bf16, stats);
         } else {
             const int M = co, N = 9 * ci, K = (int)rows_out;
             if (N >= 256) conv_launch<64, 256, 2, 1, 2>(st, x_or_dz, w_or_dz, out, g, M, N, K, ksplit, nullptr, bf16);
@@ -652,6 +711,13 @@ extern "C" int nisqa_conv3x3_gemm(int32_t mode, const float* x_or_dz, const floa
                                   int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias,
                                   int32_t ksplit, void* stream) {
     return conv3x3_gemm(false, mode, x_or_dz, w_or_dz, out, n_segments, h, w, ci, co, pad_w, bias, ksplit, stream);
+}
+// forward convolution that also leaves sum z, sum z^2 per output channel in stats2c [dev, float64, zeroed by the caller]
+extern "C" int nisqa_conv3x3_fwd_stats(int32_t split_bf16, const float* x, const float* w_, float* z, int32_t n_segments, int32_t h,
+                                       int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c,
+                                       void* stream) {
+    if (!stats2c) return NISQA_ERR_ARG;
+    return conv3x3_gemm(split_bf16 != 0, 0, x, w_, z, n_segments, h, w, ci, co, pad_w, bias, 1, stream, stats2c);
 }
 extern "C" int nisqa_conv3x3_gemm_bf16(int32_t mode, const float* x_or_dz, const float* w_or_dz, float* out, int32_t n_segments,
                                        int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias,

@@ -79,6 +79,7 @@ TRAIN_SYMBOLS = {
     'nisqa_im2col_mel': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p]),
     'nisqa_im2col3x3': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     'nisqa_conv3x3_gemm': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p]),
+    'nisqa_conv3x3_fwd_stats': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_conv3x3_gemm_bf16': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p]),
     'nisqa_col2im3x3': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     'nisqa_col_dot': (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_p]),

@@ -61,6 +61,7 @@ class HipTrainer(object):
         self.fused_l1 = os.environ.get('NISQA_HIP_TRAIN_FUSED_L1', '1') != '0'
         self._kchunk = int(os.environ.get('NISQA_HIP_TRAIN_KCHUNK', '128'))
         self.fused_bn_bwd = os.environ.get('NISQA_HIP_TRAIN_FUSED_BN_BWD', '1') != '0'
+        self.fused_fwd_stats = os.environ.get('NISQA_HIP_TRAIN_FUSED_FWD_STATS', '1') != '0'
         self._conv_fwd = fast if self.precision == 'bf16x3' else exact
         self._conv_bwd = exact if self.precision == 'f32' else fast
         self.lr = float(lr)
@@ -361,9 +362,17 @@ class HipTrainer(object):
                                             _ptr(self.P[wk]), _ptr(self.P[bk]), _ptr(z), st), 'nisqa_conv1_fwd')
             else:                                                              # implicit GEMM: patches gathered by the loaders
                 hi, wi = geo[i - 2][2]
-                self._ck(self._conv_fwd(0, _ptr(act), _ptr(self.P[wk]), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
-                                        _ptr(self.P[bk]), 1, st), 'nisqa_conv3x3_gemm fwd')
-            sums = self._coldot(z, z, rows, co)
+                if self.fused_fwd_stats:                                       # sum z, sum z^2 from the convolution's epilogue
+                    sums = self._sums[self._sum_i]
+                    self._sum_i += 1
+                    self._ck(L_.nisqa_conv3x3_fwd_stats(1 if self.precision == 'bf16x3' else 0, _ptr(act), _ptr(self.P[wk]), _ptr(z),
+                                                        S, hi, wi, ci, co, 0 if i == 6 else 1, _ptr(self.P[bk]), sums.data_ptr(),
+                                                        st), 'nisqa_conv3x3_fwd_stats')
+                else:
+                    self._ck(self._conv_fwd(0, _ptr(act), _ptr(self.P[wk]), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
+                                            _ptr(self.P[bk]), 1, st), 'nisqa_conv3x3_gemm fwd')
+            if i == 1 or not self.fused_fwd_stats:
+                sums = self._coldot(z, z, rows, co)
             self._ck(L_.nisqa_bn_act_pool_fwd(_ptr(z), sums.data_ptr(), _ptr(self.P['cnn.model.bn%d.weight' % i]),
                                               _ptr(self.P['cnn.model.bn%d.bias' % i]), _ptr(self.bn[i]['mean']),
                                               _ptr(self.bn[i]['var']), _ptr(mr), S, h, w, co, ho, wo,

@@ -170,6 +170,15 @@ def test_implicit_gemm_convolution_forward_dgrad_wgrad(h, w, ci, co, pad_w, entr
     assert (dx - x.grad).abs().max() < 2e-5 * max(1.0, float(x.grad.abs().max())) * 3
     want_dw = wt.grad.permute(0, 2, 3, 1).reshape(co, 9 * ci)
     assert (dw - want_dw).abs().max() < 1e-4 * max(1.0, float(want_dw.abs().max()))
+    # forward with the BatchNorm statistics riding along: same z bit for bit, sums = float64 column sums of that z
+    z2 = torch.empty_like(z)
+    st2 = torch.zeros(2 * co, dtype=torch.float64, device=DEV)
+    lib.check(L.nisqa_conv3x3_fwd_stats(1 if entry.endswith('bf16') else 0, _p(x.detach()), _p(wk), _p(z2), S, h, w, ci, co, pad_w,
+                                        _p(b), st2.data_ptr(), _st()), 'conv fwd + stats')
+    torch.cuda.synchronize()
+    assert torch.equal(z2, z)
+    assert (st2[:co] - z.double().sum(0)).abs().max() < 1e-9 * float(z.double().abs().sum(0).max())
+    assert (st2[co:] - (z.double() ** 2).sum(0)).abs().max() < 1e-9 * float((z.double() ** 2).sum(0).max())
 
 
 def test_im2col_mel_segments_and_floor():
