@@ -748,8 +748,9 @@ __global__ __launch_bounds__(256) void im2col_mel_kernel(const float* __restrict
 
 // conv1 (1 -> 16 channels, 9 taps) is memory-bound and its K = 9 makes a poor GEMM: forward and weight gradient read
 // the 15 x 48 segment patch from the spectrogram directly (zero-bordered copy in LDS), no patch matrix in HBM.
+template <int STRIDE = 256>
 __device__ __forceinline__ void stage_patch(float (*patch)[50], const float* __restrict__ src, float fl, int tid) {
-    for (int i = tid; i < 17 * 50; i += 256) {
+    for (int i = tid; i < 17 * 50; i += STRIDE) {
         const int j = i / 50 - 1, m = i % 50 - 1;           // frame, mel band
         patch[0][i] = ((unsigned)j < 15u && (unsigned)m < 48u) ? fmaxf(src[j * 48 + m], fl) : 0.f;
     }
@@ -874,22 +875,26 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int c, int64
                                    float* __restrict__ running_var, float* __restrict__ mean_rstd);
 NQ_DEV int c1_p2(int t, int u) { return t <= u ? 9 + t * 9 - t * (t - 1) / 2 + (u - t) : 9 + u * 9 - u * (u - 1) / 2 + (t - u); }
 
+// every WAVE walks over its own segments with its own LDS copy: no workgroup barrier inside the loop (with 256 threads per
+// segment a thread had three pixels between two barriers and the kernel was latency-bound: 89 us for 8 us of arithmetic)
+#define C1_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
                                                             const int32_t* __restrict__ seg_off, const float* __restrict__ clip_floor,
                                                             int n_clips, int n_segments, int seg_hop, double* __restrict__ mom) {
-    __shared__ float patch[17][50];
+    __shared__ float patches[4][17][50];
     __shared__ double red[C1_MOM];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    float (*patch)[50] = patches[wave];
     double acc[C1_MOM];
 #pragma unroll
     for (int i = 0; i < C1_MOM; ++i) acc[i] = 0.0;
     if (tid < C1_MOM) red[tid] = 0.0;
-    for (int s = blockIdx.x; s < n_segments; s += gridDim.x) {
+    for (int s = blockIdx.x * 4 + wave; s < n_segments; s += gridDim.x * 4) {
         const int b = find_segment(seg_off, n_clips, s);
-        __syncthreads();
-        stage_patch(patch, mel_tm + (int64_t)(frame_off[b] + (s - seg_off[b]) * seg_hop) * 48, clip_floor[b], tid);
-        __syncthreads();
-        for (int p = tid; p < 720; p += 256) {
+        C1_WSYNC();
+        stage_patch<64>(patch, mel_tm + (int64_t)(frame_off[b] + (s - seg_off[b]) * seg_hop) * 48, clip_floor[b], lane);
+        C1_WSYNC();
+        for (int p = lane; p < 720; p += 64) {
             const int m = p / 15, j = p % 15;
             double x[9];
 #pragma unroll
@@ -903,11 +908,12 @@ __global__ __launch_bounds__(256) void conv1_moments_kernel(const float* __restr
             }
         }
     }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < C1_MOM; ++i) {
         double v = acc[i];
         for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
-        if ((tid & 63) == 0) atomicAdd(&red[i], v);
+        if (lane == 0) atomicAdd(&red[i], v);
     }
     __syncthreads();
     if (tid < C1_MOM) atomicAdd(mom + tid, red[tid]);
@@ -980,10 +986,12 @@ __global__ __launch_bounds__(256) void conv1_bn_act_pool_bwd_kernel(
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ mean_rstd, const float* __restrict__ drop, const float* __restrict__ dy,
     const int32_t* __restrict__ arg, double* __restrict__ out) {
-    __shared__ float patch[17][50];
+    __shared__ float patches[4][17][50];
     __shared__ float ws[16 * 9 + 16 + 32];
     __shared__ double red[16 * 11];
-    const int tid = threadIdx.x, ch = 4 * (tid & 3);        // items stride by 256: a thread always meets the same four channels
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ch = 4 * (tid & 3);                            // items stride by 64: a lane always meets the same four channels
+    float (*patch)[50] = patches[wave];
     if (tid < 144) ws[tid] = w[tid];
     else if (tid < 160) ws[tid] = bias[tid - 144];
     else if (tid < 176) {
@@ -998,14 +1006,15 @@ __global__ __launch_bounds__(256) void conv1_bn_act_pool_bwd_kernel(
     for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int q = 0; q < 11; ++q) a[e][q] = 0.0;
-    for (int s = blockIdx.x; s < n_segments; s += gridDim.x) {
+    __syncthreads();                                        // ws
+    for (int s = blockIdx.x * 4 + wave; s < n_segments; s += gridDim.x * 4) {     // a wave per segment, no workgroup barrier
         const int b = find_segment(seg_off, n_clips, s);
-        __syncthreads();
-        stage_patch(patch, mel_tm + (int64_t)(frame_off[b] + (s - seg_off[b]) * seg_hop) * 48, clip_floor[b], tid);
-        __syncthreads();
+        C1_WSYNC();
+        stage_patch<64>(patch, mel_tm + (int64_t)(frame_off[b] + (s - seg_off[b]) * seg_hop) * 48, clip_floor[b], lane);
+        C1_WSYNC();
         f32x4 dr = {1.f, 1.f, 1.f, 1.f};
         if (drop) dr = *(const f32x4*)(drop + (int64_t)s * 16 + ch);
-        for (int i = tid; i < 168 * 4; i += 256) {
+        for (int i = lane; i < 168 * 4; i += 64) {
             const int64_t at = ((int64_t)s * 168 + (i >> 2)) * 16 + ch;
             const f32x4 g = *(const f32x4*)(dy + at) * dr;
             const i32x4 ap = *(const i32x4*)(arg + at);
@@ -1064,7 +1073,7 @@ extern "C" int nisqa_conv1_moments(const float* mel_tm, const int32_t* frame_off
                                    int32_t n_clips, int32_t n_segments, int32_t seg_hop, double* mom54, void* stream) {
     if (!mel_tm || !frame_off || !seg_off || !clip_floor || !mom54 || n_clips <= 0 || n_segments <= 0 || seg_hop <= 0) return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(conv1_moments_kernel, dim3(n_segments < 1024 ? n_segments : 1024), dim3(256), 0, (hipStream_t)stream, mel_tm,
+    hipLaunchKernelGGL(conv1_moments_kernel, dim3((n_segments + 3) / 4 < 512 ? (n_segments + 3) / 4 : 512), dim3(256), 0, (hipStream_t)stream, mel_tm,
                        frame_off, seg_off, clip_floor, n_clips, n_segments, seg_hop, mom54);
     return NQ_LAUNCH_STATUS();
 }
@@ -1097,7 +1106,7 @@ extern "C" int nisqa_conv1_bn_act_pool_bwd(const float* mel_tm, const int32_t* f
         return NISQA_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(conv1_bn_act_pool_bwd_kernel, dim3(n_segments < 1024 ? n_segments : 1024), dim3(256), 0, st, mel_tm, frame_off,
+    hipLaunchKernelGGL(conv1_bn_act_pool_bwd_kernel, dim3((n_segments + 3) / 4 < 512 ? (n_segments + 3) / 4 : 512), dim3(256), 0, st, mel_tm, frame_off,
                        seg_off, clip_floor, n_clips, n_segments, seg_hop, w, bias, gamma, beta, mean_rstd, drop, dy, arg, acc176);
     hipLaunchKernelGGL(conv1_bwd_finalize_kernel, dim3(1), dim3(144), 0, st, (const double*)acc176, mom54, w, bias, gamma, mean_rstd,
                        (int64_t)n_segments * 720, dgamma, dbeta, dw);
@@ -1566,8 +1575,10 @@ extern "C" int nisqa_bn_act_pool_bwd(const float* dy, const int32_t* arg, const 
     const int64_t cells = (int64_t)n_segments * ho * wo * c / 4, total = (int64_t)n_segments * h * w * c / 4;
     hipStream_t st = (hipStream_t)stream;
     NQ_LAUNCH_BEGIN();
-    const int g1 = grid_for(cells) < 2048 ? grid_for(cells) : 2048;
-    NQ_POOL_DISPATCH(pool_bwd_sums_kernel, dim3(g1), st, dy, arg, drop, z, mean_rstd, gamma, beta, cells, h, w, c, ho, wo, sums2);
+    // the sums kernel ends in 2c float64 atomics per block on the same addresses: blocks of >= 2048 items, at most 1024 of them
+    int64_t g1 = (cells + 2047) / 2048;
+    g1 = g1 < 1 ? 1 : (g1 > 1024 ? 1024 : g1);
+    NQ_POOL_DISPATCH(pool_bwd_sums_kernel, dim3((unsigned)g1), st, dy, arg, drop, z, mean_rstd, gamma, beta, cells, h, w, c, ho, wo, sums2);
     NQ_POOL_DISPATCH(bn_act_pool_bwd_dense_kernel, dim3(grid_for(total)), st, dy, arg, drop, z, mean_rstd, gamma, beta,
                      (const double*)sums2, total, h, w, c, ho, wo, dz, dgamma, dbeta);
     return NQ_LAUNCH_STATUS();
