@@ -1496,8 +1496,9 @@ __global__ __launch_bounds__(256) void pool_bwd_sums_kernel(
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float zv = zw[e];
-            if (zv * g[e] + bsh[e] > 0.f) {                 // ReLU gate at the winning pixel
+            float zv = zw[e];
+            asm volatile("" : "+v"(zv));                    // keep the four gates scalar: packed, hipcc emits the op_sel form of DESIGN.md 7.1
+            if (fmaf(zv, g[e], bsh[e]) > 0.f) {             // ReLU gate at the winning pixel
                 a1[e] += (double)d[e];
                 a2[e] += (double)d[e] * (double)zv;
             }
