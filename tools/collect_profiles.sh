@@ -22,12 +22,16 @@ for P in bf16x3 f32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$P -o ks -- python bench.py --no-cpu-baseline --no-extras --precision $P > /tmp/ks_$P.log 2>&1
   cp /tmp/ks_$P/ks_kernel_stats.csv $O/${R}_bench_${P}_kernel_stats.csv
 done
-python tools/bench_train.py 32 20 2>/dev/null | tail -1 > $O/${R}_train_bench.json
+for P in f32 mixed bf16x3; do NISQA_HIP_TRAIN_PRECISION=$P python tools/bench_train.py 32 20 2>/dev/null | tail -1; done > $O/${R}_train_bench.json
 rm -rf /tmp/ks_train
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_train -o ks -- python tools/bench_train.py 32 5 > /tmp/ks_train.log 2>&1
 cp /tmp/ks_train/ks_kernel_stats.csv $O/${R}_train_kernel_stats.csv
 python tools/bench_extra.py 2>/dev/null | tail -1 > $O/${R}_side_tts_pcie.json
-python tools/bench_ingest.py 1024 8,32 2>/dev/null | tail -1 > $O/${R}_side_ingest.json
-timeout 600 python bench.py --workload predict_csv --clips 20000 --bs 256 --distinct 256 2>/dev/null | tail -1 > $O/${R}_bench_predict_csv_1gpu.json
+python tools/bench_ingest.py 2048 12 2>/dev/null | tail -1 > $O/${R}_side_ingest.json
+timeout 600 python bench.py --workload predict_csv --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_predict_csv_1gpu.json
+timeout 600 python bench.py --workload predict_csv --no-cpu-baseline --bs 64 2>/dev/null | tail -1 > $O/${R}_bench_predict_csv_1gpu_bs64.json
+REPS=4 python tools/probe_loop.py 8192 256 32 2>&1 | grep "^rep" > $O/${R}_probe_loop.txt
+python tools/probe_overlap.py 2>&1 | grep -v "amdgpu.ids\|Warn" > $O/${R}_probe_overlap.txt
+for k in 0 1 32; do echo "== NQ_KO=$k"; [ -f ab_libs/clk_ko$k.so ] && NISQA_BENCH_KO=1 NISQA_HIP_LIB=$PWD/ab_libs/clk_ko$k.so python tools/phase_clock.py 2>&1 | grep -v "Warn\|amdgpu.ids"; done > $O/${R}_cnn_phase_clock_ko.txt
 python tools/probe_concurrency.py 2>/dev/null | grep -v amdgpu.ids > $O/${R}_probe_concurrency.txt
 ls -la $O
