@@ -91,3 +91,9 @@ NQ_DEV void stagger_odd_wave_slot(int first_round_blocks, int sleeps) {
 // hipPointerGetAttributes on pageable host memory).  Clear it before our launches, read it after.
 #define NQ_LAUNCH_BEGIN() (void)hipGetLastError()
 #define NQ_LAUNCH_STATUS() (hipGetLastError() == hipSuccess ? 0 : 2)
+// Workgroup i runs on XCD i % 8 (round-robin dispatch) and each XCD has its own L2.  Consecutive work items share data (the
+// token tiles of ONE clip all stream that clip's K / V; neighbouring segment groups read overlapping spectrogram frames), so
+// they are given to ONE XCD: item = (i % 8) * (n / 8) + i / 8.  With the identity mapping every XCD pulls every clip's K / V
+// (8.4 MB through a 4 MB L2: 87 MB of HBM reads per self-attention launch).  Needs n % 8 == 0; otherwise identity.
+NQ_DEV int xcd_tile(int i, int n_tiles) { return (n_tiles & 7) ? i : (i & 7) * (n_tiles >> 3) + (i >> 3); }
+

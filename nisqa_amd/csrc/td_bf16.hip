@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64) void td_proj_bf16_kernel(const float* __restric
                                                           const float* __restrict__ tw, const u16* __restrict__ twb,
                                                           float* __restrict__ x, float* __restrict__ qkv) {
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
-    const int tile0 = blockIdx.x * 32;
+    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * 32;
     const int b = find_segment_wave(tok_off, n_clips, tile0, lane);
     const int n = n_wins[b], k0 = tile0 - tok_off[b];
     if (k0 >= n) return;
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(64) void td_layer_bf16_kernel(const int32_t* __rest
                                                            const u16* __restrict__ lwb_next, const float* x_in, float* qkv_cur,
                                                            float* x_out, float* qkv_next) {
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
-    const int tile0 = blockIdx.x * 32;
+    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * 32;
     const int b = find_segment_wave(tok_off, n_clips, tile0, lane);
     const int n = n_wins[b], c0 = tok_off[b];
     if (tile0 - c0 >= n) return;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64) void pool_score_bf16_kernel(const float* __rest
                                                              const float* __restrict__ pw, const u16* __restrict__ pwb,
                                                              float* __restrict__ sc, float* __restrict__ yv) {
     const int lane = threadIdx.x, j = lane & 31, h = lane >> 5;
-    const int tile0 = blockIdx.x * 32;
+    const int tile0 = xcd_tile(blockIdx.x, gridDim.x) * 32;
     const int b = find_segment_wave(tok_off, n_clips, tile0, lane);
     if (tile0 - tok_off[b] >= n_wins[b]) return;
     const int tok = tile0 + j;
