@@ -760,3 +760,38 @@ def test_frame_to_string_equals_pandas_to_string():
     for df in odd:
         assert _fast_frame_lines(df) is None
         assert frame_to_string(df) == df.to_string(index=False)
+
+
+def test_ingest_cpu_budget_reader_cap_ring_reuse_and_path_cache(tmp_path, monkeypatch):
+    """Host details of the predict loop: the reader count respects the cgroup CPU quota, page-locked rings
+    are handed from one loop to the next, file names come out of the DataFrame once and travel with the staged groups."""
+    import pandas as pd
+    from nisqa_amd import ingest
+    from nisqa_amd.NISQA_lib import SpeechQualityDataset
+    n = ingest.cpu_budget()
+    assert isinstance(n, int) and 1 <= n <= (os.cpu_count() or 1)
+    paths = []
+    for i in range(6):
+        p = str(tmp_path / ('q%d.wav' % i))
+        synth.write_wav(p, (np.arange(300 + i) % 97).astype(np.int16), 48000)
+        paths.append(os.path.basename(p))
+    df = pd.DataFrame({'deg': paths})
+    ds = SpeechQualityDataset(df, data_dir=str(tmp_path), filename_column='deg', mos_column='predict_only', dim=True)
+    assert ds.file_paths([0, 3, 5]) == [ds.file_path(i) for i in (0, 3, 5)]
+    ds.df = df.iloc[::-1].reset_index(drop=True)                     # a new frame invalidates the cached column
+    assert ds.file_paths([0]) == [ds.file_path(0)] == [os.path.join(str(tmp_path), paths[-1])]
+    monkeypatch.setattr(ingest, 'cpu_budget', lambda: 6)
+    ing = ingest.Ingest(ds, [[0, 1, 2], [3, 4, 5]], pin=False, num_workers=64)
+    assert ing.workers == 3                                          # budget - 3 (producer, consumer, the interpreter)
+    ring = ing.ring
+    for staged in ing:
+        assert [g.names for g in staged.groups] == [ds.file_paths(g.ids) for g in staged.groups]
+        ing.ring.release_after(staged.slot, None)
+    ing.close()
+    ing.close()                                                      # idempotent
+    assert ing.stats['batches'] == 2 and ing.stats['read'] > 0
+    ing2 = ingest.Ingest(ds, [[0, 1]], pin=False, num_workers=1)     # the next loop takes over the finished loop's ring
+    assert ing2.ring is ring
+    for staged in ing2:
+        ing2.ring.release_after(staged.slot, None)
+    ing2.close()
