@@ -110,6 +110,14 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const int k0 = p0 - tok_off[b];
     const int nvalid = min(4, n_wins[b] - k0);
     if (nvalid <= 0) return;                             // whole workgroup is padding
+#ifdef NQ_STAGGER
+    // experiment: the two workgroups of a CU start in step and stay in step (same work, same duration): both waves of a SIMD
+    // are in their MFMA-free phases at the same time.  Delay the first-round workgroups that sit in the odd wave slot.
+    if (blockIdx.x < NQ_STAGGER_WGS && (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1)) {
+        const long long t0 = clock64();
+        while (clock64() - t0 < NQ_STAGGER) __builtin_amdgcn_s_sleep(64);
+    }
+#endif
     const bool valid = wave < nvalid;                    // padding waves still walk the barriers (on zeros)
     const int p = p0 + wave, k = k0 + wave;
     const unsigned R = FB_BASE + wave * FB_WAVE;         // this wave's LDS region
