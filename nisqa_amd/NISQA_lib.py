@@ -354,7 +354,7 @@ def _predict(model, ds, bs, dev, num_workers):
     # do not overlap at all, tools/probe_overlap.py: 7.5 ms per 256-clip batch against 4.5), two streams take the
     # kernels of alternate batches behind an event, a staging slot is recycled as soon as ITS copy is done, and the D2H
     # of batch i's [B, heads] rows is waited for one batch late (no device-wide sync in the loop)
-    ing = _ingest.Ingest(ds, batches, pin=on_gpu, num_workers=num_workers)
+    ing = _ingest.Ingest(ds, batches, pin=on_gpu, num_workers=num_workers, device=eng.device if on_gpu else None)
     copy_stream, streams = _loop_streams(eng.device) if on_gpu else (None, [None, None])
     inflight = []                                                   # (ids, host rows, event behind them)
 

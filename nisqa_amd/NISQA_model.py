@@ -316,13 +316,16 @@ class nisqaModel(object):
 
     def _getDevice(self):
         """reference NISQA_model.py:1032-1051 (one GPU per process: LOCAL_RANK picks it under torchrun)"""
+        def gpu():
+            # more ranks than visible GPUs (a one-GPU box under torchrun with the gloo backend): ranks share devices
+            return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) % max(1, torch.cuda.device_count()))
         if torch.cuda.is_available():
-            self.dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+            self.dev = gpu()
         else:
             self.dev = torch.device('cpu')
         if 'tr_device' in self.args:
             if self.args['tr_device'] == 'cpu':
                 self.dev = torch.device('cpu')
             elif self.args['tr_device'] == 'cuda':
-                self.dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+                self.dev = gpu()
         print('Device: {}'.format(self.dev))
