@@ -160,6 +160,10 @@ NQ_DEV void lds_st32(unsigned a, unsigned v) { *(NQ_AS3 unsigned*)(a) = v; }
 NQ_DEV void lds_st128(unsigned a, f32x4 v) { *(NQ_AS3 f32x4*)(a) = v; }
 // v = hi + lo into the two bf16 planes (lo plane `plane` bytes behind the hi plane)
 NQ_DEV void lds_store_split(unsigned a, int plane, float v) {
+#ifdef NQ_KO
+    if (NQ_KO & 64) { if (__float_as_uint(v) == 0x7fc12345u) lds_st16(a, 0); return; }      // no split arithmetic, no stores
+    if (NQ_KO & 128) { lds_st16(a, cvt_pk_bf16(v, 0.f)); return; }                          // hi plane only: half the stores
+#endif
     const unsigned hi = cvt_pk_bf16(v, 0.f);
     const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
 #ifdef NQ_KO
@@ -170,7 +174,8 @@ NQ_DEV void lds_store_split(unsigned a, int plane, float v) {
 }
 typedef int nq_i32x4 __attribute__((ext_vector_type(4)));
 // NQ_KO: knock-out bits for timing experiments (results are WRONG): 32 weight fragments read from LDS instead, 1 no weight loads, 2 no A-operand LDS reads,
-// 4 no epilogue LDS stores, 8 no MFMAs, 16 no workgroup barriers
+// 4 no epilogue LDS stores, 8 no MFMAs, 16 no workgroup barriers, 64 no hi/lo split and no plane stores, 128 hi plane only.
+// Builds that replace operands by constants run at a HIGHER shader clock: compare cycles (tools/phase_clock.py), not ms
 #ifndef NQ_KO
 #define NQ_KO 0
 #endif
