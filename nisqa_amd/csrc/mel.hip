@@ -97,7 +97,9 @@ __device__ constexpr float W16S[16] = {-0.000000000e+00f, -3.826834324e-01f, -7.
 #else
 #define MEL_WBAR() __builtin_amdgcn_wave_barrier()
 #endif
-#define MEL_WAVES 4
+// waves per workgroup: the 48 kHz-class instantiation (NQ = 1) fits 168 registers and 9.3 KB of LDS per wave -> ONE workgroup of
+// twelve waves per CU = three per SIMD (the kernel is short of resident waves); longer windows keep four
+#define MEL_WAVES_OF(NQ) ((NQ) == 1 ? 12 : 4)
 // -DNQ_MEL_CLOCK (tools/ab_build.sh melclk mel -DNQ_MEL_CLOCK; tools/mel_clock.py): shader-clock stamps at the phase
 // boundaries of a frame, summed over all frames
 #ifdef NQ_MEL_CLOCK
@@ -135,15 +137,14 @@ NQ_DEV float xmag(c32 za, c32 zb, c32 wl, c32 wc) {
 }
 
 struct mel_twiddles {
-    c32 a[4];   // W2048^(r l), r = 1..3 (a[0] unused)
     c32 b[8];   // W512^(l p)
     c32 c[8];   // W64^((l&7) q1)
-    c32 d[4];   // W4096^(4 l + r)
 };
 
 // 512-point FFT of u[a] = z[l + 64 a] * W2048^(r (l + 64 a)); returns Z_r[l + 64 q2] in u[q2]
 template <int R>
-NQ_DEV void fft512(c32 (&u)[8], const c32 (&z)[8], const mel_twiddles& tw, char* exch, int lane) {
+NQ_DEV void fft512(c32 (&u)[8], const c32 (&z)[8], const mel_twiddles& tw, char* exch, int lane, const c32* tab_a) {
+    const c32 aR = R ? tab_a[(R - 1) * 64 + lane] : cmk(1.f, 0.f);
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
         if (R == 0 || a == 0) u[a] = z[a];
@@ -153,7 +154,7 @@ NQ_DEV void fft512(c32 (&u)[8], const c32 (&z)[8], const mel_twiddles& tw, char*
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
         if (p != 0) u[p] = cmul(u[p], tw.b[p]);               // W512^(l p)
-        if (R != 0) u[p] = cmul(u[p], tw.a[R]);               // W2048^(R l): per-lane part of the pre-twiddle
+        if (R != 0) u[p] = cmul(u[p], aR);                    // W2048^(R l): per-lane part of the pre-twiddle
     }
     c32* b1 = (c32*)exch;
 #pragma unroll
@@ -184,7 +185,7 @@ NQ_DEV void fft512(c32 (&u)[8], const c32 (&z)[8], const mel_twiddles& tw, char*
 // T = float (samples as lb.load returns them) or int16_t (PCM16 as it sits in the file: the x / 32768 of soundfile is
 // folded into the window taps -- a power of two, so both instantiations produce the same bits)
 template <int NQ, typename T>
-__global__ __launch_bounds__(64 * MEL_WAVES, NQ >= 4 ? 1 : 2) void mel_frame_kernel(
+__global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_frame_kernel(
     const T* __restrict__ pcm, const int64_t* __restrict__ clip_off,
     const int32_t* __restrict__ frame_off, int n_clips, int total_frames, int frames_per_wave,
     nisqa_mel_cfg cfg, int mag_stride, int w_floats,
@@ -193,53 +194,46 @@ __global__ __launch_bounds__(64 * MEL_WAVES, NQ >= 4 ? 1 : 2) void mel_frame_ker
     const int32_t* __restrict__ band_woff, const float* __restrict__ band_w,
     float* __restrict__ mel_tm, uint32_t* __restrict__ clip_max_enc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MEL_WAVES = MEL_WAVES_OF(NQ);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* wlds = (float*)smem;                                   // shared sparse filterbank weights
     const int w_bytes = (w_floats * 4 + 15) & ~15;
-    const int per_wave = MEL_EXCH_BYTES + mag_stride * 16 + 512;   // exchange + 4 magnitude planes + slack
-    char* exch = smem + w_bytes + wave * per_wave;
-    float* mag = (float*)(exch + MEL_EXCH_BYTES);                 // |X[K]| at (K&3)*mag_stride + (K>>2)
+    // per wave: the four magnitude planes in the order r = 0, 2, 1, 3, then what the FFT exchange (5120 B) needs beyond planes
+    // 1 and 3, which it OVERLAYS (their magnitudes are written after the last transform of a frame), then slack
+    const int exch_extra = max(0, MEL_EXCH_BYTES - 8 * mag_stride);
+    const int per_wave = mag_stride * 16 + exch_extra + 512;
+    float* tab_w = (float*)(smem + w_bytes);                      // window taps (pre-scaled), 1024 floats
+    c32* tab_d = (c32*)(smem + w_bytes + 4096);                   // W4096^(4 l + r), [4][64]
+    c32* tab_a = (c32*)(smem + w_bytes + 4096 + 2048);            // W2048^(r l), r = 1..3, [3][64]
+    int* tab_band = (int*)(smem + w_bytes + 4096 + 2048 + 1536);  // (band_start, band_woff) of the 48 bands
+    float* mag = (float*)(smem + w_bytes + 8064 + wave * per_wave);   // |X[K]| at plane(K&3)*mag_stride + (K>>2), plane(r) = 0, 2, 1, 3
+    char* exch = (char*)(mag + 2 * mag_stride);                   // = planes 1, 3 (+ extra)
     // the 1/2 of |X[K]| = |2 X[K]| / 2 rides on the band weights (a power of two: same bits), not on every bin
     for (int i = tid; i < w_floats; i += 64 * MEL_WAVES) wlds[i] = 0.5f * band_w[i];
-    for (int i = lane; i < 4 * mag_stride + 128; i += 64) mag[i] = 0.f;       // planes + slack start finite
+    for (int i = lane; i < per_wave / 4; i += 64) mag[i] = 0.f;              // planes + slack start finite
+    {
+        const float sc_ = sizeof(T) == 2 ? 1.0f / 32768.0f : 1.0f;
+        for (int i = tid; i < 1024; i += 64 * MEL_WAVES) tab_w[i] = (NQ == 1 && i < cfg.win) ? window[i] * sc_ : 0.f;
+        for (int i = tid; i < 256; i += 64 * MEL_WAVES) { const float2 w = twg[4 * (i & 63) + (i >> 6)]; tab_d[i] = cmk(w.x, w.y); }
+        for (int i = tid; i < 192; i += 64 * MEL_WAVES) { const float2 w = twg[(2 * (i / 64 + 1) * (i & 63)) & 4095]; tab_a[i] = cmk(w.x, w.y); }
+        for (int i = tid; i < 48; i += 64 * MEL_WAVES) { tab_band[2 * i] = band_start[i]; tab_band[2 * i + 1] = band_woff[i]; }
+    }
     __syncthreads();
 
     // ---- per-lane constants, loaded once per wave
     mel_twiddles tw;
 #pragma unroll
-    for (int r = 1; r < 4; ++r) { const float2 w = twg[(2 * r * lane) & 4095]; tw.a[r] = cmk(w.x, w.y); }
-    tw.a[0] = cmk(1.f, 0.f);
-#pragma unroll
     for (int p = 0; p < 8; ++p) { const float2 w = twg[(8 * lane * p) & 4095]; tw.b[p] = cmk(w.x, w.y); }
 #pragma unroll
     for (int q = 0; q < 8; ++q) { const float2 w = twg[(64 * (lane & 7) * q) & 4095]; tw.c[q] = cmk(w.x, w.y); }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { const float2 w = twg[4 * lane + r]; tw.d[r] = cmk(w.x, w.y); }
     constexpr bool PCM16 = sizeof(T) == 2;
     const float scale = PCM16 ? 1.0f / 32768.0f : 1.0f;
-    float win[8][2];                                              // NQ == 1: window taps live in registers
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int m = 2 * (lane + 64 * a) + e;
-            win[a][e] = (NQ == 1 && m < cfg.win) ? window[m] * scale : 0.f;
-        }
     // band tables of this lane's DPP row: pass ps handles band 4*ps + row
     const int row = lane >> 4, l16 = lane & 15;
     // per pass: this lane's first magnitude index (plane (K&3), entry K>>2; K advances by 16 = 4 entries per
     // iteration, so the plane never changes) and first weight index.  Reads past a band's support meet zero
     // weights; they stay inside the wave's magnitude planes + 128 floats of slack that are kept finite.
-    int bmi[12], bwo[12];
-#pragma unroll
-    for (int ps = 0; ps < 12; ++ps) {
-        const int bnd = 4 * ps + row;
-        const int K0 = band_start[bnd] + l16;
-        bmi[ps] = (K0 & 3) * mag_stride + (K0 >> 2);
-        bwo[ps] = band_woff[bnd] + l16;
-    }
-
     const int f_begin = (blockIdx.x * MEL_WAVES + wave) * frames_per_wave;
     const int f_end = min(f_begin + frames_per_wave, total_frames);
     if (f_begin >= f_end) return;
@@ -294,7 +288,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, NQ >= 4 ? 1 : 2) void mel_frame_ker
             while (fn >= frame_off[bn + 1]) ++bn;
         if (NQ == 1) {
 #pragma unroll
-            for (int a = 0; a < 8; ++a) zq[0][a] = cmk(raw[a][0] * win[a][0], raw[a][1] * win[a][1]);
+            for (int a = 0; a < 8; ++a) { const c32 wv = *(const c32*)(tab_w + 2 * (lane + 64 * a)); zq[0][a] = cmk(raw[a][0] * wv.x, raw[a][1] * wv.y); }
             if (fn < f_end) load_frame(fn, bn, 0, raw);          // prefetch the next frame (clip may change)
         } else {
 #pragma unroll
@@ -329,7 +323,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, NQ >= 4 ? 1 : 2) void mel_frame_ker
         MEL_CLK(0);                                   // window + prefetch
         // r = 0: partner Z_0[512 - k] = lane (64 - l) & 63, register 7 - q2 (lane 0: register (8 - q2) & 7)
         fold(0, z);
-        fft512<0>(u, z, tw, exch, lane);
+        fft512<0>(u, z, tw, exch, lane, tab_a);
         {
             const int src = (64 - lane) & 63;
 #pragma unroll
@@ -337,7 +331,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES, NQ >= 4 ? 1 : 2) void mel_frame_ker
                 c32 zb = shfl_c(u[7 - q2], src);
                 if (lane == 0) zb = u[(8 - q2) & 7];
                 if (lane + 64 * q2 < mag_stride)
-                    mag[0 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tw.d[0], cmk(W16C[q2], W16S[q2]));
+                    mag[0 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tab_d[0 * 64 + lane], cmk(W16C[q2], W16S[q2]));
             }
             if (lane == 0 && 512 < mag_stride) mag[512] = 2.0f * fabsf(u[0].x - u[0].y);   // Nyquist bin: 2 X[2048] = 2 (Re Z0 - Im Z0)
 
@@ -345,27 +339,27 @@ __global__ __launch_bounds__(64 * MEL_WAVES, NQ >= 4 ? 1 : 2) void mel_frame_ker
         MEL_CLK(1);                                   // FFT r = 0 + magnitudes
         // r = 2: partner Z_2[511 - k] = lane 63 - l, register 7 - q2
         fold(2, z);
-        fft512<2>(u, z, tw, exch, lane);
+        fft512<2>(u, z, tw, exch, lane, tab_a);
 #pragma unroll
         for (int q2 = 0; q2 < 8; ++q2) {
             const c32 zb = shfl_c(u[7 - q2], mir);
             if (lane + 64 * q2 < mag_stride)
-                mag[2 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tw.d[2], cmk(W16C[q2], W16S[q2]));
+                mag[1 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tab_d[2 * 64 + lane], cmk(W16C[q2], W16S[q2]));
         }
         MEL_CLK(2);                                   // FFT r = 2 + magnitudes
         // r = 1 and r = 3 are each other's partners
         fold(1, z);
-        fft512<1>(u1, z, tw, exch, lane);
+        fft512<1>(u1, z, tw, exch, lane, tab_a);
         fold(3, z);
-        fft512<3>(u, z, tw, exch, lane);
+        fft512<3>(u, z, tw, exch, lane, tab_a);
         MEL_CLK(3);                                   // FFTs r = 1, 3
 #pragma unroll
         for (int q2 = 0; q2 < 8; ++q2) {
             const c32 z3m = shfl_c(u[7 - q2], mir), z1m = shfl_c(u1[7 - q2], mir);
             const c32 w16 = cmk(W16C[q2], W16S[q2]);
             if (lane + 64 * q2 < mag_stride) {
-                mag[1 * mag_stride + lane + 64 * q2] = xmag(u1[q2], z3m, tw.d[1], w16);
-                mag[3 * mag_stride + lane + 64 * q2] = xmag(u[q2], z1m, tw.d[3], w16);
+                mag[2 * mag_stride + lane + 64 * q2] = xmag(u1[q2], z3m, tab_d[1 * 64 + lane], w16);
+                mag[3 * mag_stride + lane + 64 * q2] = xmag(u[q2], z1m, tab_d[3 * 64 + lane], w16);
             }
         }
         MEL_WBAR();
@@ -378,8 +372,9 @@ __global__ __launch_bounds__(64 * MEL_WAVES, NQ >= 4 ? 1 : 2) void mel_frame_ker
             // padded length is the same for the 4 bands of a pass (zero weights beyond a band's support)
             const int nit = __builtin_amdgcn_readfirstlane(band_len[4 * ps]) >> 4;
             float part = 0.f;
-            const float* wp = wlds + bwo[ps];
-            const float* mp = mag + bmi[ps];
+            const int K0_ = tab_band[2 * (4 * ps + row)] + l16;
+            const float* wp = wlds + tab_band[2 * (4 * ps + row) + 1] + l16;
+            const float* mp = mag + (((K0_ & 1) << 1) | ((K0_ >> 1) & 1)) * mag_stride + (K0_ >> 2);   // plane order 0, 2, 1, 3
 #pragma unroll 4
             for (int it = 0; it < nit; ++it) part = fmaf(wp[16 * it], mp[4 * it], part);
             part = row16_sum(part);
@@ -450,17 +445,21 @@ static int mel_db_launch(const T* pcm, const int64_t* clip_off, const int32_t* f
     int mag_stride = (cfg->n_bins + 3) / 4;
     mag_stride += (8 - (mag_stride & 31) + 32) & 31;
     const int w_bytes = (w_floats * 4 + 15) & ~15;
-    const size_t lds = (size_t)w_bytes + MEL_WAVES * (MEL_EXCH_BYTES + mag_stride * 16 + 512);
-    // frames a wave walks over: more frames amortise its per-lane twiddle / window / band-table loads, but the chip
-    // holds 2048 waves of this kernel (8 per CU): enough frames per wave to cover the batch in one round, 4 to 32
+    const int nq = cfg->win <= 1024 ? 1 : (cfg->win <= 2048 ? 2 : 4);
+    const int waves = MEL_WAVES_OF(nq);
+    const int exch_extra = MEL_EXCH_BYTES - 8 * mag_stride > 0 ? MEL_EXCH_BYTES - 8 * mag_stride : 0;
+    const size_t lds = (size_t)w_bytes + 8064 + waves * (mag_stride * 16 + exch_extra + 512);
+    // frames a wave walks over: more frames amortise its per-lane twiddle loads and the workgroup's table fills, but the
+    // chip holds 256 x (12, 8 or 4) waves of this kernel: enough frames per wave to cover the batch in one round, 4 to 32
     static const int fpw_env = [] {
         const char* e = getenv("NISQA_MEL_FPW");
         return e && atoi(e) > 0 ? atoi(e) : 0;
     }();
-    int frames_per_wave = fpw_env ? fpw_env : (total_frames + 2047) / 2048;
+    const int resident = 256 * (nq == 1 ? 12 : (nq == 2 ? 8 : 4));
+    int frames_per_wave = fpw_env ? fpw_env : (total_frames + resident - 1) / resident;
     if (!fpw_env) frames_per_wave = frames_per_wave < 4 ? 4 : (frames_per_wave > 32 ? 32 : frames_per_wave);
-    const int per_wg = MEL_WAVES * frames_per_wave;
-    const dim3 grid((total_frames + per_wg - 1) / per_wg), block(64 * MEL_WAVES);
+    const int per_wg = waves * frames_per_wave;
+    const dim3 grid((total_frames + per_wg - 1) / per_wg), block(64 * waves);
     auto go = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, pcm, clip_off, frame_off, n_clips, total_frames,
                            frames_per_wave, *cfg, mag_stride, w_floats, window, (const float2*)twiddle, band_start,
