@@ -456,8 +456,14 @@ static int mel_db_launch(const T* pcm, const int64_t* clip_off, const int32_t* f
         return e && atoi(e) > 0 ? atoi(e) : 0;
     }();
     const int resident = 256 * (nq == 1 ? 12 : (nq == 2 ? 8 : 4));
-    int frames_per_wave = fpw_env ? fpw_env : (total_frames + resident - 1) / resident;
-    if (!fpw_env) frames_per_wave = frames_per_wave < 4 ? 4 : (frames_per_wave > 32 ? 32 : frames_per_wave);
+    // whole rounds of the resident waves: a batch that needs 1.3 rounds at 32 frames per wave takes as long as two
+    // (measured: 64 x 10 s at 16 frames per wave = 1.3 rounds: 0.41 ms against 0.28 at 21 = one round)
+    int frames_per_wave = fpw_env;
+    if (!fpw_env) {
+        const int64_t rounds = ((int64_t)total_frames + (int64_t)resident * 32 - 1) / ((int64_t)resident * 32);
+        frames_per_wave = (int)(((int64_t)total_frames + resident * rounds - 1) / (resident * rounds));
+        frames_per_wave = frames_per_wave < 4 ? 4 : (frames_per_wave > 32 ? 32 : frames_per_wave);
+    }
     const int per_wg = waves * frames_per_wave;
     const dim3 grid((total_frames + per_wg - 1) / per_wg), block(64 * waves);
     auto go = [&](auto kernel) {
