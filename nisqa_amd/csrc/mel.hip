@@ -113,6 +113,7 @@ extern "C" int nisqa_debug_mel_clock(unsigned long long* out16, int reset) {
 #else
 #define MEL_CLK(i)
 #endif
+#define MEL_TAB_BYTES (4096 + 2048 + 1536 + 6144)   /* window taps, W4096 / W2048 twiddles, per-(pass, lane) filter-bank offsets */
 #define MEL_EXCH_BYTES 5120            /* exchange 1 [8][72] complex (4608 B) and exchange 2 64 x 80 B alias */
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
@@ -206,8 +207,8 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
     float* tab_w = (float*)(smem + w_bytes);                      // window taps (pre-scaled), 1024 floats
     c32* tab_d = (c32*)(smem + w_bytes + 4096);                   // W4096^(4 l + r), [4][64]
     c32* tab_a = (c32*)(smem + w_bytes + 4096 + 2048);            // W2048^(r l), r = 1..3, [3][64]
-    int* tab_band = (int*)(smem + w_bytes + 4096 + 2048 + 1536);  // (band_start, band_woff) of the 48 bands
-    float* mag = (float*)(smem + w_bytes + 8064 + wave * per_wave);   // |X[K]| at plane(K&3)*mag_stride + (K>>2), plane(r) = 0, 2, 1, 3
+    int* tab_band = (int*)(smem + w_bytes + 4096 + 2048 + 1536);  // per (pass, lane): byte offsets of the first magnitude and the first weight
+    float* mag = (float*)(smem + w_bytes + MEL_TAB_BYTES + wave * per_wave);   // |X[K]| at plane(K&3)*mag_stride + (K>>2), plane(r) = 0, 2, 1, 3
     char* exch = (char*)(mag + 2 * mag_stride);                   // = planes 1, 3 (+ extra)
     // the 1/2 of |X[K]| = |2 X[K]| / 2 rides on the band weights (a power of two: same bits), not on every bin
     for (int i = tid; i < w_floats; i += 64 * MEL_WAVES) wlds[i] = 0.5f * band_w[i];
@@ -217,7 +218,11 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
         for (int i = tid; i < 1024; i += 64 * MEL_WAVES) tab_w[i] = (NQ == 1 && i < cfg.win) ? window[i] * sc_ : 0.f;
         for (int i = tid; i < 256; i += 64 * MEL_WAVES) { const float2 w = twg[4 * (i & 63) + (i >> 6)]; tab_d[i] = cmk(w.x, w.y); }
         for (int i = tid; i < 192; i += 64 * MEL_WAVES) { const float2 w = twg[(2 * (i / 64 + 1) * (i & 63)) & 4095]; tab_a[i] = cmk(w.x, w.y); }
-        for (int i = tid; i < 48; i += 64 * MEL_WAVES) { tab_band[2 * i] = band_start[i]; tab_band[2 * i + 1] = band_woff[i]; }
+        for (int i = tid; i < 12 * 64; i += 64 * MEL_WAVES) {           // pass ps, lane l: band 4 ps + (l >> 4), first bin K0 + (l & 15)
+            const int bnd = 4 * (i >> 6) + ((i & 63) >> 4), K0_ = band_start[bnd] + (i & 15);
+            tab_band[2 * i] = 4 * ((((K0_ & 1) << 1) | ((K0_ >> 1) & 1)) * mag_stride + (K0_ >> 2));   // plane order 0, 2, 1, 3
+            tab_band[2 * i + 1] = 4 * (band_woff[bnd] + (i & 15));
+        }
     }
     __syncthreads();
 
@@ -372,9 +377,9 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
             // padded length is the same for the 4 bands of a pass (zero weights beyond a band's support)
             const int nit = __builtin_amdgcn_readfirstlane(band_len[4 * ps]) >> 4;
             float part = 0.f;
-            const int K0_ = tab_band[2 * (4 * ps + row)] + l16;
-            const float* wp = wlds + tab_band[2 * (4 * ps + row) + 1] + l16;
-            const float* mp = mag + (((K0_ & 1) << 1) | ((K0_ >> 1) & 1)) * mag_stride + (K0_ >> 2);   // plane order 0, 2, 1, 3
+            const int2 bo = *(const int2*)(tab_band + 2 * (64 * ps + lane));
+            const float* wp = (const float*)((const char*)wlds + bo.y);
+            const float* mp = (const float*)((const char*)mag + bo.x);
 #pragma unroll 4
             for (int it = 0; it < nit; ++it) part = fmaf(wp[16 * it], mp[4 * it], part);
             part = row16_sum(part);
@@ -448,7 +453,7 @@ static int mel_db_launch(const T* pcm, const int64_t* clip_off, const int32_t* f
     const int nq = cfg->win <= 1024 ? 1 : (cfg->win <= 2048 ? 2 : 4);
     const int waves = MEL_WAVES_OF(nq);
     const int exch_extra = MEL_EXCH_BYTES - 8 * mag_stride > 0 ? MEL_EXCH_BYTES - 8 * mag_stride : 0;
-    const size_t lds = (size_t)w_bytes + 8064 + waves * (mag_stride * 16 + exch_extra + 512);
+    const size_t lds = (size_t)w_bytes + MEL_TAB_BYTES + waves * (mag_stride * 16 + exch_extra + 512);
     // frames a wave walks over: more frames amortise its per-lane twiddle loads and the workgroup's table fills, but the
     // chip holds 256 x (12, 8 or 4) waves of this kernel: enough frames per wave to cover the batch in one round, 4 to 32
     static const int fpw_env = [] {
