@@ -454,6 +454,7 @@ static int mel_db_launch(const T* pcm, const int64_t* clip_off, const int32_t* f
     const int waves = MEL_WAVES_OF(nq);
     const int exch_extra = MEL_EXCH_BYTES - 8 * mag_stride > 0 ? MEL_EXCH_BYTES - 8 * mag_stride : 0;
     const size_t lds = (size_t)w_bytes + MEL_TAB_BYTES + waves * (mag_stride * 16 + exch_extra + 512);
+    if (lds > 160 * 1024) return NISQA_ERR_ARG;      // the slaney bank of any (sr, fmax) needs <= 150.5 KB; a denser table does not fit
     // frames a wave walks over: more frames amortise its per-lane twiddle loads and the workgroup's table fills, but the
     // chip holds 256 x (12, 8 or 4) waves of this kernel: enough frames per wave to cover the batch in one round, 4 to 32
     static const int fpw_env = [] {
