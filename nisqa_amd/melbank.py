@@ -5,6 +5,8 @@ Mirrors what librosa 0.8.1 builds inside ``lb.feature.melspectrogram`` for the r
 (htk=False) -- here exported in sparse row form because each FFT bin touches at most two bands --
 plus the 4096-point twiddle table the FFT kernel indexes.
 """
+import os
+
 import numpy as np
 
 
@@ -83,8 +85,17 @@ class MelTables(object):
         length = np.zeros(self.n_mels, np.int32)
         for ps in range(self.n_mels // 4):
             length[4 * ps:4 * ps + 4] = max(16, -(-int(true_len[4 * ps:4 * ps + 4].max()) // 16) * 16)
-        woff = np.concatenate([[0], np.cumsum(length)[:-1]]).astype(np.int32)
-        w = np.zeros(int(length.sum()), np.float32)
+        # The four bands of a pass are read by the four 16-lane rows of a wave in the same instruction: their weight
+        # runs start 16 floats apart modulo the 64 LDS banks (a pass length that is a multiple of 64 would put all four
+        # rows on the same 16 banks), at the price of <= 48 floats of padding per band.
+        woff = np.zeros(self.n_mels, np.int32)
+        pos = 0
+        for m in range(self.n_mels):
+            if os.environ.get('NISQA_MEL_BANK_PAD', '1') != '0':
+                pos += (16 * (m % 4) - pos) % 64
+            woff[m] = pos
+            pos += int(length[m])
+        w = np.zeros(pos, np.float32)
         for m in range(self.n_mels):
             w[woff[m]:woff[m] + true_len[m]] = fb[m, start[m]:start[m] + true_len[m]]
         self.band_start, self.band_len, self.band_woff, self.band_w = start, length, woff, w
