@@ -258,12 +258,10 @@ class SpeechQualityDataset(object):
         return os.path.join(self.data_dir, self.df[self.filename_column].iloc[index])   # NL:2132
 
     def file_paths(self, indices):
-        """Paths of many items at once: the filename column is read out once (a pandas scalar lookup per item costs
-        more host time than staging the item's samples)."""
-        cache = getattr(self, '_path_cache', None)
-        if cache is None or cache[0] is not self.df or len(cache[1]) != len(self.df):
-            cache = self._path_cache = (self.df, self.df[self.filename_column].tolist())
-        names, d = cache[1], self.data_dir
+        """Paths of many items at once: the filename column is read out once per CALL (a pandas scalar lookup per item
+        costs more host time than staging the item's samples; nothing is cached on the dataset, so an in-place edit of
+        the column is always seen)."""
+        names, d = self.df[self.filename_column].tolist(), self.data_dir
         return [os.path.join(d, names[i]) for i in indices]
 
     def load_audio(self, index):
@@ -333,6 +331,34 @@ def _loop_streams(device):
 LOOP_STATS = {}                 # host seconds of the last _predict call by phase (tools/probe_loop.py)
 
 
+# work a launch chain should carry before a batch is closed (batch_policy): the AdaptCNN kernel runs 512 four-segment
+# workgroups at a time (2 per CU), so 16 k segments are ~8 rounds -- the size of the bs = 64 x 10 s configuration the
+# kernels were tuned on; the BiLSTM of the nisqa_tts.tar path runs ONE workgroup per (clip, direction) for as many
+# sequential steps as the longest clip has segments: 128 clips x 2 directions fill the 256 CUs
+MIN_TOKENS_SA = 16384
+MIN_CLIPS_LSTM = 128
+BATCH_BYTE_CAP = 256 << 20          # staged PCM per batch (the page-locked ring holds three such slots)
+
+
+def tokens_of(ds, n_frames, sample_rate):
+    """Segments per clip from WAV header fields alone: frames T = 1 + samples // hop (librosa centre framing, NL:2311),
+    n_wins = ceil((T - (seg_length - 1)) / seg_hop) (NL:2256-2273).  hop as melbank.MelTables derives it."""
+    sr = np.asarray(sample_rate, dtype=np.float64)
+    hop = np.maximum(1, (sr * float(ds.ms_hop_length)).astype(np.int64))
+    T = 1 + np.asarray(n_frames, dtype=np.int64) // hop
+    return np.maximum(1, -(-(T - (int(ds.seg_length) - 1)) // max(1, int(ds.seg_hop_length))))
+
+
+def batch_policy(eng, ds, indices, bs):
+    """Length-aware batches for the predict loop (ingest.LengthAware): --bs is a lower bound, batches are cut by
+    segments / clips / staged bytes after sorting a window of items by length."""
+    lstm = getattr(eng, 'arch', 0) == 1
+    return _ingest.LengthAware(indices, bs, lambda f, r: tokens_of(ds, f, r),
+                               min_tokens=0 if lstm else int(os.environ.get('NISQA_MIN_TOKENS', MIN_TOKENS_SA)),
+                               min_clips=int(os.environ.get('NISQA_MIN_CLIPS', MIN_CLIPS_LSTM)) if lstm else 1,
+                               byte_cap=int(os.environ.get('NISQA_BATCH_BYTES', BATCH_BYTE_CAP)))
+
+
 def _predict(model, ds, bs, dev, num_workers):
     """Shared body of predict_mos / predict_dim: returns y_hat [N, heads] float32 for ALL items of ds
     (clip-sharded over ranks when torch.distributed is initialised, then gathered)."""
@@ -347,7 +373,10 @@ def _predict(model, ds, bs, dev, num_workers):
     bs = max(1, int(bs))
     heads = eng.n_heads
     y_local = np.zeros((hi - lo, heads), dtype=np.float32)
-    batches = [list(range(s, min(s + bs, hi))) for s in range(lo, hi, bs)]
+    if os.environ.get('NISQA_EXACT_BS') == '1':                     # the reference's batches: index order, exactly bs clips
+        batches = [list(range(s, min(s + bs, hi))) for s in range(lo, hi, bs)]
+    else:
+        batches = batch_policy(eng, ds, range(lo, hi), bs)
     # host side (ingest.py): a producer thread + num_workers readers stage batches two ahead in page-locked buffers;
     # device side: ONE stream carries nothing but the H2D copies (a stream that also carries kernels gets its copies done
     # by a shader blit that competes with them instead of the SDMA engine: copy and kernels of neighbouring batches then

@@ -25,6 +25,13 @@ from . import lib as _lib
 from . import wavio
 
 _ALIGN = 64
+_noted = set()
+
+
+def _note_once(msg):
+    if msg not in _noted:
+        _noted.add(msg)
+        print(msg)
 
 
 def cpu_budget():
@@ -155,19 +162,85 @@ class Staged(object):
         self.slot, self.groups = slot, groups
 
 
+class LengthAware(object):
+    """Batching policy of the predict loop: the producer probes the RIFF headers of a
+    window of items (headers only, native threads), sorts the window by (sample rate, length) and cuts batches by WORK,
+    not by a clip count -- a batch is closed when it holds at least ``bs`` clips AND at least ``min_clips`` clips AND at
+    least ``min_tokens`` segments, or when the next clip would push its staged bytes over ``byte_cap``.
+
+    ``bs`` (the reference's --bs / tr_bs_val) is therefore a LOWER bound: the reference's default ``--bs 1`` coalesces
+    into full launches (results do not depend on the batch composition: eval-mode BatchNorm, per-clip masks; tested), and
+    clips of similar length share a batch, so a launch of the BiLSTM (as long as its longest clip) or of the attention
+    kernels carries no short clips waiting for a long one.  The consumer scatters result rows back by item index, so the
+    output order is the input order.
+
+    tokens_of(n_frames[int64 array], sample_rate[int array]) -> segments per clip (host arithmetic on header fields)."""
+
+    def __init__(self, indices, bs, tokens_of, min_tokens=0, min_clips=1, byte_cap=256 << 20, window=16384):
+        self.indices = list(indices)
+        self.bs, self.tokens_of = max(1, int(bs)), tokens_of
+        self.min_tokens, self.min_clips = int(min_tokens), max(1, int(min_clips))
+        self.byte_cap, self.window = int(byte_cap), max(1, int(window))
+
+    def __len__(self):
+        return len(self.indices)
+
+    def cut(self, frames, srs, widths):
+        """Batches (lists of POSITIONS into the window) for clips with the given header fields."""
+        n = len(frames)
+        if n == 0:
+            return []
+        tokens = np.maximum(1, np.asarray(self.tokens_of(frames, srs), dtype=np.int64))
+        nbytes = frames * widths
+        order = np.lexsort((np.arange(n), frames, srs))                # by rate, then length, then input order
+        out, cur, cb, ct = [], [], 0, 0
+        need = max(self.bs, self.min_clips)
+        for k in order.tolist():
+            if cur and (cb + int(nbytes[k]) > self.byte_cap or srs[k] != srs[cur[-1]] and len(cur) >= need):
+                out.append(cur)
+                cur, cb, ct = [], 0, 0
+            cur.append(k)
+            cb += int(nbytes[k])
+            ct += int(tokens[k])
+            if len(cur) >= need and ct >= self.min_tokens:
+                out.append(cur)
+                cur, cb, ct = [], 0, 0
+        if cur:
+            out.append(cur)
+        return out
+
+
 class Ingest(object):
     """Iterate over staged batches of ``ds`` (a SpeechQualityDataset): ``for staged in Ingest(...)``; the caller
     turns ``staged.groups`` into H2D copies out of ``ring.buf[staged.slot]`` and reports the event behind them with
     ``ring.release_after``.  Batches are prepared ``depth`` ahead on a producer thread."""
 
     def __init__(self, ds, batches, pin, num_workers, depth=2, device=None):
+        """``batches``: a list of index lists (staged exactly as given), or a LengthAware policy (the producer forms the
+        batches itself from the headers)."""
         self.ds, self.batches = ds, batches
         self.device = device
         self.ring = _take_ring(depth + 1, pin)
         # reader threads: what the caller asked for, but never more than the CPU budget leaves next to the producer and
-        # consumer threads (over-subscribing a quota-limited container stalls the whole loop, see cpu_budget)
-        self.workers = max(1, min(int(num_workers or 0), cpu_budget() - 3))
+        # consumer threads (over-subscribing a quota-limited container stalls the whole loop, see cpu_budget), and -- when
+        # the producer pins itself and its native pool to the GPU's NUMA node -- never more than that node offers
+        budget = cpu_budget()
+        self.numa_cpus = set()
+        if device is not None and os.environ.get('NISQA_INGEST_NUMA', '1') != '0':
+            self.numa_cpus = gpu_local_cpus(device)
+            if self.numa_cpus:
+                budget = min(budget, len(self.numa_cpus))
+        asked = int(num_workers or 0)
+        if asked <= 0 and isinstance(batches, LengthAware):
+            asked = budget                      # the reference's default (--num_workers 0): as many readers as the box allows
+        self.workers = max(1, min(asked, budget - 3))
+        if asked > self.workers:
+            _note_once('nisqa_amd.ingest: %d reader threads instead of the %d requested (CPU budget of this process: %d)'
+                       % (self.workers, asked, budget))
         self.lib = _lib.load_ingest()
+        # the filename column is read ONCE per loop (a pandas scalar lookup per item costs more host time than staging the
+        # item's samples); not cached on the dataset: an in-place edit of the column between two calls must be seen
+        self._col = ds.df[ds.filename_column].tolist() if hasattr(ds, 'df') and hasattr(ds, 'filename_column') else None
         self.q = queue.Queue(maxsize=depth)
         self.stop = threading.Event()
         self.stats = {'paths': 0.0, 'probe': 0.0, 'layout': 0.0, 'slot_wait': 0.0, 'read': 0.0, 'queue_wait': 0.0, 'batches': 0}
@@ -175,21 +248,36 @@ class Ingest(object):
         self.thread.start()
 
     # -- producer side ---------------------------------------------------------------------------------
-    def _stage(self, idx):
+    def _probe(self, idx):
+        """RIFF headers of items ``idx`` -> (names, encoded paths, header records as a numpy structured array)."""
         ds, L, n = self.ds, self.lib, len(idx)
         T, t0 = self.stats, time.perf_counter()
-        names = ds.file_paths(idx) if hasattr(ds, 'file_paths') else [ds.file_path(i) for i in idx]
-        paths = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in names])
+        if self._col is not None:                                  # the column as it was when this loop started
+            col, d = self._col, ds.data_dir
+            names = [os.path.join(d, col[i]) for i in idx]
+        else:
+            names = [ds.file_path(i) for i in idx]
+        enc = [os.fsencode(p) for p in names]
+        paths = (ctypes.c_char_p * n)(*enc)
         infos = (_lib.WavInfo * n)()
         t1 = time.perf_counter()
         T['paths'] += t1 - t0
         rc = L.nisqa_ingest_probe(paths, n, infos, self.workers)
-        t2 = time.perf_counter()
-        T['probe'] += t2 - t1
+        T['probe'] += time.perf_counter() - t1
         if rc:
             bad = next(k for k in range(n) if infos[k].status != _lib.WAV_OK)
             raise ValueError('Could not load file {}'.format(names[bad]))      # NISQA_lib.py:2305-2306
-        info = np.ctypeslib.as_array(infos)                        # structured view of the nisqa_wav_info records
+        return names, enc, np.ctypeslib.as_array(infos).copy()
+
+    def _stage(self, idx, probed=None):
+        """Stage one batch: layout from the headers, then every data chunk straight into a page-locked slot."""
+        ds, L, n = self.ds, self.lib, len(idx)
+        T = self.stats
+        names, enc, info = probed if probed is not None else self._probe(idx)
+        t2 = time.perf_counter()
+        paths = (ctypes.c_char_p * n)(*enc)
+        info = np.ascontiguousarray(info)
+        infos = ctypes.cast(info.ctypes.data, ctypes.POINTER(_lib.WavInfo))
         frames, srs = info['n_frames'], info['sample_rate']
         fast = (info['tag'] == 1) & (info['bits'] == 16) & (info['channels'] == 1)
         # batch layout from the headers alone: clips of one rate are contiguous, int16 if ALL of them are mono PCM16
@@ -216,7 +304,7 @@ class Ingest(object):
         T['read'] += time.perf_counter() - t4
         T['batches'] += 1
         if rc:
-            bad = next(k for k in range(n) if infos[k].status != _lib.WAV_OK)
+            bad = next(k for k in range(n) if info['status'][k] != _lib.WAV_OK)
             self.ring.release_after(slot, None)
             raise ValueError('Could not load file {}'.format(names[bad]))
         groups = []
@@ -233,19 +321,51 @@ class Ingest(object):
                                 nbytes, is_i16, [names[k] for k in sel.tolist()]))
         return Staged(slot, groups)
 
+    def _planned(self):
+        """Batches of a LengthAware policy: yields (idx, probed) window by window; the headers of window w + 1 are
+        probed on a helper thread while the batches of window w are staged."""
+        pol = self.batches
+        wins = [pol.indices[s:s + pol.window] for s in range(0, len(pol.indices), pol.window)]
+        box = {}
+
+        def probe_into(w):
+            try:
+                box[w] = ('ok', self._probe(wins[w]))
+            except BaseException as e:
+                box[w] = ('err', e)
+
+        helper = None
+        if wins:
+            probe_into(0)
+        for w in range(len(wins)):
+            if helper is not None:
+                helper.join()
+            kind, val = box.pop(w)
+            if kind == 'err':
+                raise val
+            if w + 1 < len(wins):
+                helper = threading.Thread(target=probe_into, args=(w + 1,), name='nisqa-probe', daemon=True)
+                helper.start()
+            else:
+                helper = None
+            names, enc, info = val
+            fast = (info['tag'] == 1) & (info['bits'] == 16) & (info['channels'] == 1)
+            cuts = pol.cut(info['n_frames'].astype(np.int64), info['sample_rate'].astype(np.int64), np.where(fast, 2, 4))
+            for pos in cuts:
+                yield [wins[w][k] for k in pos], ([names[k] for k in pos], [enc[k] for k in pos], info[pos])
+
     def _produce(self):
         try:
-            if self.device is not None and os.environ.get('NISQA_INGEST_NUMA', '1') != '0':
-                cpus = gpu_local_cpus(self.device)
-                if cpus:
-                    try:                                       # this thread only; the native reader pool inherits it
-                        os.sched_setaffinity(0, cpus)
-                    except OSError:
-                        pass
-            for idx in self.batches:
+            if self.numa_cpus:
+                try:                                       # this thread only; the native reader pool inherits it
+                    os.sched_setaffinity(0, self.numa_cpus)
+                except OSError:
+                    pass
+            it = self._planned() if isinstance(self.batches, LengthAware) else ((idx, None) for idx in self.batches)
+            for idx, probed in it:
                 if self.stop.is_set():
                     return
-                st = self._stage(idx)
+                st = self._stage(idx, probed)
                 t0 = time.perf_counter()
                 self.q.put(('ok', st))
                 self.stats['queue_wait'] += time.perf_counter() - t0

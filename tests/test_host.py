@@ -795,3 +795,116 @@ def test_ingest_cpu_budget_reader_cap_ring_reuse_and_path_cache(tmp_path, monkey
     for staged in ing2:
         ing2.ring.release_after(staged.slot, None)
     ing2.close()
+
+
+# ---- length-aware batching (round 3) -----------------------------------------------
+def _mixed_wavs(tmp_path, durs, srs=None):
+    names = []
+    for i, d in enumerate(durs):
+        sr = 48000 if srs is None else srs[i]
+        synth.write_wav(str(tmp_path / ('m%03d.wav' % i)), synth.synth_pcm16(50 + i, d, sr=sr) if sr != 48000 else synth.synth_pcm16(50 + i, d), sr)
+        names.append('m%03d.wav' % i)
+    return names
+
+
+def test_length_aware_policy_cuts_by_work_and_keeps_every_item_once():
+    from nisqa_amd import ingest
+    rng = np.random.default_rng(4)
+    frames = rng.integers(3 * 48000, 30 * 48000, 300).astype(np.int64)
+    srs = np.full(300, 48000, dtype=np.int64)
+    tok = lambda f, r: np.maximum(1, -(-(1 + f // 480 - 14) // 4))
+    pol = ingest.LengthAware(range(300), 1, tok, min_tokens=16384, byte_cap=64 << 20)
+    cuts = pol.cut(frames, srs, np.full(300, 2))
+    assert sorted(k for c in cuts for k in c) == list(range(300))              # a partition
+    flat = [k for c in cuts for k in c]
+    assert (np.diff(frames[flat]) >= 0).all()                                  # sorted by length across batches
+    for c in cuts[:-1]:
+        t, b = int(tok(frames[c], srs[c]).sum()), int(frames[c].sum() * 2)
+        assert b <= 64 << 20
+        # closed because the work target was reached, or because one more clip would not have fitted
+        nxt = flat[flat.index(c[-1]) + 1]
+        assert t >= 16384 or b + frames[nxt] * 2 > 64 << 20
+        assert t - int(tok(frames[c[-1:]], srs[c[-1:]])[0]) < 16384            # ... and not later than necessary
+    # bs is a lower bound on the clip count; min_clips (the LSTM path) likewise
+    cuts = ingest.LengthAware(range(300), 40, tok, min_tokens=0).cut(frames, srs, np.full(300, 2))
+    assert [len(c) for c in cuts] == [40] * 7 + [20]
+    cuts = ingest.LengthAware(range(300), 1, tok, min_tokens=0, min_clips=128).cut(frames, srs, np.full(300, 2))
+    assert [len(c) for c in cuts] == [128, 128, 44]
+    # rates are kept apart once a batch is big enough, mixed otherwise
+    srs2 = np.where(np.arange(300) % 2 == 0, 48000, 16000)
+    cuts = ingest.LengthAware(range(300), 150, tok, min_tokens=0).cut(frames, srs2, np.full(300, 2))
+    assert [sorted(set(srs2[c].tolist())) for c in cuts] == [[16000], [48000]]
+    assert ingest.LengthAware([], 1, tok).cut(frames[:0], srs[:0], np.zeros(0, np.int64)) == []
+
+
+@pytest.mark.parametrize('window', [4, 16384])
+def test_predict_rows_come_back_in_input_order_under_length_sorting(tmp_path, monkeypatch, window):
+    """The reference's default flags (--bs 1 --num_workers 0, run_predict.py:16-20) coalesce into work-sized batches of
+    length-sorted clips; the frame still lists the files in directory / CSV order with each file's own row."""
+    from nisqa_amd import ingest
+    from nisqa_amd import NISQA_lib as NL
+    from nisqa_amd.NISQA_model import nisqaModel
+    durs = [0.9, 0.25, 0.6, 0.3, 1.4, 0.2, 0.75, 0.5, 1.1, 0.35, 0.45]
+    names = _mixed_wavs(tmp_path, durs)
+    order = [7, 2, 9, 0, 4, 1, 10, 3, 8, 5, 6]
+    pd.DataFrame({'name': [names[i] for i in order]}).to_csv(tmp_path / 'l.csv', index=False)
+    ck = _ckpt(tmp_path)
+    seen = []
+    real_stage = ingest.Ingest._stage
+
+    def spy(self, idx, probed=None):
+        seen.append(list(idx))
+        return real_stage(self, idx, probed)
+    monkeypatch.setattr(ingest.Ingest, '_stage', spy)
+    monkeypatch.setattr(NL, 'MIN_TOKENS_SA', 60)                   # a 0.9 s clip has 20 segments
+    real_init = ingest.LengthAware.__init__
+    monkeypatch.setattr(ingest.LengthAware, '__init__',
+                        lambda self, *a, **k: real_init(self, *a, **{**k, 'window': window}))
+    m = nisqaModel(_args('predict_csv', ck, data_dir=str(tmp_path), csv_file='l.csv', csv_deg='name', bs=1, tr_bs_val=1))
+    m.model._engine = FakeEngine(5)
+    df = m.predict()
+    assert list(df['name']) == [names[i] for i in order]
+    eng = FakeEngine(5)
+    for row, i in enumerate(order):                                  # each file's own numbers, whatever batch it rode in
+        y, sr = NL.read_wav(str(tmp_path / names[i]))
+        want = eng.forward_pcm(torch.from_numpy(y), eng.plan([len(y)], sr), sr)[0].numpy()
+        assert np.allclose(df.iloc[row][['mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred']].to_numpy(dtype=np.float64), want, rtol=1e-6)
+    assert sorted(i for b in seen for i in b) == list(range(len(order)))
+    assert len(seen) < len(order)                                   # bs = 1 did NOT mean one launch chain per file
+    if window > len(order):
+        lens = [durs[order[i]] for b in seen for i in b]
+        assert lens == sorted(lens)                                  # similar lengths share a batch
+    else:
+        assert max(len(b) for b in seen) <= window
+    # NISQA_EXACT_BS=1: the reference's batches (index order, exactly bs clips)
+    seen.clear()
+    monkeypatch.setenv('NISQA_EXACT_BS', '1')
+    m = nisqaModel(_args('predict_csv', ck, data_dir=str(tmp_path), csv_file='l.csv', csv_deg='name', bs=4, tr_bs_val=4))
+    m.model._engine = FakeEngine(5)
+    df2 = m.predict()
+    assert seen == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10]]
+    assert np.allclose(df2['mos_pred'], df['mos_pred'], rtol=1e-6)
+
+
+def test_predict_sees_an_in_place_edit_of_the_filename_column(tmp_path):
+    """nothing about the file list is cached on the dataset between two predict() calls."""
+    from nisqa_amd.NISQA_model import nisqaModel
+    names = _mixed_wavs(tmp_path, [0.3, 0.5, 0.7])
+    pd.DataFrame({'name': names}).to_csv(tmp_path / 'l.csv', index=False)
+    m = nisqaModel(_args('predict_csv', _ckpt(tmp_path), data_dir=str(tmp_path), csv_file='l.csv', csv_deg='name'))
+    m.model._engine = FakeEngine(5)
+    a = m.predict()['mos_pred'].to_numpy().copy()
+    m.ds_val.df['name'] = m.ds_val.df['name'].to_numpy()[::-1].copy()      # same frame object, same length
+    b = m.predict()['mos_pred'].to_numpy()
+    assert np.allclose(b, a[::-1]) and not np.allclose(b, a)
+
+
+def test_probe_errors_surface_as_the_reference_value_error(tmp_path):
+    from nisqa_amd.NISQA_model import nisqaModel
+    names = _mixed_wavs(tmp_path, [0.3, 0.5])
+    (tmp_path / 'bad.wav').write_bytes(b'not a wav file at all')
+    pd.DataFrame({'name': names + ['bad.wav']}).to_csv(tmp_path / 'l.csv', index=False)
+    m = nisqaModel(_args('predict_csv', _ckpt(tmp_path), data_dir=str(tmp_path), csv_file='l.csv', csv_deg='name'))
+    m.model._engine = FakeEngine(5)
+    with pytest.raises(ValueError, match='Could not load file .*bad.wav'):
+        m.predict()
