@@ -26,7 +26,14 @@ Extra objects on the JSON line (DESIGN.md "Measurement"):
                       from the rocprofv3 PMC passes of the same build (profiles/rNN_pmc_kernels.json; null when absent).
   roofline_secondary  mel_frame_kernel against the fp32 VALU peak (FLOPs of the pruned FFT actually executed).
   kernels             per stage: mean ms, mfma_util / HBM bytes from the same PMC file.
-  alt_precision       the same workload on the exact-fp32 path, measured after the timed region.
+  f32                 the same workload, same --steps / --warmup, on the exact-fp32 path (the reference's own arithmetic):
+                      value_f32 at the top level, its own roofline (cnn_front_kernel against the fp32-MFMA peak, traffic and
+                      mfma_util from the same PMC file).
+  steady              the primary path again over >= 400 steps (the driver's 20-step run ends before the clocks settle).
+  side                the other BASELINE.json configurations, each bounded to a few seconds, each with its own roofline
+                      and cpu_baseline: predict_csv_1gpu (configs[2] through nisqaModel.predict(), WAV files on disk,
+                      PCIe-inclusive), tts_mixed (configs[3]: nisqa_tts.tar, mixed 3-30 s clips), train_step (configs[4]:
+                      forward + backward + Adam at bs 32).  `--leg main|tts|train|csv` runs one of them alone (profiling).
   cpu_baseline        the CPU oracle (port of the reference path) at bs = 64 on this box's host cores, rank 0, N = 1.
 """
 import argparse
@@ -62,6 +69,13 @@ FLOP_MEL_FRAME = 1024 + 9216 + 92160 + 20480 + 6828 + 6828 + 48 * 4
 PEAK_F32 = 157.3                                             # TFLOP/s fp32 (vector = fp32 MFMA), MI355X_MICROARCH.md
 PEAK_BF16_MFMA = 2500.0                                      # TFLOP/s dense, MI355X_MICROARCH.md
 N_SIMD = 1024                                                # 256 CUs x 4
+# nisqa_tts.tar (StandardCNN + fc, BiLSTM 128), per segment: conv1 48x15x16x9, conv2 24x8x32x144, conv3 12x4x64x288, conv4
+# 12x4x64x576, conv5 / conv6 6x2x64x576 each, fc 768x20 (x2 flop per multiply-add) = 9.085 MFLOP; one BiLSTM step = 2
+# directions x 4 gates x 128 units x (20 + 128) inputs x 2 = 0.303 MFLOP
+FLOP_STD_SEG = 2.0 * (48 * 15 * 16 * 9 + 24 * 8 * 32 * 144 + 12 * 4 * 64 * 288 + 12 * 4 * 64 * 576 + 2 * 6 * 2 * 64 * 576 + 768 * 20)
+FLOP_LSTM_SEG = 2.0 * 2 * 4 * 128 * (20 + 128)
+FLOP_NET_CLIP = (51.2 + 382.4 + 546.3 + 1092.6 + 327.8 + 109.3 + 12.1 + 55.5 + 20.7) * 1e6   # CNN + proj + self-att + pooling, 10 s
+PEAK_PCIE = 63.0                                             # GB/s host -> device, PCIe Gen5 x16
 
 
 def find_weights(name='nisqa.tar'):
@@ -195,41 +209,37 @@ def init_dist(a):
     return rank, world, dev, backend
 
 
-def bench_predict_csv(a):
-    """BASELINE configs[2]: nisqaModel(predict_csv).predict() over N clips, bs per GPU, ranks shard the CSV."""
+def predict_csv_job(rank, world, dev, backend, clips, bs, distinct, workers, warmup, tmp_dir=None, tag='csv'):
+    """BASELINE configs[2]: nisqaModel(predict_csv).predict() over `clips` rows of a CSV (`distinct` synthetic 10 s WAV files
+    on local disk, reused cyclically), ranks shard the CSV.  -> (seconds max over ranks, DataFrame on rank 0, description)."""
     import contextlib
     import io
     import shutil
     import tempfile
     import pandas as pd
     from nisqa_amd.NISQA_model import nisqaModel
-    rank, world, dev, backend = init_dist(a)
     margs, sd, wdesc = model_weights()
-    tmp = a.tmp_dir or tempfile.gettempdir()
-    d = os.path.join(tmp, 'nisqa_bench_csv')
+    d = os.path.join(tmp_dir or tempfile.gettempdir(), 'nisqa_bench_' + tag)
     if rank == 0:
         shutil.rmtree(d, ignore_errors=True)
         os.makedirs(d)
-        for i in range(a.distinct):
+        for i in range(distinct):
             synth.write_wav(os.path.join(d, 'c%05d.wav' % i), synth.synth_pcm16(3000 + i, SECONDS), SR)
-        pd.DataFrame({'deg': ['c%05d.wav' % (i % a.distinct) for i in range(a.clips)]}).to_csv(os.path.join(d, 'list.csv'), index=False)
+        pd.DataFrame({'deg': ['c%05d.wav' % (i % distinct) for i in range(clips)]}).to_csv(os.path.join(d, 'list.csv'), index=False)
         ck = dict(margs)
-        ck.update({'pretrained_model': False, 'tr_bs_val': a.bs, 'tr_num_workers': a.workers})
+        ck.update({'pretrained_model': False, 'tr_bs_val': bs, 'tr_num_workers': workers})
         torch.save({'args': ck, 'model_state_dict': sd}, os.path.join(d, 'model.tar'))
+        # warm-up: W batches per rank through the same path (page cache, engine, pinned ring)
+        pd.DataFrame({'deg': ['c%05d.wav' % (i % distinct) for i in range(max(1, warmup) * bs * world)]}).to_csv(
+            os.path.join(d, 'warm.csv'), index=False)
     if world > 1:
         torch.distributed.barrier()
 
     def args_for(csv):
         return {'mode': 'predict_csv', 'pretrained_model': os.path.join(d, 'model.tar'), 'deg': None, 'data_dir': d,
-                'output_dir': None, 'csv_file': csv, 'csv_deg': 'deg', 'num_workers': a.workers, 'bs': a.bs,
-                'ms_channel': None, 'tr_bs_val': a.bs, 'tr_num_workers': a.workers}
+                'output_dir': None, 'csv_file': csv, 'csv_deg': 'deg', 'num_workers': workers, 'bs': bs,
+                'ms_channel': None, 'tr_bs_val': bs, 'tr_num_workers': workers}
 
-    # warm-up: W batches per rank through the same path (page cache, engine, pinned ring)
-    if rank == 0:
-        pd.DataFrame({'deg': ['c%05d.wav' % (i % a.distinct) for i in range(max(1, a.warmup) * a.bs * world)]}).to_csv(
-            os.path.join(d, 'warm.csv'), index=False)
-    if world > 1:
-        torch.distributed.barrier()
     quiet = io.StringIO()
     with contextlib.redirect_stdout(quiet):
         nisqaModel(args_for('warm.csv')).predict()
@@ -249,7 +259,16 @@ def bench_predict_csv(a):
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     if rank == 0:
-        assert len(df) == a.clips and np.isfinite(df['mos_pred'].to_numpy()).all()
+        assert len(df) == clips and np.isfinite(df['mos_pred'].to_numpy()).all()
+        shutil.rmtree(d, ignore_errors=True)
+    return dt, df, wdesc
+
+
+def bench_predict_csv(a):
+    """`--workload predict_csv`: the configs[2] harness as its own bench line (strong scaling over a fixed CSV)."""
+    rank, world, dev, backend = init_dist(a)
+    dt, df, wdesc = predict_csv_job(rank, world, dev, backend, a.clips, a.bs, a.distinct, a.workers, a.warmup, a.tmp_dir)
+    if rank == 0:
         steps = -(-(-(-a.clips // world)) // a.bs)
         print(json.dumps({
             'metric': 'clips/sec (10 s, 48 kHz)', 'value': round(a.clips / dt, 2), 'unit': 'clips/s', 'n_gpus': world,
@@ -262,10 +281,195 @@ def bench_predict_csv(a):
                                    % (a.bs, a.clips, world),
                        'clips': a.clips, 'bs': a.bs, 'distinct_files': a.distinct, 'ingest_workers': a.workers,
                        'parallelism': 'clip-sharded x%d, final all_gather of MOS rows' % world,
-                       'collective_backend': backend, 'world_size_seen': world}}))
-        shutil.rmtree(d, ignore_errors=True)
+                       'collective_backend': backend, 'world_size_seen': world},
+            'link': {'bound': 'pcie', 'achieved': round(a.clips * SECONDS * SR * 2 / dt / 1e9, 2), 'peak': PEAK_PCIE, 'unit': 'GB/s',
+                     'frac': round(a.clips * SECONDS * SR * 2 / dt / 1e9 / PEAK_PCIE / world, 4)}}))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+# ---- side legs: the other BASELINE.json configurations on the driver-run line ---------------------------------------
+def _stage_events(n):
+    ev = []
+    for _ in range(n):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        for x in e:
+            x.record()
+        ev.append(e)
+    return ev
+
+
+def side_predict_csv(dev, cpu):
+    """configs[2] on ONE GPU, bounded: 8 192 rows / 64 distinct 10 s WAV files, bs 256, through nisqaModel.predict()
+    (file list -> native ingest -> pinned ring -> H2D -> kernels -> DataFrame).  PCIe-inclusive: the bound is the host
+    link (2 bytes per sample cross it), not the kernels."""
+    clips, bs = 8192, 256
+    from nisqa_amd import ingest as _ing
+    dt, _, _ = predict_csv_job(0, 1, dev, None, clips, bs, 64, 0, 2, tag='side_csv')
+    gbs = clips * SECONDS * SR * 2 / dt / 1e9
+    return {'config': 'configs[2] predict_csv nisqa.tar bs=256, 1 GPU, %d rows (64 distinct 10 s WAV files in the page cache), '
+                      'nisqaModel.predict() end to end incl. file listing, DataFrame and the printed table; reader threads: '
+                      'the CPU budget (%d) - 3' % (clips, _ing.cpu_budget()),
+            'value': round(clips / dt, 1), 'unit': 'clips/s', 'seconds': round(dt, 3), 'pcie_inclusive': True,
+            'roofline': {'bound': 'pcie', 'kernel': 'H2D copy of the int16 PCM (SDMA, copy-only stream)', 'achieved': round(gbs, 2),
+                         'peak': PEAK_PCIE, 'unit': 'GB/s', 'frac': round(gbs / PEAK_PCIE, 4)},
+            'cpu_baseline': cpu and {k: cpu[k] for k in ('value', 'unit', 'cores', 'kind')}}
+
+
+def tts_weights():
+    p = find_weights('nisqa_tts.tar')
+    if p:
+        ck = torch.load(p, map_location='cpu', weights_only=False)
+        return ck['args'], ck['model_state_dict'], 'nisqa_tts.tar (%s)' % os.path.relpath(p, ROOT)
+    return dict(synth.TTS_ARGS), synth.random_state_dict(9, 'NISQA_TTS'), 'random-init nisqa_tts.tar architecture'
+
+
+def side_tts(dev, reps, cpu_baseline_on, pmc):
+    """configs[3]: nisqa_tts.tar (StandardCNN + fc -> BiLSTM(128) -> last-step pooling, segment hop 1), 256 clips with
+    durations rng(7).uniform(3, 30) s, int16 PCM resident in HBM, batched by the predict loop's own policy
+    (NISQA_lib.batch_policy: sorted by length, >= 128 clips per batch, <= 256 MiB of PCM)."""
+    from nisqa_amd.engine import HipNisqa
+    from nisqa_amd import NISQA_lib as NL, ingest as _ing
+    targs, tsd, wdesc = tts_weights()
+    eng = HipNisqa(targs, tsd, dev)
+    n_clips = 256
+    durs = np.random.default_rng(7).uniform(3, 30, n_clips)
+    base = synth.synth_pcm16(5, 30.0)
+    frames = (durs * SR).astype(np.int64)
+
+    class _DS(object):                                       # the header fields batch_policy looks at
+        ms_hop_length, seg_length, seg_hop_length = targs['ms_hop_length'], targs['ms_seg_length'], targs['ms_seg_hop_length']
+    pol = NL.batch_policy(eng, _DS, range(n_clips), 1)
+    cuts = pol.cut(frames, np.full(n_clips, SR, np.int64), np.full(n_clips, 2, np.int64))
+    batches = []
+    for c in cuts:
+        plan = eng.plan([int(frames[k]) for k in c], SR)
+        x = torch.from_numpy(np.concatenate([base[:int(frames[k])] for k in c])).to(dev)
+        plan.to(dev)
+        batches.append((plan, x))
+    for plan, x in batches:
+        eng.forward_pcm(x, plan, SR)
+    torch.cuda.synchronize()
+    ev = _stage_events(reps * len(batches))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(reps):
+        for bi, (plan, x) in enumerate(batches):
+            out = eng.forward_pcm(x, plan, SR, stage_events=ev[r * len(batches) + bi])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert torch.isfinite(out).all()
+    # the same job with the batches alternating over two streams, as the predict loop runs them (the BiLSTM of one batch --
+    # one workgroup per (clip, direction), latency-bound -- under the mel + CNN of the next)
+    st2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for r in range(reps):
+        for bi, (plan, x) in enumerate(batches):
+            with torch.cuda.stream(st2[bi % 2]):
+                eng.forward_pcm(x, plan, SR)
+    torch.cuda.synchronize()
+    dt2 = (time.perf_counter() - t1) / reps
+    nb = len(batches)
+    segs = np.array([int(p.n_wins.sum()) for p, _ in batches], dtype=np.float64)
+    steps = np.array([int(p.n_wins.max()) for p, _ in batches], dtype=np.float64)
+    ms = np.array([[np.mean([ev[r * nb + bi][i].elapsed_time(ev[r * nb + bi][i + 1]) for r in range(reps)]) for i in range(4)]
+                   for bi in range(nb)])                     # [batch][mel, cnn, (unused), lstm + pool]
+    cnn_ms, lstm_ms = float(ms[:, 1].sum()), float(ms[:, 3].sum())
+    ach = float(segs.sum()) * FLOP_STD_SEG / (cnn_ms * 1e-3) / 1e12
+    tr, mu = pmc_derived(pmc.get('cnn_std_bf16_kernel'))
+    res = {'config': 'configs[3] predict_dir nisqa_tts.tar (Naturalness head), %d clips, durations rng(7).uniform(3, 30) s '
+                     '(%.0f s of audio, %d segments at hop 1), int16 PCM resident in HBM, %d length-sorted batches of %s clips '
+                     '(NISQA_lib.batch_policy), one stream; weights: %s'
+                     % (n_clips, float(durs.sum()), int(segs.sum()), nb, '/'.join(str(p.n_clips) for p, _ in batches), wdesc),
+           'value': round(n_clips / dt, 1), 'unit': 'clips/s', 'audio_seconds_per_s': round(float(durs.sum()) / dt, 1),
+           'ms_per_job': round(dt * 1e3, 3), 'value_2_streams': round(n_clips / dt2, 1),
+           'stage_ms': {'mel': round(float(ms[:, 0].sum()), 4), 'cnn_std': round(cnn_ms, 4), 'lstm_pool': round(lstm_ms, 4)},
+           'roofline': {'kernel': 'cnn_std_bf16_kernel (StandardCNN conv1-6 + fc, split-bf16 MFMA: 3 products per term)',
+                        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA, 'unit': 'TFLOP/s',
+                        'frac': round(ach / PEAK_BF16_MFMA, 4), 'flop_per_job': float(segs.sum()) * FLOP_STD_SEG,
+                        'avg_launch_ms': round(cnn_ms / nb, 4), 'launches_per_job': nb, 'traffic': tr, 'mfma_util': mu},
+           'lstm': {'kernel': 'lstm_dir_kernel + pool_last_kernel: one 512-thread workgroup per (clip, direction), sequential in time',
+                    'bound': 'latency', 'us_per_step': round(1e3 * lstm_ms / float(steps.sum()), 4),
+                    'steps_per_job': int(steps.sum()), 'workgroups_per_launch': [2 * p.n_clips for p, _ in batches],
+                    'achieved_tflops': round(float(segs.sum()) * FLOP_LSTM_SEG / (lstm_ms * 1e-3) / 1e12, 3)}}
+    if cpu_baseline_on:
+        from oracle import mel as omel, net as onet
+        n_cpu = 4
+        clip = base[:10 * SR].astype(np.float32) / np.float32(32768.0)
+        omel.melspec_db_from_audio(clip[:SR], SR, fmax=targs['ms_fmax'])           # builds the filter bank once
+        t0 = time.perf_counter()
+        specs = [omel.melspec_db_from_audio(np.roll(clip, 1000 * i), SR, fmax=targs['ms_fmax']) for i in range(n_cpu)]
+        t_mel = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        for spec in specs:
+            onet.predict_from_melspec(tsd, targs, spec)
+        t_net = time.perf_counter() - t1
+        aud = 10.0 * n_cpu
+        res['cpu_baseline'] = {'value': round(aud / (t_mel + t_net), 3), 'unit': 'audio-seconds/s', 'cores': int(torch.get_num_threads()),
+                               'kind': 'port', 'clips_per_s_at_mean_duration': round(aud / (t_mel + t_net) / float(durs.mean()), 3),
+                               'sample': '%d clips of 10 s (987 segments each), one after the other like predict_mos at bs 1: '
+                                         'oracle.mel %.2f s + oracle.net (StandardCNN on the packed segments, BiLSTM, torch CPU fp32) '
+                                         '%.2f s; the GPU job is %.0f audio-seconds' % (n_cpu, t_mel, t_net, float(durs.sum()))}
+    return res
+
+
+def side_train(dev, steps, cpu_baseline_on, pmc):
+    """configs[4]: train_nisqa_cnn_sa_ap.yaml's step (NISQA_model.py:131-152) at bs 32 x 10 s: mel front end, forward in
+    train mode, bias-aware loss, backward, BatchNorm buffers, Adam -- HipTrainer, default precision mode."""
+    from nisqa_amd.train import HipTrainer
+    bs = 32
+    args = dict(synth.MOS_ARGS)                               # model NISQA, cnn_dropout 0.2, td_sa_dropout 0.1 (the yaml's values)
+    sd = synth.random_state_dict(8, 'NISQA')
+    tr = HipTrainer(args, sd, dev, lr=1e-3)
+    pcm = np.concatenate([synth.synth_pcm16(i % 8, SECONDS) for i in range(bs)])
+    plan = tr.eng.plan([int(SECONDS * SR)] * bs, SR)
+    x = tr.eng.pcm16_to_f32(torch.from_numpy(pcm).to(dev))
+    y = np.random.default_rng(9).uniform(1, 5, (bs, 1)).astype(np.float32)
+    for _ in range(3):
+        tr.step_pcm(x, plan, SR, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.step_pcm(x, plan, SR, y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    assert np.isfinite(float(loss))
+    flop = 3.0 * FLOP_NET_CLIP * bs                            # forward + input gradients + weight gradients
+    ach = flop / dt / 1e12
+    # the ideal time of this precision mode: forward convolutions on fp32 MFMA ('mixed', 'f32') or split-bf16 ('bf16x3'),
+    # the two gradient passes on split-bf16 ('mixed', 'bf16x3') or fp32 ('f32'); attention / pooling / projection fp32
+    cnn = (FLOP_CONV1_4 + FLOP_CONV5_6) * bs
+    rest = FLOP_NET_CLIP * bs - cnn
+    pk_f, pk_b = (PEAK_BF16_MFMA if tr.precision == 'bf16x3' else PEAK_F32), (PEAK_F32 if tr.precision == 'f32' else PEAK_BF16_MFMA)
+    ideal = (cnn / pk_f + 2 * cnn / pk_b + 3 * rest / PEAK_F32) / 1e12
+    res = {'config': 'configs[4] train_nisqa_cnn_sa_ap.yaml step (forward + backward + Adam, mel front end inside the step), '
+                     'bs=32 x 10 s, %d segments, model NISQA random-init, dropout on; precision mode %r' % (int(plan.n_wins.sum()), tr.precision),
+           'value': round(bs / dt, 1), 'unit': 'clips/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'loss': round(float(loss), 5),
+           'roofline': {'kernel': 'whole step (~%s launches; no single kernel dominates)' % 'see profiles/rNN_train_kernel_stats.csv',
+                        'bound': 'mfma', 'achieved': round(ach, 2), 'unit': 'TFLOP/s',
+                        'flop_per_step': flop, 'flop_rule': '3 x forward network FLOPs (2.598 GFLOP per 10 s clip)',
+                        'peak': PEAK_F32, 'frac': round(ach / PEAK_F32, 4),
+                        'peak_note': 'fp32 MFMA peak (the reference trains in fp32); frac_of_mode_ideal prices the forward / '
+                                     'gradient convolutions at the MFMA peak of the operand type each runs on in this mode',
+                        'frac_of_bf16_peak': round(ach / PEAK_BF16_MFMA, 4),
+                        'frac_of_mode_ideal': round(ideal / dt, 4), 'mode_ideal_ms': round(ideal * 1e3, 4)},
+           'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    if cpu_baseline_on:
+        from oracle import mel as omel, net as onet, train as otrain
+        nb = 8
+        clips = [synth.synth_pcm16(i, SECONDS).astype(np.float32) / np.float32(32768.0) for i in range(nb)]
+        t0 = time.perf_counter()
+        specs = [omel.melspec_db_from_audio(c, SR) for c in clips]
+        segs = [onet.segment_specs(sp, args['ms_seg_length'], args['ms_seg_hop_length'], None) for sp in specs]
+        xs = torch.cat([onet._t(sg)[:n] for sg, n in segs], 0)            # the valid segments, clip after clip
+        torch.manual_seed(0)
+        out = otrain.train_step(sd, args, xs, np.array([n for _, n in segs]), y[:nb], lr=1e-3)
+        t = time.perf_counter() - t0
+        res['cpu_baseline'] = {'value': round(nb / t, 3), 'unit': 'clips/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+                               'sample': 'ONE step at bs = %d x 10 s (%d segments): oracle.mel + oracle.train.train_step '
+                                         '(torch CPU autograd fp32 + Adam) %.2f s, loss %.4f' % (nb, sum(n for _, n in segs), t, out['loss'])}
+    return res
 
 
 def main():
@@ -287,12 +491,21 @@ def main():
     ap.add_argument('--workers', type=int, default=16, help='predict_csv: native ingest threads per rank')
     ap.add_argument('--tmp-dir', default=None)
     ap.add_argument('--batch', type=int, default=BATCH, help='clips per step (experiments; the contract line is 64)')
+    ap.add_argument('--leg', default='all', choices=['all', 'main', 'tts', 'train', 'csv'],
+                    help='profiling runs: only this part (main = the contract workload without side legs)')
+    ap.add_argument('--no-side', action='store_true', help='skip the side legs (configs[2], [3], [4])')
     a = ap.parse_args()
     BATCH = a.batch
     if a.workload == 'predict_csv':
         return bench_predict_csv(a)
 
     rank, world, dev, backend = init_dist(a)
+    if a.leg in ('tts', 'train', 'csv'):                      # one side leg alone (rocprofv3 runs)
+        pmc, _ = pmc_kernels()
+        r = (side_tts(dev, max(1, a.steps // 4), not a.no_cpu_baseline, pmc) if a.leg == 'tts' else
+             side_train(dev, a.steps, not a.no_cpu_baseline, pmc) if a.leg == 'train' else side_predict_csv(dev, None))
+        print(json.dumps({'leg': a.leg, **r}))
+        return
     from nisqa_amd.engine import HipNisqa
     margs, sd, wdesc = model_weights()
     eng = HipNisqa(margs, sd, dev, precision=a.precision)
@@ -409,31 +622,49 @@ def main():
             'kernels': kern_tab,
         }
         if world == 1 and not a.no_extras:
-            # the other precision path on the same workload (secondary measurement, outside the timed region)
+            # the other precision path on the same workload: same --steps / --warmup, same barriers, right after the
+            # primary region.  For the default run this is the exact-fp32 path -- the reference's own arithmetic.
             other = 'f32' if eng.precision == 'bf16x3' else 'bf16x3'
             eng2 = HipNisqa(margs, sd, dev, precision=other)
-            for _ in range(2):
+            for _ in range(max(2, a.warmup)):
                 o2 = eng2.forward_pcm(pcm, plan, SR)
             torch.cuda.synchronize()
-            n2 = max(5, a.steps // 2)
-            ev2 = []
-            for _ in range(n2):
-                e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
-                for x in e:
-                    x.record()
-                ev2.append(e)
+            ev2 = _stage_events(a.steps)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for s in range(n2):
-                o2 = eng2.forward_pcm(pcm, plan, SR, stage_events=ev2[s])
+            for s_ in range(a.steps):
+                o2 = eng2.forward_pcm(pcm, plan, SR, stage_events=ev2[s_])
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t1
-            ms2 = float(np.mean([ev2[s][1].elapsed_time(ev2[s][2]) for s in range(n2)]))
-            r2 = roofline_of(other, ms2)
-            res['alt_precision'] = {'precision': other, 'value': round(BATCH * n2 / dt2, 2), 'unit': 'clips/s',
-                                    'steps': n2, 'roofline_frac': r2['frac'], 'roofline_achieved': r2['achieved'],
-                                    'roofline_peak': r2['peak'],
-                                    'max_abs_diff_vs_primary': float((o2 - outs[-1]).abs().max())}
+            st2 = {n: float(np.mean([ev2[s_][i].elapsed_time(ev2[s_][i + 1]) for s_ in range(a.steps)])) for i, n in enumerate(names)}
+            r2 = roofline_of(other, st2['cnn_front'])
+            res['value_' + other] = round(BATCH * a.steps / dt2, 2)
+            res[other] = {'precision': other, 'value': round(BATCH * a.steps / dt2, 2), 'unit': 'clips/s', 'steps': a.steps,
+                          'warmup': max(2, a.warmup), 'ms_per_step': round(1e3 * dt2 / a.steps, 4),
+                          'stage_ms': {k: round(v, 4) for k, v in st2.items()}, 'roofline': r2,
+                          'max_abs_diff_vs_primary': float((o2 - outs[-1]).abs().max())}
+            if other == 'f32':
+                trb, mub = pmc_derived(pmc.get('cnn_back_kernel'))
+                achb = FLOP_CONV5_6 * BATCH / (st2['cnn_back'] * 1e-3) / 1e12
+                res[other]['roofline_cnn_back'] = {'kernel': 'cnn_back_kernel (conv5-6, fp32 MFMA)', 'bound': 'mfma', 'achieved': round(achb, 2),
+                                                   'peak': PEAK_F32, 'unit': 'TFLOP/s', 'frac': round(achb / PEAK_F32, 4),
+                                                   'traffic': trb, 'mfma_util': mub, 'avg_launch_ms': round(st2['cnn_back'], 4)}
+            # the primary path once more over a run long enough for the clocks to settle (a 20-step region is 16 ms)
+            n3 = max(400, a.steps)
+            for _ in range(50):
+                eng.forward_pcm(pcm, plan, SR)
+            torch.cuda.synchronize()
+            ev3 = _stage_events(n3)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for s_ in range(n3):
+                eng.forward_pcm(pcm, plan, SR, stage_events=ev3[s_])
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t1
+            st3 = {n: float(np.mean([ev3[s_][i].elapsed_time(ev3[s_][i + 1]) for s_ in range(n3)])) for i, n in enumerate(names)}
+            res['steady'] = {'value': round(BATCH * n3 / dt3, 2), 'unit': 'clips/s', 'steps': n3, 'warmup': 50,
+                             'ms_per_step': round(1e3 * dt3 / n3, 4), 'stage_ms': {k: round(v, 4) for k, v in st3.items()},
+                             'roofline_frac': roofline_of(eng.precision, st3['cnn_front'])['frac']}
         if world == 1 and len(streams) == 1 and not a.no_extras:
             # same steps alternated over 3 streams (what the predict loop does with 2): launches and copies overlap
             st3 = [torch.cuda.Stream(device=dev) for _ in range(3)]
@@ -449,6 +680,18 @@ def main():
             res['overlap_3_streams'] = {'value': round(BATCH * a.steps / (time.perf_counter() - t1), 2), 'unit': 'clips/s'}
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(margs, sd)
+        if world == 1 and a.leg == 'all' and not a.no_side and not a.no_extras:
+            # BASELINE.json configs[2], [3], [4]: bounded side legs (a failure in one must not cost the contract line)
+            res['side'] = {}
+            for name, fn in (('tts_mixed', lambda: side_tts(dev, 3, not a.no_cpu_baseline, pmc)),
+                             ('train_step', lambda: side_train(dev, 10, not a.no_cpu_baseline, pmc)),
+                             ('predict_csv_1gpu', lambda: side_predict_csv(dev, res.get('cpu_baseline')))):
+                t_leg = time.perf_counter()
+                try:
+                    res['side'][name] = fn()
+                except Exception as e:                       # noqa: BLE001
+                    res['side'][name] = {'error': '%s: %s' % (type(e).__name__, e)}
+                res['side'][name]['leg_seconds'] = round(time.perf_counter() - t_leg, 1)
         print(json.dumps(res))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -419,6 +419,116 @@ def test_tts_drop_in_surface(tmp_path):
         assert abs(row['mos_pred'] - ref[0]) < 1e-3
 
 
+def test_tts_drop_in_surface_real_weights_at_default_flags(tmp_path):
+    """nisqa_tts.tar itself through run_predict.py's defaults (--bs 1 --num_workers 0): the loop coalesces the files into
+    length-sorted batches; every row vs the oracle on the same WAV file."""
+    from nisqa_amd.NISQA_model import nisqaModel
+    path = helpers.find_weights('nisqa_tts.tar')
+    if path is None:
+        pytest.skip('real checkpoint not on this machine')
+    ck_args, sd = helpers.load_checkpoint(path)
+    d = tmp_path / 'wavs'
+    d.mkdir()
+    durs = np.random.default_rng(11).uniform(0.5, 4.0, 9)
+    for i, du in enumerate(durs):
+        synth.write_wav(str(d / ('t%d.wav' % i)), synth.synth_pcm16(170 + i, float(du)), 48000)
+    a = {'mode': 'predict_dir', 'pretrained_model': path, 'deg': None, 'data_dir': str(d), 'output_dir': None,
+         'csv_file': None, 'csv_deg': None, 'num_workers': 0, 'bs': 1, 'ms_channel': None, 'tr_bs_val': 1,
+         'tr_num_workers': 0}
+    m = nisqaModel(a)
+    df = m.predict()
+    assert list(df.columns) == ['deg', 'mos_pred'] and len(df) == 9
+    for _, row in df.iterrows():
+        spec = omel.get_melspec(str(d / row['deg']), None, 4096, 0.01, 0.02, 48, m.args['ms_fmax'])
+        ref = onet.predict_from_melspec(sd, m.args, spec)
+        assert abs(row['mos_pred'] - ref[0]) < 1e-3, (row['deg'], row['mos_pred'], ref)
+
+
+def test_predict_csv_through_nisqa_model_default_flags_vs_explicit_batches(tmp_path, monkeypatch):
+    """predict_csv mode of the drop-in surface on the GPU (the CPU plumbing test uses a test double): 40 files of mixed
+    length in shuffled CSV order at the reference's default flags (--bs 1 --num_workers 0 -> work-sized, length-sorted
+    batches) against (i) the oracle on sampled rows, (ii) the same call with the reference's exact batches
+    (NISQA_EXACT_BS=1, --bs 7): rows must agree to batch-composition independence (<= 1e-5) and stay in CSV order."""
+    import pandas as pd
+    from nisqa_amd import NISQA_lib as NL
+    from nisqa_amd.NISQA_model import nisqaModel
+    args = dict(helpers.DIM_ARGS)
+    args.update({'pretrained_model': False, 'tr_bs_val': 1, 'tr_num_workers': 0})
+    sd = helpers.random_state_dict(7)
+    path = str(tmp_path / 'rand.tar')
+    torch.save({'args': args, 'model_state_dict': sd}, path)
+    rng = np.random.default_rng(21)
+    durs = rng.uniform(0.3, 6.0, 40)
+    for i, du in enumerate(durs):
+        synth.write_wav(str(tmp_path / ('f%02d.wav' % i)), synth.synth_pcm16(300 + i, float(du)), 48000)
+    order = rng.permutation(40)
+    pd.DataFrame({'wav': ['f%02d.wav' % i for i in order], 'tag': list(range(40))}).to_csv(tmp_path / 'l.csv', index=False)
+    a = {'mode': 'predict_csv', 'pretrained_model': path, 'deg': None, 'data_dir': str(tmp_path), 'output_dir': None,
+         'csv_file': 'l.csv', 'csv_deg': 'wav', 'num_workers': 0, 'bs': 1, 'ms_channel': None, 'tr_bs_val': 1, 'tr_num_workers': 0}
+    monkeypatch.setattr(NL, 'MIN_TOKENS_SA', 900)                    # several batches out of 40 short files
+    df = nisqaModel(a).predict()
+    cols = ['mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred']
+    assert list(df['wav']) == ['f%02d.wav' % i for i in order] and list(df['tag']) == list(range(40))
+    for row in (0, 7, 19, 39):
+        spec = omel.get_melspec(str(tmp_path / df['wav'].iloc[row]), None, 4096, 0.01, 0.02, 48, 20000)
+        ref = onet.predict_from_melspec(sd, args, spec)
+        assert np.abs(df[cols].iloc[row].to_numpy(dtype=np.float32) - ref).max() < 1e-3
+    monkeypatch.setenv('NISQA_EXACT_BS', '1')
+    df2 = nisqaModel(dict(a, bs=7, tr_bs_val=7, num_workers=2, tr_num_workers=2)).predict()
+    assert np.abs(df[cols].to_numpy() - df2[cols].to_numpy()).max() < 1e-5
+
+
+def test_gather_rows_over_rccl_world_1_and_world_2_on_one_device(tmp_path):
+    """dist.gather_rows with backend "nccl" (= RCCL): the branch a multi-GPU node takes.  World 1 in this process; world 2
+    as two processes sharing this one GPU (RCCL refuses two ranks on one device in some builds: then the world-2 half is
+    reported as skipped, the world-1 half still ran the nccl process group)."""
+    import subprocess
+    import sys
+    code = """
+import os, sys, numpy as np, torch
+sys.path.insert(0, %r)
+from nisqa_amd import dist
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(0)
+torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', 0))
+n = 11
+lo, hi = dist.shard_range(n)
+local = (np.arange(lo, hi, dtype=np.float32)[:, None] * 10 + np.arange(5, dtype=np.float32)[None, :])
+if world == 1:                                    # gather_rows short-circuits at world 1: drive the collective itself
+    t = torch.from_numpy(local).cuda()
+    parts = [torch.empty_like(t)]
+    torch.distributed.all_gather(parts, t)
+    full = parts[0].cpu().numpy()
+else:
+    full = dist.gather_rows(local, n, lo, hi, 'cuda:0')
+want = np.arange(n, dtype=np.float32)[:, None] * 10 + np.arange(5, dtype=np.float32)[None, :]
+assert full.shape == want.shape and (full == want).all(), full
+t = torch.ones(4, device='cuda') * (rank + 1)
+dist.all_reduce_sum_(t)
+assert float(t[0]) == sum(range(1, world + 1))
+torch.distributed.destroy_process_group()
+print('RCCL_OK', rank, world)
+""" % helpers.ROOT
+    script = tmp_path / 'rccl_probe.py'
+    script.write_text(code)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29731', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, str(script)], env=dict(env, RANK='0', WORLD_SIZE='1'), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'RCCL_OK 0 1' in r.stdout, r.stdout + r.stderr
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(k), WORLD_SIZE='2', MASTER_PORT='29732'),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for k in range(2)]
+    outs = []
+    for p_ in procs:
+        try:
+            outs.append(p_.communicate(timeout=240)[0])
+        except subprocess.TimeoutExpired:
+            p_.kill()
+            outs.append(p_.communicate()[0] + '\nTIMEOUT')
+    if all(p_.returncode == 0 for p_ in procs):
+        assert 'RCCL_OK 0 2' in outs[0] and 'RCCL_OK 1 2' in outs[1]
+    else:
+        pytest.skip('RCCL world 2 on ONE device not possible here (world 1 over the nccl backend passed): ' + outs[0][-300:])
+
+
 # ---- BASELINE configurations at their own sizes vs fixtures of the reference's modules (make_golden_configs.py) ----
 def _dim_set(name):
     if name == 'dim_real':
