@@ -90,7 +90,8 @@ extern "C" int nisqa_debug_phase_clock(unsigned long long* out16, int reset) {
 #endif
 
 // SEGX: the input is the reference's segment tensor x[B][L][1][48][15] (inner-operator mode) instead of the spectrogram
-template <bool SEGX>
+// P3: also write the pooled conv4 output as fp32 (debug / parity callers of nisqa_cnn_adapt_bf16 that pass p3_opt)
+template <bool SEGX, bool P3>
 __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
@@ -165,15 +166,10 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                 ob[u] = pb + ((j0 + 1) * 50 + m + 1) * 2;
             }
 #pragma unroll
-            for (int q = 0; q < 12; ++q) {
-                const float v = valid ? fmaxf(vraw[q], fl) : 0.f;
-                const unsigned hi = cvt_pk_bf16(v, 0.f);
-                const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
-                const unsigned a = ob[q % 3] + (q + q / 3) * 100;
-                if (q < 11 || lane < 16) {
-                    lds_st16(a, hi);
-                    lds_st16(a + FB_PPLANE, lo);
-                }
+            for (int q = 0; q < 12; q += 2) {
+                const float v0 = valid ? fmaxf(vraw[q], fl) : 0.f, v1 = valid ? fmaxf(vraw[q + 1], fl) : 0.f;
+                lds_store_split2(ob[q % 3] + (q + q / 3) * 100, ob[(q + 1) % 3] + (q + 1 + (q + 1) / 3) * 100, FB_PPLANE, v0, v1,
+                                 true, q + 1 < 11 || lane < 16);
             }
         } else {
 #pragma unroll
@@ -249,11 +245,15 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 #pragma unroll
             for (int kk = 0; kk < 7; ++kk)                 // (lanes ^ 16 on the LDS pipe; v_permlane16_swap costs ~20 VALU cycles)
                 got[kk] = (unsigned)__builtin_amdgcn_ds_swizzle((int)((r[2 * kk] & mb) | (r[2 * kk + 1] & ~mb)), 0x401F);
+            float fin[7];
 #pragma unroll
             for (int kk = 0; kk < 7; ++kk) {
                 const unsigned own = (r[2 * kk + 1] & mb) | (r[2 * kk] & ~mb);
-                lds_store_split(wr + 2 * kk * FB_RS1, FB_P1, __uint_as_float(max(own, got[kk])));
+                fin[kk] = __uint_as_float(max(own, got[kk]));
             }
+#pragma unroll
+            for (int kk = 0; kk < 6; kk += 2) lds_store_split2(wr + 2 * kk * FB_RS1, wr + 2 * (kk + 1) * FB_RS1, FB_P1, fin[kk], fin[kk + 1]);
+            lds_store_split(wr + 12 * FB_RS1, FB_P1, fin[6]);
             rd_a += 8; rd_b += 8;                          // mel m0 = 2 gl, gl = 12 hfi + 2 g2 + tt
             wr += 14 * FB_RS1;
         }
@@ -275,12 +275,13 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         }
         conv_k_bf16<16, 6, 1, 7, FB_RS1, FB_P1, FB_ZADDR, false, NQ_RING2>(acc, wrs, CNNB_W2 * 2, lane16, base, m9);
         NQ_CLK(3);
-        const float tn = tn2;
         const unsigned wr = R + (6 * hf * 5) * FB_RS2 + n * 2;
 #pragma unroll
-        for (int gl = 0; gl < 6; ++gl)
+        for (int k2 = 0; k2 < 30; k2 += 2) {              // pooled pixel k = gl * 5 + bb, two per packed split
+            float pv[2];
 #pragma unroll
-            for (int bb = 0; bb < 5; ++bb) {
+            for (int e = 0; e < 2; ++e) {
+                const int gl = (k2 + e) / 5, bb = (k2 + e) % 5;
                 float mx = -3.0e38f;
 #pragma unroll
                 for (int yy = 0; yy < 2; ++yy)
@@ -289,8 +290,10 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                         const int u = 14 * gl + 7 * yy + x;
                         mx = fmaxf(mx, acc[u >> 4][0][u & 15]);
                     }
-                lds_store_split(wr + (gl * 5 + bb) * FB_RS2, FB_P2, fmaxf(mx + tn, 0.f));
+                pv[e] = fmaxf(mx + tn2, 0.f);
             }
+            lds_store_split2(wr + k2 * FB_RS2, wr + (k2 + 1) * FB_RS2, FB_P2, pv[0], pv[1]);
+        }
     }
 
     NQ_CLK(4);
@@ -318,19 +321,16 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         NQ_CLK(5);
         const unsigned wr = R + (6 * hf * 5) * FB_RS3 + n * 2;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const float tn = tn3[nt];
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int u = 16 * t + r;
-                    if (u < 30) {
-                        const int gl = u / 10, w = u % 10, yy = w / 5, x = w - 5 * yy;
-                        lds_store_split(wr + ((2 * gl + yy) * 5 + x) * FB_RS3 + 64 * nt, FB_P3, fmaxf(acc[t][nt][r] + tn, 0.f));
-                    }
+                for (int r = 0; r < 16; r += 2) {
+                    const int u = 16 * t + r;                  // rows u, u + 1: pixel (2 gl + yy) * 5 + x = u (same order)
+                    if (u < 30)
+                        lds_store_split2(wr + u * FB_RS3 + 64 * nt, wr + (u + 1) * FB_RS3 + 64 * nt, FB_P3,
+                                         fmaxf(acc[t][nt][r] + tn3[nt], 0.f), fmaxf(acc[t][nt][r + 1] + tn3[nt], 0.f));
                 }
-        }
     }
 
     // ---- conv4 64->64 on 12x5, pool -> 6x3.  The pooled outputs of the workgroup's four segments go to a
@@ -359,14 +359,14 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         for (int g = 0; g < 3; ++g) { b5[g][0] = wfrag_load(wrs, lane16, w5b + g * 2048); b5[g][1] = wfrag_load(wrs, lane16, w5b + g * 2048 + 1024); }
         NQ_SYNC();                   // every wave has consumed its A3: the regions may be re-used
         const unsigned wr = S4 + (18 * wave + 9 * hf) * FB_RS3 + n * 2;
-        float* dst = p3 ? p3 + (size_t)p * (18 * 64) : nullptr;
+        float* dst = P3 ? p3 + (size_t)p * (18 * 64) : nullptr;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const float tn = tn4[nt];
+        for (int gl = 0; gl < 3; ++gl)
 #pragma unroll
-            for (int gl = 0; gl < 3; ++gl)
+            for (int bb = 0; bb < 3; ++bb) {
+                float pv[2];                                // the pooled pixel's channels n and n + 32
 #pragma unroll
-                for (int bb = 0; bb < 3; ++bb) {
+                for (int nt = 0; nt < 2; ++nt) {
                     float mx = -3.0e38f;
 #pragma unroll
                     for (int yy = 0; yy < 2; ++yy)
@@ -375,11 +375,11 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
                             const int u = 10 * gl + 5 * yy + x;
                             mx = fmaxf(mx, acc[u >> 4][nt][u & 15]);
                         }
-                    const float v = fmaxf(mx + tn, 0.f);
-                    if (dst && valid) dst[((3 * hf + gl) * 3 + bb) * 64 + n + 32 * nt] = v;   // optional fp32 copy (debug / parity)
-                    lds_store_split(wr + (gl * 3 + bb) * FB_RS3 + 64 * nt, FB_PS, v);
+                    pv[nt] = fmaxf(mx + tn4[nt], 0.f);
+                    if (P3 && valid) dst[((3 * hf + gl) * 3 + bb) * 64 + n + 32 * nt] = pv[nt];   // optional fp32 copy (debug / parity)
                 }
-        }
+                lds_store_split2(wr + (gl * 3 + bb) * FB_RS3, wr + (gl * 3 + bb) * FB_RS3 + 64, FB_PS, pv[0], pv[1]);
+            }
     }
     NQ_SYNC();
     NQ_CLK(8);
@@ -436,14 +436,14 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 #pragma unroll
         for (int g = 0; g < 7; ++g) { b6[g][0] = wfrag_load(wrs, lane16, w6b + g * 2048); b6[g][1] = wfrag_load(wrs, lane16, w6b + g * 2048 + 1024); }
         {
-            const float tn = tn5;
             const unsigned wr = S5 + (4 * kg) * FB_RS3 + ch * 2;
 #pragma unroll
             for (int t = 0; t < 5; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (t < 4 || kg * 4 + r < 8)               // rho = 16 t + 4 kg + r < 72
-                        lds_store_split(wr + (16 * t + r) * FB_RS3, FB_PS, fmaxf(acc5[t][r] + tn, 0.f));
+                for (int r = 0; r < 4; r += 2)
+                    if (t < 4 || kg < 2)                       // rho = 16 t + 4 kg + r < 72
+                        lds_store_split2(wr + (16 * t + r) * FB_RS3, wr + (16 * t + r + 1) * FB_RS3, FB_PS,
+                                         fmaxf(acc5[t][r] + tn5, 0.f), fmaxf(acc5[t][r + 1] + tn5, 0.f));
         }
         NQ_SYNC();
         NQ_CLK(10);
@@ -504,14 +504,13 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
         // this wave's 4 x 96 outputs (slot, channel * 6 + y) go through S4 (dead since the barrier above) so that the
         // feature rows leave as 16-byte stores: 384 contiguous bytes per slot
         const unsigned fo = S4 + wave * 2048;
-        const float tn = tn6;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rho = 16 * t + 4 * kg + r;
                 const int slot = rho / 6, y = rho - 6 * slot;
-                if (rho < 24) lds_st32(fo + (slot * 96 + i16 * 6 + y) * 4, __float_as_uint(fmaxf(acc6[t][r] + acc6b[t][r] + tn, 0.f)));
+                if (rho < 24) lds_st32(fo + (slot * 96 + i16 * 6 + y) * 4, __float_as_uint(fmaxf(acc6[t][r] + acc6b[t][r] + tn6, 0.f)));
             }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -542,9 +541,14 @@ extern "C" int nisqa_cnn_adapt_bf16(const float* mel_tm, const int32_t* frame_of
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat)
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(cnn_front_bf16_kernel<false>, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
-                       mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat,
-                       (const float*)nullptr, 0, (const uint32_t*)nullptr, 0.f);
+    if (p3_opt)
+        hipLaunchKernelGGL((cnn_front_bf16_kernel<false, true>), dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
+                           mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat,
+                           (const float*)nullptr, 0, (const uint32_t*)nullptr, 0.f);
+    else
+        hipLaunchKernelGGL((cnn_front_bf16_kernel<false, false>), dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
+                           mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat,
+                           (const float*)nullptr, 0, (const uint32_t*)nullptr, 0.f);
     return NQ_LAUNCH_STATUS();
 }
 
@@ -556,7 +560,7 @@ int nq_cnn_adapt_bf16_from_max(const float* mel_tm, const int32_t* frame_off, co
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat || !clip_max_enc)
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(cnn_front_bf16_kernel<false>, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL((cnn_front_bf16_kernel<false, false>), dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
                        mel_tm, frame_off, tok_off, n_wins, (const float*)nullptr, n_clips, seg_hop, cnn_w, cnn_wb,
                        (float*)nullptr, feat, (const float*)nullptr, 0, clip_max_enc, top_db);
     return NQ_LAUNCH_STATUS();
@@ -568,7 +572,7 @@ extern "C" int nisqa_cnn_adapt_segments_bf16(const float* x, int32_t seg_len_pad
     if (!x || seg_len_padded <= 0 || n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || !cnn_wb || !feat)
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(cnn_front_bf16_kernel<true>, dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
+    hipLaunchKernelGGL((cnn_front_bf16_kernel<true, false>), dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
                        (const float*)nullptr, (const int32_t*)nullptr, tok_off, n_wins, (const float*)nullptr, n_clips, 1,
                        cnn_w, cnn_wb, (float*)nullptr, feat, x, seg_len_padded, (const uint32_t*)nullptr, 0.f);
     return NQ_LAUNCH_STATUS();

@@ -143,6 +143,17 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
 // through a buffer resource (address = SGPR descriptor + constant lane offset + immediate).  DESIGN.md 4.5.
 // ======================================================================================================================
 #define NQ_AS3 __attribute__((address_space(3)))
+// Scheduling fences (experiment -DNQ_SB=1|3, DESIGN.md 4.5 "round 3"): hipcc's machine scheduler sinks the ring's
+// prefetches to just before their use (register-pressure heuristics: the ISA shows s_waitcnt vmcnt(1) two MFMAs behind a
+// request).  sched_barrier(0) is a wall no instruction is moved across; with one per K-step (bit 1) and one behind the
+// step's requests (bit 2) the loop comes out exactly as written (requests for step g + 2 / g + 1 first, waits of
+// vmcnt(10) / lgkmcnt(7), no stall on either).  Measured 0.401 ms against 0.391 without: the waves are not short of
+// prefetch distance, the other wave of the SIMD fills those stalls; left off.
+#ifndef NQ_SB
+#define NQ_SB 0
+#endif
+#define NQ_STEP_FENCE() do { if (NQ_SB & 1) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define NQ_ISSUE_FENCE() do { if (NQ_SB & 2) __builtin_amdgcn_sched_barrier(0); } while (0)
 #ifndef NQ_KO
 #define NQ_KO 0
 #endif
@@ -172,6 +183,23 @@ NQ_DEV void lds_store_split(unsigned a, int plane, float v) {
     lds_st16(a, hi);
     lds_st16(a + plane, lo);
 }
+// two values at once: ONE v_cvt_pk_bf16_f32 per plane for the pair, the residual as a packed subtraction, the halves of the
+// packed results stored with ds_write_b16 / ds_write_b16_d16_hi (2.5 VALU instructions per value instead of 4; the bits are
+// those of lds_store_split)
+NQ_DEV void lds_st16_hi(unsigned a, unsigned v) { *(NQ_AS3 unsigned short*)(a) = (unsigned short)(v >> 16); }
+NQ_DEV void lds_store_split2(unsigned a0, unsigned a1, int plane, float v0, float v1, bool st0 = true, bool st1 = true) {
+#ifdef NQ_KO
+    if (NQ_KO & (4 | 64 | 128)) { if (st0) lds_store_split(a0, plane, v0); if (st1) lds_store_split(a1, plane, v1); return; }
+#endif
+    const unsigned hi2 = cvt_pk_bf16(v0, v1);
+    const f32x2_t vv = {v0, v1};
+    const f32x2_t hf = {__uint_as_float(hi2 << 16), __uint_as_float(hi2 & 0xffff0000u)};
+    const f32x2_t r = vv - hf;
+    const unsigned lo2 = cvt_pk_bf16(r[0], r[1]);
+    if (st0) { lds_st16(a0, hi2); lds_st16(a0 + plane, lo2); }
+    if (st1) { lds_st16_hi(a1, hi2); lds_st16_hi(a1 + plane, lo2); }
+}
+NQ_DEV f32x16 splat16(float v) { f32x16 r; for (int q = 0; q < 16; ++q) r[q] = v; return r; }
 typedef int nq_i32x4 __attribute__((ext_vector_type(4)));
 // NQ_KO: knock-out bits for timing experiments (results are WRONG): 32 weight fragments read from LDS instead, 1 no weight loads, 2 no A-operand LDS reads,
 // 4 no epilogue LDS stores, 8 no MFMAs, 16 no workgroup barriers, 64 no hi/lo split and no plane stores, 128 hi plane only.
@@ -237,8 +265,10 @@ NQ_DEV void conv_k_bf16(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int 
     if (APF) load_a(0, 0);
 #pragma unroll
     for (int g = 0; g < TOTAL; ++g) {
+        NQ_STEP_FENCE();
         if (g + RING - 1 < TOTAL) load_b(g + RING - 1, (g + RING - 1) % RING);
         if (APF) { if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1); } else load_a(g, 0);
+        NQ_ISSUE_FENCE();
         const int sa = APF ? (g & 1) : 0, sb = g % RING;
         // product-major: consecutive MFMAs go to DIFFERENT accumulators (no dependent-accumulate bubbles)
 #pragma unroll

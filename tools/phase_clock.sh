@@ -1,11 +1,13 @@
 #!/bin/bash
-# Builds ab_libs/clock.so: the library with -DNQ_PHASE_CLOCK (clock64 stamps inside cnn_front_bf16_kernel).
+# Builds ab_libs/NAME.so (default clock): the library with -DNQ_PHASE_CLOCK (clock64 stamps inside cnn_front_bf16_kernel)
+# plus optional experiment flags:  tools/phase_clock.sh [NAME] ["-DNQ_KO=4 ..."]
 set -e
+NAME=${1:-clock}; FLAGS=$2
 cd "$(dirname "$0")/../nisqa_amd/csrc"
-mkdir -p ../../ab_libs /tmp/nq_clock
+mkdir -p ../../ab_libs /tmp/nq_$NAME
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-strict-aliasing -I../../include"
-for s in api mel cnn cnn_bf16 cnn_std cnn_std_bf16 lstm td td_bf16 train; do
-  if [ $s = cnn_bf16 ]; then /opt/rocm/bin/hipcc $F -DNQ_PHASE_CLOCK -c $s.hip -o /tmp/nq_clock/$s.o; else cp $s.o /tmp/nq_clock/$s.o; fi
+for s in api mel cnn cnn_bf16 cnn_std cnn_std_bf16 lstm td td_bf16 train probe; do
+  if [ $s = cnn_bf16 ]; then /opt/rocm/bin/hipcc $F -DNQ_PHASE_CLOCK $FLAGS -c $s.hip -o /tmp/nq_$NAME/$s.o; else cp $s.o /tmp/nq_$NAME/$s.o; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab_libs/clock.so /tmp/nq_clock/*.o
-ls -la ../../ab_libs/clock.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab_libs/$NAME.so /tmp/nq_$NAME/*.o
+ls -la ../../ab_libs/$NAME.so
