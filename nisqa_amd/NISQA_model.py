@@ -19,17 +19,26 @@ from . import NISQA_lib as NL
 
 
 def _load_checkpoint(path):
-    """torch.load(path) like the reference (NISQA_model.py:933-939), but through torch's restricted unpickler first: the
-    shipped checkpoints hold tensors, plain containers and one datetime in ``args`` -- allow-listed here.  Only when that
-    fails (a checkpoint with other pickled objects) does it fall back to the full unpickle, with a warning: a .tar from an
-    untrusted source can then run arbitrary code, exactly as with the reference."""
+    """torch.load(path) like the reference (NISQA_model.py:933-939), but through torch's restricted unpickler: the shipped
+    checkpoints hold tensors, plain containers and one datetime in ``args`` -- allow-listed here.  A checkpoint that
+    needs more than that (arbitrary pickled objects, i.e. code that runs at load time) is REFUSED unless the caller opts
+    in with NISQA_ALLOW_UNSAFE_CHECKPOINT=1 -- then it is loaded exactly as the reference does.  Missing / unreadable /
+    corrupt files raise what torch.load raises."""
     import datetime
+    import pickle
     try:
         with torch.serialization.safe_globals([datetime.datetime]):
             return torch.load(path, map_location='cpu', weights_only=True)
-    except Exception as e:                                      # noqa: BLE001 -- any unpickling refusal
-        print('nisqa_amd: {} needs the full (unsafe) unpickler: {}'.format(os.path.basename(path), str(e).split('\n')[0][:120]))
-        return torch.load(path, map_location='cpu', weights_only=False)
+    except pickle.UnpicklingError as e:                          # the restricted unpickler's refusal, nothing else
+        why = str(e).split('\n')[0][:160]
+        if os.environ.get('NISQA_ALLOW_UNSAFE_CHECKPOINT') == '1':
+            print('nisqa_amd: {} needs the full (unsafe) unpickler, allowed by NISQA_ALLOW_UNSAFE_CHECKPOINT=1: {}'.format(
+                os.path.basename(path), why))
+            return torch.load(path, map_location='cpu', weights_only=False)
+        raise RuntimeError(
+            'nisqa_amd: {} holds pickled objects beyond tensors and plain containers ({}); loading it would run code from '
+            'the file.  Set NISQA_ALLOW_UNSAFE_CHECKPOINT=1 to load it the way the reference does (torch.load, full '
+            'unpickler) if you trust its source.'.format(path, why)) from e
 
 
 def _fast_frame_lines(df, widest=None):

@@ -726,6 +726,19 @@ def test_no_kernel_contains_the_packed_f32_op_sel_form_gfx950_misreads():
     assert not bad_form.search('v_pk_add_f32 v[0:1], v[4:5], v[2:3] op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]')
 
 
+def test_shipped_library_passes_the_isa_lint():
+    """the lint also runs on the ARTIFACT (llvm-objdump of every gfx950 code object inside libnisqa_hip.so),
+    at build time (csrc/Makefile) and here -- whatever flags or compiler version produced the library that ships."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import isa_lint
+    from nisqa_amd import lib
+    if not os.path.isfile(os.path.join(isa_lint.LLVM, 'llvm-objdump')):
+        pytest.skip('llvm-objdump not on this machine')
+    n_obj, n_pk, bad = isa_lint.scan_library(lib.LIB_PATH)
+    assert n_obj >= 10 and n_pk > 1000 and not bad, (n_obj, n_pk, bad[:2])
+    assert isa_lint.BAD.search('v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,0]')
+
+
 def test_frame_to_string_equals_pandas_to_string():
     """predict() prints df.to_string(index=False) like the reference (NISQA_model.py:79); the fast formatter must give
     the same text, character for character, and must fall back to pandas for frames it does not cover."""
@@ -908,3 +921,26 @@ def test_probe_errors_surface_as_the_reference_value_error(tmp_path):
     m.model._engine = FakeEngine(5)
     with pytest.raises(ValueError, match='Could not load file .*bad.wav'):
         m.predict()
+
+
+class _Evil(object):
+    def __reduce__(self):
+        return (print, ('code ran at load time',))
+
+
+def test_checkpoint_with_pickled_objects_is_refused_unless_opted_in(tmp_path, monkeypatch, capsys):
+    """the restricted unpickler is the only path by default; I/O errors are not masked."""
+    from nisqa_amd.NISQA_model import _load_checkpoint
+    good = _ckpt(tmp_path)
+    assert set(_load_checkpoint(good)) == {'args', 'model_state_dict'}
+    bad = str(tmp_path / 'evil.tar')
+    torch.save({'args': {'x': _Evil()}, 'model_state_dict': {}}, bad)
+    monkeypatch.delenv('NISQA_ALLOW_UNSAFE_CHECKPOINT', raising=False)
+    with pytest.raises(RuntimeError, match='NISQA_ALLOW_UNSAFE_CHECKPOINT'):
+        _load_checkpoint(bad)
+    assert 'code ran at load time' not in capsys.readouterr().out
+    with pytest.raises(FileNotFoundError):
+        _load_checkpoint(str(tmp_path / 'missing.tar'))
+    monkeypatch.setenv('NISQA_ALLOW_UNSAFE_CHECKPOINT', '1')
+    ck = _load_checkpoint(bad)
+    assert 'args' in ck and 'code ran at load time' in capsys.readouterr().out
