@@ -225,6 +225,13 @@ class Ingest(object):
         # consumer threads (over-subscribing a quota-limited container stalls the whole loop, see cpu_budget), and -- when
         # the producer pins itself and its native pool to the GPU's NUMA node -- never more than that node offers
         budget = cpu_budget()
+        # one process per GPU (torchrun): the ranks of a node share its CPU quota
+        try:
+            local_world = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1')))
+        except ValueError:
+            local_world = 1
+        if local_world > 1:
+            budget = max(2, budget // local_world)
         self.numa_cpus = set()
         if device is not None and os.environ.get('NISQA_INGEST_NUMA', '1') != '0':
             self.numa_cpus = gpu_local_cpus(device)
@@ -233,7 +240,8 @@ class Ingest(object):
         asked = int(num_workers or 0)
         if asked <= 0 and isinstance(batches, LengthAware):
             asked = budget                      # the reference's default (--num_workers 0): as many readers as the box allows
-        self.workers = max(1, min(asked, budget - 3))
+        # next to the readers run the producer and the consumer thread (mostly blocked in native calls / on events)
+        self.workers = max(1, min(asked, budget - (3 if local_world == 1 else 1)))
         if asked > self.workers:
             _note_once('nisqa_amd.ingest: %d reader threads instead of the %d requested (CPU budget of this process: %d)'
                        % (self.workers, asked, budget))
