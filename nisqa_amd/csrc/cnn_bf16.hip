@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
 #pragma unroll
             for (int q = 0; q < 12; q += 2) {
                 const float v0 = valid ? fmaxf(vraw[q], fl) : 0.f, v1 = valid ? fmaxf(vraw[q + 1], fl) : 0.f;
-                lds_store_split2(ob[q % 3] + (q + q / 3) * 100, ob[(q + 1) % 3] + (q + 1 + (q + 1) / 3) * 100, FB_PPLANE, v0, v1,
+                lds_store_split2<false>(ob[q % 3] + (q + q / 3) * 100, ob[(q + 1) % 3] + (q + 1 + (q + 1) / 3) * 100, FB_PPLANE, v0, v1,
                                  true, q + 1 < 11 || lane < 16);
             }
         } else {

@@ -187,10 +187,19 @@ NQ_DEV void lds_store_split(unsigned a, int plane, float v) {
 // packed results stored with ds_write_b16 / ds_write_b16_d16_hi (2.5 VALU instructions per value instead of 4; the bits are
 // those of lds_store_split)
 NQ_DEV void lds_st16_hi(unsigned a, unsigned v) { *(NQ_AS3 unsigned short*)(a) = (unsigned short)(v >> 16); }
+template <bool KO_DW = true>
 NQ_DEV void lds_store_split2(unsigned a0, unsigned a1, int plane, float v0, float v1, bool st0 = true, bool st1 = true) {
 #ifdef NQ_KO
     if (NQ_KO & (4 | 64 | 128)) { if (st0) lds_store_split(a0, plane, v0); if (st1) lds_store_split(a1, plane, v1); return; }
 #endif
+    if (KO_DW && (NQ_KO & 256)) {          // timing experiment: ONE dword store per value (hi | lo << 16) at 4-byte lane pitch: no sub-dword
+        const unsigned h0 = cvt_pk_bf16(v0, 0.f), h1 = cvt_pk_bf16(v1, 0.f);       // bank conflicts, half the stores; results wrong
+        const unsigned l0 = cvt_pk_bf16(v0 - __uint_as_float(h0 << 16), 0.f), l1 = cvt_pk_bf16(v1 - __uint_as_float(h1 << 16), 0.f);
+        const unsigned dl = (threadIdx.x & 31) * 2 + ((threadIdx.x & 32) ? 32 : 0);
+        if (st0) lds_st32(a0 + dl, h0 | (l0 << 16));
+        if (st1) lds_st32(a1 + dl, h1 | (l1 << 16));
+        return;
+    }
     const unsigned hi2 = cvt_pk_bf16(v0, v1);
     const f32x2_t vv = {v0, v1};
     const f32x2_t hf = {__uint_as_float(hi2 << 16), __uint_as_float(hi2 & 0xffff0000u)};
