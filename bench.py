@@ -377,7 +377,7 @@ def side_tts(dev, reps, cpu_baseline_on, pmc):
                    for bi in range(nb)])                     # [batch][mel, cnn, (unused), lstm + pool]
     cnn_ms, lstm_ms = float(ms[:, 1].sum()), float(ms[:, 3].sum())
     ach = float(segs.sum()) * FLOP_STD_SEG / (cnn_ms * 1e-3) / 1e12
-    tr, mu = pmc_derived(pmc.get('cnn_std_bf16_kernel'))
+    tr, mu = pmc_derived(pmc.get('tts:cnn_std_bf16_kernel'))
     res = {'config': 'configs[3] predict_dir nisqa_tts.tar (Naturalness head), %d clips, durations rng(7).uniform(3, 30) s '
                      '(%.0f s of audio, %d segments at hop 1), int16 PCM resident in HBM, %d length-sorted batches of %s clips '
                      '(NISQA_lib.batch_policy), one stream; weights: %s'

@@ -14,13 +14,19 @@ def main():
     out, dirs = sys.argv[1], sys.argv[2:]
     frames = []
     for d in dirs:
+        prefix = ''
+        if ':=' in d:                                   # "tts:=/tmp/dir": kernels of that pass are filed as "tts:<kernel>"
+            prefix, d = d.split(':=', 1)
+            prefix += ':'
         for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
-            frames.append(pd.read_csv(f))
+            fr = pd.read_csv(f)
+            fr['_prefix'] = prefix
+            frames.append(fr)
     if not frames:
         raise SystemExit('no counter_collection.csv under ' + ' '.join(dirs))
     t = pd.concat(frames)
-    t = t[~t.Kernel_Name.str.contains('at::|rocclr|Cijk|elementwise')]
-    t['k'] = t.Kernel_Name.str.split('(').str[0].str.replace(r'^void ', '', regex=True).str.replace(r'<.*', '', regex=True)
+    t = t[~t.Kernel_Name.str.contains('at::|rocclr|Cijk|vectorized_elementwise')]
+    t['k'] = t['_prefix'] + t.Kernel_Name.str.split('(').str[0].str.replace(r'^void ', '', regex=True).str.replace(r'<.*', '', regex=True)
     g = t.groupby(['k', 'Counter_Name'])['Counter_Value'].mean()
     n = t.groupby(['k', 'Counter_Name'])['Counter_Value'].count()
     kernels = {}
