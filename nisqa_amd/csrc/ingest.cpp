@@ -166,7 +166,8 @@ void probe_one(const char* path, nisqa_wav_info* out) {
                 if (size == 0xFFFFFFFFu || body + dsize > fsize) dsize = fsize - body;
                 const int bytes = (out->bits + 7) / 8;
                 const bool enc_ok = (out->tag == NISQA_WAV_TAG_PCM && (out->bits == 8 || out->bits == 16 || out->bits == 24 || out->bits == 32)) ||
-                                    (out->tag == NISQA_WAV_TAG_FLOAT && (out->bits == 32 || out->bits == 64));
+                                    (out->tag == NISQA_WAV_TAG_FLOAT && (out->bits == 32 || out->bits == 64)) ||
+                                    ((out->tag == NISQA_WAV_TAG_ALAW || out->tag == NISQA_WAV_TAG_MULAW) && out->bits == 8);
                 if (out->channels < 1 || out->block_align != out->channels * bytes || !enc_ok) break;
                 out->data_offset = body;
                 out->n_frames = dsize / out->block_align;

@@ -55,12 +55,16 @@ def edge_clip(kind, sr=48000):
     raise KeyError(kind)
 
 
-def write_wav(path, pcm, sr=48000):
-    """Minimal PCM WAV writer (mono [n] or multi-channel [n, ch], int16/int32/uint8/float32)."""
+def write_wav(path, pcm, sr=48000, g711=None):
+    """Minimal PCM WAV writer (mono [n] or multi-channel [n, ch], int16/int32/uint8/float32); with g711 = 'alaw' /
+    'mulaw' the uint8 array holds G.711 code words (format tags 6 / 7)."""
     import struct
     pcm = np.ascontiguousarray(pcm)
     ch = 1 if pcm.ndim == 1 else pcm.shape[1]
-    if pcm.dtype == np.float32:
+    if g711 is not None:
+        assert pcm.dtype == np.uint8
+        fmt, bits = {'alaw': 6, 'mulaw': 7}[g711], 8
+    elif pcm.dtype == np.float32:
         fmt, bits = 3, 32
     elif pcm.dtype == np.int16:
         fmt, bits = 1, 16

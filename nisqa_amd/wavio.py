@@ -2,7 +2,7 @@
 reference nisqa/NISQA_lib.py:2299-2304, for RIFF/WAVE files, without librosa/soundfile.
 
 soundfile semantics: integer PCM -> float32 scaled by 1/2**(bits-1) (8-bit is unsigned, offset
-128); float WAVs pass through; multi-channel audio is averaged (librosa.to_mono) unless
+128); G.711 A-law / mu-law WAVs expand to their 16-bit table values, then 1/32768; float WAVs pass through; multi-channel audio is averaged (librosa.to_mono) unless
 ``ms_channel`` selects one channel.  The native sample rate is returned (ms_sr=None).
 Mono PCM16 -- the common case -- is returned as int16 so that only 2 bytes/sample cross PCIe; the
 1/32768 scaling then happens on the GPU (nisqa_pcm16_to_f32), bit-identical to the host scaling.
@@ -12,7 +12,25 @@ import struct
 
 import numpy as np
 
-_PCM, _FLOAT, _EXT = 1, 3, 0xFFFE
+_PCM, _FLOAT, _ALAW, _MULAW, _EXT = 1, 3, 6, 7, 0xFFFE
+
+
+def _g711_tables():
+    """G.711 expansion tables (ITU-T G.711; the 16-bit values libsndfile's alaw.c / ulaw.c hold and soundfile then scales
+    by 1/32768 like any 16-bit PCM): mu-law -> +-(((m << 3) + 0x84) << e) - 0x84), A-law -> +-((m << 4) + 8) for e = 0,
+    +-(((m << 4) + 0x108) << (e - 1)) otherwise, on the bit-inverted (mu) / 0x55-toggled (A) code word."""
+    code = np.arange(256, dtype=np.int32)
+    u = ~code & 0xFF
+    mag = ((((u & 0x0F) << 3) + 0x84) << ((u >> 4) & 7)) - 0x84
+    mulaw = np.where(u & 0x80, -mag, mag).astype(np.int16)
+    a = code ^ 0x55
+    e, m = (a >> 4) & 7, a & 0x0F
+    mag = np.where(e == 0, (m << 4) + 8, ((m << 4) + 0x108) << np.maximum(e - 1, 0))
+    alaw = np.where(a & 0x80, mag, -mag).astype(np.int16)
+    return alaw, mulaw
+
+
+_ALAW_TAB, _MULAW_TAB = _g711_tables()
 
 
 class Header(object):
@@ -62,7 +80,8 @@ def probe(path, ms_channel=None):
         (tag, ch, sr, blk, bits), off, size = _walk(fd)
         if ch < 1 or blk != ch * ((bits + 7) // 8):
             raise ValueError('bad block align')
-        if not ((tag == _PCM and bits in (8, 16, 24, 32)) or (tag == _FLOAT and bits in (32, 64))):
+        if not ((tag == _PCM and bits in (8, 16, 24, 32)) or (tag == _FLOAT and bits in (32, 64))
+                or (tag in (_ALAW, _MULAW) and bits == 8)):
             raise ValueError('unsupported WAV encoding tag={} bits={}'.format(tag, bits))
         h = Header()
         h.path, h.fd, h.tag, h.ch, h.sr, h.blk, h.bits = path, fd, tag, ch, int(sr), blk, bits
@@ -99,6 +118,9 @@ def _decode(h, data):
         if ch == 1:
             return x[:, 0]
         y = x.astype(np.float32) / np.float32(32768.0)
+    elif tag in (_ALAW, _MULAW):                   # 8-bit companded -> the 16-bit value of the G.711 table -> / 32768
+        tab = _ALAW_TAB if tag == _ALAW else _MULAW_TAB
+        y = tab[np.frombuffer(data, dtype=np.uint8).reshape(n, ch)].astype(np.float32) / np.float32(32768.0)
     elif tag == _PCM and bits == 8:
         y = (np.frombuffer(data, dtype=np.uint8).reshape(n, ch).astype(np.float32) - np.float32(128.0)) \
             / np.float32(128.0)

@@ -944,3 +944,40 @@ def test_checkpoint_with_pickled_objects_is_refused_unless_opted_in(tmp_path, mo
     monkeypatch.setenv('NISQA_ALLOW_UNSAFE_CHECKPOINT', '1')
     ck = _load_checkpoint(bad)
     assert 'args' in ck and 'code ran at load time' in capsys.readouterr().out
+
+
+@pytest.mark.parametrize('law', ['mulaw', 'alaw'])
+def test_g711_wav_files_load_like_soundfile_would(tmp_path, law):
+    """lb.load reads G.711 A-law / mu-law WAVs through libsndfile: code word -> 16-bit table value -> / 32768.  The table
+    is checked against CPython's audioop (an independent G.711 implementation); the native probe accepts the file and the
+    predict loop stages it as float32 through the host decoder."""
+    import audioop
+    import warnings
+    from nisqa_amd import wavio, lib
+    from nisqa_amd.NISQA_model import nisqaModel
+    rng = np.random.default_rng(5)
+    codes = rng.integers(0, 256, 48000 // 2, dtype=np.uint8)
+    stereo = np.stack([codes, codes[::-1]], 1)
+    synth.write_wav(str(tmp_path / 'm.wav'), codes, 48000, g711=law)
+    synth.write_wav(str(tmp_path / 's.wav'), stereo, 48000, g711=law)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        lin = audioop.ulaw2lin(codes.tobytes(), 2) if law == 'mulaw' else audioop.alaw2lin(codes.tobytes(), 2)
+    want = np.frombuffer(lin, dtype='<i2').astype(np.float32) / np.float32(32768.0)
+    y, sr = wavio.read_wav(str(tmp_path / 'm.wav'))
+    assert sr == 48000 and y.dtype == np.float32 and np.array_equal(y, want)
+    ys, _ = wavio.read_wav(str(tmp_path / 's.wav'))
+    assert np.allclose(ys, 0.5 * (want + want[::-1]), atol=1e-7)
+    y1, _ = wavio.read_wav(str(tmp_path / 's.wav'), ms_channel=1)
+    assert np.array_equal(y1, want[::-1])
+    L = lib.load_ingest()
+    infos = (lib.WavInfo * 1)()
+    paths = (ctypes.c_char_p * 1)(os.fsencode(str(tmp_path / 'm.wav')))
+    assert L.nisqa_ingest_probe(paths, 1, infos, 1) == 0 and infos[0].tag == (7 if law == 'mulaw' else 6) and infos[0].n_frames == len(codes)
+    pd.DataFrame({'name': ['m.wav', 's.wav']}).to_csv(tmp_path / 'l.csv', index=False)
+    m = nisqaModel(_args('predict_csv', _ckpt(tmp_path), data_dir=str(tmp_path), csv_file='l.csv', csv_deg='name'))
+    m.model._engine = FakeEngine(5)
+    df = m.predict()
+    eng = FakeEngine(5)
+    ref = eng.forward_pcm(torch.from_numpy(want), eng.plan([len(want)], 48000), 48000)[0].numpy()
+    assert np.allclose(df.iloc[0][['mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred']].to_numpy(dtype=np.float64), ref, rtol=1e-6)
