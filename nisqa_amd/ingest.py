@@ -207,6 +207,12 @@ class LengthAware(object):
                 cur, cb, ct = [], 0, 0
         if cur:
             out.append(cur)
+        # a small remainder does not get a launch chain of its own when the batch before it can take it (the byte cap is a
+        # staging-buffer size, soft by half): a BiLSTM launch over 7 long clips lasts as long as one over 128 of them
+        if len(out) >= 2 and len(out[-1]) * 2 < need and srs[out[-1][0]] == srs[out[-2][-1]] \
+                and int(nbytes[out[-1]].sum() + nbytes[out[-2]].sum()) <= self.byte_cap + self.byte_cap // 2:
+            tail = out.pop()
+            out[-1] = out[-1] + tail
         return out
 
 

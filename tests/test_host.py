@@ -842,7 +842,9 @@ def test_length_aware_policy_cuts_by_work_and_keeps_every_item_once():
     cuts = ingest.LengthAware(range(300), 40, tok, min_tokens=0).cut(frames, srs, np.full(300, 2))
     assert [len(c) for c in cuts] == [40] * 7 + [20]
     cuts = ingest.LengthAware(range(300), 1, tok, min_tokens=0, min_clips=128).cut(frames, srs, np.full(300, 2))
-    assert [len(c) for c in cuts] == [128, 128, 44]
+    assert [len(c) for c in cuts] == [128, 172]            # a remainder under half a batch rides with the batch before it ...
+    cuts = ingest.LengthAware(range(300), 1, tok, min_tokens=0, min_clips=128, byte_cap=200 << 20).cut(frames, srs, np.full(300, 2))
+    assert [len(c) for c in cuts] == [128, 108, 64] and all(int(frames[c].sum() * 2) <= 200 << 20 for c in cuts)   # ... when it is small and fits
     # rates are kept apart once a batch is big enough, mixed otherwise
     srs2 = np.where(np.arange(300) % 2 == 0, 48000, 16000)
     cuts = ingest.LengthAware(range(300), 150, tok, min_tokens=0).cut(frames, srs2, np.full(300, 2))
