@@ -243,6 +243,9 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
     const int f_end = min(f_begin + frames_per_wave, total_frames);
     if (f_begin >= f_end) return;
     const int start0 = -cfg.n_fft / 2 + (cfg.n_fft - cfg.win) / 2;   // first windowed sample of frame 0
+    // magnitudes are needed for K < n_bins (the last bin any band weights), i.e. plane entries k = K >> 2 < kmax; entries
+    // kmax .. mag_stride - 1 keep whatever finite values they hold (zeros / FFT exchange data) and meet zero weights only
+    const int kmax = (cfg.n_bins + 3) >> 2;
 
     int b = find_segment(frame_off, n_clips, f_begin);
     float runmax = -3.0e38f;
@@ -333,9 +336,10 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
             const int src = (64 - lane) & 63;
 #pragma unroll
             for (int q2 = 0; q2 < 8; ++q2) {
-                c32 zb = shfl_c(u[7 - q2], src);
+                if (64 * q2 >= kmax) continue;             // wave-uniform: bins above fmax are never produced (48 kHz / 20 kHz:
+                c32 zb = shfl_c(u[7 - q2], src);            // q2 = 7 is empty; fmax 8 kHz: q2 >= 3 are)
                 if (lane == 0) zb = u[(8 - q2) & 7];
-                if (lane + 64 * q2 < mag_stride)
+                if (lane + 64 * q2 < kmax)
                     mag[0 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tab_d[0 * 64 + lane], cmk(W16C[q2], W16S[q2]));
             }
             if (lane == 0 && 512 < mag_stride) mag[512] = 2.0f * fabsf(u[0].x - u[0].y);   // Nyquist bin: 2 X[2048] = 2 (Re Z0 - Im Z0)
@@ -347,8 +351,9 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
         fft512<2>(u, z, tw, exch, lane, tab_a);
 #pragma unroll
         for (int q2 = 0; q2 < 8; ++q2) {
+            if (64 * q2 >= kmax) continue;
             const c32 zb = shfl_c(u[7 - q2], mir);
-            if (lane + 64 * q2 < mag_stride)
+            if (lane + 64 * q2 < kmax)
                 mag[1 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tab_d[2 * 64 + lane], cmk(W16C[q2], W16S[q2]));
         }
         MEL_CLK(2);                                   // FFT r = 2 + magnitudes
@@ -360,9 +365,10 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
         MEL_CLK(3);                                   // FFTs r = 1, 3
 #pragma unroll
         for (int q2 = 0; q2 < 8; ++q2) {
+            if (64 * q2 >= kmax) continue;
             const c32 z3m = shfl_c(u[7 - q2], mir), z1m = shfl_c(u1[7 - q2], mir);
             const c32 w16 = cmk(W16C[q2], W16S[q2]);
-            if (lane + 64 * q2 < mag_stride) {
+            if (lane + 64 * q2 < kmax) {
                 mag[2 * mag_stride + lane + 64 * q2] = xmag(u1[q2], z3m, tab_d[1 * 64 + lane], w16);
                 mag[3 * mag_stride + lane + 64 * q2] = xmag(u[q2], z1m, tab_d[3 * 64 + lane], w16);
             }
