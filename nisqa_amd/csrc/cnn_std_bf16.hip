@@ -16,10 +16,18 @@
 #define SS_A1PLANE 6144                    /* 192 px x 16 ch bf16 */
 #define SS_PATCH 12288                     /* conv1 input: three zero-bordered bf16 planes [17][50] behind the A1 planes */
 #define SS_PPLANE 1700
-#define SS_ZERO 17408                      /* 128 B of zeros per wave */
+#define SS_ZERO 17408                      /* 128 B of zeros per wave (the generic-pointer K loops of conv2 / conv5 / conv6) */
 #define SS_WAVE 17536
-#define SS_LDS (4 * SS_WAVE)               /* 70144 B -> two workgroups (8 waves) per CU */
-#define SS_PLANE 6144                      /* S4 / S5: 48 rows x 64 ch bf16 */
+#define SS_ZADDR 2048u                     /* a zero block shared by the workgroup, above the largest tap offset (conv_k_bf16) */
+#define SS_BASE 2176u                      /* first wave region */
+#define SS_LDS (SS_BASE + 4 * SS_WAVE)     /* 72320 B -> two workgroups (8 waves) per CU */
+#define SS_PLANE 6144                      /* S4 / S5: 48 rows x 64 ch bf16, chunk-swizzled */
+/* conv2 -> conv3 -> conv4 activations: pixel rows padded by 16 bytes, NOT swizzled (every address = lane base + immediate) */
+#define SS_RS2 80                          /* A2: 48 px x 32 ch */
+#define SS_P2 (48 * SS_RS2)
+#define SS_RS3 144                         /* A3: 48 px x 64 ch */
+#define SS_P3 (48 * SS_RS3)
+static_assert(2 * SS_P3 <= SS_ZERO && 2 * SS_LDS <= 160 * 1024, "LDS plan");
 
 __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
@@ -36,28 +44,44 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
     if (nvalid <= 0) return;
     const bool valid = wave < nvalid;                    // padding waves still walk the barriers (on zeros)
     const int k = k0 + wave;
-    char* act = smem + wave * SS_WAVE;
+    char* act = smem + SS_BASE + wave * SS_WAVE;
     char* zero = act + SS_ZERO;
 
-    // ---- the 15-frame window as three zero-bordered bf16 planes (hi, mid, lo) [frame j + 1][mel m + 1]
+    // ---- the 15-frame window as three zero-bordered bf16 planes (hi, mid, lo) [frame j + 1][mel m + 1]; all 12 global loads
+    //      of the window are requested up front (one memory latency), the plane addresses are three lane-dependent bases +
+    //      immediates (element i0 = lane + 64 q = (frame, mel) = divmod(i0, 48); q = 3 t + u: frame q + t + (lane + 16 u) / 48)
+    const unsigned R = SS_BASE + (unsigned)wave * SS_WAVE; // this wave's region (the kernel has no static LDS: addresses start at 0)
     {
-        char* pb = act + SS_PATCH;
-        for (int q = lane; q < (3 * SS_PPLANE + 15) / 16; q += 64) *(f32x4*)(pb + q * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (lane < 32) ((float*)zero)[lane] = 0.f;
-        __builtin_amdgcn_wave_barrier();
         const float fl = clip_floor[b];
         const float* src = mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
-        for (int i0 = lane; i0 < 720; i0 += 64) {
-            const int j = i0 / 48, m = i0 - 48 * j;
-            const float v = valid ? fmaxf(src[i0], fl) : 0.f;
+        float vraw[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) vraw[q] = (valid && (q < 11 || lane < 16)) ? src[lane + 64 * q] : 0.f;
+        const unsigned pb = R + SS_PATCH;
+#pragma unroll
+        for (int it = 0; it < 5; ++it)                      // 319 x 16 bytes of zeros (three planes)
+            if (it < 4 || lane < (3 * SS_PPLANE + 15) / 16 - 256) lds_st128(pb + (lane + 64 * it) * 16, f32x4{0.f, 0.f, 0.f, 0.f});
+        if (lane < 32) { ((float*)zero)[lane] = 0.f; ((unsigned*)(smem + SS_ZADDR))[lane] = 0u; }   // (through the dynamic-LDS symbol: see cnn_bf16.hip)
+        __builtin_amdgcn_wave_barrier();
+        unsigned ob[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = lane + 16 * u, j0 = e >= 48 ? 1 : 0, m = e - 48 * j0;
+            ob[u] = pb + ((j0 + 1) * 50 + m + 1) * 2;
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const float v = valid ? fmaxf(vraw[q], fl) : 0.f;
             const unsigned hi = cvt_pk_bf16(v, 0.f);
             const float r1 = v - __uint_as_float(hi << 16);
             const unsigned mid = cvt_pk_bf16(r1, 0.f);
             const unsigned lo = cvt_pk_bf16(r1 - __uint_as_float(mid << 16), 0.f);
-            const int o = ((j + 1) * 50 + (m + 1)) * 2;
-            *(unsigned short*)(pb + o) = (unsigned short)hi;
-            *(unsigned short*)(pb + SS_PPLANE + o) = (unsigned short)mid;
-            *(unsigned short*)(pb + 2 * SS_PPLANE + o) = (unsigned short)lo;
+            const unsigned a = ob[q % 3] + (q + q / 3) * 100;
+            if (q < 11 || lane < 16) {
+                lds_st16(a, hi);
+                lds_st16(a + SS_PPLANE, mid);
+                lds_st16(a + 2 * SS_PPLANE, lo);
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -65,60 +89,76 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
     const int i = lane & 31, hfi = (i >> 2) & 1, qi = (i & 3) + 4 * (i >> 3);
     const int n = lane & 31, hf = lane >> 5, h = lane >> 5;
 
-    // ---- conv1 1->16 on the matrix pipe + MaxPool2d(2, stride 2, padding (0,1)): 48x15 -> 24x8; pooled column
-    //      bb covers conv columns {2bb-1, 2bb} (column -1 is pool padding and is ignored, as -inf would be)
+    // ---- conv1 1->16 on the matrix pipe + MaxPool2d(2, stride 2, padding (0,1)): 48x15 -> 24x8, TWO output pixels per MFMA
+    //      row like cnn_front_bf16_kernel (round 3; before: one pixel per row, k-slots gathered with 48 16-bit LDS reads and 24
+    //      shift-ors per tile pair).  A row = the mel pair (m0, m0 + 1) of one frame; N = 32 = (channel c, pair member dm);
+    //      K = 12 of 16 = (frame tap kx, the four mels m0 - 1 .. m0 + 2 the pair touches): contiguous in the bordered patch, so
+    //      a lane's 8 k-slots are two pairs of dwords per plane.  B[k][n] = w[c][dmm - dm][kx] (weights.py, conv1_pairs).
+    //      The input keeps THREE bf16 terms (six products): the BiLSTM head amplifies input error ten times more than the
+    //      attention head.  Pooled column bb covers frames {2 bb - 1, 2 bb} (column -1 is pool padding): in-lane; the mel
+    //      pair's maximum needs the partner 16 lanes away: lane group dm = 0 finalises the even pooled pixels of an
+    //      iteration, dm = 1 the odd ones (one ds_swizzle per pixel pair); ReLU first, maxima on non-negative floats as uints.
     {
-        const char* pb = act + SS_PATCH;
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
         f32x4 w1[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) w1[t] = *(const f32x4*)(wb + CNNB_W1 + t * 512 + lane * 8);
+        for (int t = 0; t < 3; ++t) w1[t] = wfrag_load(wrs, lane * 16, (CNNB_W1 + t * 512) * 2);
         const float tn = cw[CNN_T1 + (n & 15)];
-        int toff[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) toff[e] = h ? 2 * (2 * 50 + 2) : 2 * ((e % 3) * 50 + e / 3);
-        for (int gl = 0; gl < 12; ++gl) {
+        const int xq = min(qi, 14);                       // row 15 of a tile is padding (result unused)
+        unsigned rd_a = R + SS_PATCH + ((xq + (h ? 2 : 0)) * 50 + 24 * hfi) * 2;
+        unsigned rd_b = R + SS_PATCH + ((xq + (h ? 2 : 1)) * 50 + 24 * hfi) * 2;
+        const bool is_b = (n & 16) != 0;
+        const unsigned mb = is_b ? ~0u : 0u;
+        // A1 is chunk-swizzled (16-byte chunk (c >> 3) ^ ((pixel >> 3) & 1)); an iteration's 16 pixels start at a multiple of
+        // 16, so the swizzle bit of pixel 2 kk (+ 1) is kk >> 2: two lane bases, the rest are immediates
+        const int c = n & 15;
+        const unsigned wr0 = R + (12 * hf * 8) * 32 + (is_b ? 32 : 0) + (c & 7) * 2;
+        const unsigned wrA = wr0 + ((c >> 3) << 4), wrB = wr0 + (((c >> 3) ^ 1) << 4);
+        for (int g2 = 0; g2 < 6; ++g2) {
             f32x16 acc[2];
             f32x4 xa[2][3];
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int u = min(16 * tt + qi, 29);      // rows 30, 31 of the pair are padding (results unused)
-                const int yy = u >= 15 ? 1 : 0, x = u - 15 * yy;
-                const int y = 2 * (12 * hfi + gl) + yy;
-                const char* base = pb + (x * 50 + y) * 2;
+            for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const unsigned lo16 = *(const unsigned short*)(base + t * SS_PPLANE + toff[2 * q]);
-                        const unsigned hi16 = *(const unsigned short*)(base + t * SS_PPLANE + toff[2 * q + 1]);
-                        xa[tt][t][q] = __uint_as_float(lo16 | (hi16 << 16));
-                    }
-            }
+                for (int t = 0; t < 3; ++t) {              // dword reads (ds_read2_b32): the pairs are only 4-byte aligned
+                    const unsigned pa = rd_a + 4 * tt + t * SS_PPLANE, pq = rd_b + 4 * tt + t * SS_PPLANE;
+                    xa[tt][t] = f32x4{__uint_as_float(lds_ld32(pa)), __uint_as_float(lds_ld32(pa + 4)),
+                                      __uint_as_float(lds_ld32(pq)), __uint_as_float(lds_ld32(pq + 4))};
+                }
             acc[0] = zero16();
             acc[1] = zero16();
-            acc[0] = mfma_bf(xa[0][2], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][2], w1[0], acc[1]);
+            acc[0] = mfma_bf(xa[0][2], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][2], w1[0], acc[1]);   // smallest products first
             acc[0] = mfma_bf(xa[0][1], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[1], acc[1]);
             acc[0] = mfma_bf(xa[0][0], w1[2], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[2], acc[1]);
             acc[0] = mfma_bf(xa[0][1], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[0], acc[1]);
             acc[0] = mfma_bf(xa[0][0], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[1], acc[1]);
             acc[0] = mfma_bf(xa[0][0], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[0], acc[1]);
+            unsigned r[16];
 #pragma unroll
-            for (int bb = 0; bb < 8; ++bb) {
-                float mx = -3.0e38f;
-#pragma unroll
-                for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                    for (int x = (bb ? 2 * bb - 1 : 0); x <= (bb < 7 ? 2 * bb : 14); ++x) {
-                        const int u = 15 * yy + x;
-                        mx = fmaxf(mx, acc[u >> 4][u & 15]);
-                    }
-                const int pp = (12 * hf + gl) * 8 + bb;
-                if (n < 16)
-                    store_split(act, SS_A1PLANE, pp * 32 + (((n >> 3) ^ ((pp >> 3) & 1)) << 4) + (n & 7) * 2,
-                                fmaxf(mx + tn, 0.f));
+            for (int v = 0; v < 16; ++v) {
+                const int tt = v >> 3, bb = v & 7;
+                const float mx = bb ? fmaxf(acc[tt][2 * bb - 1], acc[tt][2 * bb]) : acc[tt][0];   // frames
+                r[v] = __float_as_uint(fmaxf(mx + tn, 0.f));
             }
+            unsigned got[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                got[kk] = (unsigned)__builtin_amdgcn_ds_swizzle((int)((r[2 * kk] & mb) | (r[2 * kk + 1] & ~mb)), 0x401F);
+            float fin[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const unsigned own = (r[2 * kk + 1] & mb) | (r[2 * kk] & ~mb);
+                fin[kk] = __uint_as_float(max(own, got[kk]));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; kk += 2) {             // pixels 16 g2 + 2 kk (+ 1 in the dm = 1 lanes) and two further
+                const unsigned w_ = (kk < 4 ? wrA : wrB) + 512 * g2 + 64 * kk;
+                lds_store_split2(w_, w_ + 64, SS_A1PLANE, fin[kk], fin[kk + 1]);
+            }
+            rd_a += 8; rd_b += 8;                          // mel m0 = 2 gl, gl = 12 hfi + 2 g2 + tt
         }
     }
+    __builtin_amdgcn_wave_barrier();
 
     // ---- conv2 16->32 on 24x8, pool 2x2 -> 12x4: tile t of a lane half = pooled row 6*half + t (2 rows x 8 cols)
     {
@@ -135,64 +175,77 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
         }
         conv3x3_bf16<16, 6, 1, 24, 8, false>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane);
         const float tn = cw[CNN_T2 + n];
+        const unsigned wr = R + (6 * hf * 4) * SS_RS2 + n * 2;
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                const float mx = fmaxf(fmaxf(acc[t][0][2 * bb], acc[t][0][2 * bb + 1]),
-                                       fmaxf(acc[t][0][8 + 2 * bb], acc[t][0][8 + 2 * bb + 1]));
-                const int pp = (6 * hf + t) * 4 + bb;
-                store_split(act, 3072, pp * 64 + (((n >> 3) ^ ((pp >> 2) & 3)) << 4) + (n & 7) * 2, fmaxf(mx + tn, 0.f));
+            for (int bb = 0; bb < 4; bb += 2) {             // pooled pixels (6 hf + t) * 4 + bb, + 1: one packed split
+                float pvv[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int q = 2 * (bb + e);
+                    const float mx = fmaxf(fmaxf(acc[t][0][q], acc[t][0][q + 1]), fmaxf(acc[t][0][8 + q], acc[t][0][8 + q + 1]));
+                    pvv[e] = fmaxf(mx + tn, 0.f);
+                }
+                lds_store_split2(wr + (4 * t + bb) * SS_RS2, wr + (4 * t + bb + 1) * SS_RS2, SS_P2, pvv[0], pvv[1]);
             }
     }
+    __builtin_amdgcn_wave_barrier();
 
-    // conv3 / conv4 on 12x4: a lane half owns 3 pooled rows = 3 groups of 8 pixels; u = 8*gl + 4*yy + x
-    int py[2], px[2];
-    bool pv[2];
+    // conv3 / conv4 on 12x4: a lane half owns 3 pooled rows = 3 groups of 8 pixels; u = 8*gl + 4*yy + x.  Second-generation
+    // K loop (conv_bf16.hpp: lane-static tap masks, one select per tap and tile, fragments through a buffer descriptor)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
+    const unsigned lane16 = lane * 16;
+    unsigned base34[2], m34[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int u = 16 * t + qi;
-        pv[t] = u < 24;
-        py[t] = 2 * (3 * hfi + (u >> 3)) + ((u >> 2) & 1);
-        px[t] = u & 3;
+        const int py = 2 * (3 * hfi + (u >> 3)) + ((u >> 2) & 1), px = u & 3;
+        m34[t] = tap_mask(u < 24, py, px, 12, 4);
+        base34[t] = (py - 1) * 4 + (px - 1);              // pixel index of tap (-1, -1)
     }
     {
         f32x16 acc[2][2];
+        unsigned base[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<32, 2, 2, 12, 4, true>(acc, act, zero, wb + CNNB_W3, py, px, pv, lane);
+            base[t] = R + base34[t] * SS_RS2 + (h << 4);
+        }
+        conv_k_bf16<32, 2, 2, 4, SS_RS2, SS_P2, SS_ZADDR, true, 3>(acc, wrs, CNNB_W3 * 2, lane16, base, m34);
+        const unsigned wr = R + (24 * hf) * SS_RS3 + n * 2; // pixel (2 (3 hf + (u >> 3)) + ((u >> 2) & 1)) * 4 + (u & 3) = 24 hf + u
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int c = n + 32 * nt;
-            const float tn = cw[CNN_T3 + c];
+            const float tn = cw[CNN_T3 + n + 32 * nt];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < 16; r += 2) {
                     const int u = 16 * t + r;
-                    if (u < 24) {
-                        const int pp = (2 * (3 * hf + (u >> 3)) + ((u >> 2) & 1)) * 4 + (u & 3);
-                        store_split(act, 6144, pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2,
-                                    fmaxf(acc[t][nt][r] + tn, 0.f));
-                    }
+                    if (u < 24)
+                        lds_store_split2(wr + u * SS_RS3 + 64 * nt, wr + (u + 1) * SS_RS3 + 64 * nt, SS_P3,
+                                         fmaxf(acc[t][nt][r] + tn, 0.f), fmaxf(acc[t][nt][r + 1] + tn, 0.f));
                 }
         }
     }
+    __builtin_amdgcn_wave_barrier();
 
     // ---- conv4 64->64 on 12x4, pool -> 6x2.  The pooled outputs of the four segments go to a SHARED pair of
     //      bf16 planes S4[48 rows][64 ch] (row = 12 * wave + pixel) for the N-split conv5 / conv6.
-    char* s4 = smem;                       // wave 0's region (its A3 is dead by then)
-    char* s5 = smem + SS_WAVE;             // wave 1's region
-    float* s6 = (float*)smem;              // conv6 output, fp32 [48][64], over S4
+    char* s4 = smem + SS_BASE;             // wave 0's region (its A3 is dead by then)
+    char* s5 = smem + SS_BASE + SS_WAVE;   // wave 1's region
+    float* s6 = (float*)(smem + SS_BASE);  // conv6 output, fp32 [48][64], over S4
     {
         f32x16 acc[2][2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
-        conv3x3_bf16<64, 2, 2, 12, 4, true>(acc, act, zero, wb + CNNB_W4, py, px, pv, lane);
+        unsigned base[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) base[t] = R + base34[t] * SS_RS3 + (h << 4);
+        conv_k_bf16<64, 2, 2, 4, SS_RS3, SS_P3, SS_ZADDR, true, 3>(acc, wrs, CNNB_W4 * 2, lane16, base, m34);
         __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -223,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
     {
         const int i16 = lane & 15, kg = lane >> 4;
         const int ch = 16 * wave + i16;
-        const char* zero3 = smem + 3 * SS_WAVE + SS_ZERO;  // wave 3's zero block: S4 / S5 / S6 never cover it
+        const char* zero3 = smem + SS_BASE + 3 * SS_WAVE + SS_ZERO;  // wave 3's zero block: S4 / S5 / S6 never cover it
         int ry[3], rx[3], rb[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) {

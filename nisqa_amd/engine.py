@@ -142,7 +142,7 @@ class HipNisqa(object):
             self.cnn_w = up(_w.pack_standard_cnn(state_dict))
             self.td_w = up(_w.pack_lstm_laststep(state_dict))
             self.pool_w = torch.zeros(4, dtype=torch.float32, device=self.device)
-            self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict).view(np.int16)) if self.precision == 'bf16x3' else None
+            self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict, conv1_pairs=True).view(np.int16)) if self.precision == 'bf16x3' else None
             self.td_wb = self.pool_wb = None
             self._mel = {}
             self._ws = {}
