@@ -273,12 +273,28 @@ def _save_results(nm, tr, epoch, loss, ep_runtime, r, db_results, best):
         nm.results_hist.loc[epoch] = results
     nm.results_hist.to_csv(os.path.join(out_dir, nm.runname + '__results.csv'), index=False)
     if a['tr_checkpoint'] == 'every_epoch' or (a['tr_checkpoint'] == 'best_only' and best):
-        torch.save({'runname': nm.runname, 'epoch': epoch + 1, 'model_args': nm.model_args, 'args': a,
+        torch.save({'runname': nm.runname, 'epoch': epoch + 1, 'model_args': _plain(nm.model_args), 'args': _plain(a),
                     'model_state_dict': tr.state_dict(),
                     'optimizer_state_dict': {'step': tr.t, 'lr': tr.lr, 'exp_avg': tr.m.cpu(), 'exp_avg_sq': tr.v.cpu(),
                                              'layout': 'nisqa_amd flat buffer (HipTrainer.keys / kshape order)'},
-                    'db_results': db_results, 'results': results, 'model_name': nm.model.name},
+                    'db_results': _plain(db_results), 'results': _plain(results), 'model_name': nm.model.name},
                    os.path.join(out_dir, filename))
+
+
+def _plain(x):
+    """Containers with numpy scalars / arrays -> plain Python numbers and lists, so that a checkpoint written here loads
+    through torch's restricted unpickler (NISQA_model._load_checkpoint) -- numpy's pickle constructors are not on its list."""
+    if isinstance(x, dict):
+        return {k: _plain(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_plain(v) for v in x)
+    if isinstance(x, np.generic):
+        return x.item()
+    if isinstance(x, np.ndarray):
+        return x.tolist()
+    if isinstance(x, pd.DataFrame):
+        return _plain(x.to_dict(orient='list'))
+    return x
 
 
 def make_runname_and_write_yaml(nm):
