@@ -983,3 +983,36 @@ def test_g711_wav_files_load_like_soundfile_would(tmp_path, law):
     eng = FakeEngine(5)
     ref = eng.forward_pcm(torch.from_numpy(want), eng.plan([len(want)], 48000), 48000)[0].numpy()
     assert np.allclose(df.iloc[0][['mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred']].to_numpy(dtype=np.float64), ref, rtol=1e-6)
+
+
+def test_length_aware_policy_invariants_on_random_inputs():
+    """Property test (hypothesis): whatever the lengths, rates, hints and caps, the batches are a partition of the window,
+    no batch but a merged tail exceeds the byte cap (and never by more than half), every batch but the last of a rate
+    reaches the clip / work lower bounds unless the byte cap closed it, and within a rate lengths ascend across batches."""
+    from hypothesis import given, settings, strategies as st
+    from nisqa_amd import ingest
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(st.tuples(st.integers(700, 1500000), st.sampled_from([16000, 48000])), min_size=0, max_size=120),
+           st.integers(1, 40), st.integers(0, 3000), st.integers(1, 24), st.integers(1 << 16, 1 << 23))
+    def check(items, bs, min_tokens, min_clips, cap):
+        frames = np.array([f for f, _ in items], dtype=np.int64)
+        srs = np.array([r for _, r in items], dtype=np.int64)
+        tok = lambda f, r: np.maximum(1, (1 + f // (r // 100) - 14 + 3) // 4)
+        pol = ingest.LengthAware(range(len(items)), bs, tok, min_tokens=min_tokens, min_clips=min_clips, byte_cap=cap)
+        cuts = pol.cut(frames, srs, np.full(len(items), 2, dtype=np.int64))
+        assert sorted(k for c in cuts for k in c) == list(range(len(items)))
+        need = max(bs, min_clips)
+        for i, c in enumerate(cuts):
+            assert c, 'empty batch'
+            b = int(frames[c].sum() * 2)
+            assert b <= cap + cap // 2 or len(c) == 1                      # one clip larger than the cap still gets its batch
+            last_of_rate = i + 1 == len(cuts) or srs[cuts[i + 1][0]] != srs[c[-1]]
+            if not last_of_rate and len(set(srs[c].tolist())) == 1:
+                nxt = cuts[i + 1][0]
+                full = len(c) >= need and int(tok(frames[c], srs[c]).sum()) >= min_tokens
+                assert full or b + int(frames[nxt]) * 2 > cap
+        for r in set(srs.tolist()):
+            seq = [int(frames[k]) for c in cuts for k in c if srs[k] == r]
+            assert seq == sorted(seq)
+    check()
