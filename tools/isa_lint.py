@@ -42,6 +42,9 @@ def scan_library(path):
 
 def main():
     path = sys.argv[1]
+    if not os.path.isfile(os.path.join(LLVM, 'llvm-objdump')):
+        print('isa_lint: llvm-objdump not found under %s -- artifact NOT linted (tests/test_host.py lints the sources)' % LLVM)
+        return 0
     n_obj, n_pk, bad = scan_library(path)
     if n_obj == 0 or n_pk == 0:
         print('isa_lint: found %d gfx950 code objects and %d packed-f32 instructions in %s: the scan itself is broken' % (n_obj, n_pk, path))
