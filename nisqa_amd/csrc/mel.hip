@@ -185,7 +185,15 @@ NQ_DEV void fft512(c32 (&u)[8], const c32 (&z)[8], const mel_twiddles& tw, char*
 // full 4096): z[n] for n >= 512 q folds onto n - 512 q with the radix-4 factor (-i)^(q r) before the 512-point FFTs
 // T = float (samples as lb.load returns them) or int16_t (PCM16 as it sits in the file: the x / 32768 of soundfile is
 // folded into the window taps -- a power of two, so both instantiations produce the same bits)
-template <int NQ, typename T>
+// FB: filter-bank trip counts known at compile time (round 3).  The twelve passes of the sparse bank are chains of dependent
+// LDS round trips (run-time trip count -> no overlap between passes); with the counts of the two shipped configurations as
+// constants every pass is unrolled, its reads issue together and the twelve row sums interleave.  0: generic (any sample
+// rate / fmax); 1: 48 kHz, fmax 20 kHz (nisqa.tar, nisqa_mos_only.tar); 2: 48 kHz, fmax 8 kHz (nisqa_tts.tar).  The kernel
+// checks the table it was given against the constants once per wave and falls back to the generic loop on a mismatch.
+__device__ constexpr int MEL_FB_NIT[3][12] = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+                                              {1, 1, 1, 2, 2, 3, 4, 5, 6, 9, 12, 17},
+                                              {1, 1, 1, 1, 1, 2, 2, 2, 3, 4, 4, 6}};
+template <int NQ, typename T, int FB = 0>
 __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_frame_kernel(
     const T* __restrict__ pcm, const int64_t* __restrict__ clip_off,
     const int32_t* __restrict__ frame_off, int n_clips, int total_frames, int frames_per_wave,
@@ -249,6 +257,11 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
 
     int b = find_segment(frame_off, n_clips, f_begin);
     float runmax = -3.0e38f;
+    bool fb_const = FB != 0;                                // wave-uniform: the table matches the compile-time trip counts
+    if (FB != 0) {
+#pragma unroll
+        for (int ps = 0; ps < 12; ++ps) fb_const = fb_const && (__builtin_amdgcn_readfirstlane(band_len[4 * ps]) >> 4) == MEL_FB_NIT[FB][ps];
+    }
 
     // raw (unwindowed) samples of frame f, reflect-padded like np.pad(mode='reflect')
     auto load_frame = [&](int f, int bb, int quarter, float (&raw)[8][2]) {
@@ -378,6 +391,24 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
 
         // ---- sparse slaney filterbank: 4 bands per pass (one per 16-lane row)
         float mine = 0.f;
+        if (FB != 0 && fb_const) {
+            float part[12];
+#pragma unroll
+            for (int ps = 0; ps < 12; ++ps) {
+                const int2 bo = *(const int2*)(tab_band + 2 * (64 * ps + lane));
+                const float* wp = (const float*)((const char*)wlds + bo.y);
+                const float* mp = (const float*)((const char*)mag + bo.x);
+                float acc_ = 0.f;
+#pragma unroll
+                for (int it = 0; it < MEL_FB_NIT[FB][ps]; ++it) acc_ = fmaf(wp[16 * it], mp[4 * it], acc_);
+                part[ps] = acc_;
+            }
+#pragma unroll
+            for (int ps = 0; ps < 12; ++ps) part[ps] = row16_sum(part[ps]);
+#pragma unroll
+            for (int ps = 0; ps < 12; ++ps)
+                if (l16 == ps) mine = part[ps];             // lane 16*row + ps holds band 4*ps + row
+        } else
 #pragma unroll
         for (int ps = 0; ps < 12; ++ps) {
             // padded length is the same for the 4 bands of a pass (zero weights beyond a band's support)
@@ -483,7 +514,12 @@ static int mel_db_launch(const T* pcm, const int64_t* clip_off, const int32_t* f
                            frames_per_wave, *cfg, mag_stride, w_floats, window, (const float2*)twiddle, band_start,
                            band_len, band_woff, band_w, mel_tm, clip_max_enc);
     };
-    if (cfg->win <= 1024) go(mel_frame_kernel<1, T>);
+    // the two shipped front ends at 48 kHz get the instantiations with compile-time filter-bank trip counts (checked in the kernel)
+    const int fb = getenv("NISQA_MEL_FB_GENERIC") ? 0 : (cfg->hop == 480 && cfg->win == 960 && cfg->n_bins == 1707) ? 1
+                   : (cfg->hop == 480 && cfg->win == 960 && cfg->n_bins == 683) ? 2 : 0;
+    if (cfg->win <= 1024 && fb == 1) go(mel_frame_kernel<1, T, 1>);
+    else if (cfg->win <= 1024 && fb == 2) go(mel_frame_kernel<1, T, 2>);
+    else if (cfg->win <= 1024) go(mel_frame_kernel<1, T>);
     else if (cfg->win <= 2048) go(mel_frame_kernel<2, T>);
     else go(mel_frame_kernel<4, T>);
     return NQ_LAUNCH_STATUS();
