@@ -253,7 +253,9 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
     const int start0 = -cfg.n_fft / 2 + (cfg.n_fft - cfg.win) / 2;   // first windowed sample of frame 0
     // magnitudes are needed for K < n_bins (the last bin any band weights), i.e. plane entries k = K >> 2 < kmax; entries
     // kmax .. mag_stride - 1 keep whatever finite values they hold (zeros / FFT exchange data) and meet zero weights only
-    const int kmax = (cfg.n_bins + 3) >> 2;
+    // (a compile-time constant in the FB instantiations, which the launcher selects BY n_bins: the per-group guards below
+    // then fold away and the eight magnitude groups of a transform become one basic block the scheduler can interleave)
+    const int kmax = FB == 1 ? (1707 + 3) / 4 : FB == 2 ? (683 + 3) / 4 : (cfg.n_bins + 3) >> 2;
 
     int b = find_segment(frame_off, n_clips, f_begin);
     float runmax = -3.0e38f;
