@@ -137,6 +137,23 @@ NQ_DEV float xmag(c32 za, c32 zb, c32 wl, c32 wc) {
     return __builtin_amdgcn_sqrtf(x2.x + x2.y);          // |2 X[K]|; v_sqrt_f32 (1 ulp): 5e-7 dB, saves ~10 VALU per bin
 }
 
+// two bins at once, their dependent chains interleaved link by link: on gfx950 a packed-f32 operation that reads the result
+// of the packed operation right before it costs an s_nop; hipcc's scheduler does not model that and leaves chains as chains
+NQ_DEV void xmag2(c32 za0, c32 zb0, c32 wl0, c32 wc0, c32 za1, c32 zb1, c32 wl1, c32 wc1, float& m0, float& m1) {
+    const c32 a0 = cadd_conj(za0, zb0), a1 = cadd_conj(za1, zb1);
+    const c32 d0 = csub_conj(za0, zb0), d1 = csub_conj(za1, zb1);
+    c32 p0 = c32{d0.x, d0.x} * wl0, p1 = c32{d1.x, d1.x} * wl1;                       // cmul(d, wl), link by link
+    p0 = __builtin_elementwise_fma(c32{d0.y, d0.y}, c32{-wl0.y, wl0.x}, p0);
+    p1 = __builtin_elementwise_fma(c32{d1.y, d1.y}, c32{-wl1.y, wl1.x}, p1);
+    c32 q0 = c32{p0.x, p0.x} * wc0, q1 = c32{p1.x, p1.x} * wc1;                       // cmul(., wc)
+    q0 = __builtin_elementwise_fma(c32{p0.y, p0.y}, c32{-wc0.y, wc0.x}, q0);
+    q1 = __builtin_elementwise_fma(c32{p1.y, p1.y}, c32{-wc1.y, wc1.x}, q1);
+    const c32 x0 = cadd_mi(a0, q0), x1 = cadd_mi(a1, q1);
+    const c32 s0 = x0 * x0, s1 = x1 * x1;
+    m0 = __builtin_amdgcn_sqrtf(s0.x + s0.y);
+    m1 = __builtin_amdgcn_sqrtf(s1.x + s1.y);
+}
+
 struct mel_twiddles {
     c32 b[8];   // W512^(l p)
     c32 c[8];   // W64^((l&7) q1)
@@ -256,6 +273,8 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
     // (a compile-time constant in the FB instantiations, which the launcher selects BY n_bins: the per-group guards below
     // then fold away and the eight magnitude groups of a transform become one basic block the scheduler can interleave)
     const int kmax = FB == 1 ? (1707 + 3) / 4 : FB == 2 ? (683 + 3) / 4 : (cfg.n_bins + 3) >> 2;
+    constexpr int ZG = FB != 0 ? 8 : 2, MG = FB != 0 ? 4 : 1;                   // magnitude groups whose partners are fetched ahead (registers: the generic
+                                                         // instantiation sits at the 168-register limit of three waves per SIMD)
 
     int b = find_segment(frame_off, n_clips, f_begin);
     float runmax = -3.0e38f;
@@ -349,13 +368,31 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
         fft512<0>(u, z, tw, exch, lane, tab_a);
         {
             const int src = (64 - lane) & 63;
+            // partners first (ZG groups ahead), then the magnitude chains two groups per call: the dependent chains of packed
+            // operations interleave instead of running one behind the other with s_nop between their links (round 3)
 #pragma unroll
-            for (int q2 = 0; q2 < 8; ++q2) {
-                if (64 * q2 >= kmax) continue;             // wave-uniform: bins above fmax are never produced (48 kHz / 20 kHz:
-                c32 zb = shfl_c(u[7 - q2], src);            // q2 = 7 is empty; fmax 8 kHz: q2 >= 3 are)
-                if (lane == 0) zb = u[(8 - q2) & 7];
-                if (lane + 64 * q2 < kmax)
-                    mag[0 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tab_d[0 * 64 + lane], cmk(W16C[q2], W16S[q2]));
+            for (int q0 = 0; q0 < 8; q0 += ZG) {
+                c32 zb[ZG];
+#pragma unroll
+                for (int e = 0; e < ZG; ++e) {
+                    const int q2 = q0 + e;
+                    if (64 * q2 >= kmax) continue;         // wave-uniform: bins above fmax are never produced
+                    zb[e] = shfl_c(u[7 - q2], src);
+                    if (lane == 0) zb[e] = u[(8 - q2) & 7];
+                }
+#pragma unroll
+                for (int e = 0; e < ZG; e += 2) {
+                    const int q2 = q0 + e;
+                    if (64 * q2 >= kmax) continue;
+                    const c32 wl = tab_d[0 * 64 + lane];
+                    if (64 * (q2 + 1) < kmax) {
+                        float m0, m1;
+                        xmag2(u[q2], zb[e], wl, cmk(W16C[q2], W16S[q2]), u[q2 + 1], zb[e + 1], wl, cmk(W16C[q2 + 1], W16S[q2 + 1]), m0, m1);
+                        if (lane + 64 * q2 < kmax) mag[0 * mag_stride + lane + 64 * q2] = m0;
+                        if (lane + 64 * (q2 + 1) < kmax) mag[0 * mag_stride + lane + 64 * (q2 + 1)] = m1;
+                    } else if (lane + 64 * q2 < kmax)
+                        mag[0 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb[e], wl, cmk(W16C[q2], W16S[q2]));
+                }
             }
             if (lane == 0 && 512 < mag_stride) mag[512] = 2.0f * fabsf(u[0].x - u[0].y);   // Nyquist bin: 2 X[2048] = 2 (Re Z0 - Im Z0)
 
@@ -365,11 +402,24 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
         fold(2, z);
         fft512<2>(u, z, tw, exch, lane, tab_a);
 #pragma unroll
-        for (int q2 = 0; q2 < 8; ++q2) {
-            if (64 * q2 >= kmax) continue;
-            const c32 zb = shfl_c(u[7 - q2], mir);
-            if (lane + 64 * q2 < kmax)
-                mag[1 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb, tab_d[2 * 64 + lane], cmk(W16C[q2], W16S[q2]));
+        for (int q0 = 0; q0 < 8; q0 += ZG) {
+            c32 zb[ZG];
+#pragma unroll
+            for (int e = 0; e < ZG; ++e)
+                if (64 * (q0 + e) < kmax) zb[e] = shfl_c(u[7 - q0 - e], mir);
+#pragma unroll
+            for (int e = 0; e < ZG; e += 2) {
+                const int q2 = q0 + e;
+                if (64 * q2 >= kmax) continue;
+                const c32 wl = tab_d[2 * 64 + lane];
+                if (64 * (q2 + 1) < kmax) {
+                    float m0, m1;
+                    xmag2(u[q2], zb[e], wl, cmk(W16C[q2], W16S[q2]), u[q2 + 1], zb[e + 1], wl, cmk(W16C[q2 + 1], W16S[q2 + 1]), m0, m1);
+                    if (lane + 64 * q2 < kmax) mag[1 * mag_stride + lane + 64 * q2] = m0;
+                    if (lane + 64 * (q2 + 1) < kmax) mag[1 * mag_stride + lane + 64 * (q2 + 1)] = m1;
+                } else if (lane + 64 * q2 < kmax)
+                    mag[1 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb[e], wl, cmk(W16C[q2], W16S[q2]));
+            }
         }
         MEL_CLK(2);                                   // FFT r = 2 + magnitudes
         // r = 1 and r = 3 are each other's partners
@@ -379,13 +429,22 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
         fft512<3>(u, z, tw, exch, lane, tab_a);
         MEL_CLK(3);                                   // FFTs r = 1, 3
 #pragma unroll
-        for (int q2 = 0; q2 < 8; ++q2) {
-            if (64 * q2 >= kmax) continue;
-            const c32 z3m = shfl_c(u[7 - q2], mir), z1m = shfl_c(u1[7 - q2], mir);
-            const c32 w16 = cmk(W16C[q2], W16S[q2]);
-            if (lane + 64 * q2 < kmax) {
-                mag[2 * mag_stride + lane + 64 * q2] = xmag(u1[q2], z3m, tab_d[1 * 64 + lane], w16);
-                mag[3 * mag_stride + lane + 64 * q2] = xmag(u[q2], z1m, tab_d[3 * 64 + lane], w16);
+        for (int q0 = 0; q0 < 8; q0 += MG) {               // MG groups at a time: 2 MG partners, then 2 MG chains
+            c32 z3m[MG], z1m[MG];
+#pragma unroll
+            for (int e = 0; e < MG; ++e)
+                if (64 * (q0 + e) < kmax) { z3m[e] = shfl_c(u[7 - q0 - e], mir); z1m[e] = shfl_c(u1[7 - q0 - e], mir); }
+#pragma unroll
+            for (int e = 0; e < MG; ++e) {
+                const int q2 = q0 + e;
+                if (64 * q2 >= kmax) continue;
+                const c32 w16 = cmk(W16C[q2], W16S[q2]);
+                float m1_, m3_;
+                xmag2(u1[q2], z3m[e], tab_d[1 * 64 + lane], w16, u[q2], z1m[e], tab_d[3 * 64 + lane], w16, m1_, m3_);
+                if (lane + 64 * q2 < kmax) {
+                    mag[2 * mag_stride + lane + 64 * q2] = m1_;
+                    mag[3 * mag_stride + lane + 64 * q2] = m3_;
+                }
             }
         }
         MEL_WBAR();
