@@ -29,6 +29,15 @@
 #define SS_P3 (48 * SS_RS3)
 static_assert(2 * SS_P3 <= SS_ZERO && 2 * SS_LDS <= 160 * 1024, "LDS plan");
 
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+NQ_DEV float row16_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
 __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
@@ -271,6 +280,14 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
     }
     __syncthreads();
 
+    // fc_out (768 -> 20) is split over the waves like conv5 / conv6: wave w computes outputs 5 w .. 5 w + 4 of all four segments
+    // (a quarter of the weights per wave: 60 floats per lane instead of 240), and those 60 floats are requested NOW, so that
+    // they arrive under conv5 / conv6 (before: twelve exposed L2 round trips behind the last barrier)
+    struct __attribute__((packed, aligned(4))) fc5_t { float v[5]; };
+    fc5_t wfc_pre[12];
+    __builtin_amdgcn_sched_barrier(0);                     // not earlier: conv2..conv4 need the registers
+#pragma unroll
+    for (int m = 0; m < 12; ++m) wfc_pre[m] = *(const fc5_t*)(cw + CNNS_FC_W + (size_t)(m * 64 + lane) * 20 + 5 * wave);
     // ---- conv5 / conv6 (3x3, padding 1, on 6x2) with N split over the waves: wave w owns output channels
     //      16w..16w+15 of all four segments; rows rho = 16 t + i16 <-> (slot = rho / 12, pixel = rho % 12)
     {
@@ -332,30 +349,50 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
         }
     }
 
-    // ---- fc_out 768 -> 20: wave w = segment slot w; lane takes k' = lane + 64 m (k' = pixel * 64 + c)
-    if (valid) {
-        float o[20];
+    // ---- fc_out 768 -> 20, N split over the waves: lane takes k' = lane + 64 m (k' = pixel * 64 + c) of ALL four segments
+    //      (48 LDS reads of conv6's fp32 output) against its wave's five output columns (wfc_pre).  The 20 sums over the
+    //      wave (4 segments x 5 outputs) are a reduce-scatter -- 10 + 5 exchanges, then four DPP steps on 5 values -- instead
+    //      of 20 six-step butterflies; row r of the wave ends up holding segment r.
+    {
+        float o[4][5];
 #pragma unroll
-        for (int j = 0; j < 20; ++j) o[j] = 0.f;
-        const float* wfc = cw + CNNS_FC_W;
-#pragma unroll 2
-        for (int m = 0; m < 12; ++m) {
-            const float a = s6[(12 * wave + m) * 64 + lane];
-            const f32x4* wr = (const f32x4*)(wfc + (size_t)(m * 64 + lane) * 20);
+        for (int sg = 0; sg < 4; ++sg)
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const f32x4 w4 = wr[q];
+            for (int j = 0; j < 5; ++j) o[sg][j] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[4 * q + e] = fmaf(a, w4[e], o[4 * q + e]);
+        for (int m = 0; m < 12; ++m)
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const float a = s6[(12 * sg + m) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) o[sg][j] = fmaf(a, wfc_pre[m].v[j], o[sg][j]);
             }
+        // lanes l, l ^ 32: the lower half keeps segments 0, 1, the upper half segments 2, 3
+        float p10[2][5];
+        const bool up = lane >= 32;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float give = up ? o[sg][j] : o[2 + sg][j], keep = up ? o[2 + sg][j] : o[sg][j];
+                p10[sg][j] = keep + __shfl_xor(give, 32);
+            }
+        // lanes l, l ^ 16: bit 4 clear keeps the first segment of its two, bit 4 set the second
+        float p5[5];
+        const bool hi16 = (lane & 16) != 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const float give = hi16 ? p10[0][j] : p10[1][j], keep = hi16 ? p10[1][j] : p10[0][j];
+            p5[j] = keep + __shfl_xor(give, 16);
         }
         float mine = 0.f;
 #pragma unroll
-        for (int j = 0; j < 20; ++j) {
-            const float v = wave_sum(o[j]);
-            if (lane == j) mine = v;
+        for (int j = 0; j < 5; ++j) {
+            const float t = row16_sum_dpp(p5[j]);
+            if ((lane & 15) == j) mine = t;
         }
-        if (lane < 20) feat20[(size_t)(p0 + wave) * 20 + lane] = mine + cw[CNNS_FC_B + lane];
+        const int sg = lane >> 4, jo = 5 * wave + (lane & 15);
+        if ((lane & 15) < 5 && sg < nvalid) feat20[(size_t)(p0 + sg) * 20 + jo] = mine + cw[CNNS_FC_B + jo];
     }
 }
 
