@@ -303,36 +303,54 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
             rx[t] = pix & 1;
             rb[t] = slot * 12;
         }
+        // the 9 x 3 tap addresses of a lane are static (row -> pixel map, image bounds, chunk swizzle): computed once for
+        // both layers as offsets into the S4 / S5 planes (round 3; before: per tap, tile, step and layer); K-step s = 1 is
+        // the address ^ 64 (the chunk index is (4 s + kg) ^ swizzle and the zero block is 128-byte aligned)
+        unsigned poff[9][3];
+        unsigned pok = 0;                                   // bit 3 tap + t: the tap is inside the image
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int y = ry[t] + tap / 3 - 1, x = rx[t] + tap % 3 - 1;
+                const bool ok = (unsigned)y < 6u && (unsigned)x < 2u;
+                const int pix = rb[t] + y * 2 + x;
+                poff[tap][t] = (unsigned)(pix * 128 + ((kg ^ ((pix >> 1) & 7)) << 4));
+                pok |= ok ? (1u << (3 * tap + t)) : 0u;
+            }
+        const unsigned Z3 = SS_BASE + 3 * SS_WAVE + SS_ZERO;
+        const __amdgpu_buffer_rsrc_t wrs5 = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
 #pragma unroll 1
         for (int layer = 0; layer < 2; ++layer) {
-            const char* src = layer ? s5 : s4;
+            const unsigned srcA = layer ? SS_BASE + SS_WAVE : SS_BASE;
             f32x4 acc5[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc5[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4* w5 = (const f32x4*)(wb + (layer ? CNNB_W6 : CNNB_W5)) + (size_t)wave * (18 * 2 * 64) + lane;
-            f32x4 bq[2][2];
-            bq[0][0] = w5[0]; bq[0][1] = w5[64];
-#pragma unroll
-            for (int g = 0; g < 18; ++g) {
-                if (g + 1 < 18) { bq[(g + 1) & 1][0] = w5[(g + 1) * 128]; bq[(g + 1) & 1][1] = w5[(g + 1) * 128 + 64]; }
-                const int tap = g >> 1, s = g & 1;
-                const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
-                f32x4 ah[3], al[3];
+            const int wbyte = ((layer ? CNNB_W6 : CNNB_W5) + wave * (18 * 2 * 512)) * 2;
+            f32x4 bq[4][2], aq[2][3][2];                   // fragments three K-steps ahead, A rows one step ahead
+            auto load_a = [&](int g) {
+                const int tap = g >> 1, sx = (g & 1) << 6;
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
-                    const int y = ry[t] + dy, x = rx[t] + dx;
-                    const bool ok = (unsigned)y < 6u && (unsigned)x < 2u;
-                    const int pix = rb[t] + y * 2 + x;
-                    const char* ph = ok ? src + pix * 128 + (((4 * s + kg) ^ ((pix >> 1) & 7)) << 4) : zero3;
-                    ah[t] = *(const f32x4*)ph;
-                    al[t] = *(const f32x4*)(ok ? ph + SS_PLANE : zero3);
+                    const bool ok = (pok >> (3 * tap + t)) & 1u;
+                    const unsigned ah_ = ok ? (srcA + poff[tap][t]) ^ sx : Z3;
+                    aq[g & 1][t][0] = lds_ld128(ah_);
+                    aq[g & 1][t][1] = lds_ld128(ok ? ah_ + SS_PLANE : Z3);
                 }
+            };
 #pragma unroll
-                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][1], acc5[t]);
+            for (int g = 0; g < 3; ++g) { bq[g][0] = wfrag_load(wrs5, lane * 16, wbyte + g * 2048); bq[g][1] = wfrag_load(wrs5, lane * 16, wbyte + g * 2048 + 1024); }
+            load_a(0);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(al[t], bq[g & 1][0], acc5[t]);
+            for (int g = 0; g < 18; ++g) {
+                if (g + 3 < 18) { bq[(g + 3) & 3][0] = wfrag_load(wrs5, lane * 16, wbyte + (g + 3) * 2048); bq[(g + 3) & 3][1] = wfrag_load(wrs5, lane * 16, wbyte + (g + 3) * 2048 + 1024); }
+                if (g + 1 < 18) load_a(g + 1);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(ah[t], bq[g & 1][0], acc5[t]);
+                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(aq[g & 1][t][0], bq[g & 3][1], acc5[t]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(aq[g & 1][t][1], bq[g & 3][0], acc5[t]);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(aq[g & 1][t][0], bq[g & 3][0], acc5[t]);
             }
             const float tn = cw[(layer ? CNN_T6 : CNN_T5) + ch];
             // conv6's fp32 output goes over S4, which every wave finished reading before the barrier that ended conv5
