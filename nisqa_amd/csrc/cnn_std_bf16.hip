@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p0 = blockIdx.x * 4;                      // tok_off is a multiple of 32: no clip straddling
-    const int b = find_segment(tok_off, n_clips, p0);
+    const int b = __builtin_amdgcn_readfirstlane(find_segment_wave(tok_off, n_clips, p0, lane));   // one vector load + ballot, not a chain of log2(n) scalar loads
     const int k0 = p0 - tok_off[b];
     const int nvalid = min(4, n_wins[b] - k0);
     if (nvalid <= 0) return;
