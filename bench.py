@@ -300,10 +300,10 @@ def _stage_events(n):
 
 
 def side_predict_csv(dev, cpu):
-    """configs[2] on ONE GPU, bounded: 8 192 rows / 64 distinct 10 s WAV files, bs 256, through nisqaModel.predict()
+    """configs[2] on ONE GPU, bounded: 24 576 rows / 64 distinct 10 s WAV files, bs 256, through nisqaModel.predict()
     (file list -> native ingest -> pinned ring -> H2D -> kernels -> DataFrame).  PCIe-inclusive: the bound is the host
     link (2 bytes per sample cross it), not the kernels."""
-    clips, bs = 8192, 256
+    clips, bs = 24576, 256
     from nisqa_amd import ingest as _ing
     dt, _, _ = predict_csv_job(0, 1, dev, None, clips, bs, 64, 0, 2, tag='side_csv')
     gbs = clips * SECONDS * SR * 2 / dt / 1e9
