@@ -111,6 +111,53 @@ def test_mel_other_sample_rates(eng_rand, sr):
         assert err < MEL_TOL
 
 
+@pytest.mark.parametrize('fmax', [20000, 8000])
+def test_mel_specialised_filter_bank_equals_generic_and_falls_back_on_a_foreign_table(fmax, monkeypatch):
+    """Round 3: the two shipped 48 kHz front ends run mel_frame_kernel instantiations with compile-time filter-bank trip counts
+    (selected by hop / win / n_bins, checked against the table once per wave).  (i) They must give the generic kernel's
+    spectrogram bit for bit (NISQA_MEL_FB_GENERIC=1 forces the generic one); (ii) a table with the same n_bins but other pass
+    lengths (one pass padded by 16 zero weights) must be noticed by the kernel and take the generic loop: same bits again."""
+    import ctypes
+    from nisqa_amd import lib as L_
+    args = dict(helpers.DIM_ARGS, ms_fmax=fmax)
+    eng = _engine(args, helpers.random_state_dict(7, 'NISQA_DIM'), 'bf16x3')
+    pcm = [synth.synth_pcm16(60, 1.1), synth.synth_pcm16(61, 0.5), synth.edge_clip('sine')]
+    x = torch.from_numpy(np.concatenate(pcm)).to(eng.device)               # int16
+    plan = eng.plan([len(p) for p in pcm], 48000)
+    spec, _ = eng.mel(x, plan, 48000, clamp=False)
+    monkeypatch.setenv('NISQA_MEL_FB_GENERIC', '1')
+    gen, _ = eng.mel(x, plan, 48000, clamp=False)
+    monkeypatch.delenv('NISQA_MEL_FB_GENERIC')
+    torch.cuda.synchronize()
+    assert torch.equal(spec, gen)
+    # foreign table: pass 0 (bands 0..3) padded from 16 to 32 entries with zero weights
+    mt = eng.mel_tables(48000)
+    t = mt['host']
+    length = t.band_len.copy()
+    length[0:4] += 16
+    woff = np.zeros(48, np.int32)
+    pos = 0
+    for m in range(48):
+        pos += (16 * (m % 4) - pos) % 64
+        woff[m] = pos
+        pos += int(length[m])
+    w = np.zeros(pos, np.float32)
+    for m in range(48):
+        w[woff[m]:woff[m] + t.true_len[m]] = t.dense[m, t.band_start[m]:t.band_start[m] + t.true_len[m]]
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+    d_len, d_woff, d_w = up(length), up(woff), up(w)
+    cfg = L_.MelCfg(t.n_fft, t.hop, t.win, t.n_mels, t.n_bins, int(w.size), 1e-8, 80.0)
+    d = plan.to(eng.device)
+    out = torch.empty_like(spec)
+    cmax = torch.zeros(plan.n_clips, dtype=torch.int32, device=eng.device)
+    p_ = lambda a: ctypes.c_void_p(a.data_ptr())
+    L_.check(eng.lib.nisqa_mel_db_pcm16(p_(x), p_(d['clip_off']), p_(d['frame_off']), plan.n_clips, plan.total_frames,
+                                        ctypes.byref(cfg), p_(mt['window']), p_(mt['twiddle']), p_(mt['band_start']), p_(d_len),
+                                        p_(d_woff), p_(d_w), p_(out), p_(cmax), eng._stream()), 'nisqa_mel_db_pcm16')
+    torch.cuda.synchronize()
+    assert torch.equal(out, spec)
+
+
 def test_pcm16_conversion(eng_rand):
     p = clip_pcm(0)
     d = eng_rand.pcm16_to_f32(torch.from_numpy(p).to(eng_rand.device))
