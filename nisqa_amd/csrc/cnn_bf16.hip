@@ -53,10 +53,18 @@
 #define FB_PPLANE 1700                     /* bytes per patch plane (850 bf16) */
 #define FB_ZADDR 2048u                     /* the shared zero block */
 #define FB_BASE 2176u                      /* first wave region */
+#ifdef NQ_OCC        /* occupancy probe (results wrong: the wave regions overlap): NQ_OCC workgroups per CU */
+#define FB_WAVE ((((160u * 1024u / NQ_OCC) - 4096u - FB_BASE) / 4u) & ~63u)   /* 4 KB slack: the allocation granule */
+#define FB_WGS NQ_OCC
+#else
 #define FB_WAVE 19584u
+#define FB_WGS 2
+#endif
 #define FB_LDS (FB_BASE + 4 * FB_WAVE)     /* 80512 B -> two workgroups (8 waves) per CU */
+#ifndef NQ_OCC
 static_assert(FB_PATCH + 2 * FB_PPLANE <= FB_WAVE && 2 * FB_P3 <= FB_WAVE && 2 * FB_PS <= 2 * FB_WAVE, "LDS plan");
-static_assert(2 * FB_LDS <= 160 * 1024, "two workgroups per CU");
+#endif
+static_assert(FB_WGS * FB_LDS <= 160 * 1024, "workgroups per CU");
 
 __device__ constexpr int bwin75_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 2 : b == 3 ? 4 : 5; }
 __device__ constexpr int bwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b == 2 ? 5 : b == 3 ? 6 : 7; }
@@ -92,7 +100,7 @@ extern "C" int nisqa_debug_phase_clock(unsigned long long* out16, int reset) {
 // SEGX: the input is the reference's segment tensor x[B][L][1][48][15] (inner-operator mode) instead of the spectrogram
 // P3: also write the pooled conv4 output as fp32 (debug / parity callers of nisqa_cnn_adapt_bf16 that pass p3_opt)
 template <bool SEGX, bool P3>
-__global__ __launch_bounds__(256, 2) void cnn_front_bf16_kernel(
+__global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
     const float* __restrict__ clip_floor, int n_clips, int seg_hop,
