@@ -89,6 +89,30 @@ int nisqa_conv3x3_gemm_bf16(int32_t mode, const float* x_or_dz, const float* w_o
  * arithmetic of nisqa_conv3x3_gemm_bf16. */
 int nisqa_conv3x3_fwd_stats(int32_t split_bf16, const float* x, const float* w_, float* z, int32_t n_segments, int32_t h,
                             int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c, void* stream);
+/* Forward and input-gradient convolutions of the AdaptCNN layers 2..6, SEGMENT-RESIDENT (csrc/train_conv.hip): a workgroup
+ * stages the activations of a few whole segments in LDS once (split into bf16 hi + lo once) and runs the K loop of the
+ * inference kernel over them; arithmetic = nisqa_conv3x3_gemm_bf16 (three products per term, fp32 accumulation).
+ * Replaces, for the five layer shapes of config/train_nisqa_cnn_sa_ap.yaml, what PyTorch does inside
+ * nisqa/NISQA_lib.py:690-705 (conv forward) and in autograd's convolution backward (NISQA_model.py:142-143).
+ *   nisqa_segconv_supported  1 if (h, w, ci, co, pad_w) is one of those shapes ((24,7,16,32,1) (12,5,32,64,1) (12,5,64,64,1)
+ *                            (6,3,64,64,1) (6,3,64,64,0)); otherwise callers use nisqa_conv3x3_gemm_bf16
+ *   nisqa_segconv_frag_bytes size of the packed weight fragments of one layer and mode (-1: bad arguments)
+ *   nisqa_segconv_pack       w[co][9*ci] -> fragments (bf16 hi / lo, MFMA B-operand order); mode 0 forward, mode 1 input
+ *                            gradient (taps mirrored, matrix transposed).  Once per optimiser step.
+ *   nisqa_segconv_bf16       mode 0: z[S*h*wo][co] = conv(x[S][h*w][ci]) + bias (may be NULL); stats2c (may be NULL; float64,
+ *                            zeroed by the caller) += sum z, sum z^2 per channel;
+ *                            mode 1: dx[S*h*w][ci] = conv^T(dz[S][h*wo][co]); bias and stats2c must be NULL.
+ *                            frags = nisqa_segconv_pack of the same mode. */
+int nisqa_segconv_supported(int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w);
+int64_t nisqa_segconv_frag_bytes(int32_t mode, int32_t ci, int32_t co);
+int nisqa_segconv_pack(int32_t mode, const float* w, int32_t ci, int32_t co, uint16_t* frags, void* stream);
+int nisqa_segconv_bf16(int32_t mode, const float* src, const uint16_t* frags, float* out, int32_t n_segments, int32_t h,
+                       int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c, void* stream);
+/* Weight gradient of the same layers, segment-resident: dw[co][9*ci] += dz^T * patches(x) (dw zeroed by the caller, like
+ * nisqa_conv3x3_gemm mode 2); x[S][h*w][ci], dz[S][h*wo][co].  A workgroup keeps its part of dw in registers over all the
+ * segments it walks over and adds it to dw once (fp32 atomics). */
+int nisqa_segconv_wgrad_bf16(const float* x, const float* dz, float* dw, int32_t n_segments, int32_t h, int32_t w, int32_t ci,
+                             int32_t co, int32_t pad_w, void* stream);
 /* adjoint of nisqa_im2col3x3 (gather form, no atomics): dx[S][H*W][C] = sum of the patch entries that read it */
 int nisqa_col2im3x3(const float* dcol, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t pad_w, float* dx,
                     void* stream);

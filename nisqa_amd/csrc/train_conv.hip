@@ -1,0 +1,582 @@
+// Segment-resident 3 x 3 convolutions of the training step on split-bf16 MFMA (include/nisqa_train.h: nisqa_segconv_*):
+// forward z = conv(x, w) + b and input gradient dx = conv^T(dz, w) of the AdaptCNN layers 2..6 (reference
+// nisqa/NISQA_lib.py:688-710 in train mode; NISQA_model.py:131-152 drives forward + backward).
+//
+// The implicit GEMMs of train.hip gather every K-tile of the patch matrix from HBM / L2 with index arithmetic, split it
+// into bf16 hi + lo on the way into LDS and pay two workgroup barriers per 32 k: each activation is fetched and split nine
+// times (once per tap), and the matrix pipe waits for the gathers.  Train-mode BatchNorm forbids carrying a
+// segment through several layers, but ONE layer can still be done the way the inference kernel does it (cnn_bf16.hip):
+//   * a workgroup of four waves owns SEGS consecutive segments: their activations ([S][H*W][C] fp32, contiguous) are read
+//     ONCE with 128-bit loads, split once, and kept as two bf16 planes (hi, lo), pixel rows padded by 16 bytes;
+//   * the output pixels of those segments are the M rows, 32 per tile, MT tiles per wave; the K loop is conv_k_bf16
+//     (conv_bf16.hpp): A fragments are ds_read_b128 at lane base + (tap, channel-step) immediates, out-of-image taps go to
+//     a shared zero block by a lane-static 9-bit mask, no barrier inside the loop;
+//   * weight fragments stream from L2 through a buffer descriptor into a 3-deep register ring; they are packed (and split)
+//     once per optimiser step by segconv_pack_kernel -- 0.4 MB for all five layers and both directions;
+//   * the input gradient is the same kernel: a convolution of dz with the taps mirrored and the weight matrix transposed
+//     (both folded into the packing), and horizontal padding 2 - pad_w.
+// Forward epilogue: + bias, z to HBM, and the BatchNorm batch statistics (sum z, sum z^2 per channel, float64) ride along
+// exactly as in conv_gemm_bf16_kernel.
+#include <stdlib.h>
+#include "common.hpp"
+// one scheduling fence per K-step of conv_k_bf16 in THIS unit: the two workgroups of a CU run in step here, nobody fills the
+// stalls of a sunk prefetch (measured -9 % forward, -15 % input gradient; the inference kernel, whose waves are out of step,
+// is faster without: conv_bf16.hpp)
+#ifndef NQ_SB
+#define NQ_SB 1
+#endif
+#include "conv_bf16.hpp"
+#include "../../include/nisqa_hip.h"
+#include "../../include/nisqa_train.h"
+
+#define SC_ZADDR 2048u                     /* 128-byte zero block above the largest tap offset */
+#define SC_BASE 2176u                      /* hi plane; the lo plane follows */
+// -DSC_CLOCK: shader-clock stamps per phase, summed per wave into g_sc_clk[wave slot][8] (tools/bench_segconv.py prints them)
+#ifdef SC_CLOCK
+__device__ unsigned long long g_sc_clk[8192 * 8];
+#define SC_CLK(i) do { const long long t_ = clock64(); clk[i] += t_ - tprev; tprev = t_; } while (0)
+extern "C" int nisqa_debug_segconv_clock(unsigned long long* out8, int reset) {
+    if (out8) {
+        unsigned long long* h = (unsigned long long*)malloc(sizeof(g_sc_clk));
+        if (!h || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sc_clk), sizeof(g_sc_clk)) != hipSuccess) { free(h); return -1; }
+        for (int q = 0; q < 8; ++q) out8[q] = 0;
+        for (int w = 0; w < 8192; ++w)
+            for (int q = 0; q < 8; ++q) out8[q] += h[(size_t)w * 8 + q];
+        free(h);
+    }
+    if (reset) {
+        void* d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_sc_clk)) != hipSuccess || hipMemset(d, 0, sizeof(g_sc_clk)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define SC_CLK(i)
+#endif
+#ifndef SC_RING
+#define SC_RING 3            /* weight-fragment ring of the K loop (slots) */
+#endif
+#ifndef SC_NOFENCE
+#define SC_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SC_FENCE()
+#endif
+
+// ---- fragment packing: [step g][NT][hi, lo][64 lanes][8 bf16];  step g = (tap, 16-channel group), lane l holds column
+//      n = 32 nt + (l & 31) and reduction channels 16 (g % S16) + 8 (l >> 5) .. + 7 of that tap
+//   mode 0 (forward):  B[(tap, ci)][n = co] = w[co][tap * CI + ci]
+//   mode 1 (dgrad):    B[(tap, co)][n = ci] = w[co][(8 - tap) * CI + ci]
+__global__ __launch_bounds__(256) void segconv_pack_kernel(const float* __restrict__ w, int ci, int co, int mode,
+                                                           unsigned short* __restrict__ out) {
+    const int kc = mode ? co : ci, n_real = mode ? ci : co;
+    const int s16 = kc / 16, nt_n = (n_real + 31) / 32;
+    const int total = 9 * s16 * nt_n * 64 * 8;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int e = i & 7, lane = (i >> 3) & 63, nt = (i >> 9) % nt_n, g = (i >> 9) / nt_n;
+        const int tap = g / s16, c = 16 * (g % s16) + 8 * (lane >> 5) + e, n = 32 * nt + (lane & 31);
+        float v = 0.f;
+        if (n < n_real) v = mode ? w[(size_t)c * (9 * ci) + (8 - tap) * ci + n] : w[(size_t)n * (9 * ci) + tap * ci + c];
+        const unsigned hi = bf16_bits(v);
+        const unsigned lo = bf16_bits(v - bf16_val(hi));
+        const size_t o = (((size_t)(g * nt_n + nt) * 2) * 64 + lane) * 8 + e;
+        out[o] = (unsigned short)hi;
+        out[o + 512] = (unsigned short)lo;
+    }
+}
+
+extern "C" int64_t nisqa_segconv_frag_bytes(int32_t mode, int32_t ci, int32_t co) {
+    if (mode < 0 || mode > 1 || ci < 16 || co < 16 || (ci & 15) || (co & 15)) return -1;
+    const int kc = mode ? co : ci, n_real = mode ? ci : co;
+    return (int64_t)9 * (kc / 16) * ((n_real + 31) / 32) * 2 * 1024;
+}
+
+extern "C" int nisqa_segconv_pack(int32_t mode, const float* w, int32_t ci, int32_t co, uint16_t* frags, void* stream) {
+    if (!w || !frags || nisqa_segconv_frag_bytes(mode, ci, co) < 0) return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    const int total = (int)(nisqa_segconv_frag_bytes(mode, ci, co) / 4);          // elements of one plane pair / 2
+    hipLaunchKernelGGL(segconv_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, ci, co, mode, frags);
+    return NQ_LAUNCH_STATUS();
+}
+
+// CIN: channels of the staged tensor (the reduction runs over 9 x CIN); NT: 32-column tiles of the output channels
+// HR x WR: output pixels of a segment (the rows); HS x WS: pixels of the staged tensor; source pixel of row (y, x) and
+// tap (ty, tx) is (y + ty - 1, x + tx - PADX)
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD>
+struct segconv_cfg {
+    static constexpr int RS = 2 * CIN + 16;
+    static constexpr int PXS = HS * WS, PXR = HR * WR;
+    static constexpr int PLANE = SEGS * PXS * RS;
+    static constexpr unsigned LDS = SC_BASE + 2 * PLANE;
+    static constexpr int ROWS = SEGS * PXR;
+    static constexpr int F4 = SEGS * PXS * CIN / 4;          // 128-bit groups of the workgroup's activations
+    static constexpr int NV = (F4 + 255) / 256;
+    static_assert(ROWS <= 4 * MT * 32, "rows of the workgroup's segments must fit its tiles");
+    static_assert(SC_BASE >= (unsigned)((WS + PADX) * RS), "tap (-1, -PADX) of pixel 0 must not address below 0");
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+};
+
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD>
+__global__ __launch_bounds__(256, 2) void segconv_bf16_kernel(
+    const float* __restrict__ src, const unsigned short* __restrict__ frags, float* __restrict__ out, int n_segments,
+    const float* __restrict__ bias, double* __restrict__ stats) {
+    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int n_groups = (n_segments + SEGS - 1) / SEGS;
+
+    // ---- rows of this wave's tiles: lane-static geometry (a short last group is staged as zeros and masked in the epilogue)
+    const bool active = (wave * MT) * 32 < C::ROWS;              // otherwise this wave's tiles are all padding
+    unsigned base[MT], m9[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int r = (wave * MT + t) * 32 + (lane0 & 31);
+        const bool valid = r < C::ROWS;
+        const int sg = r / C::PXR, pix = r - sg * C::PXR, y = pix / WR, x = pix - y * WR;
+        unsigned m = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ys = y + tap / 3 - 1, xs = x + tap % 3 - PADX;
+            m |= (valid && (unsigned)ys < (unsigned)HS && (unsigned)xs < (unsigned)WS) ? (1u << tap) : 0u;
+        }
+        m9[t] = m;
+        base[t] = valid ? SC_BASE + (unsigned)(((sg * HS + y - 1) * WS + (x - PADX)) * C::RS) + 16u * (lane0 >> 5)
+                        : SC_BASE + 16u * (lane0 >> 5);
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)frags, 0, 9 * (CIN / 16) * NT * 2048, 0x00020000);
+    if (tid0 < 32) *(unsigned*)(smem + SC_ZADDR + 4 * tid0) = 0u;  // through the symbol: the kernel must be seen to use LDS
+    const bool with_stats = FWD && stats != nullptr;
+    double s1[NT], s2[NT];                                       // this lane's column sums over all groups of the workgroup
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        s1[nt] = s2[nt] = 0.0;
+        const int col = 32 * nt + (lane0 & 31);
+        bv[nt] = (FWD && bias && col < NOUT) ? bias[col] : 0.f;
+    }
+
+    // The workgroup walks over groups of SEGS segments.  The two workgroups of a CU run in step, so the loads, the K loop and
+    // the stores of a group would overlap with nothing (measured: 120 us for a layer whose K loops need 50).  Registers for a
+    // whole group of raw activations across the K loop are not to be had (60 more: the compiler spills), so the NEXT group is
+    // only TOUCHED before the K loop -- one dword per 128-byte line, 2 registers -- which brings it from HBM into L2 while
+    // the matrix pipe works; the real loads of the next iteration hit L2.  Output stores are never waited for.
+    constexpr int LINES = SEGS * C::PXS * CIN / 32;             // 128-byte lines of a group
+    constexpr int NTOUCH = (LINES + 255) / 256;
+#ifdef SC_CLOCK
+    long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        // (the thread's indices are re-defined opaquely per iteration: otherwise every staging address and every output offset
+        // of the epilogue is computed once before the loop and kept in registers across it -- 100+ of them)
+        int tid = tid0, lane = lane0;
+        asm volatile("" : "+v"(tid), "+v"(lane));
+        {
+            const int seg0 = grp * SEGS;
+            const f32x4* g = (const f32x4*)(src + (size_t)seg0 * C::PXS * CIN);
+            const int lim = min(SEGS, n_segments - seg0) * C::PXS * CIN / 4;
+            f32x4 v[C::NV];
+#pragma unroll
+            for (int j = 0; j < C::NV; ++j) {
+                const int i = tid + 256 * j;
+                v[j] = i < lim ? g[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            SC_CLK(0);                                          // requests issued
+            __syncthreads();                                    // every wave has left the K loop over the previous planes
+            SC_CLK(1);
+#pragma unroll
+            for (int j = 0; j < C::NV; ++j) {
+                const int i = tid + 256 * j;
+                if (C::F4 % 256 == 0 || i < C::F4) {
+                    const int pix = (4 * i) / CIN, c = (4 * i) % CIN;
+                    const unsigned a = SC_BASE + pix * C::RS + 2 * c;
+                    const unsigned h0 = cvt_pk_bf16(v[j][0], v[j][1]), h1 = cvt_pk_bf16(v[j][2], v[j][3]);
+                    const unsigned l0 = cvt_pk_bf16(v[j][0] - __uint_as_float(h0 << 16), v[j][1] - __uint_as_float(h0 & 0xffff0000u));
+                    const unsigned l1 = cvt_pk_bf16(v[j][2] - __uint_as_float(h1 << 16), v[j][3] - __uint_as_float(h1 & 0xffff0000u));
+                    lds_st32(a, h0); lds_st32(a + 4, h1);
+                    lds_st32(a + C::PLANE, l0); lds_st32(a + C::PLANE + 4, l1);
+                }
+            }
+        }
+        SC_CLK(2);                                              // split + stored (includes the wait for the loads)
+        __syncthreads();
+        SC_CLK(3);
+        float touch[NTOUCH];
+        {
+            const int nxt = grp + (int)gridDim.x;
+            const float* g = src + (size_t)nxt * SEGS * C::PXS * CIN;
+            const int lim = nxt < n_groups ? min(SEGS, n_segments - nxt * SEGS) * C::PXS * CIN / 32 : 0;
+#pragma unroll
+            for (int j = 0; j < NTOUCH; ++j) {
+                const int i = tid + 256 * j;
+                touch[j] = i < lim ? g[32 * i] : 0.f;
+            }
+        }
+        SC_FENCE();                                             // keep the requests above the K loop (hipcc sinks loads to their use)
+        // loop-invariant code motion would lift the per-tap address selects of every tile out of the group loop (72 registers
+        // live across everything: spills); opaque re-definitions keep them inside
+#pragma unroll
+        for (int t = 0; t < MT; ++t) asm volatile("" : "+v"(base[t]), "+v"(m9[t]));
+
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = zero16();
+        if (active) conv_k_bf16<CIN, MT, NT, WS, C::RS, C::PLANE, SC_ZADDR, (MT * NT <= 4), SC_RING>(acc, rsrc, 0, lane0 * 16, base, m9);
+
+        SC_CLK(4);                                              // K loop
+        const int seg0 = grp * SEGS;
+        const int rows = min(SEGS, n_segments - seg0) * C::PXR;
+        float* o = out + (size_t)seg0 * C::PXR * NOUT;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = 32 * nt + (lane & 31);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (wave * MT + t) * 32 + NQ_DROW(r, lane >> 5);
+                    if (row < rows && col < NOUT) {
+                        const float zv = acc[t][nt][r] + bv[nt];
+                        o[(size_t)row * NOUT + col] = zv;
+                        if (FWD) { s1[nt] += (double)zv; s2[nt] += (double)zv * (double)zv; }
+                    }
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < NTOUCH; ++j) asm volatile("" ::"v"(touch[j]));      // the touches end here, not before
+        SC_CLK(5);                                              // epilogue
+#ifdef SC_CLOCK
+        clk[6] += 1;
+#endif
+    }
+#ifdef SC_CLOCK
+    if (lane0 == 0) {
+        const int slot = (blockIdx.x * 4 + wave) & 8191;
+        for (int q = 0; q < 7; ++q) g_sc_clk[slot * 8 + q] += clk[q];
+        g_sc_clk[slot * 8 + 7] += 1;
+    }
+#endif
+
+    // ---- BatchNorm statistics of the workgroup's rows: lane pairs, the four waves through LDS, one atomic per channel
+    if (with_stats) {
+        double* red = (double*)(smem + SC_BASE);
+        __syncthreads();                                        // the planes are dead
+        for (int q = tid0; q < 2 * 32 * NT; q += 256) red[q] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = 32 * nt + (lane0 & 31);
+            const double a1 = s1[nt] + __shfl_xor(s1[nt], 32), a2 = s2[nt] + __shfl_xor(s2[nt], 32);
+            if (lane0 < 32 && col < NOUT) {
+                atomicAdd(&red[col], a1);
+                atomicAdd(&red[32 * NT + col], a2);
+            }
+        }
+        __syncthreads();
+        for (int q = tid0; q < 32 * NT; q += 256)
+            if (q < NOUT) {
+                atomicAdd(stats + q, red[q]);
+                atomicAdd(stats + NOUT + q, red[32 * NT + q]);
+            }
+    }
+}
+
+static int sc_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+                ? p.multiProcessorCount : 256;
+    }
+    return n;
+}
+
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD>
+static void segconv_launch(hipStream_t st, const float* src, const uint16_t* frags, float* out, int n_segments,
+                           const float* bias, double* stats) {
+    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD> C;
+    static int per_cu = 0;                                      // resident workgroups per CU (registers and LDS), asked once
+    if (!per_cu) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD>, 256,
+                                                         C::LDS) != hipSuccess || nb < 1)
+            nb = 2;
+        per_cu = nb;
+    }
+    const int n_groups = (n_segments + SEGS - 1) / SEGS;
+    const int grid = n_groups < per_cu * sc_cu_count() ? n_groups : per_cu * sc_cu_count();
+    hipLaunchKernelGGL((segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD>), dim3(grid), dim3(256), C::LDS, st, src,
+                       frags, out, n_segments, bias, stats);
+}
+
+// the five layer shapes of the AdaptCNN at the reference's pooling sizes (config/train_nisqa_cnn_sa_ap.yaml:
+// cnn_pool_1 [24, 7], cnn_pool_2 [12, 5], cnn_pool_3 [6, 3]); for anything else nisqa_segconv_supported says 0 and the
+// caller keeps nisqa_conv3x3_gemm_bf16
+#define SC_KEY(h_, w_, ci_, co_) ((((h_) * 100 + (w_)) * 100 + (ci_)) * 100 + (co_))
+extern "C" int nisqa_segconv_supported(int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w) {
+    const int key = SC_KEY(h, w, ci, co);
+    if (pad_w == 0) return key == SC_KEY(6, 3, 64, 64);
+    return pad_w == 1 && (key == SC_KEY(24, 7, 16, 32) || key == SC_KEY(12, 5, 32, 64) || key == SC_KEY(12, 5, 64, 64) ||
+                          key == SC_KEY(6, 3, 64, 64));
+}
+extern "C" int nisqa_segconv_bf16(int32_t mode, const float* src, const uint16_t* frags, float* out, int32_t n_segments,
+                                  int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias,
+                                  double* stats2c, void* stream) {
+    if (mode < 0 || mode > 1 || !src || !frags || !out || n_segments <= 0 || (mode == 1 && (bias || stats2c)) ||
+        !nisqa_segconv_supported(h, w, ci, co, pad_w))
+        return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    NQ_LAUNCH_BEGIN();
+    const int key = ((h * 100 + w) * 100 + ci) * 100 + co;
+    const int n = n_segments;
+    if (mode == 0) {
+        if (key == SC_KEY(24, 7, 16, 32) && pad_w == 1) segconv_launch<16, 1, 32, 24, 7, 24, 7, 1, 3, 4, true>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<32, 2, 64, 12, 5, 12, 5, 1, 4, 2, true>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, 4, 2, true>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 14, 2, true>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 1, 6, 3, 0, 15, 1, true>(st, src, frags, out, n, bias, stats2c);
+        else return NISQA_ERR_ARG;
+    } else {                                                  // staged tensor = dz [S][h * wo][co], rows = the h * w input pixels
+        if (key == SC_KEY(24, 7, 16, 32) && pad_w == 1) segconv_launch<32, 1, 16, 24, 7, 24, 7, 1, 2, 3, false>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<64, 1, 32, 12, 5, 12, 5, 1, 4, 2, false>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, 4, 2, false>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 14, 2, false>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 3, 6, 1, 2, 14, 2, false>(st, src, frags, out, n, nullptr, nullptr);
+        else return NISQA_ERR_ARG;
+    }
+    return NQ_LAUNCH_STATUS();
+}
+
+// ======================================================================================================================
+// Weight gradient, segment-resident: dw[co][tap * CI + ci] += sum over the pixels of every segment of
+// dz[px][co] * x[px + tap][ci]  -- a GEMM with M = co, N = (tap, ci), K = pixels.  The implicit GEMM (train.hip, mode 2)
+// gathers both operands per K-tile from HBM with index arithmetic and restarts its accumulators per row chunk (split-K,
+// atomics per chunk).  Here a workgroup stages the x and dz of SEGS whole segments once (x with a ZERO BORDER, so a tap is
+// a constant address offset and needs no mask), its four waves split the N tiles and keep their part of dw in registers
+// across ALL the groups the workgroup walks over (one set of atomics per workgroup at the end).
+//   * k is the pixel, i.e. the planes' ROW index: fragments come out of ds_read_b64_tr_b16, gfx950's transposing LDS read
+//     (in a 16-lane group lane s points at row s >> 2, columns 4 (s & 3) .. + 3 of a [4 rows][16 columns] block and lane i
+//     receives column i; two reads = the 8 k of a lane; mapping read off the hardware by tools/micro/trread.hip);
+//   * eight waves; wave w owns the N tiles w, w + 8, ... (or, MSPLIT = 2, one of the two M tiles and every fourth N tile); a
+//     tile's (tap, channel) offset is one add per read; A (dz) fragments are shared by a wave's tiles;
+//   * two LDS buffers: the next group is requested before the K loop and split into the other buffer behind it, one barrier
+//     per group.
+// ======================================================================================================================
+typedef short sc_s16x4 __attribute__((ext_vector_type(4)));
+NQ_DEV f32x4 sc_tr_frag(unsigned a0, unsigned a1) {
+    const sc_s16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((NQ_AS3 sc_s16x4*)(a0));
+    const sc_s16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((NQ_AS3 sc_s16x4*)(a1));
+    struct { sc_s16x4 a, b; } both = {x0, x1};
+    return __builtin_bit_cast(f32x4, both);
+}
+
+template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT>
+struct segwgrad_cfg {
+    static constexpr int RSX = 2 * CI + 16, RSZ = 2 * CO + 16;
+    static constexpr int XPW = W + 2 * PADW, XPH = H + 2;
+    static constexpr int PXX = XPH * XPW, PXI = H * W, PXZ = H * WO;
+    static constexpr int PLX = SEGS * PXX * RSX;
+    static constexpr int KROWS = SEGS * PXZ;
+    static constexpr int PLZ = (KROWS + 1) * RSZ;            // + one zero row: the k rows behind the last pixel
+    static constexpr unsigned ZB = 2u * PLX;                 // inside a buffer: x hi, x lo, dz hi, dz lo
+    static constexpr unsigned BUF = 2u * PLX + 2u * PLZ;
+    static constexpr unsigned LDS = 2u * BUF;                // two buffers: group g + 1 is staged while group g is multiplied
+    static constexpr int KSTEPS = (KROWS + 15) / 16;
+    static constexpr int MT = CO / 32, MTW = MT / MSPLIT;    // M tiles of the layer / of a wave
+    static constexpr int NSPLIT = 8 / MSPLIT;                // waves along N
+    static constexpr int NTILES = (9 * CI + 31) / 32;
+    static constexpr int NTW = (NTILES + NSPLIT - 1) / NSPLIT;
+    static constexpr int FX = SEGS * PXI * CI / 4, FZ = SEGS * PXZ * CO / 4;     // 128-bit groups of a group's x / dz
+    static constexpr int NVX = (FX + 511) / 512, NVZ = (FZ + 511) / 512;
+    static_assert(LDS <= 160 * 1024, "LDS");
+    static_assert(BUF % 16 == 0 && CI % 16 == 0 && CO % 32 == 0 && MT % MSPLIT == 0, "shapes");
+};
+
+// K loop of a wave: its N tiles are wq, wq + NSPLIT, ...; noff[j] = byte offset of tile j (tap, channels) in an x plane
+template <typename C>
+NQ_DEV void segwgrad_kloop(f32x16 (&acc)[C::MTW][C::NTW], const unsigned (&za)[C::KSTEPS][2], const unsigned (&xa)[C::KSTEPS][2],
+                           const unsigned (&noff)[C::NTW], int n_own) {
+#pragma unroll
+    for (int st = 0; st < C::KSTEPS; ++st) {
+        __builtin_amdgcn_sched_barrier(0);                     // a step's reads stay in their step (register pressure)
+        f32x4 ah[C::MTW], al[C::MTW];
+#pragma unroll
+        for (int m = 0; m < C::MTW; ++m) {
+            ah[m] = sc_tr_frag(za[st][0] + 64 * m, za[st][1] + 64 * m);
+            al[m] = sc_tr_frag(za[st][0] + 64 * m + C::PLZ, za[st][1] + 64 * m + C::PLZ);
+        }
+#pragma unroll
+        for (int j = 0; j < C::NTW; ++j) {
+            if (j < n_own) {                                   // wave-uniform
+                const unsigned a0 = xa[st][0] + noff[j], a1 = xa[st][1] + noff[j];
+                const f32x4 bh = sc_tr_frag(a0, a1);
+                const f32x4 bl = sc_tr_frag(a0 + C::PLX, a1 + C::PLX);
+#pragma unroll
+                for (int m = 0; m < C::MTW; ++m) acc[m][j] = mfma_bf(ah[m], bl, acc[m][j]);
+#pragma unroll
+                for (int m = 0; m < C::MTW; ++m) acc[m][j] = mfma_bf(al[m], bh, acc[m][j]);
+#pragma unroll
+                for (int m = 0; m < C::MTW; ++m) acc[m][j] = mfma_bf(ah[m], bh, acc[m][j]);
+            }
+        }
+    }
+}
+
+template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT>
+__global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                               float* __restrict__ dw, int n_segments) {
+    typedef segwgrad_cfg<CI, CO, H, W, WO, PADW, SEGS, MSPLIT> C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int wq = wave / MSPLIT, wm = wave % MSPLIT;           // this wave's N residue and M part
+    const int n_groups = (n_segments + SEGS - 1) / SEGS;
+    // zero both buffers once: the borders of the x planes and the zero rows of dz stay zero
+    for (unsigned a = 16u * tid0; a < C::LDS; a += 16u * 512u) *(f32x4*)(smem + a) = f32x4{0.f, 0.f, 0.f, 0.f};
+    // lane-static read addresses (buffer 0): k row of (step, read) -> dz row / x pixel at tap (0, 0) in padded coordinates
+    const int g16 = (lane0 >> 4) & 1;
+    unsigned za0[C::KSTEPS][2], xa0[C::KSTEPS][2];
+#pragma unroll
+    for (int st = 0; st < C::KSTEPS; ++st)
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int r = 16 * st + 8 * (lane0 >> 5) + 4 * rd + ((lane0 & 15) >> 2);
+            const bool valid = r < C::KROWS;
+            const int sg = r / C::PXZ, p = r - sg * C::PXZ, y = p / WO, xo = p - y * WO;
+            za0[st][rd] = C::ZB + (unsigned)((valid ? r : C::KROWS) * C::RSZ) + 2u * (16 * g16 + 4 * (lane0 & 3)) + 64u * C::MTW * wm;
+            xa0[st][rd] = (unsigned)((valid ? sg * C::PXX + y * C::XPW + xo : 0) * C::RSX) + 2u * (4 * (lane0 & 3));
+        }
+    const int n_own = (C::NTILES - wq + C::NSPLIT - 1) / C::NSPLIT;      // N tiles of this wave
+    unsigned noff[C::NTW];
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j) {
+        const int n0 = 32 * (wq + C::NSPLIT * j) + (CI == 16 ? 16 * g16 : 0);
+        const int tap = min(n0 / CI, 8);                        // columns behind 9 * CI: computed on valid memory, never stored
+        noff[j] = (unsigned)(((tap / 3) * C::XPW + tap % 3) * C::RSX + 2 * (n0 % CI)) + (CI == 16 ? 0u : 32u * g16);
+    }
+    f32x16 acc[C::MTW][C::NTW];
+#pragma unroll
+    for (int m = 0; m < C::MTW; ++m)
+#pragma unroll
+        for (int j = 0; j < C::NTW; ++j) acc[m][j] = zero16();
+
+    f32x4 vx[C::NVX], vz[C::NVZ];
+    auto request = [&](int grp, int tid) {
+        const int seg0 = grp * SEGS;
+        const int nseg = grp < n_groups ? min(SEGS, n_segments - seg0) : 0;
+        const f32x4* gx = (const f32x4*)(x + (size_t)seg0 * C::PXI * CI);
+        const f32x4* gz = (const f32x4*)(dz + (size_t)seg0 * C::PXZ * CO);
+#pragma unroll
+        for (int j = 0; j < C::NVX; ++j) {
+            const int i = tid + 512 * j;
+            vx[j] = i < nseg * C::PXI * CI / 4 ? gx[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < C::NVZ; ++j) {
+            const int i = tid + 512 * j;
+            vz[j] = i < nseg * C::PXZ * CO / 4 ? gz[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto deposit = [&](unsigned buf, int tid) {                  // split and store the requested group into buffer `buf`
+#pragma unroll
+        for (int j = 0; j < C::NVX; ++j) {
+            const int i = tid + 512 * j;
+            if (C::FX % 512 == 0 || i < C::FX) {
+                const int pix = (4 * i) / CI, c = (4 * i) % CI;
+                const int sg = pix / C::PXI, p = pix - sg * C::PXI, y = p / W, xx = p - y * W;
+                const unsigned a = buf + (unsigned)((sg * C::PXX + (y + 1) * C::XPW + xx + PADW) * C::RSX) + 2 * c;
+                const unsigned h0 = cvt_pk_bf16(vx[j][0], vx[j][1]), h1 = cvt_pk_bf16(vx[j][2], vx[j][3]);
+                const unsigned l0 = cvt_pk_bf16(vx[j][0] - __uint_as_float(h0 << 16), vx[j][1] - __uint_as_float(h0 & 0xffff0000u));
+                const unsigned l1 = cvt_pk_bf16(vx[j][2] - __uint_as_float(h1 << 16), vx[j][3] - __uint_as_float(h1 & 0xffff0000u));
+                lds_st32(a, h0); lds_st32(a + 4, h1);
+                lds_st32(a + C::PLX, l0); lds_st32(a + C::PLX + 4, l1);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < C::NVZ; ++j) {
+            const int i = tid + 512 * j;
+            if (C::FZ % 512 == 0 || i < C::FZ) {
+                const int pix = (4 * i) / CO, c = (4 * i) % CO;
+                const unsigned a = buf + C::ZB + (unsigned)(pix * C::RSZ) + 2 * c;
+                const unsigned h0 = cvt_pk_bf16(vz[j][0], vz[j][1]), h1 = cvt_pk_bf16(vz[j][2], vz[j][3]);
+                const unsigned l0 = cvt_pk_bf16(vz[j][0] - __uint_as_float(h0 << 16), vz[j][1] - __uint_as_float(h0 & 0xffff0000u));
+                const unsigned l1 = cvt_pk_bf16(vz[j][2] - __uint_as_float(h1 << 16), vz[j][3] - __uint_as_float(h1 & 0xffff0000u));
+                lds_st32(a, h0); lds_st32(a + 4, h1);
+                lds_st32(a + C::PLZ, l0); lds_st32(a + C::PLZ + 4, l1);
+            }
+        }
+    };
+
+    int grp = blockIdx.x;
+    request(grp, tid0);
+    __syncthreads();                                            // the zero fill is complete
+    deposit(0u, tid0);
+    __syncthreads();
+    unsigned cur = 0u;
+    for (; grp < n_groups; grp += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));                          // keep the staging addresses inside the loop
+        request(grp + gridDim.x, tid);                          // the next group travels while this one is multiplied
+        __builtin_amdgcn_sched_barrier(0);                      // (hipcc would sink these loads to their use behind the K loop)
+        unsigned za[C::KSTEPS][2], xa[C::KSTEPS][2];
+#pragma unroll
+        for (int st = 0; st < C::KSTEPS; ++st)
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                za[st][rd] = za0[st][rd] + cur;
+                xa[st][rd] = xa0[st][rd] + cur;
+            }
+        segwgrad_kloop<C>(acc, za, xa, noff, n_own);
+        __builtin_amdgcn_sched_barrier(0);
+        deposit(C::BUF - cur, tid);                             // the other buffer: last read before the previous barrier
+        __syncthreads();
+        cur = C::BUF - cur;
+    }
+    // ---- this workgroup's share of dw
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j) {
+        const int nt = wq + C::NSPLIT * j;
+        const int col = 32 * nt + (lane0 & 31);
+        if (nt < C::NTILES && col < 9 * CI) {
+#pragma unroll
+            for (int m = 0; m < C::MTW; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * (C::MTW * wm + m) + NQ_DROW(r, lane0 >> 5);
+                    atomicAdd(dw + (size_t)row * (9 * CI) + col, acc[m][j][r]);
+                }
+        }
+    }
+}
+
+template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT>
+static void segwgrad_launch(hipStream_t st, const float* x, const float* dz, float* dw, int n_segments) {
+    typedef segwgrad_cfg<CI, CO, H, W, WO, PADW, SEGS, MSPLIT> C;
+    static bool attr = false;
+    if (!attr) {                                                // more than 64 KB of dynamic LDS
+        (void)hipFuncSetAttribute((const void*)segwgrad_bf16_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+        attr = true;
+    }
+    const int n_groups = (n_segments + SEGS - 1) / SEGS;
+    const int grid = n_groups < sc_cu_count() ? n_groups : sc_cu_count();
+    hipLaunchKernelGGL((segwgrad_bf16_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT>), dim3(grid), dim3(512), C::LDS, st, x, dz, dw,
+                       n_segments);
+}
+
+// dw[co][9 * ci] += dz^T * patches(x)  (dw zeroed by the caller, as for nisqa_conv3x3_gemm mode 2); same five shapes
+extern "C" int nisqa_segconv_wgrad_bf16(const float* x, const float* dz, float* dw, int32_t n_segments, int32_t h, int32_t w,
+                                        int32_t ci, int32_t co, int32_t pad_w, void* stream) {
+    if (!x || !dz || !dw || n_segments <= 0 || !nisqa_segconv_supported(h, w, ci, co, pad_w)) return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    NQ_LAUNCH_BEGIN();
+    const int key = SC_KEY(h, w, ci, co);
+    if (key == SC_KEY(24, 7, 16, 32)) segwgrad_launch<16, 32, 24, 7, 7, 1, 1, 1>(st, x, dz, dw, n_segments);
+    else if (key == SC_KEY(12, 5, 32, 64)) segwgrad_launch<32, 64, 12, 5, 5, 1, 1, 2>(st, x, dz, dw, n_segments);
+    else if (key == SC_KEY(12, 5, 64, 64)) segwgrad_launch<64, 64, 12, 5, 5, 1, 1, 1>(st, x, dz, dw, n_segments);
+    else if (pad_w == 1) segwgrad_launch<64, 64, 6, 3, 3, 1, 4, 1>(st, x, dz, dw, n_segments);
+    else segwgrad_launch<64, 64, 6, 3, 1, 0, 8, 1>(st, x, dz, dw, n_segments);
+    return NQ_LAUNCH_STATUS();
+}

@@ -81,6 +81,11 @@ TRAIN_SYMBOLS = {
     'nisqa_conv3x3_gemm': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p]),
     'nisqa_conv3x3_fwd_stats': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_conv3x3_gemm_bf16': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p]),
+    'nisqa_segconv_supported': (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    'nisqa_segconv_frag_bytes': (ctypes.c_int64, [c_i32, c_i32, c_i32]),
+    'nisqa_segconv_pack': (ctypes.c_int, [c_i32, c_p, c_i32, c_i32, c_p, c_p]),
+    'nisqa_segconv_bf16': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
+    'nisqa_segconv_wgrad_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     'nisqa_col2im3x3': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     'nisqa_col_dot': (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_p]),
     'nisqa_bn_act_pool_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,

@@ -64,6 +64,11 @@ class HipTrainer(object):
         self.fused_fwd_stats = os.environ.get('NISQA_HIP_TRAIN_FUSED_FWD_STATS', '1') != '0'
         self._conv_fwd = fast if self.precision == 'bf16x3' else exact
         self._conv_bwd = exact if self.precision == 'f32' else fast
+        # split-bf16 forward / input-gradient convolutions segment-resident (csrc/train_conv.hip) where the layer shape is
+        # one of the reference configuration's; weight fragments are packed once per step (_segconv_frags)
+        self.segconv = os.environ.get('NISQA_HIP_TRAIN_SEGCONV', '1') != '0' and self.precision != 'f32'
+        self._sc_frags = {}
+        self._step_no = 0
         self.lr = float(lr)
         self.n_layers = int(a['td_sa_num_layers'])
         self.heads = ['pool_layers.%d.model.' % h for h in range(5)] if a['model'] == 'NISQA_DIM' else ['pool.model.']
@@ -152,6 +157,22 @@ class HipTrainer(object):
 
     def _new(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _segconv_frags(self, mode, i, hi, wi, ci, co, pad):
+        """Packed weight fragments of conv<i> for this step (mode 0 forward, 1 input gradient), or None when the layer shape
+        is not one csrc/train_conv.hip instantiates (the implicit GEMM stays)."""
+        if not self.segconv or not self.lib.nisqa_segconv_supported(hi, wi, ci, co, pad):
+            return None
+        key = (mode, i)
+        ent = self._sc_frags.get(key)
+        if ent is None:
+            nb = self.lib.nisqa_segconv_frag_bytes(mode, ci, co)
+            ent = self._sc_frags[key] = [torch.empty(nb // 2, dtype=torch.int16, device=self.device), -1]
+        if ent[1] != self._step_no:                                            # once per step: the weights change with every Adam update
+            self._ck(self.lib.nisqa_segconv_pack(mode, _ptr(self.P['cnn.model.conv%d.weight' % i]), ci, co, ent[0].data_ptr(),
+                                                 self._st()), 'nisqa_segconv_pack')
+            ent[1] = self._step_no
+        return ent[0]
 
     def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, ksplit=1, ao=0, bo=0, co=0, bias=None, relu=0):
         self._ck(self.lib.nisqa_gemm_f32_one(_ptr(A, ao), _ptr(B, bo), _ptr(C, co), M, N, K, lda, ldb, ldc, ta, tb, ksplit,
@@ -318,6 +339,7 @@ class HipTrainer(object):
     def _step(self, mel, frame_off, n_wins, floor, y, masks, bias):
         L_ = self.lib
         self._prepare(n_wins)
+        self._step_no += 1
         B, S, st = self.B, self.S, self._st()
         hop = int(self.args['ms_seg_hop_length'])
         self.gflat.zero_()
@@ -362,7 +384,16 @@ class HipTrainer(object):
                                             _ptr(self.P[wk]), _ptr(self.P[bk]), _ptr(z), st), 'nisqa_conv1_fwd')
             else:                                                              # implicit GEMM: patches gathered by the loaders
                 hi, wi = geo[i - 2][2]
-                if self.fused_fwd_stats:                                       # sum z, sum z^2 from the convolution's epilogue
+                fr = self._segconv_frags(0, i, hi, wi, ci, co, 0 if i == 6 else 1) if self.precision == 'bf16x3' else None
+                if fr is not None:
+                    sums = None
+                    if self.fused_fwd_stats:
+                        sums = self._sums[self._sum_i]
+                        self._sum_i += 1
+                    self._ck(L_.nisqa_segconv_bf16(0, _ptr(act), fr.data_ptr(), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
+                                                   _ptr(self.P[bk]), sums.data_ptr() if sums is not None else None, st),
+                             'nisqa_segconv_bf16 fwd')
+                elif self.fused_fwd_stats:                                     # sum z, sum z^2 from the convolution's epilogue
                     sums = self._sums[self._sum_i]
                     self._sum_i += 1
                     self._ck(L_.nisqa_conv3x3_fwd_stats(1 if self.precision == 'bf16x3' else 0, _ptr(act), _ptr(self.P[wk]), _ptr(z),
@@ -547,11 +578,20 @@ class HipTrainer(object):
             else:
                 hi, wi = geo[i - 2][2]
                 pad = 0 if i == 6 else 1
-                self._ck(self._conv_bwd(2, _ptr(c['x']), _ptr(dz), _ptr(self.G[wk]), S, hi, wi, ci, co, pad, None,
-                                               self._ksplit(rows, co, 9 * ci), st), 'nisqa_conv3x3_gemm wgrad')
+                if self.segconv and L_.nisqa_segconv_supported(hi, wi, ci, co, pad):
+                    self._ck(L_.nisqa_segconv_wgrad_bf16(_ptr(c['x']), _ptr(dz), _ptr(self.G[wk]), S, hi, wi, ci, co, pad, st),
+                             'nisqa_segconv_wgrad_bf16')
+                else:
+                    self._ck(self._conv_bwd(2, _ptr(c['x']), _ptr(dz), _ptr(self.G[wk]), S, hi, wi, ci, co, pad, None,
+                                            self._ksplit(rows, co, 9 * ci), st), 'nisqa_conv3x3_gemm wgrad')
                 da = self._new(S, hi * wi, ci)
-                self._ck(self._conv_bwd(1, _ptr(dz), _ptr(self.P[wk]), _ptr(da), S, hi, wi, ci, co, pad, None, 1, st),
-                         'nisqa_conv3x3_gemm dgrad')
+                fr = self._segconv_frags(1, i, hi, wi, ci, co, pad)
+                if fr is not None:
+                    self._ck(L_.nisqa_segconv_bf16(1, _ptr(dz), fr.data_ptr(), _ptr(da), S, hi, wi, ci, co, pad, None, None, st),
+                             'nisqa_segconv_bf16 dgrad')
+                else:
+                    self._ck(self._conv_bwd(1, _ptr(dz), _ptr(self.P[wk]), _ptr(da), S, hi, wi, ci, co, pad, None, 1, st),
+                             'nisqa_conv3x3_gemm dgrad')
             c['x'] = None
 
         self._flush_casts()

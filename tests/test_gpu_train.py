@@ -181,6 +181,65 @@ def test_implicit_gemm_convolution_forward_dgrad_wgrad(h, w, ci, co, pad_w, entr
     assert (st2[co:] - (z.double() ** 2).sum(0)).abs().max() < 1e-9 * float((z.double() ** 2).sum(0).max())
 
 
+@pytest.mark.parametrize('S', [1, 14, 37, 61, 600])
+@pytest.mark.parametrize('h,w,ci,co,pad_w', [(24, 7, 16, 32, 1), (12, 5, 32, 64, 1), (12, 5, 64, 64, 1), (6, 3, 64, 64, 1), (6, 3, 64, 64, 0)])
+def test_segment_resident_convolutions_forward_dgrad_wgrad(h, w, ci, co, pad_w, S):
+    """csrc/train_conv.hip against torch autograd (the tolerances of the implicit GEMMs) and against
+    nisqa_conv3x3_gemm_bf16 -- same arithmetic, different summation order; segment counts that are not multiples of the
+    segments a workgroup owns."""
+    lib, L = _L()
+    assert L.nisqa_segconv_supported(h, w, ci, co, pad_w) == 1
+    wo = w + 2 * pad_w - 2
+    x = _r(S, h * w, ci, seed=60).requires_grad_(True)
+    wt = (_r(co, ci, 3, 3, seed=61) * 0.2).requires_grad_(True)
+    b = _r(co, seed=62)
+    z_t = F.conv2d(x.view(S, h, w, ci).permute(0, 3, 1, 2), wt, b, padding=(1, pad_w))
+    dz = _r(S, h * wo, co, seed=63)
+    (z_t.permute(0, 2, 3, 1).reshape(S, h * wo, co) * dz).sum().backward()
+    wk = wt.detach().permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+    fr = []
+    for mode in (0, 1):
+        nb = L.nisqa_segconv_frag_bytes(mode, ci, co)
+        assert nb > 0
+        f = torch.empty(nb // 2, dtype=torch.int16, device=DEV)
+        lib.check(L.nisqa_segconv_pack(mode, _p(wk), ci, co, f.data_ptr(), _st()), 'segconv pack')
+        fr.append(f)
+    z = torch.full((S * h * wo, co), float('nan'), device=DEV)
+    st2 = torch.zeros(2 * co, dtype=torch.float64, device=DEV)
+    lib.check(L.nisqa_segconv_bf16(0, _p(x.detach()), fr[0].data_ptr(), _p(z), S, h, w, ci, co, pad_w, _p(b), st2.data_ptr(), _st()),
+              'segconv fwd')
+    dx = torch.full((S, h * w, ci), float('nan'), device=DEV)
+    lib.check(L.nisqa_segconv_bf16(1, _p(dz), fr[1].data_ptr(), _p(dx), S, h, w, ci, co, pad_w, None, None, _st()), 'segconv dgrad')
+    z_g = torch.empty_like(z)
+    lib.check(L.nisqa_conv3x3_gemm_bf16(0, _p(x.detach()), _p(wk), _p(z_g), S, h, w, ci, co, pad_w, _p(b), 1, _st()), 'conv fwd')
+    dx_g = torch.empty_like(dx)
+    lib.check(L.nisqa_conv3x3_gemm_bf16(1, _p(dz), _p(wk), _p(dx_g), S, h, w, ci, co, pad_w, None, 1, _st()), 'conv dgrad')
+    torch.cuda.synchronize()
+    want_z = z_t.detach().permute(0, 2, 3, 1).reshape(S * h * wo, co)
+    print('segconv max|d| z %.2e of %.1f (vs implicit GEMM %.2e), dx %.2e of %.1f (vs implicit GEMM %.2e)' % (
+        float((z - want_z).abs().max()), float(want_z.abs().max()), float((z - z_g).abs().max()),
+        float((dx - x.grad).abs().max()), float(x.grad.abs().max()), float((dx - dx_g).abs().max())))
+    assert (z - want_z).abs().max() < 2e-5 * max(1.0, float(want_z.abs().max())) * 3
+    assert (dx - x.grad).abs().max() < 2e-5 * max(1.0, float(x.grad.abs().max())) * 3
+    assert (st2[:co] - z.double().sum(0)).abs().max() < 1e-9 * float(z.double().abs().sum(0).max())
+    assert (st2[co:] - (z.double() ** 2).sum(0)).abs().max() < 1e-9 * float((z.double() ** 2).sum(0).max())
+    dw = torch.zeros(co, 9 * ci, device=DEV)
+    lib.check(L.nisqa_segconv_wgrad_bf16(_p(x.detach()), _p(dz), _p(dw), S, h, w, ci, co, pad_w, _st()), 'segconv wgrad')
+    torch.cuda.synchronize()
+    want_dw = wt.grad.permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    print('segconv dw %.2e of %.1f' % (float((dw - want_dw).abs().max()), float(want_dw.abs().max())))
+    assert (dw - want_dw).abs().max() < 1e-4 * max(1.0, float(want_dw.abs().max()))
+    # bias and statistics are optional
+    z3 = torch.empty_like(z)
+    lib.check(L.nisqa_segconv_bf16(0, _p(x.detach()), fr[0].data_ptr(), _p(z3), S, h, w, ci, co, pad_w, None, None, _st()), 'segconv fwd')
+    torch.cuda.synchronize()
+    assert (z3 + b - z).abs().max() < 1e-5 * max(1.0, float(z.abs().max()))
+    # unsupported shapes and misuse are refused
+    assert L.nisqa_segconv_supported(h + 1, w, ci, co, pad_w) == 0
+    assert L.nisqa_segconv_bf16(0, _p(x.detach()), fr[0].data_ptr(), _p(z3), S, h + 1, w, ci, co, pad_w, None, None, _st()) == 1
+    assert L.nisqa_segconv_bf16(1, _p(dz), fr[1].data_ptr(), _p(dx), S, h, w, ci, co, pad_w, _p(b), None, _st()) == 1
+
+
 def test_im2col_mel_segments_and_floor():
     lib, L = _L()
     T = [40, 15]
