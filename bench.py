@@ -455,6 +455,24 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
                         'frac_of_bf16_peak': round(ach / PEAK_BF16_MFMA, 4),
                         'frac_of_mode_ideal': round(ideal / dt, 4), 'mode_ideal_ms': round(ideal * 1e3, 4)},
            'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
+    # the same step in the other precision modes (train.py: 'f32' everything exact, 'bf16x3' forward convolutions on
+    # split-bf16 too -- within 1e-4 of y_hat, gradients of a fine-tuning step from nisqa.tar within 2.2 %)
+    other = {}
+    for mode in ('f32', 'bf16x3'):
+        if mode == tr.precision:
+            continue
+        tr2 = HipTrainer(args, sd, dev, lr=1e-3, precision=mode)
+        for _ in range(3):
+            tr2.step_pcm(x, plan, SR, y)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tr2.step_pcm(x, plan, SR, y)
+        torch.cuda.synchronize()
+        d2 = (time.perf_counter() - t0) / steps
+        other[mode] = {'ms_per_step': round(d2 * 1e3, 3), 'value': round(bs / d2, 1), 'frac_of_fp32_peak': round(flop / d2 / 1e12 / PEAK_F32, 4)}
+        del tr2
+    res['other_precision_modes'] = other
     if cpu_baseline_on:
         from oracle import mel as omel, net as onet, train as otrain
         nb = 8

@@ -53,6 +53,15 @@ extern "C" int nisqa_debug_segconv_clock(unsigned long long* out8, int reset) {
 #else
 #define SC_CLK(i)
 #endif
+#ifndef SC_W_MSPLIT
+#define SC_W_MSPLIT 1         /* weight gradient of the 64 -> 64 layers: 1 = a wave takes both M tiles and every 8th N tile, 2 = one M tile, every 4th */
+#endif
+#ifndef SC_SEGS60
+#define SC_SEGS60 4            /* segments per workgroup of the 12 x 5 layers (two 32-row tiles per wave at 4, one at 2) */
+#endif
+#ifndef SC_WGS
+#define SC_WGS 2
+#endif
 #ifndef SC_RING
 #define SC_RING 3            /* weight-fragment ring of the K loop (slots) */
 #endif
@@ -116,7 +125,7 @@ struct segconv_cfg {
 };
 
 template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD>
-__global__ __launch_bounds__(256, 2) void segconv_bf16_kernel(
+__global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
     const float* __restrict__ src, const unsigned short* __restrict__ frags, float* __restrict__ out, int n_segments,
     const float* __restrict__ bias, double* __restrict__ stats) {
     typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD> C;
@@ -333,15 +342,15 @@ extern "C" int nisqa_segconv_bf16(int32_t mode, const float* src, const uint16_t
     const int n = n_segments;
     if (mode == 0) {
         if (key == SC_KEY(24, 7, 16, 32) && pad_w == 1) segconv_launch<16, 1, 32, 24, 7, 24, 7, 1, 3, 4, true>(st, src, frags, out, n, bias, stats2c);
-        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<32, 2, 64, 12, 5, 12, 5, 1, 4, 2, true>(st, src, frags, out, n, bias, stats2c);
-        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, 4, 2, true>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<32, 2, 64, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, true>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, true>(st, src, frags, out, n, bias, stats2c);
         else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 14, 2, true>(st, src, frags, out, n, bias, stats2c);
         else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 1, 6, 3, 0, 15, 1, true>(st, src, frags, out, n, bias, stats2c);
         else return NISQA_ERR_ARG;
     } else {                                                  // staged tensor = dz [S][h * wo][co], rows = the h * w input pixels
         if (key == SC_KEY(24, 7, 16, 32) && pad_w == 1) segconv_launch<32, 1, 16, 24, 7, 24, 7, 1, 2, 3, false>(st, src, frags, out, n, nullptr, nullptr);
-        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<64, 1, 32, 12, 5, 12, 5, 1, 4, 2, false>(st, src, frags, out, n, nullptr, nullptr);
-        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, 4, 2, false>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<64, 1, 32, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, false>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, false>(st, src, frags, out, n, nullptr, nullptr);
         else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 14, 2, false>(st, src, frags, out, n, nullptr, nullptr);
         else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 3, 6, 1, 2, 14, 2, false>(st, src, frags, out, n, nullptr, nullptr);
         else return NISQA_ERR_ARG;
@@ -575,8 +584,8 @@ extern "C" int nisqa_segconv_wgrad_bf16(const float* x, const float* dz, float* 
     const int key = SC_KEY(h, w, ci, co);
     if (key == SC_KEY(24, 7, 16, 32)) segwgrad_launch<16, 32, 24, 7, 7, 1, 1, 1>(st, x, dz, dw, n_segments);
     else if (key == SC_KEY(12, 5, 32, 64)) segwgrad_launch<32, 64, 12, 5, 5, 1, 1, 2>(st, x, dz, dw, n_segments);
-    else if (key == SC_KEY(12, 5, 64, 64)) segwgrad_launch<64, 64, 12, 5, 5, 1, 1, 1>(st, x, dz, dw, n_segments);
-    else if (pad_w == 1) segwgrad_launch<64, 64, 6, 3, 3, 1, 4, 1>(st, x, dz, dw, n_segments);
-    else segwgrad_launch<64, 64, 6, 3, 1, 0, 8, 1>(st, x, dz, dw, n_segments);
+    else if (key == SC_KEY(12, 5, 64, 64)) segwgrad_launch<64, 64, 12, 5, 5, 1, 1, SC_W_MSPLIT>(st, x, dz, dw, n_segments);
+    else if (pad_w == 1) segwgrad_launch<64, 64, 6, 3, 3, 1, 4, SC_W_MSPLIT>(st, x, dz, dw, n_segments);
+    else segwgrad_launch<64, 64, 6, 3, 1, 0, 8, SC_W_MSPLIT>(st, x, dz, dw, n_segments);
     return NQ_LAUNCH_STATUS();
 }

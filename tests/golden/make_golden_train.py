@@ -31,11 +31,18 @@ def batch(seed, n_clips, heads):
     return specs, y
 
 
-def run(name, args, seed_sd, seed_batch, n_clips, lr):
+def run(name, args, seed_sd, seed_batch, n_clips, lr, checkpoint=None):
+    """checkpoint: start from the reference's published weights (fine-tuning) instead of a seeded random state_dict; the
+    fixture then holds the first step only (loss, y_hat, gradients) -- the weights themselves stay in the checkpoint."""
     NL = ref_shim.import_reference_lib()
-    args = dict(args)
+    args = dict(args or {})
+    if checkpoint is not None:
+        ck = torch.load(checkpoint, map_location='cpu')
+        args = dict(ck['args'])
+        sd0 = {k: v.numpy() for k, v in ck['model_state_dict'].items()}
     args.update({'cnn_dropout': 0.0, 'td_sa_dropout': 0.0, 'pool_att_dropout': 0.0})
-    sd0 = synth.random_state_dict(seed_sd, args['model'])
+    if checkpoint is None:
+        sd0 = synth.random_state_dict(seed_sd, args['model'])
     margs = {k: args[k] for k in ref_shim.MODEL_ARG_KEYS}
     model = {'NISQA': NL.NISQA, 'NISQA_DIM': NL.NISQA_DIM}[args['model']](**margs)
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd0.items()}, strict=True)
@@ -59,16 +66,20 @@ def run(name, args, seed_sd, seed_batch, n_clips, lr):
         if step == 1:
             for k, p in model.named_parameters():
                 out['grad/' + k] = p.grad.detach().numpy().copy()
+        if checkpoint is not None:
+            break
         opt.step()
         opt.zero_grad()
         for k, v in model.state_dict().items():
             if step == 1 or k.split('.')[-1].startswith(('running', 'num_batches')):    # step 2: buffers only (size)
                 out['sd%d/%s' % (step, k)] = v.detach().numpy().copy()
     np.savez_compressed(os.path.join(HERE, 'train_%s.npz' % name), **out)
-    print(name, 'loss', out['loss1'], out['loss2'], 'segments', int(sum(nw)))
+    print(name, 'loss', out['loss1'], out.get('loss2'), 'segments', int(sum(nw)))
 
 
 if __name__ == '__main__':
     torch.manual_seed(0)
     run('mos', synth.MOS_ARGS, 8, 31, 4, 1e-3)
     run('dim', synth.DIM_ARGS, 7, 32, 3, 1e-3)
+    if os.path.isfile('/root/reference/weights/nisqa.tar'):
+        run('dim_real', None, -1, 33, 6, 1e-3, checkpoint='/root/reference/weights/nisqa.tar')

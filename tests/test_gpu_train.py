@@ -558,6 +558,40 @@ def test_training_step_matches_reference_fixture(name, precision):
     HipNisqa(args, tr.state_dict(), DEV)
 
 
+@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x3'])
+def test_training_step_from_the_published_weights(precision):
+    """Fine-tuning step from nisqa.tar (fixture: the reference's NISQA_DIM in train mode on the same seeded batch,
+    tests/golden/make_golden_train.py run('dim_real')): a trained network, not a random initialisation -- the case the
+    split-bf16 forward convolutions are judged on."""
+    from nisqa_amd.train import HipTrainer
+    import make_golden_train as mk
+    path = helpers.find_weights('nisqa.tar')
+    if path is None:
+        pytest.skip('nisqa.tar not staged (oracle/_ref/weights)')
+    g = helpers.golden('train_dim_real.npz')
+    args, sd = helpers.load_checkpoint(path)
+    args = dict(args)
+    args.update({'cnn_dropout': 0.0, 'td_sa_dropout': 0.0, 'pool_att_dropout': 0.0})
+    specs, y = mk.batch(int(g['seed_batch']), int(g['n_clips']), 5)
+    tr = HipTrainer(args, {k: v.numpy() for k, v in sd.items()}, DEV, lr=float(g['lr']), precision=precision)
+    loss = tr.step_spec(specs, y)
+    torch.cuda.synchronize()
+    dy = float(np.abs(tr.last['y_hat'].cpu().numpy() - g['y_hat1']).max())
+    worst, wk = 0.0, None
+    for k, gr in tr.grads().items():
+        want = g['grad/' + k]
+        if _conv_bias(k):
+            continue
+        e = float(np.abs(gr.numpy() - want).max()) / max(1e-3, float(np.abs(want).max()))
+        if e > worst:
+            worst, wk = e, k
+    print('published weights,', precision, ': loss %.6f (reference %.6f), |d y_hat| %.2e, worst relative gradient error %.2e (%s)' % (
+        float(loss), float(g['loss1']), dy, worst, wk))
+    assert float(loss) == pytest.approx(float(g['loss1']), rel=1e-4)
+    assert dy < 1e-3
+    assert worst < (1e-3 if precision != 'bf16x3' else 5e-2), (worst, wk)
+
+
 @pytest.mark.parametrize('name', ['mos', 'dim'])
 def test_training_step_with_split_bf16_forward_convolutions(name):
     """precision='bf16x3' also runs the FORWARD convolutions on split-bf16 MFMA.  Loss, y_hat and BatchNorm buffers stay
