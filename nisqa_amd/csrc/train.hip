@@ -1172,6 +1172,13 @@ static int grid_for(int64_t total) {
     return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
 }
 
+// grid-stride kernels whose threads keep per-channel constants across iterations: one resident round of workgroups (256 CUs x
+// 8 blocks of 256 threads x 2), so that a thread sees ~10+ elements instead of one and the constants are worth keeping
+static int grid_resident(int64_t total) {
+    const int64_t g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
 // geometries of the CNN-SA-AP model get their own instantiation, anything else the generic one
 #define NQ_GEOM_DISPATCH(KERNEL, GRID, ST, ...)                                                                   \
     do {                                                                                                          \
@@ -1330,14 +1337,18 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(
     const float* __restrict__ drop, float* __restrict__ y, int32_t* __restrict__ arg) {
     const int h = H ? H : h_, w = H ? W : w_, c = H ? C : c_, ho = H ? HO : ho_, wo = H ? WO : wo_;
     const int c4 = c / 4;
+    // compiled shapes: c / 4 divides the 256-thread stride, so a thread meets the SAME four channels in every iteration and
+    // their constants are computed once (the generic instantiation recomputes them per element)
+    constexpr bool INV = H != 0 && 256 % ((C ? C : 4) / 4) == 0;
+    f32x4 g, bsh;
+    if (INV) bn_affine4(gamma, beta, mean_rstd, c, 4 * ((int)threadIdx.x % c4), g, bsh);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int ch = 4 * (int)(i % c4);
         const int64_t op = i / c4;
         const int64_t s = op / (ho * wo);
         const int o = (int)(op - s * (ho * wo));
         const int oy = o / wo, ox = o % wo;
-        f32x4 g, bsh;
-        bn_affine4(gamma, beta, mean_rstd, c, ch, g, bsh);
+        if (!INV) bn_affine4(gamma, beta, mean_rstd, c, ch, g, bsh);
         f32x4 best = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
         i32x4 bp = {0, 0, 0, 0};
         for (int yy = win_lo(oy, h, ho); yy < win_hi(oy, h, ho); ++yy)
@@ -1378,7 +1389,7 @@ extern "C" int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const f
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, c,
                        (int64_t)n_segments * h * w, running_mean, running_var, mean_rstd);
-    NQ_POOL_DISPATCH(bn_act_pool_fwd_kernel, dim3(grid_for(total)), (hipStream_t)stream, z, gamma, beta,
+    NQ_POOL_DISPATCH(bn_act_pool_fwd_kernel, dim3(grid_resident(total)), (hipStream_t)stream, z, gamma, beta,
                      (const float*)mean_rstd, total, h, w, c, ho, wo, drop, y, arg);
     return NQ_LAUNCH_STATUS();
 }
@@ -1480,11 +1491,13 @@ __global__ __launch_bounds__(256) void pool_bwd_sums_kernel(
     const int h = H ? H : h_, w = H ? W : w_, c = H ? C : c_, ho = H ? HO : ho_, wo = H ? WO : wo_;
     const int c4 = c / 4;
     double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+    constexpr bool INV = H != 0 && 256 % ((C ? C : 4) / 4) == 0;        // see bn_act_pool_fwd_kernel
+    f32x4 g, bsh;
+    if (INV) bn_affine4(gamma, beta, mean_rstd, c, 4 * ((int)threadIdx.x % c4), g, bsh);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int ch = 4 * (int)(i % c4);
         const int64_t s = (i / c4) / (ho * wo);
-        f32x4 g, bsh;
-        bn_affine4(gamma, beta, mean_rstd, c, ch, g, bsh);
+        if (!INV) bn_affine4(gamma, beta, mean_rstd, c, ch, g, bsh);
         f32x4 d = ((const f32x4*)dy)[i];
         if (drop) d *= *(const f32x4*)(drop + s * c + ch);
         f32x4 zw;
@@ -1522,13 +1535,9 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_dense_kernel(
         dbeta[ch] = (float)sums2[ch];
         dgamma[ch] = (float)(rstd * (sums2[c + ch] - mean * sums2[ch]));
     }
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        const int ch = 4 * (int)(i % c4);
-        const int64_t pix = i / c4;
-        const int64_t s = pix / (h * w);
-        const int p = (int)(pix - s * (h * w));
-        const int yy = p / w, xx = p % w;
-        f32x4 g, bsh, mean, rstd, m1, m2;
+    constexpr bool INV = H != 0 && 256 % ((C ? C : 4) / 4) == 0;        // see bn_act_pool_fwd_kernel
+    f32x4 g, bsh, mean, rstd, m1, m2;
+    auto channel_constants = [&](int ch) {                  // eight float64 operations per channel: once per thread where INV
         bn_affine4(gamma, beta, mean_rstd, c, ch, g, bsh);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1537,6 +1546,15 @@ __global__ __launch_bounds__(256) void bn_act_pool_bwd_dense_kernel(
             m1[e] = (float)(sums2[ch + e] * inv);
             m2[e] = (float)((double)rstd[e] * (sums2[c + ch + e] - (double)mean[e] * sums2[ch + e]) * inv);
         }
+    };
+    if (INV) channel_constants(4 * ((int)threadIdx.x % c4));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int ch = 4 * (int)(i % c4);
+        const int64_t pix = i / c4;
+        const int64_t s = pix / (h * w);
+        const int p = (int)(pix - s * (h * w));
+        const int yy = p / w, xx = p % w;
+        if (!INV) channel_constants(ch);
         const f32x4 zi = ((const f32x4*)z)[i];
         const f32x4 yb = zi * g + bsh;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -1580,7 +1598,7 @@ extern "C" int nisqa_bn_act_pool_bwd(const float* dy, const int32_t* arg, const 
     int64_t g1 = (cells + 2047) / 2048;
     g1 = g1 < 1 ? 1 : (g1 > 1024 ? 1024 : g1);
     NQ_POOL_DISPATCH(pool_bwd_sums_kernel, dim3((unsigned)g1), st, dy, arg, drop, z, mean_rstd, gamma, beta, cells, h, w, c, ho, wo, sums2);
-    NQ_POOL_DISPATCH(bn_act_pool_bwd_dense_kernel, dim3(grid_for(total)), st, dy, arg, drop, z, mean_rstd, gamma, beta,
+    NQ_POOL_DISPATCH(bn_act_pool_bwd_dense_kernel, dim3(grid_resident(total)), st, dy, arg, drop, z, mean_rstd, gamma, beta,
                      (const double*)sums2, total, h, w, c, ho, wo, dz, dgamma, dbeta);
     return NQ_LAUNCH_STATUS();
 }
