@@ -106,6 +106,10 @@ int nisqa_conv3x3_fwd_stats(int32_t split_bf16, const float* x, const float* w_,
 int nisqa_segconv_supported(int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w);
 int64_t nisqa_segconv_frag_bytes(int32_t mode, int32_t ci, int32_t co);
 int nisqa_segconv_pack(int32_t mode, const float* w, int32_t ci, int32_t co, uint16_t* frags, void* stream);
+/* nisqa_segconv_pack for n_jobs <= 10 (layer, mode) pairs in one launch; all arrays are HOST arrays of n_jobs entries
+ * (w[j], frags[j] device pointers) */
+int nisqa_segconv_pack_many(int32_t n_jobs, const int32_t* modes, const float* const* w, const int32_t* ci, const int32_t* co,
+                            uint16_t* const* frags, void* stream);
 int nisqa_segconv_bf16(int32_t mode, const float* src, const uint16_t* frags, float* out, int32_t n_segments, int32_t h,
                        int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c, void* stream);
 /* Weight gradient of the same layers, segment-resident: dw[co][9*ci] += dz^T * patches(x) (dw zeroed by the caller, like

@@ -18,6 +18,7 @@ Parameters live in ONE flat device buffer in "kernel layout" (conv weights as [C
 the first Linear in [y][c] order); ``state_dict()`` / ``load_state_dict()`` convert to and from the reference's keys
 and shapes, so checkpoints interoperate with the reference and with the inference engine.
 """
+import ctypes
 import math
 import os
 
@@ -65,10 +66,10 @@ class HipTrainer(object):
         self._conv_fwd = fast if self.precision == 'bf16x3' else exact
         self._conv_bwd = exact if self.precision == 'f32' else fast
         # split-bf16 forward / input-gradient convolutions segment-resident (csrc/train_conv.hip) where the layer shape is
-        # one of the reference configuration's; weight fragments are packed once per step (_segconv_frags)
+        # one of the reference configuration's; weight fragments are packed once per step (_segconv_pack)
         self.segconv = os.environ.get('NISQA_HIP_TRAIN_SEGCONV', '1') != '0' and self.precision != 'f32'
-        self._sc_frags = {}
-        self._step_no = 0
+        self._sc_frags, self._sc_bufs = {}, {}
+        self._prep_key = None
         self.lr = float(lr)
         self.n_layers = int(a['td_sa_num_layers'])
         self.heads = ['pool_layers.%d.model.' % h for h in range(5)] if a['model'] == 'NISQA_DIM' else ['pool.model.']
@@ -158,21 +159,32 @@ class HipTrainer(object):
     def _new(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
-    def _segconv_frags(self, mode, i, hi, wi, ci, co, pad):
-        """Packed weight fragments of conv<i> for this step (mode 0 forward, 1 input gradient), or None when the layer shape
-        is not one csrc/train_conv.hip instantiates (the implicit GEMM stays)."""
-        if not self.segconv or not self.lib.nisqa_segconv_supported(hi, wi, ci, co, pad):
-            return None
-        key = (mode, i)
-        ent = self._sc_frags.get(key)
-        if ent is None:
-            nb = self.lib.nisqa_segconv_frag_bytes(mode, ci, co)
-            ent = self._sc_frags[key] = [torch.empty(nb // 2, dtype=torch.int16, device=self.device), -1]
-        if ent[1] != self._step_no:                                            # once per step: the weights change with every Adam update
-            self._ck(self.lib.nisqa_segconv_pack(mode, _ptr(self.P['cnn.model.conv%d.weight' % i]), ci, co, ent[0].data_ptr(),
-                                                 self._st()), 'nisqa_segconv_pack')
-            ent[1] = self._step_no
-        return ent[0]
+    def _segconv_pack(self, geo):
+        """Weight fragments of this step for every layer / direction csrc/train_conv.hip takes (mode 0 forward -- 'bf16x3'
+        only --, mode 1 input gradient): ONE launch (nisqa_segconv_pack_many).  self._sc_frags[(mode, i)] is absent where the
+        layer shape is not instantiated; the implicit GEMM stays there."""
+        self._sc_frags = {}
+        if not self.segconv:
+            return
+        jobs = []
+        for i in range(2, 7):
+            ci, co = _CONV[i - 1]
+            hi, wi = geo[i - 2][2]
+            if not self.lib.nisqa_segconv_supported(hi, wi, ci, co, 0 if i == 6 else 1):
+                continue
+            for mode in ((0, 1) if self.precision == 'bf16x3' else (1,)):
+                buf = self._sc_bufs.get((mode, i))
+                if buf is None:
+                    buf = self._sc_bufs[(mode, i)] = torch.empty(self.lib.nisqa_segconv_frag_bytes(mode, ci, co) // 2,
+                                                                 dtype=torch.int16, device=self.device)
+                jobs.append((mode, self.P['cnn.model.conv%d.weight' % i].data_ptr(), ci, co, buf.data_ptr()))
+                self._sc_frags[(mode, i)] = buf
+        if jobs:
+            n = len(jobs)
+            arr_i = lambda k: (ctypes.c_int32 * n)(*[j[k] for j in jobs])
+            arr_p = lambda k: (ctypes.c_void_p * n)(*[j[k] for j in jobs])
+            self._ck(self.lib.nisqa_segconv_pack_many(n, arr_i(0), arr_p(1), arr_i(2), arr_i(3), arr_p(4), self._st()),
+                     'nisqa_segconv_pack_many')
 
     def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, ksplit=1, ao=0, bo=0, co=0, bias=None, relu=0):
         self._ck(self.lib.nisqa_gemm_f32_one(_ptr(A, ao), _ptr(B, bo), _ptr(C, co), M, N, K, lda, ldb, ldc, ta, tb, ksplit,
@@ -243,35 +255,58 @@ class HipTrainer(object):
         tok = np.concatenate(([0], np.cumsum(L)))
         sq = np.concatenate(([0], np.cumsum(L * L)))
         self.B, self.S, self.L, self.tok, self.sq = B, S, L, tok, sq
-        up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
-        self.seg_off = up(tok.astype(np.int32))
+        # index tables of the step (segment offsets, one descriptor per clip for every grouped GEMM, softmax / pooling row
+        # tables): built on the host, packed into ONE page-locked buffer and sent with one asynchronous copy -- fifteen
+        # pageable .to(device) calls each blocked the host behind everything queued on the stream -- and kept while the
+        # batch's segment counts repeat
+        key = L.tobytes()
+        if key != self._prep_key or os.environ.get('NISQA_HIP_TRAIN_NO_PREP_CACHE') == '1':     # (the switch: timing of the rebuild)
+            parts = [('seg_off', tok.astype(np.int32))]
 
-        def desc(kind, a_off, b_off, c_off, M, N, K, lda, ldb, ldc):
-            z = np.zeros((B, 10), np.int64)
-            for j, col in enumerate((a_off, b_off, c_off, M, N, K, lda, ldb, ldc)):
-                z[:, j] = col
-            tiles = ((z[:, 3] + 63) // 64) * ((z[:, 4] + 63) // 64)
-            z[:, 9] = np.concatenate(([0], np.cumsum(tiles)[:-1]))
-            return kind, (up(z), int(tiles.sum()))
+            def desc(kind, a_off, b_off, c_off, M, N, K, lda, ldb, ldc):
+                z = np.zeros((B, 10), np.int64)
+                for j, col in enumerate((a_off, b_off, c_off, M, N, K, lda, ldb, ldc)):
+                    z[:, j] = col
+                tiles = ((z[:, 3] + 63) // 64) * ((z[:, 4] + 63) // 64)
+                z[:, 9] = np.concatenate(([0], np.cumsum(tiles)[:-1]))
+                parts.append(('desc_' + kind, z))
+                return kind, int(tiles.sum())
 
-        t, s, b = tok[:-1], sq[:-1], np.arange(B)
-        self._desc = dict([
-            desc('qk', t * 192, t * 192, s, L, L, 64, 192, 192, L),
-            desc('pv', s, t * 192, t * 64, L, 64, L, L, 192, 64),
-            desc('dp', t * 64, t * 192, s, L, L, 64, 64, 192, L),
-            desc('dv', s, t * 64, t * 192, L, 64, L, L, 64, 192),
-            desc('dq', s, t * 192, t * 192, L, 64, L, L, 192, 192),
-            desc('dk', s, t * 192, t * 192, L, 64, L, L, 192, 192),
-            desc('pool', t, t * 64, b * 64, 1, 64, L, L, 64, 64),
-            desc('datt', b * 64, t * 64, t, 1, L, 64, 64, 64, L),
-            desc('outer', t, b * 64, t * 64, L, 64, 1, L, 64, 64),
-        ])
-        rows_b = np.repeat(np.arange(B), L)
-        within = np.arange(S) - tok[rows_b]
-        self.att_off = up((sq[rows_b] + within * L[rows_b]).astype(np.int64))
-        self.att_len = up(L[rows_b].astype(np.int32))
-        self.pool_off = up(tok[:-1].astype(np.int64))
-        self.pool_len = up(L.astype(np.int32))
+            t, s, b = tok[:-1], sq[:-1], np.arange(B)
+            tiles = dict([
+                desc('qk', t * 192, t * 192, s, L, L, 64, 192, 192, L),
+                desc('pv', s, t * 192, t * 64, L, 64, L, L, 192, 64),
+                desc('dp', t * 64, t * 192, s, L, L, 64, 64, 192, L),
+                desc('dv', s, t * 64, t * 192, L, 64, L, L, 64, 192),
+                desc('dq', s, t * 192, t * 192, L, 64, L, L, 192, 192),
+                desc('dk', s, t * 192, t * 192, L, 64, L, L, 192, 192),
+                desc('pool', t, t * 64, b * 64, 1, 64, L, L, 64, 64),
+                desc('datt', b * 64, t * 64, t, 1, L, 64, 64, 64, L),
+                desc('outer', t, b * 64, t * 64, L, 64, 1, L, 64, 64),
+            ])
+            rows_b = np.repeat(np.arange(B), L)
+            within = np.arange(S) - tok[rows_b]
+            parts += [('att_off', (sq[rows_b] + within * L[rows_b]).astype(np.int64)), ('att_len', L[rows_b].astype(np.int32)),
+                      ('pool_off', tok[:-1].astype(np.int64)), ('pool_len', L.astype(np.int32))]
+            offs, total = [], 0
+            for _, a in parts:
+                offs.append(total)
+                total += (a.nbytes + 15) // 16 * 16
+            pin = self.device.type == 'cuda'
+            host = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=pin)
+            hv = host.numpy()
+            for (_, a), o in zip(parts, offs):
+                hv[o:o + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+            buf = host.to(self.device, non_blocking=pin)
+            tv = {}
+            for (k, a), o in zip(parts, offs):
+                tv[k] = buf[o:o + a.nbytes].view({'int32': torch.int32, 'int64': torch.int64}[a.dtype.name]).view(a.shape)
+            self._prep_key, self._prep_host, self._prep_buf = key, host, buf       # host stays alive until the copy has run
+            self._prep_tables = (tv, tiles)
+        tv, tiles = self._prep_tables
+        self.seg_off = tv['seg_off']
+        self._desc = {k: (tv['desc_' + k], n) for k, n in tiles.items()}
+        self.att_off, self.att_len, self.pool_off, self.pool_len = tv['att_off'], tv['att_len'], tv['pool_off'], tv['pool_len']
         self._sums.zero_()
         self._sum_i = 0
         self._casts = []
@@ -339,7 +374,6 @@ class HipTrainer(object):
     def _step(self, mel, frame_off, n_wins, floor, y, masks, bias):
         L_ = self.lib
         self._prepare(n_wins)
-        self._step_no += 1
         B, S, st = self.B, self.S, self._st()
         hop = int(self.args['ms_seg_hop_length'])
         self.gflat.zero_()
@@ -349,6 +383,7 @@ class HipTrainer(object):
         # ================= forward: AdaptCNN in train mode =================
         geo = [(48, 15, self.pools[0]), (24, 7, self.pools[1]), (12, 5, (12, 5)), (12, 5, self.pools[2]), (6, 3, (6, 3)),
                (6, 1, (6, 1))]                                               # conv output (H, W) and the pool after it
+        self._segconv_pack(geo)
         cnn = []
         act = None
         for i in range(1, 7):
@@ -384,7 +419,7 @@ class HipTrainer(object):
                                             _ptr(self.P[wk]), _ptr(self.P[bk]), _ptr(z), st), 'nisqa_conv1_fwd')
             else:                                                              # implicit GEMM: patches gathered by the loaders
                 hi, wi = geo[i - 2][2]
-                fr = self._segconv_frags(0, i, hi, wi, ci, co, 0 if i == 6 else 1) if self.precision == 'bf16x3' else None
+                fr = self._sc_frags.get((0, i))
                 if fr is not None:
                     sums = None
                     if self.fused_fwd_stats:
@@ -578,14 +613,14 @@ class HipTrainer(object):
             else:
                 hi, wi = geo[i - 2][2]
                 pad = 0 if i == 6 else 1
-                if self.segconv and L_.nisqa_segconv_supported(hi, wi, ci, co, pad):
+                if (1, i) in self._sc_frags:
                     self._ck(L_.nisqa_segconv_wgrad_bf16(_ptr(c['x']), _ptr(dz), _ptr(self.G[wk]), S, hi, wi, ci, co, pad, st),
                              'nisqa_segconv_wgrad_bf16')
                 else:
                     self._ck(self._conv_bwd(2, _ptr(c['x']), _ptr(dz), _ptr(self.G[wk]), S, hi, wi, ci, co, pad, None,
                                             self._ksplit(rows, co, 9 * ci), st), 'nisqa_conv3x3_gemm wgrad')
                 da = self._new(S, hi * wi, ci)
-                fr = self._segconv_frags(1, i, hi, wi, ci, co, pad)
+                fr = self._sc_frags.get((1, i))
                 if fr is not None:
                     self._ck(L_.nisqa_segconv_bf16(1, _ptr(dz), fr.data_ptr(), _ptr(da), S, hi, wi, ci, co, pad, None, None, st),
                              'nisqa_segconv_bf16 dgrad')

@@ -397,7 +397,7 @@ def test_library_exports_every_declared_symbol():
 def test_training_operators_are_declared_and_exported():
     from nisqa_amd import lib
     hdr = open(os.path.join(ROOT, 'include', 'nisqa_train.h')).read()
-    declared = set(re.findall(r'^\s*int\s+(nisqa_[a-z0-9_]+)\s*\(', hdr, re.M))
+    declared = set(re.findall(r'^\s*(?:int|int64_t)\s+(nisqa_[a-z0-9_]+)\s*\(', hdr, re.M))
     assert declared == set(lib.TRAIN_SYMBOLS), declared ^ set(lib.TRAIN_SYMBOLS)
     L = lib.load()
     out = subprocess.check_output(['nm', '-D', '--defined-only', lib.LIB_PATH]).decode()
