@@ -377,8 +377,17 @@ class HipTrainer(object):
         B, S, st = self.B, self.S, self._st()
         hop = int(self.args['ms_seg_hop_length'])
         self.gflat.zero_()
-        y_dev = torch.as_tensor(np.asarray(y, np.float32)).reshape(B, len(self.heads)).contiguous().to(self.device)
-        bias_dev = None if bias is None else torch.as_tensor(np.asarray(bias, np.float32)).reshape(B, 4).contiguous().to(self.device)
+        # labels (and bias coefficients) through page-locked memory: a pageable .to(device) blocks the host until the
+        # previous step has drained, and the GPU then idles while this step's first launches are being issued
+        def up(a, cols):
+            a = np.ascontiguousarray(np.asarray(a, np.float32).reshape(B, cols))
+            if self.device.type != 'cuda':
+                return torch.from_numpy(a).to(self.device)
+            h = torch.empty(a.shape, dtype=torch.float32, pin_memory=True)     # caching host allocator: reuse is stream-safe
+            h.numpy()[...] = a
+            return h.to(self.device, non_blocking=True)
+        y_dev = up(y, len(self.heads))
+        bias_dev = None if bias is None else up(bias, 4)
 
         # ================= forward: AdaptCNN in train mode =================
         geo = [(48, 15, self.pools[0]), (24, 7, self.pools[1]), (12, 5, (12, 5)), (12, 5, self.pools[2]), (6, 3, (6, 3)),
