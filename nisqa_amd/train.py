@@ -37,6 +37,46 @@ def _ptr(t, off=0):
     return t.data_ptr() + 4 * off
 
 
+def step_tables(L):
+    """Index tables of one training step for clips of L[b] segments (host, numpy): [(name, array)], {grouped GEMM: tiles}.
+    seg_off: exclusive prefix sum of L (int32); desc_<kind>: one row per clip for nisqa_gemm_f32 -- (a_off, b_off, c_off, M, N,
+    K, lda, ldb, ldc, first 64 x 64 tile) in elements -- for the ragged attention products QK^T / PV and their four gradients
+    and for the pooling reductions (NISQA_lib.py:1025-1040, 1171-1183 as batched matmuls over padded tensors in the
+    reference); att_off / att_len: start and length of every softmax row in the packed [sum L^2] score buffer; pool_off /
+    pool_len: the same per clip for the attention-pooling softmax."""
+    L = np.asarray(L, dtype=np.int64)
+    B, S = len(L), int(L.sum())
+    tok = np.concatenate(([0], np.cumsum(L)))
+    sq = np.concatenate(([0], np.cumsum(L * L)))
+    parts = [('seg_off', tok.astype(np.int32))]
+    tiles = {}
+
+    def desc(kind, a_off, b_off, c_off, M, N, K, lda, ldb, ldc):
+        z = np.zeros((B, 10), np.int64)
+        for j, col in enumerate((a_off, b_off, c_off, M, N, K, lda, ldb, ldc)):
+            z[:, j] = col
+        nt = ((z[:, 3] + 63) // 64) * ((z[:, 4] + 63) // 64)
+        z[:, 9] = np.concatenate(([0], np.cumsum(nt)[:-1]))
+        parts.append(('desc_' + kind, z))
+        tiles[kind] = int(nt.sum())
+
+    t, s, b = tok[:-1], sq[:-1], np.arange(B)
+    desc('qk', t * 192, t * 192, s, L, L, 64, 192, 192, L)
+    desc('pv', s, t * 192, t * 64, L, 64, L, L, 192, 64)
+    desc('dp', t * 64, t * 192, s, L, L, 64, 64, 192, L)
+    desc('dv', s, t * 64, t * 192, L, 64, L, L, 64, 192)
+    desc('dq', s, t * 192, t * 192, L, 64, L, L, 192, 192)
+    desc('dk', s, t * 192, t * 192, L, 64, L, L, 192, 192)
+    desc('pool', t, t * 64, b * 64, 1, 64, L, L, 64, 64)
+    desc('datt', b * 64, t * 64, t, 1, L, 64, 64, 64, L)
+    desc('outer', t, b * 64, t * 64, L, 64, 1, L, 64, 64)
+    rows_b = np.repeat(np.arange(B), L)
+    within = np.arange(S) - tok[rows_b]
+    parts += [('att_off', (sq[rows_b] + within * L[rows_b]).astype(np.int64)), ('att_len', L[rows_b].astype(np.int32)),
+              ('pool_off', tok[:-1].astype(np.int64)), ('pool_len', L.astype(np.int32))]
+    return parts, tiles
+
+
 class HipTrainer(object):
     def __init__(self, args, state_dict, device=None, lr=1e-3, precision=None):
         """precision of conv2..6 (everything else is fp32 in every mode); NISQA_HIP_TRAIN_PRECISION sets the default:
@@ -261,33 +301,7 @@ class HipTrainer(object):
         # batch's segment counts repeat
         key = L.tobytes()
         if key != self._prep_key or os.environ.get('NISQA_HIP_TRAIN_NO_PREP_CACHE') == '1':     # (the switch: timing of the rebuild)
-            parts = [('seg_off', tok.astype(np.int32))]
-
-            def desc(kind, a_off, b_off, c_off, M, N, K, lda, ldb, ldc):
-                z = np.zeros((B, 10), np.int64)
-                for j, col in enumerate((a_off, b_off, c_off, M, N, K, lda, ldb, ldc)):
-                    z[:, j] = col
-                tiles = ((z[:, 3] + 63) // 64) * ((z[:, 4] + 63) // 64)
-                z[:, 9] = np.concatenate(([0], np.cumsum(tiles)[:-1]))
-                parts.append(('desc_' + kind, z))
-                return kind, int(tiles.sum())
-
-            t, s, b = tok[:-1], sq[:-1], np.arange(B)
-            tiles = dict([
-                desc('qk', t * 192, t * 192, s, L, L, 64, 192, 192, L),
-                desc('pv', s, t * 192, t * 64, L, 64, L, L, 192, 64),
-                desc('dp', t * 64, t * 192, s, L, L, 64, 64, 192, L),
-                desc('dv', s, t * 64, t * 192, L, 64, L, L, 64, 192),
-                desc('dq', s, t * 192, t * 192, L, 64, L, L, 192, 192),
-                desc('dk', s, t * 192, t * 192, L, 64, L, L, 192, 192),
-                desc('pool', t, t * 64, b * 64, 1, 64, L, L, 64, 64),
-                desc('datt', b * 64, t * 64, t, 1, L, 64, 64, 64, L),
-                desc('outer', t, b * 64, t * 64, L, 64, 1, L, 64, 64),
-            ])
-            rows_b = np.repeat(np.arange(B), L)
-            within = np.arange(S) - tok[rows_b]
-            parts += [('att_off', (sq[rows_b] + within * L[rows_b]).astype(np.int64)), ('att_len', L[rows_b].astype(np.int32)),
-                      ('pool_off', tok[:-1].astype(np.int64)), ('pool_len', L.astype(np.int32))]
+            parts, tiles = step_tables(L)
             offs, total = [], 0
             for _, a in parts:
                 offs.append(total)

@@ -1016,3 +1016,29 @@ def test_length_aware_policy_invariants_on_random_inputs():
             seq = [int(frames[k]) for c in cuts for k in c if srs[k] == r]
             assert seq == sorted(seq)
     check()
+
+
+def test_training_step_tables_describe_the_ragged_products():
+    """nisqa_amd.train.step_tables (host side of HipTrainer._prepare): one descriptor row per clip for each grouped GEMM, the
+    softmax row tables, segment offsets -- checked against a direct construction of the ragged attention of three clips."""
+    from nisqa_amd.train import step_tables
+    L = np.array([3, 70, 1])
+    parts, tiles = step_tables(L)
+    tv = dict(parts)
+    tok, sq = np.array([0, 3, 73, 74]), np.array([0, 9, 4909, 4910])
+    assert tv['seg_off'].dtype == np.int32 and list(tv['seg_off']) == list(tok)
+    qk = tv['desc_qk']
+    assert qk.shape == (3, 10) and qk.dtype == np.int64
+    assert list(qk[:, 0]) == list(tok[:-1] * 192) and list(qk[:, 2]) == list(sq[:-1])         # Q rows of the clip, its score block
+    assert list(qk[:, 3]) == list(L) and list(qk[:, 4]) == list(L) and list(qk[:, 5]) == [64, 64, 64]
+    assert list(qk[:, 9]) == [0, 1, 5] and tiles['qk'] == 6                                   # 1 + 2 x 2 + 1 tiles of 64 x 64
+    pv = tv['desc_pv']
+    assert list(pv[:, 3]) == list(L) and list(pv[:, 4]) == [64, 64, 64] and list(pv[:, 5]) == list(L) and tiles['pv'] == 4
+    assert list(tv['desc_pool'][:, 3]) == [1, 1, 1] and tiles['pool'] == 3
+    # softmax rows: row r of clip b starts at sq[b] + r * L[b] and has L[b] entries
+    want_off = np.concatenate([sq[b] + np.arange(L[b]) * L[b] for b in range(3)])
+    assert tv['att_off'].dtype == np.int64 and np.array_equal(tv['att_off'], want_off)
+    assert np.array_equal(tv['att_len'], np.repeat(L, L)) and tv['att_len'].dtype == np.int32
+    assert list(tv['pool_off']) == list(tok[:-1]) and list(tv['pool_len']) == list(L)
+    # every kind the trainer asks for is there
+    assert set(tiles) == {'qk', 'pv', 'dp', 'dv', 'dq', 'dk', 'pool', 'datt', 'outer'}
