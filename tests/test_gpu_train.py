@@ -790,6 +790,38 @@ def test_training_step_edge_shapes_match_oracle():
     assert worst < 1e-3, (worst, wk)
 
 
+@pytest.mark.parametrize('precision', ['mixed', 'bf16x3'])
+def test_segment_resident_and_implicit_convolution_paths_agree_in_the_step(precision, monkeypatch):
+    """HipTrainer with the segment-resident convolutions (default) and with NISQA_HIP_TRAIN_SEGCONV=0 (implicit GEMMs): the
+    same split-bf16 arithmetic in a different summation order -- loss, y_hat and every gradient agree to 2e-4 of a tensor's
+    largest entry."""
+    from nisqa_amd.train import HipTrainer
+    import make_golden_train as mk
+    args = dict(synth.DIM_ARGS)
+    args.update({'cnn_dropout': 0.0, 'td_sa_dropout': 0.0, 'pool_att_dropout': 0.0})
+    sd = synth.random_state_dict(7, 'NISQA_DIM')
+    specs, y = mk.batch(41, 5, 5)
+
+    def run(a, segconv):
+        monkeypatch.setenv('NISQA_HIP_TRAIN_SEGCONV', '1' if segconv else '0')
+        tr = HipTrainer(a, sd, DEV, lr=1e-3, precision=precision)
+        assert tr.segconv == segconv
+        loss = tr.step_spec(specs, y)
+        torch.cuda.synchronize()
+        return float(loss), tr.last['y_hat'].cpu().numpy(), tr.grads(), dict(tr._sc_frags)
+
+    l1, y1, g1, fr1 = run(args, True)
+    l0, y0, g0, fr0 = run(args, False)
+    assert len(fr1) == (10 if precision == 'bf16x3' else 5) and not fr0
+    # 'mixed': identical fp32 forward; 'bf16x3': two summation orders of the split-bf16 forward, each ~7e-5 from fp32
+    assert l1 == pytest.approx(l0, rel=1e-5 if precision == 'mixed' else 1e-4)
+    assert np.abs(y1 - y0).max() < (1e-6 if precision == 'mixed' else 2e-4)
+    worst = max(float(np.abs(g1[k].numpy() - g0[k].numpy()).max()) / max(1e-3, float(np.abs(g0[k].numpy()).max())) for k in g0
+                if not _conv_bias(k))
+    print('segment-resident vs implicit convolutions,', precision, ': worst relative gradient difference %.2e' % worst)
+    assert worst < (2e-4 if precision == 'mixed' else 5e-2)     # 'bf16x3': forward rounding differs too (sensitivity: DESIGN.md 4.7)
+
+
 @pytest.mark.parametrize('model', ['NISQA', 'NISQA_DIM'])
 def test_train_loop_from_yaml_style_args_writes_loadable_checkpoints(tmp_path, capsys, model):
     """nisqaModel(args).train() as run_train.py drives it: tiny synthetic corpus, two epochs, from scratch."""
