@@ -205,28 +205,32 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
     // the stores of a group would overlap with nothing (measured: 120 us for a layer whose K loops need 50).  Registers for a
     // whole group of raw activations across the K loop are not to be had (60 more: the compiler spills), so the NEXT group is
     // only TOUCHED before the K loop -- one dword per 128-byte line, 2 registers -- which brings it from HBM into L2 while
-    // the matrix pipe works; the real loads of the next iteration hit L2.  Output stores are never waited for.
+    // the matrix pipe works; its real loads are issued right behind the K loop, ahead of the output stores, and hit L2.
+    // Output stores are never waited for.
     constexpr int LINES = SEGS * C::PXS * CIN / 32;             // 128-byte lines of a group
     constexpr int NTOUCH = (LINES + 255) / 256;
 #ifdef SC_CLOCK
     long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
 #endif
+    f32x4 v[C::NV];
+    auto request = [&](int grp, int tid) {                      // the 128-bit loads of a group, all in flight together
+        const int seg0 = grp * SEGS;
+        const f32x4* g = (const f32x4*)(src + (size_t)seg0 * C::PXS * CIN);
+        const int lim = grp < n_groups ? min(SEGS, n_segments - seg0) * C::PXS * CIN / 4 : 0;
+#pragma unroll
+        for (int j = 0; j < C::NV; ++j) {
+            const int i = tid + 256 * j;
+            v[j] = i < lim ? g[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    request(blockIdx.x, tid0);
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         // (the thread's indices are re-defined opaquely per iteration: otherwise every staging address and every output offset
         // of the epilogue is computed once before the loop and kept in registers across it -- 100+ of them)
         int tid = tid0, lane = lane0;
         asm volatile("" : "+v"(tid), "+v"(lane));
         {
-            const int seg0 = grp * SEGS;
-            const f32x4* g = (const f32x4*)(src + (size_t)seg0 * C::PXS * CIN);
-            const int lim = min(SEGS, n_segments - seg0) * C::PXS * CIN / 4;
-            f32x4 v[C::NV];
-#pragma unroll
-            for (int j = 0; j < C::NV; ++j) {
-                const int i = tid + 256 * j;
-                v[j] = i < lim ? g[i] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            SC_CLK(0);                                          // requests issued
+            SC_CLK(0);
             __syncthreads();                                    // every wave has left the K loop over the previous planes
             SC_CLK(1);
 #pragma unroll
@@ -271,6 +275,11 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
         if (active) conv_k_bf16<CIN, MT, NT, WS, C::RS, C::PLANE, SC_ZADDR, (MT * NT <= 4), SC_RING>(acc, rsrc, 0, lane0 * 16, base, m9);
 
         SC_CLK(4);                                              // K loop
+        // the next group's real loads go out BEFORE this group's output stores (they would queue behind 64 stores per lane
+        // otherwise: 13 % of a group's time); its lines were touched into L2 before the K loop, the accumulators are the only
+        // other large live set here
+        request(grp + (int)gridDim.x, tid);
+        __builtin_amdgcn_sched_barrier(0);
         const int seg0 = grp * SEGS;
         const int rows = min(SEGS, n_segments - seg0) * C::PXR;
         float* o = out + (size_t)seg0 * C::PXR * NOUT;
