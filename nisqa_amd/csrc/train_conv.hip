@@ -570,11 +570,15 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
     deposit(0u, tid0);
     __syncthreads();
     unsigned cur = 0u;
+#ifdef SC_CLOCK
+    long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
+#endif
     for (; grp < n_groups; grp += gridDim.x) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));                          // keep the staging addresses inside the loop
         request(grp + gridDim.x, tid);                          // the next group travels while this one is multiplied
         __builtin_amdgcn_sched_barrier(0);                      // (hipcc would sink these loads to their use behind the K loop)
+        SC_CLK(0);                                              // requests issued
         unsigned za[C::KSTEPS][2], xa[C::KSTEPS][2];
 #pragma unroll
         for (int st = 0; st < C::KSTEPS; ++st)
@@ -585,10 +589,19 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
             }
         segwgrad_kloop<C>(acc, za, xa, noff, n_own);
         __builtin_amdgcn_sched_barrier(0);
+        SC_CLK(4);                                              // K loop
         deposit(C::BUF - cur, tid);                             // the other buffer: last read before the previous barrier
+        SC_CLK(2);                                              // wait for the loads + split + store
         __syncthreads();
+        SC_CLK(3);
         cur = C::BUF - cur;
+#ifdef SC_CLOCK
+        clk[6] += 1;
+#endif
     }
+#ifdef SC_CLOCK
+    tprev = clock64();
+#endif
     // ---- this workgroup's share of dw
 #pragma unroll
     for (int j = 0; j < C::NTW; ++j) {
@@ -604,6 +617,14 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
                 }
         }
     }
+#ifdef SC_CLOCK
+    SC_CLK(5);                                                  // the atomics (issue only)
+    if (lane0 == 0) {
+        const int slot = (blockIdx.x * 8 + wave) & 8191;
+        for (int q = 0; q < 7; ++q) g_sc_clk[slot * 8 + q] += clk[q];
+        g_sc_clk[slot * 8 + 7] += 1;
+    }
+#endif
 }
 
 template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT>

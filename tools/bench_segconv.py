@@ -58,12 +58,14 @@ for (h, w, ci, co, pad) in [(24, 7, 16, 32, 1), (12, 5, 32, 64, 1), (12, 5, 64, 
         import ctypes
         dbg.restype, dbg.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]
         names = ['issue loads', 'barrier (prev K loops)', 'wait + split + store', 'barrier', 'K loop', 'epilogue']
-        for mode, nm in ((0, 'fwd'), (1, 'dgrad')):
+        for mode, nm in ((0, 'fwd'), (1, 'dgrad'), (2, 'wgrad')):
             dbg(None, 1)
             if mode == 0:
                 L.nisqa_segconv_bf16(0, p(x), p(fr[0]), p(z), S, h, w, ci, co, pad, p(b), p(st2), st)
-            else:
+            elif mode == 1:
                 L.nisqa_segconv_bf16(1, p(dz), p(fr[1]), p(dx), S, h, w, ci, co, pad, None, None, st)
+            else:                                # wgrad: 'epilogue' = the final atomics (per wave, not per group)
+                L.nisqa_segconv_wgrad_bf16(p(x), p(dz), p(dw), S, h, w, ci, co, pad, st)
             torch.cuda.synchronize()
             o8 = (ctypes.c_ulonglong * 8)()
             dbg(o8, 0)
