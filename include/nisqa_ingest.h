@@ -35,12 +35,14 @@ extern "C" {
 #define NISQA_WAV_TAG_FLOAT 3
 #define NISQA_WAV_TAG_ALAW 6         /* G.711 A-law, 8 bits per sample */
 #define NISQA_WAV_TAG_MULAW 7        /* G.711 mu-law, 8 bits per sample */
+#define NISQA_WAV_TAG_BIG_ENDIAN 0x10000   /* flag OR-ed into tag: a RIFX file -- header fields were read big-endian and the
+                                              samples of the data chunk ARE big-endian (nisqa_ingest_read copies them verbatim) */
 
 typedef struct nisqa_wav_info {
     int32_t status;        /* NISQA_WAV_* */
-    int32_t tag;           /* NISQA_WAV_TAG_PCM | _FLOAT | _ALAW | _MULAW */
+    int32_t tag;           /* NISQA_WAV_TAG_PCM | _FLOAT | _ALAW | _MULAW, possibly | NISQA_WAV_TAG_BIG_ENDIAN */
     int32_t channels;
-    int32_t bits;          /* 8, 16, 24, 32 (PCM) / 32, 64 (float) / 8 (A-law, mu-law) */
+    int32_t bits;          /* 1..32 (PCM, in a container of (bits + 7) / 8 bytes) / 32, 64 (float) / 8 (A-law, mu-law) */
     int32_t block_align;   /* channels * bytes per sample */
     int32_t sample_rate;
     int64_t data_offset;   /* byte offset of the data chunk body in the file */

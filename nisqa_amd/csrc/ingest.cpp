@@ -110,6 +110,8 @@ int thread_count(int requested) {
 
 inline uint32_t le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline uint32_t le16(const unsigned char* p) { return p[0] | (p[1] << 8); }
+inline uint32_t rd32(const unsigned char* p, bool be) { return be ? (p[3] | (p[2] << 8) | (p[1] << 16) | ((uint32_t)p[0] << 24)) : le32(p); }
+inline uint32_t rd16(const unsigned char* p, bool be) { return be ? (uint32_t)(p[1] | (p[0] << 8)) : le16(p); }
 
 bool pread_full(int fd, void* dst, size_t want, off_t at) {
     char* d = (char*)dst;
@@ -123,7 +125,7 @@ bool pread_full(int fd, void* dst, size_t want, off_t at) {
     return true;
 }
 
-// Walk the RIFF chunks like soundfile/libsndfile does for the cases lb.load meets: 'fmt ' (PCM, IEEE float,
+// Walk the RIFF (or RF64, or big-endian RIFX) chunks like soundfile/libsndfile does for the cases lb.load meets: 'fmt ' (PCM, IEEE float,
 // WAVE_FORMAT_EXTENSIBLE with the sub-format in the GUID's first two bytes) then 'data'; other chunks are skipped
 // (word-aligned); a data size of 0xFFFFFFFF or one that overruns the file means "to end of file".
 void probe_one(const char* path, nisqa_wav_info* out) {
@@ -136,7 +138,8 @@ void probe_one(const char* path, nisqa_wav_info* out) {
     unsigned char head[4096];
     const ssize_t got = pread(fd, head, sizeof(head), 0);
     out->status = NISQA_WAV_ERR_FORMAT;
-    if (got >= 12 && (!std::memcmp(head, "RIFF", 4) || !std::memcmp(head, "RF64", 4)) && !std::memcmp(head + 8, "WAVE", 4)) {
+    const bool be = got >= 4 && !std::memcmp(head, "RIFX", 4);       // big-endian variant: header fields AND samples
+    if (got >= 12 && (!std::memcmp(head, "RIFF", 4) || !std::memcmp(head, "RF64", 4) || be) && !std::memcmp(head + 8, "WAVE", 4)) {
         int64_t pos = 12;
         bool have_fmt = false;
         while (pos + 8 <= fsize) {
@@ -144,20 +147,20 @@ void probe_one(const char* path, nisqa_wav_info* out) {
             const unsigned char* h = hb;
             if (pos + 8 <= got) h = head + pos;
             else if (!pread_full(fd, hb, 8, pos)) break;
-            const uint32_t size = le32(h + 4);
+            const uint32_t size = rd32(h + 4, be);
             const int64_t body = pos + 8;
             if (!std::memcmp(h, "fmt ", 4)) {
-                unsigned char fb[26] = {0};
-                const size_t need = size >= 26 ? 26 : 16;
+                unsigned char fb[28] = {0};
+                const size_t need = size >= 28 ? 28 : 16;
                 if (size < 16) break;
                 if (body + (int64_t)need <= got) std::memcpy(fb, head + body, need);
                 else if (!pread_full(fd, fb, need, body)) break;
-                int tag = (int)le16(fb);
-                out->channels = (int)le16(fb + 2);
-                out->sample_rate = (int32_t)le32(fb + 4);
-                out->block_align = (int)le16(fb + 12);
-                out->bits = (int)le16(fb + 14);
-                if (tag == 0xFFFE && size >= 26) tag = (int)le16(fb + 24);
+                int tag = (int)rd16(fb, be);
+                out->channels = (int)rd16(fb + 2, be);
+                out->sample_rate = (int32_t)rd32(fb + 4, be);
+                out->block_align = (int)rd16(fb + 12, be);
+                out->bits = (int)rd16(fb + 14, be);
+                if (tag == 0xFFFE && size >= 28) tag = (int)(rd32(fb + 24, be) & 0xFFFFu);     // Data1 of the sub-format GUID
                 out->tag = tag;
                 have_fmt = true;
             } else if (!std::memcmp(h, "data", 4)) {
@@ -165,12 +168,15 @@ void probe_one(const char* path, nisqa_wav_info* out) {
                 int64_t dsize = size;
                 if (size == 0xFFFFFFFFu || body + dsize > fsize) dsize = fsize - body;
                 const int bytes = (out->bits + 7) / 8;
-                const bool enc_ok = (out->tag == NISQA_WAV_TAG_PCM && (out->bits == 8 || out->bits == 16 || out->bits == 24 || out->bits == 32)) ||
+                // PCM: any width up to 32 bits in its container of (bits + 7) / 8 bytes (12- and 20-bit samples are left-justified in
+                // 2 / 3 bytes; libsndfile reads the container)
+                const bool enc_ok = (out->tag == NISQA_WAV_TAG_PCM && out->bits >= 1 && out->bits <= 32) ||
                                     (out->tag == NISQA_WAV_TAG_FLOAT && (out->bits == 32 || out->bits == 64)) ||
                                     ((out->tag == NISQA_WAV_TAG_ALAW || out->tag == NISQA_WAV_TAG_MULAW) && out->bits == 8);
                 if (out->channels < 1 || out->block_align != out->channels * bytes || !enc_ok) break;
                 out->data_offset = body;
                 out->n_frames = dsize / out->block_align;
+                if (be) out->tag |= NISQA_WAV_TAG_BIG_ENDIAN;
                 out->status = NISQA_WAV_OK;
                 break;
             }

@@ -1,7 +1,8 @@
 """WAV ingest for the predict path: what ``lb.load(path, sr=None[, mono=False])`` does at
-reference nisqa/NISQA_lib.py:2299-2304, for RIFF/WAVE files, without librosa/soundfile.
+reference nisqa/NISQA_lib.py:2299-2304, for RIFF / RF64 / RIFX (big-endian) WAVE files, without librosa/soundfile.
 
-soundfile semantics: integer PCM -> float32 scaled by 1/2**(bits-1) (8-bit is unsigned, offset
+soundfile semantics: integer PCM -> float32 scaled by 1/2**(8*bytes-1) of its CONTAINER (1-4 bytes per sample = bits
+rounded up; 12- or 20-bit samples sit left-justified in 2 / 3 bytes; a 1-byte container is unsigned, offset
 128); G.711 A-law / mu-law WAVs expand to their 16-bit table values, then 1/32768; float WAVs pass through; multi-channel audio is averaged (librosa.to_mono) unless
 ``ms_channel`` selects one channel.  The native sample rate is returned (ms_sr=None).
 Mono PCM16 -- the common case -- is returned as int16 so that only 2 bytes/sample cross PCIe; the
@@ -36,7 +37,7 @@ _ALAW_TAB, _MULAW_TAB = _g711_tables()
 class Header(object):
     """An opened WAV file whose RIFF chunks have been walked: format fields, position and frame count of the data
     chunk.  ``fast`` marks mono PCM16, whose data chunk can be copied verbatim (2 bytes/sample cross PCIe)."""
-    __slots__ = ('path', 'fd', 'tag', 'ch', 'sr', 'blk', 'bits', 'data_off', 'n', 'fast', 'ms_channel')
+    __slots__ = ('path', 'fd', 'tag', 'ch', 'sr', 'blk', 'bits', 'data_off', 'n', 'fast', 'ms_channel', 'be')
 
     def close(self):
         if self.fd is not None:
@@ -47,21 +48,23 @@ class Header(object):
 def _walk(fd):
     size_file = os.fstat(fd).st_size
     head = os.pread(fd, 4096, 0)
-    if len(head) < 12 or head[0:4] not in (b'RIFF', b'RF64') or head[8:12] != b'WAVE':
+    if len(head) < 12 or head[0:4] not in (b'RIFF', b'RF64', b'RIFX') or head[8:12] != b'WAVE':
         raise ValueError('not a RIFF/WAVE file')
+    be = head[0:4] == b'RIFX'                          # big-endian variant: every header field and every sample
+    E = '>' if be else '<'
     pos, fmt = 12, None
     while pos + 8 <= size_file:
         hdr = head[pos:pos + 8] if pos + 8 <= len(head) else os.pread(fd, 8, pos)
         if len(hdr) < 8:
             break
-        cid, size = hdr[0:4], struct.unpack('<I', hdr[4:8])[0]
+        cid, size = hdr[0:4], struct.unpack(E + 'I', hdr[4:8])[0]
         body = pos + 8
         if cid == b'fmt ':
-            raw = head[body:body + 26] if body + 26 <= len(head) else os.pread(fd, 26, body)
-            tag, ch, sr, _, blk, bits = struct.unpack('<HHIIHH', raw[:16])
-            if tag == _EXT and size >= 26:
-                tag = struct.unpack('<H', raw[24:26])[0]
-            fmt = (tag, ch, sr, blk, bits)
+            raw = head[body:body + 28] if body + 28 <= len(head) else os.pread(fd, 28, body)
+            tag, ch, sr, _, blk, bits = struct.unpack(E + 'HHIIHH', raw[:16])
+            if tag == _EXT and size >= 28 and len(raw) >= 28:
+                tag = struct.unpack(E + 'I', raw[24:28])[0] & 0xFFFF      # Data1 of the sub-format GUID (a 32-bit field)
+            fmt = (tag, ch, sr, blk, bits, be)
         elif cid == b'data':
             if size == 0xFFFFFFFF or body + size > size_file:
                 size = size_file - body
@@ -77,16 +80,16 @@ def probe(path, ms_channel=None):
     fd = None
     try:
         fd = os.open(path, os.O_RDONLY)
-        (tag, ch, sr, blk, bits), off, size = _walk(fd)
+        (tag, ch, sr, blk, bits, be), off, size = _walk(fd)
         if ch < 1 or blk != ch * ((bits + 7) // 8):
             raise ValueError('bad block align')
-        if not ((tag == _PCM and bits in (8, 16, 24, 32)) or (tag == _FLOAT and bits in (32, 64))
+        if not ((tag == _PCM and 1 <= bits <= 32) or (tag == _FLOAT and bits in (32, 64))
                 or (tag in (_ALAW, _MULAW) and bits == 8)):
             raise ValueError('unsupported WAV encoding tag={} bits={}'.format(tag, bits))
         h = Header()
-        h.path, h.fd, h.tag, h.ch, h.sr, h.blk, h.bits = path, fd, tag, ch, int(sr), blk, bits
+        h.path, h.fd, h.tag, h.ch, h.sr, h.blk, h.bits, h.be = path, fd, tag, ch, int(sr), blk, bits, be
         h.data_off, h.n, h.ms_channel = off, size // blk, ms_channel
-        h.fast = tag == _PCM and bits == 16 and ch == 1
+        h.fast = tag == _PCM and bits == 16 and ch == 1 and not be
         return h
     except Exception:
         if fd is not None:
@@ -113,28 +116,32 @@ def read_data_into(h, out):
 def _decode(h, data):
     """bytes of the data chunk -> int16 [n] (mono PCM16) or float32 [n], with lb.load's semantics."""
     tag, ch, bits, n = h.tag, h.ch, h.bits, h.n
-    if tag == _PCM and bits == 16:
-        x = np.frombuffer(data, dtype='<i2').reshape(n, ch)
+    E = '>' if h.be else '<'
+    cont = h.blk // ch                             # bytes per sample: libsndfile reads the container, whatever `bits` says
+    if tag == _PCM and cont == 2:
+        x = np.frombuffer(data, dtype=E + 'i2').reshape(n, ch)
         if ch == 1:
-            return x[:, 0]
+            return x[:, 0].astype(np.int16)        # (native byte order)
         y = x.astype(np.float32) / np.float32(32768.0)
     elif tag in (_ALAW, _MULAW):                   # 8-bit companded -> the 16-bit value of the G.711 table -> / 32768
         tab = _ALAW_TAB if tag == _ALAW else _MULAW_TAB
         y = tab[np.frombuffer(data, dtype=np.uint8).reshape(n, ch)].astype(np.float32) / np.float32(32768.0)
-    elif tag == _PCM and bits == 8:
+    elif tag == _PCM and cont == 1:
         y = (np.frombuffer(data, dtype=np.uint8).reshape(n, ch).astype(np.float32) - np.float32(128.0)) \
             / np.float32(128.0)
-    elif tag == _PCM and bits == 24:
+    elif tag == _PCM and cont == 3:
         b = np.frombuffer(data, dtype=np.uint8).reshape(n, ch, 3).astype(np.int32)
+        if h.be:
+            b = b[..., ::-1]
         v = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16)
         v = np.where(v >= (1 << 23), v - (1 << 24), v)
         y = (v.astype(np.float64) / 8388608.0).astype(np.float32)
-    elif tag == _PCM and bits == 32:
-        y = (np.frombuffer(data, dtype='<i4').reshape(n, ch).astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif tag == _PCM and cont == 4:
+        y = (np.frombuffer(data, dtype=E + 'i4').reshape(n, ch).astype(np.float64) / 2147483648.0).astype(np.float32)
     elif tag == _FLOAT and bits == 32:
-        y = np.frombuffer(data, dtype='<f4').reshape(n, ch).astype(np.float32)
+        y = np.frombuffer(data, dtype=E + 'f4').reshape(n, ch).astype(np.float32)
     else:
-        y = np.frombuffer(data, dtype='<f8').reshape(n, ch).astype(np.float32)
+        y = np.frombuffer(data, dtype=E + 'f8').reshape(n, ch).astype(np.float32)
     if ch == 1:
         y = y[:, 0]
     elif h.ms_channel is not None:

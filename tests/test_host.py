@@ -1042,3 +1042,72 @@ def test_training_step_tables_describe_the_ragged_products():
     assert list(tv['pool_off']) == list(tok[:-1]) and list(tv['pool_len']) == list(L)
     # every kind the trainer asks for is there
     assert set(tiles) == {'qk', 'pv', 'dp', 'dv', 'dq', 'dk', 'pool', 'datt', 'outer'}
+
+
+def _scipy_wav_files():
+    import scipy
+    d = os.path.join(os.path.dirname(scipy.__file__), 'io', 'tests', 'data')
+    import glob
+    return sorted(glob.glob(os.path.join(d, '*.wav')))
+
+
+def test_wav_reader_against_files_written_by_other_tools():
+    """Independent vectors for the ingest row: the WAV files scipy ships for its own reader tests (written by other tools:
+    RIFX big-endian, RF64, WAVE_FORMAT_EXTENSIBLE, 5 / 12 / 20 / 24 / 32-bit PCM, 32 / 64-bit float, mu-law, truncated and
+    corrupt headers).  Wherever scipy.io.wavfile reads a file of a width soundfile knows (<= 32 bits), wavio.read_wav and the
+    native probe must read it too and agree bit for bit after soundfile's scaling; what scipy rejects as corrupt must raise
+    the reference's error (NISQA_lib.py:2305-2306)."""
+    import warnings
+    import scipy.io.wavfile as sw
+    from nisqa_amd import wavio
+    files = _scipy_wav_files()
+    if len(files) < 10:
+        pytest.skip('scipy test data not installed')
+    lib, L = _ingest_lib()
+    seen = set()
+    for f in files:
+        name = os.path.basename(f)
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                sr, ref = sw.read(f)
+        except Exception:
+            ref = None
+        paths = (ctypes.c_char_p * 1)(os.fsencode(f))
+        info = (lib.WavInfo * 1)()
+        bad = L.nisqa_ingest_probe(paths, 1, info, 1)
+        if ref is None and 'ulaw' not in name:                 # corrupt on purpose (scipy has no mu-law decoder; we do)
+            with pytest.raises(ValueError, match='Could not load file'):
+                wavio.read_wav(f)
+            assert bad == 1
+            seen.add('corrupt')
+            continue
+        if ref is not None and ref.dtype == np.int64:          # 36 .. 64-bit PCM: libsndfile has no such format either
+            with pytest.raises(ValueError, match='Could not load file'):
+                wavio.read_wav(f)
+            assert bad == 1
+            seen.add('wide')
+            continue
+        y, sr2 = wavio.read_wav(f)
+        assert bad == 0 and info[0].sample_rate == sr2 and info[0].n_frames == len(y), name
+        assert bool(info[0].tag & 0x10000) == ('-be' in name or 'Hz-be-' in name), name      # NISQA_WAV_TAG_BIG_ENDIAN
+        if ref is None:
+            seen.add('ulaw')
+            continue
+        assert sr2 == sr, name
+        r = ref.astype(ref.dtype.newbyteorder('='))
+        if r.dtype == np.uint8:
+            rf = (r.astype(np.float32) - np.float32(128)) / np.float32(128)
+        elif r.dtype == np.int16:
+            rf = r.astype(np.float32) / np.float32(32768)
+        elif r.dtype == np.int32:                               # 20 / 24-bit arrive left-justified in 32 bits
+            rf = (r.astype(np.float64) / 2.0 ** 31).astype(np.float32)
+        else:
+            rf = r.astype(np.float32)
+        if rf.ndim == 2:
+            rf = np.mean(rf.T, axis=0, dtype=np.float32)        # librosa.to_mono
+        if y.dtype == np.int16:
+            y = y.astype(np.float32) / np.float32(32768)
+        assert y.shape == rf.shape and np.array_equal(y, rf), name
+        seen.add(str(ref.dtype) + ('/be' if info[0].tag & 0x10000 else ''))
+    assert {'corrupt', 'wide', 'ulaw', 'uint8', 'int16', 'int32', 'float32', 'float64'} <= seen and any(k.endswith('/be') for k in seen), seen
