@@ -542,20 +542,27 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # The sustained-MFMA probe of the roofline (peak_sustained, ~100 ms of dense MFMA) runs BEFORE the warm-up steps, on every
+    # rank: the power management raises the clocks over the first ~20 ms of load after any quiet period, and a 20-step timed
+    # region (16 ms) behind 5 warm-up steps would be measured on that ramp -- 4 % below the rate of every later step
+    # (tools/probe_clock_ramp2.py: 0.746 against 0.718 ms per step; `steady` below is the cross-check).
+    # NISQA_BENCH_PROBE_LAST=1 restores the old order (probe after the timed region).
+    sus, probe_first = None, (not a.no_extras and os.environ.get('NISQA_BENCH_PROBE_LAST') != '1')
+    if probe_first:
+        sus = mfma_sustained(dev)
+
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
     for st in streams:
         st.wait_stream(torch.cuda.current_stream(dev))
-    for i in range(max(a.warmup, len(streams))):
-        with torch.cuda.stream(streams[i % len(streams)]):
-            out = eng.forward_pcm(pcm, plan, SR)
-    barrier()
-
-    evs = []
+    evs = []                                             # (created before the warm-up: no host work between it and the timed region)
     for _ in range(a.steps):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         for x in e:
             x.record(streams[len(evs) % len(streams)])   # forces handle creation; re-recorded inside the library
         evs.append(e)
+    for i in range(max(a.warmup, len(streams))):
+        with torch.cuda.stream(streams[i % len(streams)]):
+            out = eng.forward_pcm(pcm, plan, SR)
     barrier()
     t0 = time.perf_counter()
     outs = []
@@ -603,7 +610,7 @@ def main():
         if k.get('GRBM_GUI_ACTIVE') and k.get('_ms'):
             roof['shader_clock_mhz_profiled'] = round(k['GRBM_GUI_ACTIVE'] / 8.0 / (k['_ms'] * 1e-3) / 1e6, 0)
         if world == 1 and not a.no_extras and eng.precision == 'bf16x3':
-            sus = mfma_sustained(dev)
+            sus = sus or mfma_sustained(dev)
             roof['peak_sustained'] = {'what': 'dense v_mfma_f32_32x32x16_bf16 on register operands, measured on this GPU just now: '
                                               'zero operands reach the data-sheet peak, random operands are power-limited',
                                       **sus, 'frac_of_sustained_random': round(roof['achieved'] / sus['random']['tflops'], 4)}
@@ -632,6 +639,9 @@ def main():
                        'parallelism': 'clip-sharded x%d, final all_gather of MOS rows' % world,
                        'collective_backend': backend, 'world_size_seen': world},
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
+            'clock_state': ('the sustained-MFMA probe of roofline.peak_sustained (~100 ms of dense MFMA) ran before the warm-up steps: '
+                            'the timed steps start at the loaded clock state (a short region behind an idle GPU measures 4 % low; '
+                            'NISQA_BENCH_PROBE_LAST=1 restores the old order)') if probe_first else 'no load before the warm-up steps',
             'roofline': roof,
             'roofline_secondary': {'kernel': 'mel_frame_kernel (pruned 4 x FFT-512 + sparse mel bank + dB)', 'bound': 'valu',
                                    'achieved': round(mel_ach, 2), 'peak': PEAK_F32, 'unit': 'TFLOP/s',
