@@ -1111,3 +1111,36 @@ def test_wav_reader_against_files_written_by_other_tools():
         assert y.shape == rf.shape and np.array_equal(y, rf), name
         seen.add(str(ref.dtype) + ('/be' if info[0].tag & 0x10000 else ''))
     assert {'corrupt', 'wide', 'ulaw', 'uint8', 'int16', 'int32', 'float32', 'float64'} <= seen and any(k.endswith('/be') for k in seen), seen
+
+
+def test_big_endian_pcm16_never_takes_the_verbatim_int16_path(tmp_path):
+    """A RIFX mono PCM16 file has the layout of the fast path (2 bytes per sample, mono) but byte-swapped samples: staged next
+    to little-endian files of the same rate, its group must go through the host decoder (float32), and the samples must be
+    those of the little-endian twin."""
+    import struct
+    from nisqa_amd import ingest
+    rng = np.random.default_rng(17)
+    pcm = (rng.standard_normal(901) * 3000).astype(np.int16)
+    le = str(tmp_path / 'le.wav')
+    synth.write_wav(le, pcm, 16000)
+    fmt = struct.pack('>HHIIHH', 1, 1, 16000, 32000, 2, 16)
+    body = b'fmt ' + struct.pack('>I', 16) + fmt + b'data' + struct.pack('>I', 2 * len(pcm)) + pcm.astype('>i2').tobytes()
+    be = str(tmp_path / 'be.wav')
+    open(be, 'wb').write(b'RIFX' + struct.pack('>I', 4 + len(body)) + b'WAVE' + body)
+    y_be, sr = wavio.read_wav(be)
+    y_le, _ = wavio.read_wav(le)
+    assert sr == 16000 and y_be.dtype == np.int16 and np.array_equal(y_be, y_le) and np.array_equal(y_le, pcm)
+    h = wavio.probe(be)
+    assert h.be and not h.fast
+    h.close()
+    ing = ingest.Ingest(_ListDataset([le, be, le]), [[0, 1, 2]], pin=False, num_workers=2)
+    try:
+        staged = next(iter(ing))
+        (g,) = staged.groups
+        assert not g.is_i16 and g.sr == 16000 and g.lengths == [901, 901, 901]
+        host = ing.ring.buf[staged.slot][g.offset:g.offset + g.nbytes].view(torch.float32).numpy()
+        want = pcm.astype(np.float32) / np.float32(32768.0)
+        np.testing.assert_array_equal(host, np.concatenate([want, want, want]))
+        ing.ring.release_after(staged.slot, None)
+    finally:
+        ing.close()
