@@ -24,6 +24,7 @@ from . import dist as _dist
 from .evaluation import (calc_eval_metrics, calc_mapped, calc_mapping, calc_rmse, calc_rmse_star, eval_results,  # noqa: F401
                          fit_first_order, fit_monotonic_third_order, fit_second_order, fit_third_order, is_const)
 from . import ingest as _ingest
+from . import lib as _lib_mod
 from .wavio import read_wav
 
 
@@ -370,6 +371,22 @@ def _predict(model, ds, bs, dev, num_workers):
     on_gpu = eng.device.type == 'cuda'
     n = len(ds)
     lo, hi = _dist.shard_range(n)
+    bounds = None
+    rank, world = _dist.world()
+    if world > 1 and os.environ.get('NISQA_SHARD_BY_COUNT') != '1':
+        # work-balanced contiguous shards: every rank probes the RIFF headers of its count share (native threads, headers
+        # only), the per-clip segment counts are summed into one vector on all ranks, and the shard boundaries follow its
+        # prefix sum -- a length-sorted list of mixed 3-30 s clips otherwise gives the last rank several times the first
+        # one's work.  An unreadable header counts as one segment here; the error itself is raised where the reference
+        # raises it, when the file is loaded.
+        tok = np.zeros(n, dtype=np.int64)
+        if hi > lo:
+            info = _ingest.probe_headers(ds, range(lo, hi), num_workers)
+            ok = info['status'] == _lib_mod.WAV_OK
+            tok[lo:hi] = np.where(ok, tokens_of(ds, np.where(ok, info['n_frames'], 0), np.where(ok, info['sample_rate'], 48000)), 1)
+        tok = _dist.all_reduce_sum_i64(tok)
+        bounds = _dist.balanced_bounds(tok, world)
+        lo, hi = bounds[rank]
     bs = max(1, int(bs))
     heads = eng.n_heads
     y_local = np.zeros((hi - lo, heads), dtype=np.float32)
@@ -447,7 +464,7 @@ def _predict(model, ds, bs, dev, num_workers):
         ing.close()
         LOOP_STATS.clear()
         LOOP_STATS.update(T)
-    return _dist.gather_rows(y_local, n, lo, hi, dev)
+    return _dist.gather_rows(y_local, n, lo, hi, dev, bounds)
 
 
 def predict_mos(model, ds, bs, dev, num_workers=0):

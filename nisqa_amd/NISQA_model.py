@@ -18,12 +18,94 @@ import yaml
 from . import NISQA_lib as NL
 
 
+class _Inert(object):
+    """What an unknown pickle global becomes in the salvage load: a thing that can be called, built, indexed and appended
+    to and does nothing -- no code of the file runs, no module is imported on its behalf."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Inert()
+
+    def __setstate__(self, state):
+        pass
+
+    def __setitem__(self, k, v):
+        pass
+
+    def append(self, v):
+        pass
+
+    def extend(self, v):
+        pass
+
+    def __reduce__(self):
+        raise TypeError('salvage stub')
+
+
+def _salvage_pickle_module():
+    """A ``pickle_module`` for torch.load whose Unpickler resolves ONLY the globals a tensor checkpoint needs (torch's
+    tensor / storage rebuild helpers, OrderedDict, datetime, a few builtins) and turns every other global into _Inert."""
+    import _codecs
+    import collections
+    import datetime
+    import pickle
+    import types
+    allowed = {('collections', 'OrderedDict'): collections.OrderedDict, ('datetime', 'datetime'): datetime.datetime,
+               ('_codecs', 'encode'): _codecs.encode,      # how protocol 2 spells a bytes literal (datetime's state)
+               ('builtins', 'set'): set, ('builtins', 'frozenset'): frozenset, ('builtins', 'list'): list,
+               ('builtins', 'dict'): dict, ('builtins', 'tuple'): tuple, ('builtins', 'int'): int, ('builtins', 'float'): float,
+               ('builtins', 'bool'): bool, ('builtins', 'str'): str, ('builtins', 'bytes'): bytes,
+               ('builtins', 'complex'): complex, ('builtins', 'slice'): slice, ('builtins', 'range'): range}
+    for name in ('_rebuild_tensor_v2', '_rebuild_tensor', '_rebuild_parameter', '_rebuild_parameter_with_state'):
+        if hasattr(torch._utils, name):
+            allowed[('torch._utils', name)] = getattr(torch._utils, name)
+    for name in ('FloatStorage', 'DoubleStorage', 'HalfStorage', 'BFloat16Storage', 'LongStorage', 'IntStorage', 'ShortStorage',
+                 'CharStorage', 'ByteStorage', 'BoolStorage', 'Size', 'device'):
+        if hasattr(torch, name):
+            allowed[('torch', name)] = getattr(torch, name)
+    allowed[('torch.storage', 'UntypedStorage')] = torch.UntypedStorage
+    allowed[('torch.serialization', '_get_layout')] = torch.serialization._get_layout
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            got = allowed.get((module, name))
+            if got is None and module == 'torch' and isinstance(getattr(torch, name, None), torch.dtype):
+                got = getattr(torch, name)
+            return _Inert if got is None else got
+
+    mod = types.ModuleType('nisqa_salvage_pickle')
+    mod.Unpickler, mod.load, mod.loads = Unpickler, pickle.load, pickle.loads
+    mod.__name__ = 'pickle'                       # torch.load consults the module's name in one branch
+    return mod
+
+
+def _plain(v, depth=0):
+    """True if v is made of plain Python values / containers / datetime / tensors only (no salvage stub anywhere)."""
+    import datetime
+    if v is None or isinstance(v, (bool, int, float, str, bytes, complex, datetime.datetime, torch.Tensor, torch.Size)):
+        return True
+    if depth > 8:
+        return False
+    if isinstance(v, dict):
+        return all(_plain(k, depth + 1) and _plain(x, depth + 1) for k, x in v.items())
+    if isinstance(v, (list, tuple, set, frozenset)):
+        return all(_plain(x, depth + 1) for x in v)
+    return False
+
+
 def _load_checkpoint(path):
     """torch.load(path) like the reference (NISQA_model.py:933-939), but through torch's restricted unpickler: the shipped
-    checkpoints hold tensors, plain containers and one datetime in ``args`` -- allow-listed here.  A checkpoint that
-    needs more than that (arbitrary pickled objects, i.e. code that runs at load time) is REFUSED unless the caller opts
-    in with NISQA_ALLOW_UNSAFE_CHECKPOINT=1 -- then it is loaded exactly as the reference does.  Missing / unreadable /
-    corrupt files raise what torch.load raises."""
+    checkpoints hold tensors, plain containers and one datetime in ``args`` -- allow-listed here.
+
+    A checkpoint the reference's TRAINER wrote also carries ``db_results`` DataFrames and numpy scalars next to the tensors
+    (reference NISQA_model.py:1096-1108) and the restricted unpickler rejects it.  Such a file is SALVAGED: a second pass
+    with an unpickler that resolves only tensor-rebuild globals and replaces every other global by an inert stub -- no code
+    of the file runs -- from which only ``args`` and ``model_state_dict`` are kept, which is all that loading needs
+    (NISQA_model.py:941-942, 1023).  If a stub ended up INSIDE those two (arguments that are not plain values), the file is
+    refused unless the caller opts in with NISQA_ALLOW_UNSAFE_CHECKPOINT=1 -- then it is loaded exactly as the reference
+    does.  Missing / unreadable / corrupt files raise what torch.load raises."""
     import datetime
     import pickle
     try:
@@ -35,10 +117,22 @@ def _load_checkpoint(path):
             print('nisqa_amd: {} needs the full (unsafe) unpickler, allowed by NISQA_ALLOW_UNSAFE_CHECKPOINT=1: {}'.format(
                 os.path.basename(path), why))
             return torch.load(path, map_location='cpu', weights_only=False)
+        try:
+            ck = torch.load(path, map_location='cpu', weights_only=False, pickle_module=_salvage_pickle_module())
+            ok = isinstance(ck, dict) and isinstance(ck.get('args'), dict) and isinstance(ck.get('model_state_dict'), dict) \
+                and _plain(ck['args']) and all(isinstance(k, str) and isinstance(v, torch.Tensor)
+                                                for k, v in ck['model_state_dict'].items())
+        except Exception:
+            ok = False
+        if ok:
+            dropped = sorted(k for k in ck if k not in ('args', 'model_state_dict'))
+            print('nisqa_amd: {} holds pickled objects beyond tensors and plain containers; loaded args and model_state_dict '
+                  'only (ignored without running them: {})'.format(os.path.basename(path), ', '.join(map(str, dropped)) or '-'))
+            return {'args': ck['args'], 'model_state_dict': ck['model_state_dict']}
         raise RuntimeError(
-            'nisqa_amd: {} holds pickled objects beyond tensors and plain containers ({}); loading it would run code from '
-            'the file.  Set NISQA_ALLOW_UNSAFE_CHECKPOINT=1 to load it the way the reference does (torch.load, full '
-            'unpickler) if you trust its source.'.format(path, why)) from e
+            'nisqa_amd: {} holds pickled objects beyond tensors and plain containers ({}) inside its args / model_state_dict; '
+            'loading it would run code from the file.  Set NISQA_ALLOW_UNSAFE_CHECKPOINT=1 to load it the way the reference '
+            'does (torch.load, full unpickler) if you trust its source.'.format(path, why)) from e
 
 
 def _fast_frame_lines(df, widest=None):

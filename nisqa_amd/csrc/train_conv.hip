@@ -337,28 +337,45 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
     }
 }
 
+// Launch state that depends on the DEVICE (CU count, resident workgroups per CU, the > 64 KB dynamic-LDS opt-in) is cached
+// per device ordinal: a process that drives a second GPU asks again for that GPU.  Atomics make the caches safe to fill
+// from several host threads (the worst case is two threads asking the runtime the same question once).
+#include <atomic>
+static constexpr int SC_MAX_DEV = 64;
+static int sc_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SC_MAX_DEV) dev = 0;
+    return dev;
+}
 static int sc_cu_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
+    static std::atomic<int> n[SC_MAX_DEV];
+    const int dev = sc_device();
+    int v = n[dev].load(std::memory_order_relaxed);
+    if (!v) {
         hipDeviceProp_t p;
-        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-                ? p.multiProcessorCount : 256;
+        v = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+        n[dev].store(v, std::memory_order_relaxed);
     }
-    return n;
+    return v;
 }
 
 template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD>
 static void segconv_launch(hipStream_t st, const float* src, const uint16_t* frags, float* out, int n_segments,
                            const float* bias, double* stats) {
     typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD> C;
-    static int per_cu = 0;                                      // resident workgroups per CU (registers and LDS), asked once
+    static std::atomic<int> per_cu_dev[SC_MAX_DEV];             // resident workgroups per CU (registers and LDS), asked once per device
+    const int dev = sc_device();
+    int per_cu = per_cu_dev[dev].load(std::memory_order_relaxed);
     if (!per_cu) {
+        // 50-80 KB of dynamic LDS: opt in explicitly (a runtime that enforces the 64 KB default would refuse the launch)
+        (void)hipFuncSetAttribute((const void*)segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD>, 256,
                                                          C::LDS) != hipSuccess || nb < 1)
             nb = 2;
         per_cu = nb;
+        per_cu_dev[dev].store(nb, std::memory_order_relaxed);
     }
     const int n_groups = (n_segments + SEGS - 1) / SEGS;
     const int grid = n_groups < per_cu * sc_cu_count() ? n_groups : per_cu * sc_cu_count();
@@ -630,11 +647,12 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
 template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT>
 static void segwgrad_launch(hipStream_t st, const float* x, const float* dz, float* dw, int n_segments) {
     typedef segwgrad_cfg<CI, CO, H, W, WO, PADW, SEGS, MSPLIT> C;
-    static bool attr = false;
-    if (!attr) {                                                // more than 64 KB of dynamic LDS
+    static std::atomic<bool> attr[SC_MAX_DEV];
+    const int dev = sc_device();
+    if (!attr[dev].load(std::memory_order_relaxed)) {           // more than 64 KB of dynamic LDS, per device
         (void)hipFuncSetAttribute((const void*)segwgrad_bf16_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
-        attr = true;
+        attr[dev].store(true, std::memory_order_relaxed);
     }
     const int n_groups = (n_segments + SEGS - 1) / SEGS;
     const int grid = n_groups < sc_cu_count() ? n_groups : sc_cu_count();

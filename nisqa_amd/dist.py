@@ -28,13 +28,51 @@ def shard_range(n):
     return shard_bounds(n, r, w)
 
 
-def gather_rows(local, n, lo, hi, dev):
-    """All ranks get the full [n, C] array assembled from every rank's [hi-lo, C] rows."""
+def balanced_bounds(weights, world_size):
+    """Contiguous [lo, hi) per rank with (nearly) equal WORK: boundary k sits where the prefix sum of ``weights`` (segments
+    per clip from the header probe) crosses k / world of the total, rounded to the nearer side.  Equal clip COUNTS give the
+    last rank of a length-sorted list of 3-30 s clips several times the first rank's work (SURVEY.md 8e asks for contiguous
+    index ranges; it does not ask for equal counts).  Every rank computes the same list from the same weights."""
+    w = np.maximum(np.asarray(weights, dtype=np.float64), 0.0)
+    n, ws = len(w), int(world_size)
+    if n == 0 or w.sum() <= 0:
+        return [shard_bounds(n, r, ws) for r in range(ws)]
+    pre = np.concatenate(([0.0], np.cumsum(w)))
+    cuts = [0]
+    for k in range(1, ws):
+        t = pre[-1] * k / ws
+        j = int(np.searchsorted(pre, t, side='left'))              # first prefix >= target
+        if j > 0 and t - pre[j - 1] < pre[min(j, n)] - t:
+            j -= 1
+        cuts.append(min(max(j, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(ws)]
+
+
+def all_reduce_sum_i64(a):
+    """Sum of a host int64 array over the ranks (the header-probe exchange of the work-balanced shards: every rank fills
+    its share of a zero vector).  Device staging under RCCL, host tensors under gloo."""
+    import torch.distributed as dist
+    r, w = world()
+    if w == 1:
+        return a
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64))
+    if dist.get_backend() == 'nccl':
+        t = t.cuda()
+    dist.all_reduce(t)
+    return t.cpu().numpy()
+
+
+def gather_rows(local, n, lo, hi, dev, bounds=None):
+    """All ranks get the full [n, C] array assembled from every rank's [hi-lo, C] rows.  bounds: the [lo, hi) of every
+    rank when the shards are not shard_bounds(n, k, world) (work-balanced shards)."""
     r, w = world()
     if w == 1:
         return local
+    if bounds is None:
+        bounds = [shard_bounds(n, k, w) for k in range(w)]
     C = local.shape[1]
-    cap = -(-n // w)                                    # rows per rank, padded to the largest shard
+    cap = max(1, max(b - a for a, b in bounds))         # rows per rank, padded to the largest shard
     backend = torch.distributed.get_backend()
     tdev = torch.device(dev) if backend == 'nccl' else torch.device('cpu')
     buf = torch.zeros((cap, C), dtype=torch.float32, device=tdev)
@@ -43,7 +81,7 @@ def gather_rows(local, n, lo, hi, dev):
     torch.distributed.all_gather(parts, buf)
     out = np.zeros((n, C), dtype=np.float32)
     for k in range(w):
-        a, b = shard_bounds(n, k, w)
+        a, b = bounds[k]
         out[a:b] = parts[k][:b - a].cpu().numpy()
     return out
 

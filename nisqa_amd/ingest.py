@@ -79,6 +79,28 @@ def gpu_local_cpus(device):
         return set()
 
 
+def probe_headers(ds, indices, num_workers=0):
+    """RIFF header records (numpy structured array of lib.WavInfo: status, n_frames, sample_rate, ...) of the items
+    ``indices`` of a SpeechQualityDataset, native threads, headers only.  Nothing is raised for an unreadable file: its
+    ``status`` says so (the work-balanced shards of the predict loop only need lengths; the reference's ValueError is
+    raised where the reference raises it, when the file is loaded)."""
+    idx = list(indices)
+    n = len(idx)
+    col, d = ds.df[ds.filename_column].tolist(), ds.data_dir
+    enc = [os.fsencode(os.path.join(d, col[i])) for i in idx]
+    paths = (ctypes.c_char_p * n)(*enc)
+    infos = (_lib.WavInfo * n)()
+    asked = int(num_workers or 0)
+    try:
+        local_world = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1')))
+    except ValueError:
+        local_world = 1
+    budget = max(1, cpu_budget() // local_world)
+    workers = max(1, min(asked if asked > 0 else budget, budget))
+    _lib.load_ingest().nisqa_ingest_probe(paths, n, infos, workers)
+    return np.ctypeslib.as_array(infos).copy()
+
+
 class StagingRing(object):
     """``n_slots`` page-locked byte buffers, grown on demand.  A slot handed to the consumer comes back with
     ``release_after(slot, event)``; ``acquire`` blocks until then and until ``event`` (the HIP event recorded
@@ -185,32 +207,60 @@ class LengthAware(object):
     def __len__(self):
         return len(self.indices)
 
+    @staticmethod
+    def staged_bytes(frames, srs, widths, pos):
+        """Bytes Ingest._stage lays out for the clips ``pos``: clips of one sample rate form a group, and a group is staged
+        as int16 only if ALL its clips are mono PCM16 (width 2) -- one stereo / 24-bit / float / G.711 file widens its whole
+        group to float32."""
+        pos = np.asarray(pos, dtype=np.int64)
+        total = 0
+        for sr in np.unique(srs[pos]):
+            sel = pos[srs[pos] == sr]
+            total += int(frames[sel].sum()) * (2 if (widths[sel] == 2).all() else 4)
+        return total
+
     def cut(self, frames, srs, widths):
-        """Batches (lists of POSITIONS into the window) for clips with the given header fields."""
+        """Batches (lists of POSITIONS into the window) for clips with the given header fields.  Within a sample rate the
+        clips that stage as int16 (mono PCM16, width 2) come before the ones that need the host decoder (width 4), so a
+        batch mixes the two only at the seam; the byte cap is charged with what _stage really lays out (staged_bytes: a
+        float clip in a rate group makes every clip of that group 4 bytes per sample).  ``bs`` / ``min_clips`` /
+        ``min_tokens`` are lower bounds, ``byte_cap`` is the memory knob (page-locked host memory and HBM per batch in
+        flight): --bs does not bound memory."""
         n = len(frames)
         if n == 0:
             return []
         tokens = np.maximum(1, np.asarray(self.tokens_of(frames, srs), dtype=np.int64))
-        nbytes = frames * widths
-        order = np.lexsort((np.arange(n), frames, srs))                # by rate, then length, then input order
-        out, cur, cb, ct = [], [], 0, 0
+        order = np.lexsort((np.arange(n), frames, widths, srs))        # by rate, then int16-before-float, then length, then input order
+        out, cur, ct = [], [], 0
+        grp = {}                                                       # rate -> [int16 frames, float frames] of the open batch
         need = max(self.bs, self.min_clips)
+
+        def cost(g):
+            return sum(4 * (a + b) if b else 2 * a for a, b in g.values())
+
         for k in order.tolist():
-            if cur and (cb + int(nbytes[k]) > self.byte_cap or srs[k] != srs[cur[-1]] and len(cur) >= need):
-                out.append(cur)
-                cur, cb, ct = [], 0, 0
+            sr, slot = int(srs[k]), 0 if widths[k] == 2 else 1
+            if cur:
+                trial = dict(grp)
+                a = list(trial.get(sr, (0, 0)))
+                a[slot] += int(frames[k])
+                trial[sr] = a
+                if cost(trial) > self.byte_cap or srs[k] != srs[cur[-1]] and len(cur) >= need:
+                    out.append(cur)
+                    cur, ct, grp = [], 0, {}
             cur.append(k)
-            cb += int(nbytes[k])
+            a = grp.setdefault(sr, [0, 0])
+            a[slot] += int(frames[k])
             ct += int(tokens[k])
             if len(cur) >= need and ct >= self.min_tokens:
                 out.append(cur)
-                cur, cb, ct = [], 0, 0
+                cur, ct, grp = [], 0, {}
         if cur:
             out.append(cur)
         # a small remainder does not get a launch chain of its own when the batch before it can take it (the byte cap is a
         # staging-buffer size, soft by half): a BiLSTM launch over 7 long clips lasts as long as one over 128 of them
         if len(out) >= 2 and len(out[-1]) * 2 < need and srs[out[-1][0]] == srs[out[-2][-1]] \
-                and int(nbytes[out[-1]].sum() + nbytes[out[-2]].sum()) <= self.byte_cap + self.byte_cap // 2:
+                and self.staged_bytes(frames, srs, widths, out[-2] + out[-1]) <= self.byte_cap + self.byte_cap // 2:
             tail = out.pop()
             out[-1] = out[-1] + tail
         return out
@@ -258,14 +308,17 @@ class Ingest(object):
         self.q = queue.Queue(maxsize=depth)
         self.stop = threading.Event()
         self.stats = {'paths': 0.0, 'probe': 0.0, 'layout': 0.0, 'slot_wait': 0.0, 'read': 0.0, 'queue_wait': 0.0, 'batches': 0}
+        self._helper = None                        # header-probe helper of _planned (joined in close)
         self.thread = threading.Thread(target=self._produce, name='nisqa-ingest', daemon=True)
         self.thread.start()
 
     # -- producer side ---------------------------------------------------------------------------------
-    def _probe(self, idx):
-        """RIFF headers of items ``idx`` -> (names, encoded paths, header records as a numpy structured array)."""
+    def _probe(self, idx, stats=None):
+        """RIFF headers of items ``idx`` -> (names, encoded paths, header records as a numpy structured array).  stats: the
+        dict the 'paths' / 'probe' seconds are added to (the helper thread of _planned passes its own: two threads never
+        write self.stats)."""
         ds, L, n = self.ds, self.lib, len(idx)
-        T, t0 = self.stats, time.perf_counter()
+        T, t0 = self.stats if stats is None else stats, time.perf_counter()
         if self._col is not None:                                  # the column as it was when this loop started
             col, d = self._col, ds.data_dir
             names = [os.path.join(d, col[i]) for i in idx]
@@ -343,10 +396,16 @@ class Ingest(object):
         box = {}
 
         def probe_into(w):
+            # runs on the helper thread: timings stay local and are merged by the producer; a loop that was closed
+            # (self.stop) probes nothing more
+            loc = {'paths': 0.0, 'probe': 0.0}
             try:
-                box[w] = ('ok', self._probe(wins[w]))
+                if self.stop.is_set():
+                    box[w] = ('stop', None, loc)
+                    return
+                box[w] = ('ok', self._probe(wins[w], loc), loc)
             except BaseException as e:
-                box[w] = ('err', e)
+                box[w] = ('err', e, loc)
 
         helper = None
         if wins:
@@ -354,11 +413,16 @@ class Ingest(object):
         for w in range(len(wins)):
             if helper is not None:
                 helper.join()
-            kind, val = box.pop(w)
+                self._helper = None
+            kind, val, loc = box.pop(w)
+            for k_, v_ in loc.items():
+                self.stats[k_] += v_
+            if kind == 'stop':
+                return
             if kind == 'err':
                 raise val
             if w + 1 < len(wins):
-                helper = threading.Thread(target=probe_into, args=(w + 1,), name='nisqa-probe', daemon=True)
+                helper = self._helper = threading.Thread(target=probe_into, args=(w + 1,), name='nisqa-probe', daemon=True)
                 helper.start()
             else:
                 helper = None
@@ -408,6 +472,9 @@ class Ingest(object):
         except queue.Empty:
             pass
         self.thread.join(timeout=30)
+        helper = self._helper
+        if helper is not None:                     # a probe of the next window still running: it sees self.stop, or finishes
+            helper.join(timeout=30)
         if not self.thread.is_alive():
             _give_ring(self.ring)                  # the consumer's release events are still attached: reset() waits for them
         self.ring = None

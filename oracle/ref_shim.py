@@ -7,22 +7,69 @@ an EMPTY stand-in module is registered as ``sys.modules['librosa']`` before
 the import.  Only torch code of the reference then runs (model classes NL:29-1417,
 ``segment_specs`` NL:2239-2282); ``lb.load`` / ``lb.feature.melspectrogram`` /
 ``lb.core.amplitude_to_db`` are never reached.  /root/reference exists only in
-the build container: this module is used by ``tests/golden/make_golden.py``
-and by CPU tests that skip when the reference is absent, never on the GPU box.
+the build container; ``__graft_entry__.build()`` stages ``nisqa/NISQA_lib.py`` under
+``oracle/_ref/nisqa/`` (git-ignored, shipped with the snapshot like the checkpoints under
+``oracle/_ref/weights/``), and REFERENCE_ROOT falls back to ``oracle/_ref`` where /root/reference
+does not exist -- so the reference's torch half is importable on the GPU box too (live-reference
+``-m gpu`` test, ``bench.py``'s ``cpu_baseline``).  Nothing of the product imports this module.
+
+``import_reference_lib(functional_librosa=True)`` registers a stand-in whose three entry points the
+reference calls -- ``lb.load``, ``lb.feature.melspectrogram``, ``lb.core.amplitude_to_db``
+(NISQA_lib.py:2299-2330) -- are served by ``oracle/mel.py`` (the restatement of librosa 0.8.1, PARITY
+UNPINNED): the reference's own ``get_librosa_melspec`` / ``SpeechQualityDataset`` / ``predict_dim`` then run
+unmodified end to end, with only the third-party arithmetic replaced.
 """
 import os
 import sys
 import types
 
-REFERENCE_ROOT = os.environ.get('NISQA_REFERENCE_ROOT', '/root/reference')
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_STAGED = os.path.join(_HERE, '_ref')
+REFERENCE_ROOT = os.environ.get('NISQA_REFERENCE_ROOT') or (
+    '/root/reference' if os.path.isfile('/root/reference/nisqa/NISQA_lib.py') else _STAGED)
 
 
 def reference_available():
     return os.path.isfile(os.path.join(REFERENCE_ROOT, 'nisqa', 'NISQA_lib.py'))
 
 
-def import_reference_lib():
-    """Return the reference's ``nisqa.NISQA_lib`` module (torch parts usable)."""
+def _functional_librosa():
+    """A ``librosa`` stand-in that serves exactly the three calls of NISQA_lib.py:2299-2330 from oracle/mel.py."""
+    from . import mel as omel
+    import numpy as np
+    lb = types.ModuleType('librosa')
+    lb.feature, lb.core = types.ModuleType('librosa.feature'), types.ModuleType('librosa.core')
+
+    def load(path, sr=None, mono=True):
+        if sr is not None:
+            raise NotImplementedError('oracle covers ms_sr=None (all shipped checkpoints)')
+        if mono:
+            return omel.load_wav(path)
+        from scipy.io import wavfile                       # mono=False: (channels, n), the caller picks a row
+        rate, data = wavfile.read(path)
+        if data.ndim == 1:
+            return omel.load_wav(path)
+        chans = [omel.load_wav(path, ms_channel=c)[0] for c in range(data.shape[1])]
+        return np.stack(chans), int(rate)
+
+    def melspectrogram(y=None, sr=None, S=None, n_fft=None, hop_length=None, win_length=None, window='hann', center=True,
+                       pad_mode='reflect', power=1.0, n_mels=None, fmin=0.0, fmax=None, htk=False, norm='slaney'):
+        assert S is None and window == 'hann' and center and pad_mode == 'reflect' and power == 1.0 and not htk \
+            and norm == 'slaney' and fmin == 0.0
+        mag = omel.stft_mag(y, n_fft, hop_length, win_length)
+        return np.dot(omel.mel_filterbank(sr, n_fft, n_mels, fmin, fmax), mag).astype(np.float32)
+
+    def amplitude_to_db(S, ref=1.0, amin=1e-4, top_db=80.0):
+        assert ref == 1.0
+        return omel.amplitude_to_db(S, amin=amin, top_db=top_db)
+
+    lb.load, lb.feature.melspectrogram, lb.core.amplitude_to_db = load, melspectrogram, amplitude_to_db
+    return lb
+
+
+def import_reference_lib(functional_librosa=False):
+    """Return the reference's ``nisqa.NISQA_lib`` module (torch parts usable).  functional_librosa: the module's ``lb``
+    is the oracle-backed stand-in above instead of an empty one, so its mel front end runs too (PARITY UNPINNED there)."""
     if not reference_available():
         raise ImportError('reference tree not present at ' + REFERENCE_ROOT)
     sys.dont_write_bytecode = True            # keep /root/reference clean
@@ -35,7 +82,10 @@ def import_reference_lib():
         sys.path.insert(0, REFERENCE_ROOT)
     import importlib
     try:
-        return importlib.import_module('nisqa.NISQA_lib')
+        mod = importlib.import_module('nisqa.NISQA_lib')
+        if functional_librosa and not hasattr(getattr(mod, 'lb', None), 'load'):
+            mod.lb = _functional_librosa()
+        return mod
     finally:
         if standin:                            # the reference keeps its own `lb`; nobody else should see the stand-in
             del sys.modules['librosa']
@@ -59,3 +109,36 @@ def build_reference_model(args, state_dict):
     model.load_state_dict(state_dict, strict=True)
     model.eval()
     return model, NL
+
+
+def reference_predict(checkpoint, data_dir, files, bs, num_workers=0, ms_channel=None, timings=None):
+    """The reference's predict path on CPU, its own code end to end (NISQA_model.py:745-776 dataset construction, 928-1030
+    model construction, NISQA_lib.py:1420-1467 predict_mos / predict_dim: DataLoader -> SpeechQualityDataset.__getitem__
+    -> get_librosa_melspec -> segment_specs padded to [B, ms_max_segments, 1, 48, 15] -> model(x, n_wins)), with librosa's
+    three entry points served by oracle/mel.py (PARITY UNPINNED there).  files: basenames under data_dir.
+    -> float32 [N, heads].  timings (dict, optional) receives the wall seconds of the predict call."""
+    import time
+    import pandas as pd
+    import torch
+    NL = import_reference_lib(functional_librosa=True)
+    ck = torch.load(checkpoint, map_location='cpu')
+    args = dict(ck['args'])
+    args.setdefault('double_ended', args['model'] == 'NISQA_DE')
+    args.setdefault('dim', args['model'] == 'NISQA_DIM')
+    model = {'NISQA': NL.NISQA, 'NISQA_DIM': NL.NISQA_DIM}[args['model']](**{k: args[k] for k in MODEL_ARG_KEYS})
+    model.load_state_dict(ck['model_state_dict'], strict=True)
+    ds = NL.SpeechQualityDataset(
+        pd.DataFrame(list(files), columns=['deg']), df_con=None, data_dir=data_dir, filename_column='deg',
+        mos_column='predict_only', seg_length=args['ms_seg_length'], max_length=args['ms_max_segments'], to_memory=None,
+        to_memory_workers=None, seg_hop_length=args['ms_seg_hop_length'], transform=None, ms_n_fft=args['ms_n_fft'],
+        ms_hop_length=args['ms_hop_length'], ms_win_length=args['ms_win_length'], ms_n_mels=args['ms_n_mels'],
+        ms_sr=args['ms_sr'], ms_fmax=args['ms_fmax'], ms_channel=ms_channel, double_ended=args['double_ended'],
+        dim=args['dim'], filename_column_ref=None)
+    t0 = time.perf_counter()
+    if args['dim']:
+        y_hat, _ = NL.predict_dim(model, ds, bs, 'cpu', num_workers=num_workers)
+    else:
+        y_hat, _ = NL.predict_mos(model, ds, bs, 'cpu', num_workers=num_workers)
+    if timings is not None:
+        timings['predict_s'] = time.perf_counter() - t0
+    return y_hat.astype('float32')

@@ -31,7 +31,19 @@ def batch(seed, n_clips, heads):
     return specs, y
 
 
-def run(name, args, seed_sd, seed_batch, n_clips, lr, checkpoint=None):
+def batch_cfg5(seed, n_clips=32, heads=1, frames=1001):
+    """BASELINE configs[4] at its own size: bs 32 clips of 10 s -> [48, 1001] spectrogram-shaped arrays (247 segments each,
+    7 904 per batch), labels rng.uniform(1, 5) as SURVEY 8d gives them, one NaN label."""
+    rng = np.random.default_rng(seed)
+    env = [np.clip(-38 + 14 * np.sin(np.linspace(0, rng.uniform(3, 20), frames) + rng.uniform(0, 6)), -80, 0) for _ in range(n_clips)]
+    specs = [(e[None, :] + 9 * rng.standard_normal((48, frames)) - 0.3 * np.arange(48)[:, None]).astype(np.float32) for e in env]
+    specs = [np.maximum(s, s.max() - 80) for s in specs]                       # amplitude_to_db's top_db clamp (NL:2330)
+    y = rng.uniform(1, 5, (n_clips, heads)).astype(np.float32)
+    y[3, heads - 1] = np.nan
+    return specs, y
+
+
+def run(name, args, seed_sd, seed_batch, n_clips, lr, checkpoint=None, maker=None):
     """checkpoint: start from the reference's published weights (fine-tuning) instead of a seeded random state_dict; the
     fixture then holds the first step only (loss, y_hat, gradients) -- the weights themselves stay in the checkpoint."""
     NL = ref_shim.import_reference_lib()
@@ -48,7 +60,7 @@ def run(name, args, seed_sd, seed_batch, n_clips, lr, checkpoint=None):
     model.load_state_dict({k: torch.as_tensor(v) for k, v in sd0.items()}, strict=True)
     model.train()
     heads = 5 if args['model'] == 'NISQA_DIM' else 1
-    specs, y = batch(seed_batch, n_clips, heads)
+    specs, y = (maker or batch)(seed_batch, n_clips, heads)
     L = args['ms_max_segments']
     xs, nw = zip(*[onet.segment_specs(s, args['ms_seg_length'], args['ms_seg_hop_length'], L) for s in specs])
     x, n_wins = torch.stack(xs), torch.tensor(nw)
@@ -66,7 +78,25 @@ def run(name, args, seed_sd, seed_batch, n_clips, lr, checkpoint=None):
         if step == 1:
             for k, p in model.named_parameters():
                 out['grad/' + k] = p.grad.detach().numpy().copy()
-        if checkpoint is not None:
+        if checkpoint is not None or maker is not None:
+            for k, v in model.state_dict().items():                    # BatchNorm buffers after the first forward
+                if k.split('.')[-1].startswith(('running', 'num_batches')):
+                    out['sd1/' + k] = v.detach().numpy().copy()
+            if maker is not None:
+                # the same modules once more in float64 (same weights, same batch): what the fp32 gradients above are
+                # rounded versions of.  At 7 904 segments the reference's own fp32 summation order is worth up to 5e-4 of
+                # a tensor's largest entry; tests judge the HIP step against BOTH (stored rounded to float32)
+                m64 = type(model)(**margs).double()
+                m64.load_state_dict({k: torch.as_tensor(v).double() if torch.as_tensor(v).is_floating_point() else torch.as_tensor(v)
+                                     for k, v in sd0.items()}, strict=True)
+                m64.train()
+                yh = m64(x.double(), n_wins)
+                l64 = sum(loss_fn.get_loss(yt[:, h].double().view(-1, 1), yh[:, h].view(-1, 1), np.arange(n_clips)) for h in range(heads))
+                l64.backward()
+                out['loss1_f64'] = float(l64.detach())
+                out['y_hat1_f64'] = yh.detach().numpy()
+                for k, p in m64.named_parameters():
+                    out['grad64/' + k] = p.grad.detach().numpy().astype(np.float32)
             break
         opt.step()
         opt.zero_grad()
@@ -79,7 +109,15 @@ def run(name, args, seed_sd, seed_batch, n_clips, lr, checkpoint=None):
 
 if __name__ == '__main__':
     torch.manual_seed(0)
-    run('mos', synth.MOS_ARGS, 8, 31, 4, 1e-3)
-    run('dim', synth.DIM_ARGS, 7, 32, 3, 1e-3)
-    if os.path.isfile('/root/reference/weights/nisqa.tar'):
-        run('dim_real', None, -1, 33, 6, 1e-3, checkpoint='/root/reference/weights/nisqa.tar')
+    want = set(sys.argv[1:])                                   # case names; none = all
+    real = '/root/reference/weights/nisqa.tar'
+    cases = [('mos', lambda: run('mos', synth.MOS_ARGS, 8, 31, 4, 1e-3)),
+             ('dim', lambda: run('dim', synth.DIM_ARGS, 7, 32, 3, 1e-3)),
+             ('dim_real', lambda: run('dim_real', None, -1, 33, 6, 1e-3, checkpoint=real)),
+             # BASELINE configs[4] at its own size (bs 32 x 10 s = 7 904 segments): the configuration's own model (NISQA,
+             # random initialisation, as `pretrained_model: false` gives it) and a fine-tuning step of NISQA_DIM from nisqa.tar
+             ('cfg5_mos', lambda: run('cfg5_mos', synth.MOS_ARGS, 11, 9, 32, 1e-3, maker=batch_cfg5)),
+             ('cfg5_dim_real', lambda: run('cfg5_dim_real', None, -1, 10, 32, 1e-3, checkpoint=real, maker=batch_cfg5))]
+    for name, fn in cases:
+        if (not want or name in want) and (not name.endswith('real') or os.path.isfile(real)):
+            fn()

@@ -364,6 +364,43 @@ def test_predict_dir_drop_in_surface(tmp_path):
     assert np.abs(np.array([df2[c].iloc[0] for c in cols], np.float32) - ref).max() < 1e-3
 
 
+@pytest.mark.parametrize('ckpt,precision', [('nisqa.tar', 'bf16x3'), ('nisqa.tar', 'f32'), ('nisqa_mos_only.tar', 'bf16x3'),
+                                            ('nisqa_tts.tar', 'bf16x3')])
+def test_against_the_live_reference_loop_on_fresh_random_clips(tmp_path, ckpt, precision, monkeypatch):
+    """Not a committed fixture: FRESH clips every run (seed from os.urandom, printed), scored by the reference's OWN loop on
+    the CPU -- NISQA_lib.py as shipped (staged by build() under oracle/_ref/nisqa, git-ignored): SpeechQualityDataset ->
+    get_librosa_melspec -> segment_specs padded to [B, ms_max_segments, 1, 48, 15] -> DataLoader -> model(x, n_wins) of
+    predict_dim / predict_mos -- with librosa's three entry points served by oracle/mel.py (mel stage PARITY UNPINNED), and
+    by nisqaModel.predict() of this repository in predict_dir mode on the same files.  Bar 1e-3 (north_star)."""
+    from oracle import ref_shim
+    from nisqa_amd.NISQA_model import nisqaModel
+    path = helpers.find_weights(ckpt)
+    if path is None or not ref_shim.reference_available():
+        pytest.skip('reference checkpoint / NISQA_lib.py not staged (oracle/_ref)')
+    seed = int.from_bytes(os.urandom(4), 'little')
+    rng = np.random.default_rng(seed)
+    d = tmp_path / 'wavs'
+    d.mkdir()
+    names = []
+    for i in range(6):
+        dur = float(rng.uniform(0.5, 9.0))
+        pcm = synth.synth_pcm16(int(rng.integers(1 << 30)), dur)
+        if i == 4:                                               # one stereo file: lb.load averages the channels
+            pcm = np.stack([pcm, synth.synth_pcm16(int(rng.integers(1 << 30)), dur)], 1)
+        synth.write_wav(str(d / ('f%d.wav' % i)), pcm, 48000)
+        names.append('f%d.wav' % i)
+    monkeypatch.setenv('NISQA_HIP_PRECISION', precision)
+    a = {'mode': 'predict_dir', 'pretrained_model': path, 'deg': None, 'data_dir': str(d), 'output_dir': None,
+         'csv_file': None, 'csv_deg': None, 'num_workers': 0, 'bs': 4, 'ms_channel': None, 'tr_bs_val': 4, 'tr_num_workers': 0}
+    df = nisqaModel(a).predict()
+    cols = [c for c in ('mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred') if c in df.columns]
+    got = df.set_index('deg').loc[names, cols].to_numpy(np.float32)
+    ref = ref_shim.reference_predict(path, str(d), names, bs=4)
+    err = float(np.abs(got - ref[:, :len(cols)]).max())
+    print('live reference loop, %s %s, seed %d: max|d| %.3g over %d clips x %d outputs' % (ckpt, precision, seed, err, len(names), len(cols)))
+    assert got.shape == ref.shape and err < 1e-3, (seed, err)
+
+
 def test_inner_operator_forward_on_segment_tensors(eng_rand, batch):
     """model(x[B,L,1,48,15], n_wins) -- the reference's inner operator (NL:260-268) -- and Dataset.__getitem__."""
     from nisqa_amd import NISQA_lib as NL

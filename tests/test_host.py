@@ -617,6 +617,108 @@ def test_shard_bounds_cover_everything():
             assert max(hi - lo for lo, hi in b) - min(hi - lo for lo, hi in b) <= 1
 
 
+def test_balanced_bounds_equalise_work_on_length_sorted_lists():
+    """Work-balanced contiguous shards: on a length-sorted list of mixed 3-30 s clips equal COUNTS give the last
+    rank several times the first rank's segments; the prefix-sum boundaries keep every rank within 10 % of the mean."""
+    from nisqa_amd import dist
+    rng = np.random.default_rng(7)
+    tok = np.sort(np.maximum(1, -(-(1 + (rng.uniform(3, 30, 100000) * 48000).astype(np.int64) // 480 - 14) // 4)))
+    for w in (2, 3, 4, 8):
+        b = dist.balanced_bounds(tok, w)
+        assert b[0][0] == 0 and b[-1][1] == len(tok) and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        work = np.array([tok[lo:hi].sum() for lo, hi in b], dtype=np.float64)
+        assert np.abs(work / work.mean() - 1).max() < 0.01, work
+        by_count = np.array([tok[slice(*dist.shard_bounds(len(tok), r, w))].sum() for r in range(w)], dtype=np.float64)
+        assert by_count.max() / by_count.min() > (1.5 if w == 2 else 2.5)                   # what it replaces
+    # degenerate inputs: nothing to balance -> the count shards; fewer items than ranks -> empty shards, still a partition
+    assert dist.balanced_bounds(np.zeros(7), 3) == [dist.shard_bounds(7, r, 3) for r in range(3)]
+    assert dist.balanced_bounds([], 2) == [(0, 0), (0, 0)]
+    b = dist.balanced_bounds([5, 1], 4)
+    assert b[0][0] == 0 and b[-1][1] == 2 and all(b[i][1] == b[i + 1][0] and b[i][0] <= b[i][1] for i in range(3))
+    b = dist.balanced_bounds([1, 1, 1, 100], 2)
+    assert b == [(0, 3), (3, 4)]
+
+
+_WORKER_BAL = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import numpy as np, torch, pandas as pd
+import test_host as T
+from nisqa_amd import NISQA_lib as NL, synth
+rank = int(sys.argv[1]); world = int(sys.argv[2])
+torch.distributed.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=rank, world_size=world)
+files = %(files)r
+ds = NL.SpeechQualityDataset(pd.DataFrame(files, columns=['deg']), data_dir=%(wavs)r, filename_column='deg',
+                             mos_column='predict_only', dim=True, seg_length=15, seg_hop_length=4, ms_hop_length=0.01)
+model = NL.NISQA_DIM(**{k: v for k, v in synth.DIM_ARGS.items() if k.startswith(('cnn_', 'td', 'pool', 'ms_seg_length', 'ms_n_mels'))})
+seen = []
+class Eng(T.FakeEngine):
+    def forward_pcm(self, pcm, plan, sr):
+        seen.append(int(np.sum(plan.n_wins)))
+        return super().forward_pcm(pcm, plan, sr)
+model._engine = Eng(5)
+y, _ = NL.predict_dim(model, ds, 2, 'cpu', 0)
+json.dump({'y': y.tolist(), 'tokens': int(sum(seen))}, open(os.path.join(%(out)r, 'r%%d.json' %% rank), 'w'))
+torch.distributed.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_predict_loop_shards_by_work_on_a_length_sorted_list(tmp_path, world):
+    """gloo, world 2 and 3, a length-sorted list of 0.2 ... 2.4 s clips: every rank's segment count (what its engine was
+    handed) is within 10 % of the mean, every rank ends with the full frame in INPUT order, equal to a one-process run."""
+    import json
+    import socket
+    d = tmp_path / 'w'
+    d.mkdir()
+    durs = np.sort(np.concatenate((np.random.default_rng(3).uniform(0.2, 2.4, 44), [0.2, 2.4])))
+    names = _mixed_wavs(d, durs.tolist())
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER_BAL % {'root': ROOT, 'port': port, 'wavs': str(d), 'out': str(tmp_path), 'files': names})
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world)], env=env) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    res = [json.load(open(tmp_path / ('r%d.json' % r))) for r in range(world)]
+    assert all(r['y'] == res[0]['y'] for r in res)
+    tok = np.array([r['tokens'] for r in res], dtype=np.float64)
+    assert np.abs(tok / tok.mean() - 1).max() < 0.10, tok
+    from nisqa_amd import NISQA_lib as NL
+    ds = NL.SpeechQualityDataset(pd.DataFrame(names, columns=['deg']), data_dir=str(d), filename_column='deg',
+                                 mos_column='predict_only', dim=True, seg_length=15, seg_hop_length=4, ms_hop_length=0.01)
+    model = NL.NISQA_DIM(**{k: v for k, v in synth.DIM_ARGS.items()
+                            if k.startswith(('cnn_', 'td', 'pool', 'ms_seg_length', 'ms_n_mels'))})
+    model._engine = FakeEngine(5)
+    y, _ = NL.predict_dim(model, ds, 2, 'cpu', 0)
+    np.testing.assert_allclose(np.array(res[0]['y']), y, rtol=0, atol=1e-6)
+    assert (np.diff(y[:, 0]) != 0).any()
+
+
+def test_byte_cap_charges_what_staging_lays_out_for_mixed_sample_widths():
+    """ADVICE r3: one stereo / 24-bit / float file widens its whole sample-rate group to float32 in Ingest._stage; the
+    batch policy charges the byte cap with exactly that (LengthAware.staged_bytes) and sorts int16 clips before float ones
+    inside a rate, so a batch mixes the two only at the seam."""
+    from nisqa_amd import ingest
+    rng = np.random.default_rng(11)
+    n = 400
+    frames = rng.integers(3 * 48000, 12 * 48000, n).astype(np.int64)
+    srs = np.full(n, 48000, dtype=np.int64)
+    widths = np.where(rng.random(n) < 0.1, 4, 2)                               # 10 % of the files need the host decoder
+    tok = lambda f, r: np.maximum(1, -(-(1 + f // 480 - 14) // 4))
+    cap = 32 << 20
+    pol = ingest.LengthAware(range(n), 1, tok, min_tokens=1 << 30, byte_cap=cap)     # only the byte cap closes batches
+    cuts = pol.cut(frames, srs, widths)
+    assert sorted(k for c in cuts for k in c) == list(range(n))
+    staged = [pol.staged_bytes(frames, srs, widths, c) for c in cuts]
+    assert max(staged[:-1]) <= cap and staged[-1] <= cap + cap // 2              # the tail merge is soft by half, no more
+    mixed = [c for c in cuts if len(set(widths[c].tolist())) == 2]
+    assert len(mixed) <= 1                                                       # the seam
+    # what the old accounting (frames x own width) would have let through: a batch of int16 clips plus one float clip
+    c = [int(k) for k in np.flatnonzero(widths == 2)[:20]] + [int(np.flatnonzero(widths == 4)[0])]
+    assert pol.staged_bytes(frames, srs, widths, c) == int(frames[c].sum()) * 4 > int((frames[c] * widths[c]).sum())
+
+
 _WORKER = r'''
 import os, sys, json
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
@@ -946,6 +1048,34 @@ def test_checkpoint_with_pickled_objects_is_refused_unless_opted_in(tmp_path, mo
     monkeypatch.setenv('NISQA_ALLOW_UNSAFE_CHECKPOINT', '1')
     ck = _load_checkpoint(bad)
     assert 'args' in ck and 'code ran at load time' in capsys.readouterr().out
+
+
+def test_checkpoint_written_by_the_reference_trainer_is_salvaged_without_running_it(tmp_path, monkeypatch, capsys):
+    """the reference's trainer saves db_results DataFrames and numpy scalars next to the tensors (reference
+    NISQA_model.py:1096-1108); the restricted unpickler rejects such a file.  It is loaded through the salvage unpickler:
+    only tensor-rebuild globals resolve, everything else becomes an inert stub (the file's code never runs), and only
+    args + model_state_dict are kept.  A stub INSIDE args still refuses."""
+    from nisqa_amd.NISQA_model import _load_checkpoint
+    monkeypatch.delenv('NISQA_ALLOW_UNSAFE_CHECKPOINT', raising=False)
+    sd = synth.random_state_dict(7)
+    args = dict(synth.DIM_ARGS, now=__import__('datetime').datetime(2021, 3, 4))
+    p = str(tmp_path / 'trained.tar')
+    torch.save({'args': args, 'model_state_dict': sd, 'epoch': np.int64(3), 'r': {'r_p_mean_file': np.float64(0.9)},
+                'db_results': {'db': pd.DataFrame({'x': [1.0, 2.0]})}, 'optimizer_state_dict': {'state': {0: torch.zeros(3)}},
+                'trap': _Evil()}, p)
+    ck = _load_checkpoint(p)
+    out = capsys.readouterr().out
+    assert 'code ran at load time' not in out and 'loaded args and model_state_dict only' in out
+    assert set(ck) == {'args', 'model_state_dict'} and ck['args'] == args
+    assert all(torch.equal(ck['model_state_dict'][k], torch.as_tensor(sd[k])) for k in sd) and len(ck['model_state_dict']) == len(sd)
+    # the whole drop-in surface takes it
+    from nisqa_amd import NISQA_lib as NL
+    m = NL.NISQA_DIM(**{k: v for k, v in ck['args'].items() if k.startswith(('cnn_', 'td', 'pool', 'ms_seg_length', 'ms_n_mels'))})
+    m.load_state_dict(ck['model_state_dict'], strict=True)
+    bad = str(tmp_path / 'bad_args.tar')
+    torch.save({'args': dict(args, lr=np.float64(1e-3)), 'model_state_dict': sd}, bad)
+    with pytest.raises(RuntimeError, match='NISQA_ALLOW_UNSAFE_CHECKPOINT'):
+        _load_checkpoint(bad)
 
 
 @pytest.mark.parametrize('law', ['mulaw', 'alaw'])

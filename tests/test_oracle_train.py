@@ -73,6 +73,36 @@ def test_train_step_oracle_matches_reference_fixture(name):
             np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=2e-4 * max(1, np.abs(want).max()))
 
 
+def test_train_step_oracle_matches_reference_fixture_at_configs4_size():
+    """BASELINE configs[4] at its own size: bs 32 x 10 s = 7 904 segments (tests/golden/make_golden_train.py 'cfg5_mos',
+    written by the reference's NISQA module in train mode).  The sums over 13x more rows than the small fixtures are what
+    changes with size; the oracle is pinned there too before the GPU step is judged against either."""
+    g = helpers.golden('train_cfg5_mos.npz')
+    args = dict(synth.MOS_ARGS)
+    sd = synth.random_state_dict(int(g['seed_sd']), 'NISQA')
+    specs, y = mk.batch_cfg5(int(g['seed_batch']), int(g['n_clips']), 1)
+    segs = torch.cat([onet.segment_specs(s, 15, 4, None)[0] for s in specs])
+    n_wins = [int(v) for v in g['n_wins']]
+    assert segs.shape[0] == sum(n_wins) == 7904
+    r1 = otrain.train_step(sd, args, segs, n_wins, y, lr=float(g['lr']))
+    assert r1['loss'] == pytest.approx(float(g['loss1']), rel=2e-5)
+    np.testing.assert_allclose(r1['y_hat'], g['y_hat1'], rtol=0, atol=2e-5)
+    worst, wk = 0.0, None
+    for k in otrain.param_keys(sd):
+        want = g['grad/' + k]
+        if _conv_bias(k):
+            continue
+        e = float(np.abs(r1['grads'][k] - want).max()) / max(1e-3, float(np.abs(want).max()))
+        if e > worst:
+            worst, wk = e, k
+    print('configs[4] size: oracle vs reference, worst relative gradient error %.2e (%s)' % (worst, wk))
+    assert worst < 5e-4, (worst, wk)
+    for k, v in r1['sd'].items():
+        if 'running' in k:
+            want = g['sd1/' + k]
+            np.testing.assert_allclose(v.numpy(), want, rtol=0, atol=1e-4 * max(1, np.abs(want).max()))
+
+
 def test_explicit_dropout_masks_and_bias_mapping():
     _, args, sd, segs, n_wins, y = _case('mos')
     rng = np.random.default_rng(0)
