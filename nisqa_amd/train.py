@@ -125,6 +125,7 @@ class HipTrainer(object):
         self._sums = torch.zeros((96 + 24 * len(self.heads), 512), dtype=torch.float64, device=self.device)
         self._cast_table, self._cast_key = None, None
         self._rng_seed, self._rng_off = int(torch.initial_seed()) & (2 ** 64 - 1), 0     # torch.manual_seed governs the masks
+        self._debug = {} if os.environ.get('NISQA_HIP_TRAIN_DEBUG') == '1' else None
 
     # ---- parameters ------------------------------------------------------------------------------------
     def _layout(self, sd):
@@ -628,6 +629,8 @@ class HipTrainer(object):
                                           _ptr(self.G['cnn.model.bn%d.weight' % i]), _ptr(self.G['cnn.model.bn%d.bias' % i]),
                                           sb.data_ptr(), st), 'nisqa_bn_bwd2')
             wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
+            if self._debug is not None:                                      # tools/diag_cfg5.py: intermediates of the backward pass
+                self._debug['da%d' % i], self._debug['dz%d' % i], self._debug['z%d' % i] = da, dz, c['z']
             if sb is not None:
                 self._defer_cast(sb, 0, co, self.G[bk])
             if i == 1:

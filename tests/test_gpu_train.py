@@ -617,10 +617,18 @@ def test_training_step_at_configs4_size_matches_reference_fixture(name, precisio
     against fixtures written by the reference's modules in train mode (make_golden_train.py 'cfg5_*': the configuration's
     own model from a random initialisation, and a fine-tuning step of NISQA_DIM from nisqa.tar).  Split-K atomics, float64
     moment sums and split-bf16 weight-gradient accumulation run over 13x more rows here than in the small fixtures.
-    The fixture holds the reference's fp32 gradients AND the same modules' float64 gradients: at this size the
-    reference's own fp32 summation order is worth up to 1.4e-3 of a tensor's largest entry (pool.model.linear1.bias),
-    so the HIP step is held to the float64 values with a bound of 2e-3 and to the fp32 ones with 3e-3 ('f32' / 'mixed');
-    'bf16x3' (split-bf16 FORWARD convolutions) keeps the loose 5e-2 gradient bound of the small fixtures."""
+
+    What the bound has to allow for (measured, DESIGN.md 4.7 "configs[4] size"): the fixture holds the reference's fp32
+    gradients AND the same modules' float64 gradients.  Any two fp32 evaluations of the forward pass differ by ~1e-6 in the
+    convolution outputs z, and with 9-91 M values per layer a handful lie that close to their channel's batch mean: their
+    ReLU gates FLIP (tests/test_oracle_train.py counts them between two CPU summation orders: 1-17 per layer).  A gradient
+    entry is a sum with heavy cancellation, so ONE flipped element with a large upstream gradient moves an entry of
+    conv5.weight by 5e-3 of the tensor's largest entry (round 4: row 109 866, channel 4, |z - mean| = 1e-6, traced with
+    tools/diag_cfg5.py against a float64 restatement kept with its intermediates); an independent fp32 evaluation on the CPU
+    (unfold + matmul convolutions) deviates from float64 by up to 1.2e-3, the reference's own fp32 by up to 1.4e-3.
+    Hence: every tensor within 1e-2 (max-abs, relative to its largest entry) AND within 3e-3 in the Frobenius norm of the
+    float64 gradients ('f32' / 'mixed'); 'bf16x3' (split-bf16 FORWARD convolutions: z moves by 5e-6 relative, more flips)
+    keeps the loose 5e-2 max-abs bound of the small fixtures and 2e-2 in the norm."""
     from nisqa_amd.train import HipTrainer
     g, args, sd, specs, y = _cfg5_case(name)
     tr = HipTrainer(args, sd, DEV, lr=float(g['lr']), precision=precision)
@@ -628,8 +636,8 @@ def test_training_step_at_configs4_size_matches_reference_fixture(name, precisio
     torch.cuda.synchronize()
     assert tr.last['y_hat'].shape[0] == 32 and int(sum(g['n_wins'])) == 7904
     dy = float(np.abs(tr.last['y_hat'].cpu().numpy() - g['y_hat1']).max())
-    w32 = w64 = wref = 0.0
-    k32 = k64 = None
+    w32 = w64 = wref = l64 = lref = 0.0
+    k32 = k64 = kl = None
     for k, gr in tr.grads().items():
         if _conv_bias(k):
             assert np.abs(gr.numpy()).max() < 1e-4
@@ -637,21 +645,26 @@ def test_training_step_at_configs4_size_matches_reference_fixture(name, precisio
         a32, a64 = g['grad/' + k], g['grad64/' + k]
         sc = max(1e-3, float(np.abs(a64).max()))
         e32, e64 = float(np.abs(gr.numpy() - a32).max()) / sc, float(np.abs(gr.numpy() - a64).max()) / sc
+        nrm = max(1e-3 * math.sqrt(a64.size), float(np.linalg.norm(a64)))
+        n64 = float(np.linalg.norm(gr.numpy() - a64)) / nrm
         wref = max(wref, float(np.abs(a32 - a64).max()) / sc)
+        lref = max(lref, float(np.linalg.norm(a32 - a64)) / nrm)
         if e32 > w32:
             w32, k32 = e32, k
         if e64 > w64:
             w64, k64 = e64, k
-    print('%s %s: loss %.6f (reference %.6f, float64 %.6f), |d y_hat| %.2e, worst relative gradient error vs reference fp32 '
-          '%.2e (%s), vs reference float64 %.2e (%s); the reference fp32 vs its own float64: %.2e' % (
-              name, precision, float(loss), float(g['loss1']), float(g['loss1_f64']), dy, w32, k32, w64, k64, wref))
+        if n64 > l64:
+            l64, kl = n64, k
+    print('%s %s: loss %.6f (reference %.6f, float64 %.6f), |d y_hat| %.2e; worst gradient tensor vs the reference float64: max-abs '
+          '%.2e (%s), Frobenius %.2e (%s); vs the reference fp32: max-abs %.2e (%s); the reference fp32 vs its own float64: max-abs '
+          '%.2e, Frobenius %.2e' % (name, precision, float(loss), float(g['loss1']), float(g['loss1_f64']), dy, w64, k64, l64, kl,
+                                    w32, k32, wref, lref))
     assert float(loss) == pytest.approx(float(g['loss1']), rel=1e-4)
     assert dy < (1e-4 if precision != 'bf16x3' else 2e-4)
     if precision == 'bf16x3':
-        assert w64 < 5e-2, (w64, k64)
+        assert w64 < 5e-2 and l64 < 2e-2, (w64, k64, l64, kl)
     else:
-        assert w64 < 2e-3, (w64, k64)
-        assert w32 < 3e-3, (w32, k32)
+        assert w64 < 1e-2 and l64 < 3e-3, (w64, k64, l64, kl)
     for k, v in tr.state_dict().items():
         if k.endswith('num_batches_tracked'):
             assert int(v) == int(g['sd1/' + k])
