@@ -190,6 +190,58 @@ int nisqa_cast_scatter(const double* src, const int32_t* table, int32_t n_entrie
 /* torch.optim.Adam (betas 0.9 / 0.999, eps 1e-8, no weight decay), step counter t >= 1, on flat buffers */
 int nisqa_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float lr, int32_t t, void* stream);
 
+/* ---- The self-attention block + attention-pooling heads + loss of the training step as ONE call (csrc/train_td.hip) ----
+ * Replaces, for the CNN-SA-AP model in train mode, SelfAttention.forward / SelfAttentionLayer.forward (NISQA_lib.py:988-996,
+ * 1025-1040), PoolAttFF.forward (NISQA_lib.py:1171-1183), biasLoss.get_loss (NISQA_lib.py:1880-1892, 1946-1950) and autograd's
+ * backward of all of them (NISQA_model.py:142-143): a dozen launches (token-tile kernels that chain their products through
+ * registers, flash-style attention forward and backward with the dropout masks inside, one grouped split-K GEMM for every
+ * weight gradient, one column-sum launch for every bias / LayerNorm gradient) instead of ~116 operator launches.  fp32 MFMA.
+ *
+ * Parameter offsets `poff` (HOST array, int32, offsets in floats into `params` and `grads`), in this order:
+ *   [0] linear.weight as [64][384] with columns in the feature tensor's (y, c) order  [1] linear.bias  [2] norm1.weight  [3] norm1.bias
+ *   per layer l at 4 + 12 l: in_proj_weight [192][64], in_proj_bias, out_proj.weight, out_proj.bias, norm1.weight, norm1.bias,
+ *                            linear1.weight, linear1.bias, linear2.weight, linear2.bias, norm2.weight, norm2.bias
+ *   per head h at 4 + 12 L + 6 h: linear1.weight [128][64], linear1.bias, linear2.weight [128], linear2.bias, linear3.weight [64],
+ *                            linear3.bias
+ * Token spaces: the caller's tokens (segments) are packed clip after clip (seg_off); inside the block every clip is padded to
+ * whole 32-token tiles (ptok_off, multiples of 32; tile_clip[t] = clip of tile t).
+ *
+ * nisqa_tdtrain_plan (host only, no GPU work): out[0] = workspace floats, out[1] = fragment-buffer floats, out[2] = groups and
+ *   out[3] = 64 x 64 tiles of the weight-gradient GEMM, out[4] = column-sum jobs, out[5] / out[6] / out[7] = offsets (floats)
+ *   inside the workspace of the INPUT features [n_tokens][384] (the CNN writes them there), of their gradient [n_tokens][384]
+ *   and of y_hat [n_clips][n_heads]; the loss (total, then one term per head) follows y_hat at out[7] + round_up(n_clips *
+ *   n_heads, 4); from out[8]: the GEMM descriptors [groups][10] then the column-sum jobs [jobs][6] (int64), which the caller
+ *   uploads and passes back as wgrad_desc / colsum_jobs.  cap = capacity of out in int64s.
+ * nisqa_tdtrain_step: forward, loss, backward.  Adds every parameter gradient of the block into `grads` (zeroed by the
+ *   caller), writes y_hat, loss and the feature gradient.  labels [n_clips][n_heads] (NaN = unlabelled), bias_map [n_clips][4]
+ *   cubic coefficients or NULL, inv_count [n_heads] = 1 / (labelled clips of the whole batch, all ranks) or 0.  mask_* are the
+ *   dropout multipliers of each layer in the CALLER's token order (mask_p: [sum L^2] attention probabilities, row-major per
+ *   clip at sq_off; mask_1 / mask_f / mask_2: [n_tokens][64]) or NULL. */
+typedef struct nisqa_tdtrain_args {
+    int32_t n_clips, n_tokens, n_tokens_padded, n_layers, n_heads, n_wgrad_groups, n_wgrad_tiles, n_colsum_jobs;
+    const int32_t* seg_off;      /* device [n_clips + 1] */
+    const int32_t* ptok_off;     /* device [n_clips + 1] */
+    const int32_t* tile_clip;    /* device [n_tokens_padded / 32] */
+    const int64_t* sq_off;       /* device [n_clips + 1]: prefix sum of L^2 */
+    const float* params;         /* device, flat parameter buffer */
+    float* grads;                /* device, flat gradient buffer (same offsets) */
+    const int32_t* poff;         /* HOST */
+    float* ws;                   /* device, out[0] floats */
+    float* frags;                /* device, out[1] floats */
+    const float* labels;         /* device */
+    const float* bias_map;       /* device or NULL */
+    const float* inv_count;      /* device [n_heads] */
+    const float* mask_p[4];
+    const float* mask_1[4];
+    const float* mask_f[4];
+    const float* mask_2[4];
+    const int64_t* wgrad_desc;   /* device [n_wgrad_groups][10] */
+    const int64_t* colsum_jobs;  /* device [n_colsum_jobs][6] */
+} nisqa_tdtrain_args;
+int nisqa_tdtrain_plan(int32_t n_clips, int32_t n_tokens, int32_t n_tokens_padded, int32_t n_layers, int32_t n_heads,
+                       const int32_t* poff, int64_t* out, int64_t cap);
+int nisqa_tdtrain_step(const nisqa_tdtrain_args* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

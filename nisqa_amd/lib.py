@@ -65,9 +65,21 @@ SYMBOLS = {
     'nisqa_probe_mfma_sustained': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p]),
 }
 
+class TdTrainArgs(ctypes.Structure):
+    """nisqa_tdtrain_args (include/nisqa_train.h)"""
+    _fields_ = [('n_clips', c_i32), ('n_tokens', c_i32), ('n_tokens_padded', c_i32), ('n_layers', c_i32), ('n_heads', c_i32),
+                ('n_wgrad_groups', c_i32), ('n_wgrad_tiles', c_i32), ('n_colsum_jobs', c_i32),
+                ('seg_off', c_p), ('ptok_off', c_p), ('tile_clip', c_p), ('sq_off', c_p), ('params', c_p), ('grads', c_p),
+                ('poff', c_p), ('ws', c_p), ('frags', c_p), ('labels', c_p), ('bias_map', c_p), ('inv_count', c_p),
+                ('mask_p', c_p * 4), ('mask_1', c_p * 4), ('mask_f', c_p * 4), ('mask_2', c_p * 4),
+                ('wgrad_desc', c_p), ('colsum_jobs', c_p)]
+
+
 # include/nisqa_train.h: operators of the training step (same shared library)
 c_f = ctypes.c_float
 TRAIN_SYMBOLS = {
+    'nisqa_tdtrain_plan': (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_i64]),
+    'nisqa_tdtrain_step': (ctypes.c_int, [ctypes.POINTER(TdTrainArgs), c_p]),
     'nisqa_gemm_f32': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f, c_p]),
     'nisqa_gemm_f32_one': (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32,
                                           c_f, c_p, c_i32, c_p]),

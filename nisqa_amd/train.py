@@ -108,6 +108,9 @@ class HipTrainer(object):
         # split-bf16 forward / input-gradient convolutions segment-resident (csrc/train_conv.hip) where the layer shape is
         # one of the reference configuration's; weight fragments are packed once per step (_segconv_pack)
         self.segconv = os.environ.get('NISQA_HIP_TRAIN_SEGCONV', '1') != '0' and self.precision != 'f32'
+        # self-attention block + pooling heads + loss, forward and backward, as one C call of a dozen launches (csrc/train_td.hip)
+        self.fused_td = os.environ.get('NISQA_HIP_TRAIN_FUSED_TD', '1') != '0'
+        self._td_ws = self._td_frags = None
         self._sc_frags, self._sc_bufs = {}, {}
         self._prep_key = None
         self.lr = float(lr)
@@ -119,6 +122,7 @@ class HipTrainer(object):
             raise NotImplementedError('pool_att_dropout > 0 is not built (0 in every shipped config)')
         self.t = 0
         self._layout(state_dict)
+        self._td_poff = self._td_param_offsets()
         self.load_state_dict(state_dict)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
@@ -143,6 +147,20 @@ class HipTrainer(object):
         self.gflat = torch.zeros_like(self.flat)
         self.P = {k: self.flat[self.off[k]:self.off[k] + int(np.prod(self.kshape[k]))].view(self.kshape[k]) for k in keys}
         self.G = {k: self.gflat[self.off[k]:self.off[k] + int(np.prod(self.kshape[k]))].view(self.kshape[k]) for k in keys}
+
+    def _td_param_offsets(self):
+        """Offsets of the self-attention / pooling parameters in the flat buffers, in the order nisqa_tdtrain_* documents."""
+        pfx = 'time_dependency.model.'
+        keys = [pfx + 'linear.weight', pfx + 'linear.bias', pfx + 'norm1.weight', pfx + 'norm1.bias']
+        for l in range(self.n_layers):
+            p = pfx + 'layers.%d.' % l
+            keys += [p + 'self_attn.in_proj_weight', p + 'self_attn.in_proj_bias', p + 'self_attn.out_proj.weight',
+                     p + 'self_attn.out_proj.bias', p + 'norm1.weight', p + 'norm1.bias', p + 'linear1.weight', p + 'linear1.bias',
+                     p + 'linear2.weight', p + 'linear2.bias', p + 'norm2.weight', p + 'norm2.bias']
+        for hp in self.heads:
+            keys += [hp + 'linear1.weight', hp + 'linear1.bias', hp + 'linear2.weight', hp + 'linear2.bias', hp + 'linear3.weight',
+                     hp + 'linear3.bias']
+        return np.array([self.off[k] for k in keys], dtype=np.int32)
 
     @staticmethod
     def _to_kernel(k, v):
@@ -303,6 +321,10 @@ class HipTrainer(object):
         key = L.tobytes()
         if key != self._prep_key or os.environ.get('NISQA_HIP_TRAIN_NO_PREP_CACHE') == '1':     # (the switch: timing of the rebuild)
             parts, tiles = step_tables(L)
+            td_plan = None
+            if self.fused_td:
+                tparts, td_plan = self._td_plan(L)
+                parts = parts + tparts
             offs, total = [], 0
             for _, a in parts:
                 offs.append(total)
@@ -318,7 +340,9 @@ class HipTrainer(object):
                 tv[k] = buf[o:o + a.nbytes].view({'int32': torch.int32, 'int64': torch.int64}[a.dtype.name]).view(a.shape)
             self._prep_key, self._prep_host, self._prep_buf = key, host, buf       # host stays alive until the copy has run
             self._prep_tables = (tv, tiles)
+            self._td_plan_cur = td_plan
         tv, tiles = self._prep_tables
+        self._tv = tv
         self.seg_off = tv['seg_off']
         self._desc = {k: (tv['desc_' + k], n) for k, n in tiles.items()}
         self.att_off, self.att_len, self.pool_off, self.pool_len = tv['att_off'], tv['att_len'], tv['pool_off'], tv['pool_len']
@@ -350,6 +374,8 @@ class HipTrainer(object):
         self._casts.append(((s.data_ptr() - self._sums.data_ptr()) // 8 + lo, (dst.data_ptr() - self.gflat.data_ptr()) // 4, n))
 
     def _flush_casts(self):
+        if not self._casts:
+            return
         key = tuple(self._casts)
         if key != self._cast_key:
             self._cast_key = key
@@ -386,93 +412,91 @@ class HipTrainer(object):
         floor = torch.full((len(specs),), -3.0e38, dtype=torch.float32, device=self.device)
         return self._step(mel, frame_off, n_wins, floor, y, masks, bias)
 
-    def _step(self, mel, frame_off, n_wins, floor, y, masks, bias):
+    def _td_plan(self, L):
+        """Tables of the fused self-attention block for clips of L[b] segments: padded token offsets (32 per tile), the clip of
+        every tile, the prefix sum of L^2, and what nisqa_tdtrain_plan lays out (workspace / fragment sizes, the descriptors of
+        the one weight-gradient GEMM and of the one column-sum launch) -> ([(name, array)], plan dict)."""
+        L = np.asarray(L, dtype=np.int64)
+        B, S = len(L), int(L.sum())
+        tiles = (L + 31) // 32
+        ptok = np.concatenate(([0], np.cumsum(tiles * 32)))
+        NP = int(ptok[-1])
+        H = len(self.heads)
+        cap = 8 + (1 + 4 * self.n_layers + 2 * H) * 10 + (2 + 6 * self.n_layers + H) * 6
+        out = np.zeros(cap, dtype=np.int64)
+        self._ck(self.lib.nisqa_tdtrain_plan(B, S, NP, self.n_layers, H, self._td_poff.ctypes.data, out.ctypes.data, cap),
+                 'nisqa_tdtrain_plan')
+        ng, nj = int(out[2]), int(out[4])
+        plan = dict(NP=NP, ws=int(out[0]), frags=int(out[1]), groups=ng, tiles=int(out[3]), jobs=nj, feat=int(out[5]),
+                    dfeat=int(out[6]), yhat=int(out[7]), loss=int(out[7]) + (B * H + 3) // 4 * 4)
+        parts = [('td_ptok_off', ptok.astype(np.int32)), ('td_tile_clip', np.repeat(np.arange(B), tiles).astype(np.int32)),
+                 ('td_sq_off', np.concatenate(([0], np.cumsum(L * L))).astype(np.int64)),
+                 ('td_desc', out[8:8 + ng * 10].copy()), ('td_jobs', out[8 + ng * 10:8 + ng * 10 + nj * 6].copy())]
+        return parts, plan
+
+    def _td_buffers(self):
+        """Workspace and fragment buffer of the fused block for the current batch shape (kept while they are large enough);
+        the CNN writes its features straight into the workspace."""
+        pl = self._td_plan_cur
+        if self._td_ws is None or self._td_ws.numel() < pl['ws']:
+            self._td_ws = torch.empty(pl['ws'], dtype=torch.float32, device=self.device)
+        if self._td_frags is None or self._td_frags.numel() < pl['frags']:
+            self._td_frags = torch.empty(pl['frags'], dtype=torch.float32, device=self.device)
+        return pl
+
+    def _td_fused(self, y, bias, masks):
+        """nisqa_tdtrain_step on the features the CNN left in the workspace -> (y_hat, loss, d loss / d feat)."""
+        pl, tv = self._td_plan_cur, self._tv
+        B, S, H = self.B, self.S, len(self.heads)
+        yv = np.asarray(y, np.float32).reshape(B, H)
+        cnt = (~np.isnan(yv)).sum(0).astype(np.float32)
+        if _dist.world()[1] > 1:                       # the loss is a mean over the labelled clips of the WHOLE batch
+            cnt = _dist.all_reduce_sum_(torch.from_numpy(cnt.copy())).numpy()
+        inv = np.where(cnt > 0, 1.0 / np.maximum(cnt, 1), 0.0).astype(np.float32)
+        # labels, 1 / count per head and the bias-mapping coefficients in ONE page-locked upload
+        n_host = B * H + 8 + (B * 4 if bias is not None else 0)
+        pin = self.device.type == 'cuda'
+        host = torch.empty(n_host, dtype=torch.float32, pin_memory=pin)
+        hv = host.numpy()
+        hv[:B * H] = yv.reshape(-1)
+        hv[B * H:B * H + 8] = 0
+        hv[B * H:B * H + H] = inv
+        if bias is not None:
+            hv[B * H + 8:] = np.asarray(bias, np.float32).reshape(-1)
+        dev = host.to(self.device, non_blocking=pin)
+        a = _lib.TdTrainArgs()
+        a.n_clips, a.n_tokens, a.n_tokens_padded, a.n_layers, a.n_heads = B, S, pl['NP'], self.n_layers, H
+        a.n_wgrad_groups, a.n_wgrad_tiles, a.n_colsum_jobs = pl['groups'], pl['tiles'], pl['jobs']
+        a.seg_off, a.ptok_off, a.tile_clip = self.seg_off.data_ptr(), tv['td_ptok_off'].data_ptr(), tv['td_tile_clip'].data_ptr()
+        a.sq_off = tv['td_sq_off'].data_ptr()
+        a.params, a.grads, a.poff = self.flat.data_ptr(), self.gflat.data_ptr(), self._td_poff.ctypes.data
+        a.ws, a.frags = self._td_ws.data_ptr(), self._td_frags.data_ptr()
+        a.labels, a.inv_count = dev.data_ptr(), dev.data_ptr() + 4 * B * H
+        a.bias_map = dev.data_ptr() + 4 * (B * H + 8) if bias is not None else None
+        n_sq = int(self.sq[-1])
+        keep = [dev]
+        for l in range(self.n_layers):
+            for field, key, shape in ((a.mask_p, 'td%d_p' % l, (n_sq,)), (a.mask_1, 'td%d_1' % l, (S, 64)),
+                                      (a.mask_f, 'td%d_f' % l, (S, 64)), (a.mask_2, 'td%d_2' % l, (S, 64))):
+                m = self._mask(masks, key, shape, self.p_td)
+                keep.append(m)
+                field[l] = m.data_ptr() if m is not None else None
+        a.wgrad_desc, a.colsum_jobs = tv['td_desc'].data_ptr(), tv['td_jobs'].data_ptr()
+        self._ck(self.lib.nisqa_tdtrain_step(ctypes.byref(a), self._st()), 'nisqa_tdtrain_step')
+        self._td_keep = keep                            # explicit masks / the label buffer stay alive until the step has run
+        ws = self._td_ws
+        y_hat = ws[pl['yhat']:pl['yhat'] + B * H].view(B, H)
+        loss = ws[pl['loss']:pl['loss'] + 1]
+        if _dist.world()[1] > 1:
+            loss = _dist.all_reduce_sum_(loss.clone())
+        da = ws[pl['dfeat']:pl['dfeat'] + S * 384].view(S, 6, 64)
+        return y_hat, loss, da
+
+    def _td_unfused(self, feat, y, y_dev, bias_dev, masks):
+        """The self-attention block, the pooling heads and the loss operator by operator (round-3 path, ~116 launches; kept
+        behind NISQA_HIP_TRAIN_FUSED_TD=0 as the cross-check of csrc/train_td.hip) -> (y_hat, loss, d loss / d feat)."""
         L_ = self.lib
-        self._prepare(n_wins)
         B, S, st = self.B, self.S, self._st()
-        hop = int(self.args['ms_seg_hop_length'])
-        self.gflat.zero_()
-        # labels (and bias coefficients) through page-locked memory: a pageable .to(device) blocks the host until the
-        # previous step has drained, and the GPU then idles while this step's first launches are being issued
-        def up(a, cols):
-            a = np.ascontiguousarray(np.asarray(a, np.float32).reshape(B, cols))
-            if self.device.type != 'cuda':
-                return torch.from_numpy(a).to(self.device)
-            h = torch.empty(a.shape, dtype=torch.float32, pin_memory=True)     # caching host allocator: reuse is stream-safe
-            h.numpy()[...] = a
-            return h.to(self.device, non_blocking=True)
-        y_dev = up(y, len(self.heads))
-        bias_dev = None if bias is None else up(bias, 4)
-
-        # ================= forward: AdaptCNN in train mode =================
-        geo = [(48, 15, self.pools[0]), (24, 7, self.pools[1]), (12, 5, (12, 5)), (12, 5, self.pools[2]), (6, 3, (6, 3)),
-               (6, 1, (6, 1))]                                               # conv output (H, W) and the pool after it
-        self._segconv_pack(geo)
-        cnn = []
-        act = None
-        for i in range(1, 7):
-            ci, co = _CONV[i - 1]
-            h, w, (ho, wo) = geo[i - 1]
-            rows = S * h * w
-            wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
-            drop = self._mask(masks, _DROP_AFTER.get(i), (S, co), self.p_cnn) if i in _DROP_AFTER else None
-            out = self._new(S, ho * wo, co)
-            arg = self._new(S, ho * wo, co, dtype=torch.int32)
-            mr = self._new(2 * co)
-            if i == 1 and self.fused_l1:
-                # layer 1 straight from the spectrogram: its 720-pixel activations are never written (csrc/train.hip,
-                # "Layer 1 without its activations"): patch moments -> batch statistics -> recomputed pooling windows
-                mom = self._sums[self._sum_i][:54]
-                sums = self._sums[self._sum_i + 1][:32]
-                self._sum_i += 2
-                self._ck(L_.nisqa_conv1_moments(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
-                                                mom.data_ptr(), st), 'nisqa_conv1_moments')
-                self._ck(L_.nisqa_conv1_bn_act_pool_fwd(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
-                                                        _ptr(self.P[wk]), _ptr(self.P[bk]), mom.data_ptr(),
-                                                        _ptr(self.P['cnn.model.bn1.weight']), _ptr(self.P['cnn.model.bn1.bias']),
-                                                        _ptr(self.bn[1]['mean']), _ptr(self.bn[1]['var']), sums.data_ptr(), _ptr(mr),
-                                                        _ptr(drop) if drop is not None else None, _ptr(out), arg.data_ptr(), st),
-                         'nisqa_conv1_bn_act_pool_fwd')
-                self.bn[i]['n'] += 1
-                cnn.append(dict(x=None, z=None, arg=arg, mr=mr, drop=drop, h=h, w=w, ho=ho, wo=wo, ci=ci, co=co, rows=rows, mom=mom))
-                act = out
-                continue
-            z = self._new(rows, co)
-            if i == 1:                                                         # straight from the spectrogram, no patches
-                self._ck(L_.nisqa_conv1_fwd(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
-                                            _ptr(self.P[wk]), _ptr(self.P[bk]), _ptr(z), st), 'nisqa_conv1_fwd')
-            else:                                                              # implicit GEMM: patches gathered by the loaders
-                hi, wi = geo[i - 2][2]
-                fr = self._sc_frags.get((0, i))
-                if fr is not None:
-                    sums = None
-                    if self.fused_fwd_stats:
-                        sums = self._sums[self._sum_i]
-                        self._sum_i += 1
-                    self._ck(L_.nisqa_segconv_bf16(0, _ptr(act), fr.data_ptr(), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
-                                                   _ptr(self.P[bk]), sums.data_ptr() if sums is not None else None, st),
-                             'nisqa_segconv_bf16 fwd')
-                elif self.fused_fwd_stats:                                     # sum z, sum z^2 from the convolution's epilogue
-                    sums = self._sums[self._sum_i]
-                    self._sum_i += 1
-                    self._ck(L_.nisqa_conv3x3_fwd_stats(1 if self.precision == 'bf16x3' else 0, _ptr(act), _ptr(self.P[wk]), _ptr(z),
-                                                        S, hi, wi, ci, co, 0 if i == 6 else 1, _ptr(self.P[bk]), sums.data_ptr(),
-                                                        st), 'nisqa_conv3x3_fwd_stats')
-                else:
-                    self._ck(self._conv_fwd(0, _ptr(act), _ptr(self.P[wk]), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
-                                            _ptr(self.P[bk]), 1, st), 'nisqa_conv3x3_gemm fwd')
-            if i == 1 or not self.fused_fwd_stats:
-                sums = self._coldot(z, z, rows, co)
-            self._ck(L_.nisqa_bn_act_pool_fwd(_ptr(z), sums.data_ptr(), _ptr(self.P['cnn.model.bn%d.weight' % i]),
-                                              _ptr(self.P['cnn.model.bn%d.bias' % i]), _ptr(self.bn[i]['mean']),
-                                              _ptr(self.bn[i]['var']), _ptr(mr), S, h, w, co, ho, wo,
-                                              _ptr(drop) if drop is not None else None, _ptr(out), arg.data_ptr(), st),
-                     'nisqa_bn_act_pool_fwd')
-            self.bn[i]['n'] += 1
-            cnn.append(dict(x=act, z=z, arg=arg, mr=mr, drop=drop, h=h, w=w, ho=ho, wo=wo, ci=ci, co=co, rows=rows))
-            act = out
-        feat = act                                                             # [S][6][64] = [S][384] in (y, c) order
-
         # ================= forward: self-attention =================
         pfx = 'time_dependency.model.'
         x0 = self._linear_fwd(feat, pfx + 'linear.weight', pfx + 'linear.bias', S, 384, 64)
@@ -590,6 +614,108 @@ class HipTrainer(object):
             dx = self._ew(4, dxin, aux=dr1)
         dx0 = self._ln_bwd(dx, xh0, rs0, pfx + 'norm1.weight', pfx + 'norm1.bias', S)
         da = self._linear_bwd(dx0, feat, pfx + 'linear.weight', pfx + 'linear.bias', S, 384, 64)        # [S][6][64]
+
+        return y_hat, loss, da
+
+    def _step(self, mel, frame_off, n_wins, floor, y, masks, bias):
+        L_ = self.lib
+        self._prepare(n_wins)
+        B, S, st = self.B, self.S, self._st()
+        hop = int(self.args['ms_seg_hop_length'])
+        self.gflat.zero_()
+        # labels (and bias coefficients) through page-locked memory: a pageable .to(device) blocks the host until the
+        # previous step has drained, and the GPU then idles while this step's first launches are being issued
+        def up(a, cols):
+            a = np.ascontiguousarray(np.asarray(a, np.float32).reshape(B, cols))
+            if self.device.type != 'cuda':
+                return torch.from_numpy(a).to(self.device)
+            h = torch.empty(a.shape, dtype=torch.float32, pin_memory=True)     # caching host allocator: reuse is stream-safe
+            h.numpy()[...] = a
+            return h.to(self.device, non_blocking=True)
+        y_dev = bias_dev = None
+        if not self.fused_td:
+            y_dev = up(y, len(self.heads))
+            bias_dev = None if bias is None else up(bias, 4)
+        else:
+            pl = self._td_buffers()
+
+        # ================= forward: AdaptCNN in train mode =================
+        geo = [(48, 15, self.pools[0]), (24, 7, self.pools[1]), (12, 5, (12, 5)), (12, 5, self.pools[2]), (6, 3, (6, 3)),
+               (6, 1, (6, 1))]                                               # conv output (H, W) and the pool after it
+        self._segconv_pack(geo)
+        cnn = []
+        act = None
+        for i in range(1, 7):
+            ci, co = _CONV[i - 1]
+            h, w, (ho, wo) = geo[i - 1]
+            rows = S * h * w
+            wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
+            drop = self._mask(masks, _DROP_AFTER.get(i), (S, co), self.p_cnn) if i in _DROP_AFTER else None
+            if i == 6 and self.fused_td:                  # the features go straight into the fused block's workspace
+                out = self._td_ws[pl['feat']:pl['feat'] + S * ho * wo * co].view(S, ho * wo, co)
+            else:
+                out = self._new(S, ho * wo, co)
+            arg = self._new(S, ho * wo, co, dtype=torch.int32)
+            mr = self._new(2 * co)
+            if i == 1 and self.fused_l1:
+                # layer 1 straight from the spectrogram: its 720-pixel activations are never written (csrc/train.hip,
+                # "Layer 1 without its activations"): patch moments -> batch statistics -> recomputed pooling windows
+                mom = self._sums[self._sum_i][:54]
+                sums = self._sums[self._sum_i + 1][:32]
+                self._sum_i += 2
+                self._ck(L_.nisqa_conv1_moments(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
+                                                mom.data_ptr(), st), 'nisqa_conv1_moments')
+                self._ck(L_.nisqa_conv1_bn_act_pool_fwd(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
+                                                        _ptr(self.P[wk]), _ptr(self.P[bk]), mom.data_ptr(),
+                                                        _ptr(self.P['cnn.model.bn1.weight']), _ptr(self.P['cnn.model.bn1.bias']),
+                                                        _ptr(self.bn[1]['mean']), _ptr(self.bn[1]['var']), sums.data_ptr(), _ptr(mr),
+                                                        _ptr(drop) if drop is not None else None, _ptr(out), arg.data_ptr(), st),
+                         'nisqa_conv1_bn_act_pool_fwd')
+                self.bn[i]['n'] += 1
+                cnn.append(dict(x=None, z=None, arg=arg, mr=mr, drop=drop, h=h, w=w, ho=ho, wo=wo, ci=ci, co=co, rows=rows, mom=mom))
+                act = out
+                continue
+            z = self._new(rows, co)
+            if i == 1:                                                         # straight from the spectrogram, no patches
+                self._ck(L_.nisqa_conv1_fwd(_ptr(mel), _ptr(frame_off), _ptr(self.seg_off), _ptr(floor), B, S, hop,
+                                            _ptr(self.P[wk]), _ptr(self.P[bk]), _ptr(z), st), 'nisqa_conv1_fwd')
+            else:                                                              # implicit GEMM: patches gathered by the loaders
+                hi, wi = geo[i - 2][2]
+                fr = self._sc_frags.get((0, i))
+                if fr is not None:
+                    sums = None
+                    if self.fused_fwd_stats:
+                        sums = self._sums[self._sum_i]
+                        self._sum_i += 1
+                    self._ck(L_.nisqa_segconv_bf16(0, _ptr(act), fr.data_ptr(), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
+                                                   _ptr(self.P[bk]), sums.data_ptr() if sums is not None else None, st),
+                             'nisqa_segconv_bf16 fwd')
+                elif self.fused_fwd_stats:                                     # sum z, sum z^2 from the convolution's epilogue
+                    sums = self._sums[self._sum_i]
+                    self._sum_i += 1
+                    self._ck(L_.nisqa_conv3x3_fwd_stats(1 if self.precision == 'bf16x3' else 0, _ptr(act), _ptr(self.P[wk]), _ptr(z),
+                                                        S, hi, wi, ci, co, 0 if i == 6 else 1, _ptr(self.P[bk]), sums.data_ptr(),
+                                                        st), 'nisqa_conv3x3_fwd_stats')
+                else:
+                    self._ck(self._conv_fwd(0, _ptr(act), _ptr(self.P[wk]), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
+                                            _ptr(self.P[bk]), 1, st), 'nisqa_conv3x3_gemm fwd')
+            if i == 1 or not self.fused_fwd_stats:
+                sums = self._coldot(z, z, rows, co)
+            self._ck(L_.nisqa_bn_act_pool_fwd(_ptr(z), sums.data_ptr(), _ptr(self.P['cnn.model.bn%d.weight' % i]),
+                                              _ptr(self.P['cnn.model.bn%d.bias' % i]), _ptr(self.bn[i]['mean']),
+                                              _ptr(self.bn[i]['var']), _ptr(mr), S, h, w, co, ho, wo,
+                                              _ptr(drop) if drop is not None else None, _ptr(out), arg.data_ptr(), st),
+                     'nisqa_bn_act_pool_fwd')
+            self.bn[i]['n'] += 1
+            cnn.append(dict(x=act, z=z, arg=arg, mr=mr, drop=drop, h=h, w=w, ho=ho, wo=wo, ci=ci, co=co, rows=rows))
+            act = out
+        feat = act                                                             # [S][6][64] = [S][384] in (y, c) order
+
+        # ================= self-attention block, pooling heads, loss: forward and backward =================
+        if self.fused_td:
+            y_hat, loss, da = self._td_fused(y, bias, masks)
+        else:
+            y_hat, loss, da = self._td_unfused(feat, y, y_dev, bias_dev, masks)
 
         # ================= backward: AdaptCNN =================
         for i in range(6, 0, -1):

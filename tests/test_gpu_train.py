@@ -721,6 +721,56 @@ def test_training_step_at_configs4_size_with_dropout_masks_matches_oracle():
         assert worst < 3e-3, (worst, wk)
 
 
+@pytest.mark.parametrize('name,use_masks', [('mos', False), ('dim', False), ('dim', True), ('mos', True)])
+def test_fused_self_attention_block_matches_the_operator_by_operator_path(name, use_masks, monkeypatch):
+    """csrc/train_td.hip (the self-attention block, the pooling heads and the loss as a dozen launches: nisqa_tdtrain_step)
+    against the round-3 path that drives the same mathematics as ~116 operator launches (each of them tested against
+    autograd above): same batch, same weights, same dropout masks, the bias-mapped loss in the masked cases -> loss, y_hat
+    and EVERY gradient (the CNN's included: it receives the block's input gradient) agree to fp32 rounding."""
+    from nisqa_amd.train import HipTrainer
+    g, args, sd, specs, y = _case(name)
+    n_wins = [int(v) for v in g['n_wins']]
+    S, mk, bias = sum(n_wins), None, None
+    if use_masks:
+        rng = np.random.default_rng(3)
+        drop = lambda shape, p: ((rng.random(shape) >= p).astype(np.float32) / (1 - p))
+        mk = {key: drop((S, c), 0.2) for key, c in (('cnn_d1', 32), ('cnn_d2', 64), ('cnn_d3', 64), ('cnn_d4', 64))}
+        for l in range(2):
+            mk['td%d_p' % l] = np.concatenate([drop((n, n), 0.1).reshape(-1) for n in n_wins])
+            for t in ('1', 'f', '2'):
+                mk['td%d_%s' % (l, t)] = drop((S, 64), 0.1)
+        bias = np.tile(np.array([[0.1, 0.9, 0.02, -0.001]], np.float32), (len(n_wins), 1))
+    res = {}
+    for fused in ('1', '0'):
+        monkeypatch.setenv('NISQA_HIP_TRAIN_FUSED_TD', fused)
+        tr = HipTrainer(args, sd, DEV, lr=1e-3, precision='f32')
+        assert tr.fused_td == (fused == '1')
+        loss = tr.step_spec(specs, y, masks=mk, bias=bias)
+        torch.cuda.synchronize()
+        res[fused] = (float(loss), tr.last['y_hat'].cpu().numpy().copy(), tr.grads(), tr.state_dict())
+    (l1, y1, g1, s1), (l0, y0, g0, s0) = res['1'], res['0']
+    assert l1 == pytest.approx(l0, rel=1e-5)
+    assert np.abs(y1 - y0).max() < 1e-5
+    worst, wk = 0.0, None
+    for k in g0:
+        if _conv_bias(k):
+            continue
+        if float(np.abs(g0[k].numpy()).max()) < 1e-4:             # analytically zero (the score bias under the softmax): rounding noise
+            assert float(np.abs(g1[k].numpy()).max()) < 1e-4, k
+            continue
+        e = float(np.abs(g1[k].numpy() - g0[k].numpy()).max()) / max(1e-3, float(np.abs(g0[k].numpy()).max()))
+        if e > worst:
+            worst, wk = e, k
+    print(name, 'masks' if use_masks else 'no masks', ': fused vs operator path: loss', l1, l0, 'worst relative gradient difference', worst, wk)
+    assert worst < 2e-5, (worst, wk)
+    for k in s0:                                                   # the Adam step on those gradients
+        if not k.endswith('num_batches_tracked'):
+            gref = g0.get(k)
+            solid = np.abs(gref.numpy()) > 1e-3 * max(1e-3, float(np.abs(gref.numpy()).max())) if gref is not None and not _conv_bias(k) else None
+            d = np.abs(s1[k].numpy() - s0[k].numpy())
+            assert (d[solid].max(initial=0) if solid is not None else d.max(initial=0) * (0 if _conv_bias(k) else 1)) < 1e-4, k
+
+
 @pytest.mark.parametrize('name', ['mos', 'dim'])
 def test_training_step_with_split_bf16_forward_convolutions(name):
     """precision='bf16x3' also runs the FORWARD convolutions on split-bf16 MFMA.  Loss, y_hat and BatchNorm buffers stay

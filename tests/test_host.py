@@ -1174,6 +1174,42 @@ def test_training_step_tables_describe_the_ragged_products():
     assert set(tiles) == {'qk', 'pv', 'dp', 'dv', 'dq', 'dk', 'pool', 'datt', 'outer'}
 
 
+def test_fused_self_attention_block_plan_tables():
+    """nisqa_tdtrain_plan (host side of csrc/train_td.hip, no GPU work): the padded token space, the descriptors of the one
+    weight-gradient GEMM (d Y^T X per parameter matrix, tiles counted like nisqa_gemm_f32 counts them) and the column-sum
+    jobs land on the parameters' own offsets; buffers do not overlap."""
+    from nisqa_amd import lib
+    L = lib.load()
+    for lens, nl, nh in (([5, 40, 32, 1], 2, 5), ([247] * 3, 2, 1), ([33], 1, 1)):
+        lens = np.array(lens)
+        B, S = len(lens), int(lens.sum())
+        NP = int(((lens + 31) // 32 * 32).sum())
+        n_par = 4 + 12 * nl + 6 * nh
+        poff = (np.arange(n_par, dtype=np.int32) * 50000)
+        cap = 8 + (1 + 4 * nl + 2 * nh) * 10 + (2 + 6 * nl + nh) * 6
+        out = np.zeros(cap, dtype=np.int64)
+        assert L.nisqa_tdtrain_plan(B, S, NP, nl, nh, poff.ctypes.data, out.ctypes.data, cap) == 0
+        assert L.nisqa_tdtrain_plan(B, S, NP, nl, nh, poff.ctypes.data, out.ctypes.data, cap - 1) == lib.NISQA_ERR_ARG
+        assert L.nisqa_tdtrain_plan(B, S, NP + 1, nl, nh, poff.ctypes.data, out.ctypes.data, cap) == lib.NISQA_ERR_ARG
+        ws, ng, tiles, nj = int(out[0]), int(out[2]), int(out[3]), int(out[4])
+        assert ng == 1 + 4 * nl + 2 * nh and nj == 2 + 6 * nl + nh
+        d = out[8:8 + ng * 10].reshape(ng, 10)
+        j = out[8 + ng * 10:8 + ng * 10 + nj * 6].reshape(nj, 6)
+        nt = ((d[:, 3] + 63) // 64) * ((d[:, 4] + 63) // 64)
+        assert tiles == nt.sum() and (d[:, 9] == np.concatenate(([0], np.cumsum(nt)[:-1]))).all()
+        assert (d[0, 3:9] == [64, 384, S, 64, 384, 384]).all() and d[0, 1] == out[5] and d[0, 2] == poff[0]
+        assert set(d[:, 2].tolist()) == {int(poff[i]) for i in ([0] + [4 + 12 * l + q for l in range(nl) for q in (0, 2, 6, 8)]
+                                                               + [4 + 12 * nl + 6 * h + q for h in range(nh) for q in (0, 2)])}
+        assert (d[1:, 5] == NP).all() and (j[:, 3] == NP).all()
+        # operand extents stay inside the workspace and the spans of different buffers do not overlap
+        spans = sorted({(int(a), int(a + k * m)) for a, k, m in zip(d[:, 0], d[:, 5], d[:, 3])} |
+                       {(int(b), int(b + k * n)) for b, k, n in zip(d[:, 1], d[:, 5], d[:, 4])})
+        assert spans[-1][1] <= ws and all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+        bias_like = {int(poff[i]) for i in ([1, 2, 3] + [4 + 12 * l + q for l in range(nl) for q in (1, 3, 4, 5, 7, 9, 10, 11)]
+                                            + [4 + 12 * nl + 6 * h + 1 for h in range(nh)])}
+        assert {int(v) for v in j[:, 4:6].reshape(-1) if v >= 0} == bias_like
+
+
 def _scipy_wav_files():
     import scipy
     d = os.path.join(os.path.dirname(scipy.__file__), 'io', 'tests', 'data')
