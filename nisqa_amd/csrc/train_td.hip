@@ -80,26 +80,54 @@ NQ_DEV void mul_t(f32x16 (&v)[MT], const f32x16 (&m)[MT]) {
         for (int r = 0; r < 16; ++r) v[mt][r] *= m[mt][r];
 }
 
-// out[mt] += A (fragments, [4 KT steps][MT][64 lanes][4]) * in   (in: KT tiles of 32 features x 32 tokens in D layout)
+// out[mt] += A (fragments, [4 KT steps][MT][64 lanes][4]) * in   (in: KT tiles of 32 features x 32 tokens in D layout).
+// One wave per SIMD runs these kernels (a chain of dependent products per 32-token tile), so nobody else hides the L2 round
+// trip of a fragment: they are requested two steps ahead into a three-slot ring, held in place by scheduling fences.
 template <int KT, int MT>
 NQ_DEV void chain_gemm(const f32x4* __restrict__ af, const f32x16 (&in)[KT], f32x16 (&out)[MT], int lane) {
     constexpr int STEPS = 4 * KT;
-    f32x4 a[2][MT];
+    f32x4 a[3][MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a[0][mt] = af[mt * 64 + lane];
+    for (int mt = 0; mt < MT; ++mt) {
+        a[0][mt] = af[mt * 64 + lane];
+        a[1][mt] = af[(MT + mt) * 64 + lane];
+    }
 #pragma unroll
     for (int s = 0; s < STEPS; ++s) {
-        if (s + 1 < STEPS) {
+        if (s + 2 < STEPS) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) a[(s + 1) & 1][mt] = af[((s + 1) * MT + mt) * 64 + lane];
+            for (int mt = 0; mt < MT; ++mt) a[(s + 2) % 3][mt] = af[((s + 2) * MT + mt) * 64 + lane];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) out[mt] = mfma32(a[s & 1][mt][kk], in[s >> 2][4 * (s & 3) + kk], out[mt]);
+            for (int mt = 0; mt < MT; ++mt) out[mt] = mfma32(a[s % 3][mt][kk], in[s >> 2][4 * (s & 3) + kk], out[mt]);
         __builtin_amdgcn_sched_barrier(0);
     }
+}
+
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));   // four consecutive floats at any 4-byte boundary
+
+// the 16 dropout multipliers of this lane's row for the 32 columns col0 .. col0 + 31 of a [.. x n] mask, in D-row order
+// (register 4 g + e <-> column 8 g + 4 hf + e): four 16-byte reads; in a row's last tile (columns beyond n) element-wise, 1 there
+NQ_DEV f32x16 ld_mask_row(const float* __restrict__ row, int col0, int n, int hf) {
+    f32x16 m;
+    if (col0 + 32 <= n) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4_u v = *(const f32x4_u*)(row + col0 + 8 * g + 4 * hf);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m[4 * g + e] = v[e];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int col = col0 + NQ_DROW(r, hf);
+            m[r] = col < n ? row[col] : 1.f;
+        }
+    }
+    return m;
 }
 
 // LayerNorm over the 64 features of a token (32 in this lane, 32 in lane ^ 32); x -> gamma * xhat + beta, xhat and rstd kept
@@ -213,16 +241,30 @@ __global__ __launch_bounds__(64) void tdt_proj_fwd_kernel(tdt_common c, const fl
     const f32x4* af = (const f32x4*)f_w0;
     f32x16 acc[2];
     ld_vec<2>(b0, acc, hf);
-#pragma unroll 4
+    // this lane's half of its token's 384 features: 48 independent 16-byte reads requested together (a lane walks its own
+    // row, 1.5 KB from its neighbour's: nothing coalesces, so the reads are latency, not bandwidth)
+    f32x4 bv[48];
+#pragma unroll
     for (int s = 0; s < 48; ++s) {
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (valid) bv = frow[2 * s + hf];
-        const f32x4 a0 = af[(s * 2 + 0) * 64 + lane], a1 = af[(s * 2 + 1) * 64 + lane];
+        bv[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (valid) bv[s] = frow[2 * s + hf];
+    }
+    f32x4 a[3][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) { a[0][mt] = af[mt * 64 + lane]; a[1][mt] = af[(2 + mt) * 64 + lane]; }
+#pragma unroll
+    for (int s = 0; s < 48; ++s) {
+        if (s + 2 < 48) {
+            a[(s + 2) % 3][0] = af[((s + 2) * 2 + 0) * 64 + lane];
+            a[(s + 2) % 3][1] = af[((s + 2) * 2 + 1) * 64 + lane];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            acc[0] = mfma32(a0[kk], bv[kk], acc[0]);
-            acc[1] = mfma32(a1[kk], bv[kk], acc[1]);
+            acc[0] = mfma32(a[s % 3][0][kk], bv[s][kk], acc[0]);
+            acc[1] = mfma32(a[s % 3][1][kk], bv[s][kk], acc[1]);
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
     f32x16 xh[2];
     float rstd;
@@ -257,22 +299,36 @@ __global__ __launch_bounds__(64) void tdt_layer_fwd_kernel(tdt_common c, tdt_lay
     zero_t<2>(o);
     float m = -INFINITY, l = 0.f;
     const int nkt = (n + 31) >> 5;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int key0 = c0 + 32 * kt;
-        f32x4 kA[8], vf[2][4];
-        const float* krow = L.k + (size_t)(key0 + j) * 64 + 4 * hf;
+    const bool use_mask = mrow != nullptr && valid;
+    // K rows of tile kt + 1 are requested while tile kt is multiplied; V^T and the dropout multipliers of tile kt are
+    // requested at its start and used behind its 32 QK^T MFMAs
+    f32x4 kA[8], kB[8];
+    {
+        const float* krow = L.k + (size_t)(c0 + j) * 64 + 4 * hf;
 #pragma unroll
         for (int s = 0; s < 8; ++s) kA[s] = *(const f32x4*)(krow + 8 * s);
+    }
+    auto tile = [&](int kt, const f32x4 (&kcur)[8], f32x4 (&knext)[8]) {
+        const int key0 = c0 + 32 * kt;
+        f32x4 vf[2][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             vf[0][g] = *(const f32x4*)(L.vT + (size_t)j * np + key0 + 8 * g + 4 * hf);
             vf[1][g] = *(const f32x4*)(L.vT + (size_t)(j + 32) * np + key0 + 8 * g + 4 * hf);
         }
+        f32x16 mk;
+        if (use_mask) mk = ld_mask_row(mrow, 32 * kt, n, hf);
+        if (kt + 1 < nkt) {
+            const float* krow = L.k + (size_t)(key0 + 32 + j) * 64 + 4 * hf;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) knext[s] = *(const f32x4*)(krow + 8 * s);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 sacc = zero16();                                   // S^T tile: rows = keys, columns = queries
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) sacc = mfma32(kA[s][kk], qf[s][kk], sacc);
+            for (int kk = 0; kk < 4; ++kk) sacc = mfma32(kcur[s][kk], qf[s][kk], sacc);
         float mx = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -291,12 +347,9 @@ __global__ __launch_bounds__(64) void tdt_layer_fwd_kernel(tdt_common c, tdt_lay
         rs += __shfl_xor(rs, 32);
         l = l * alpha + rs;
         m = m_new;
-        if (mrow && valid) {                                      // dropout on the probabilities (nn.MultiheadAttention)
+        if (use_mask) {                                           // dropout on the probabilities (nn.MultiheadAttention)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 32 * kt + NQ_DROW(r, hf);
-                if (key < n) sacc[r] *= mrow[key];
-            }
+            for (int r = 0; r < 16; ++r) sacc[r] *= mk[r];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
@@ -307,6 +360,10 @@ __global__ __launch_bounds__(64) void tdt_layer_fwd_kernel(tdt_common c, tdt_lay
                 o[0] = mfma32(vf[0][g][kk], sacc[4 * g + kk], o[0]);
                 o[1] = mfma32(vf[1][g][kk], sacc[4 * g + kk], o[1]);
             }
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        tile(kt, kA, kB);
+        if (kt + 1 < nkt) tile(kt + 1, kB, kA);
     }
     const float inv_l = 1.0f / l;
 #pragma unroll
@@ -582,34 +639,50 @@ __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_laye
             cf[s] = *(const f32x4*)(L.dctx + (size_t)ptok * 64 + 8 * s + 4 * hf);
         }
         const float lse = L.lse[ptok], dd = L.dd[ptok];
+        const bool use_mask = mbase != nullptr && valid;
+        const float* mrow = use_mask ? mbase + (int64_t)kq * n : nullptr;
         f32x16 dq[2];
         zero_t<2>(dq);
-        for (int kt = 0; kt < ntile; ++kt) {
-            const int key0 = c0 + 32 * kt;
-            f32x4 kA[8], vA[8], kf[2][4];
-            const float* krow = L.k + (size_t)(key0 + j) * 64 + 4 * hf;
-            const float* vrow = L.v + (size_t)(key0 + j) * 64 + 4 * hf;
+        // K / V rows of tile kt + 1 are requested while tile kt is multiplied; K^T and the dropout multipliers of tile kt at
+        // its start, used behind its 64 MFMAs
+        f32x4 kA[8], vA[8], kB[8], vB[8];
+        {
+            const float* krow = L.k + (size_t)(c0 + j) * 64 + 4 * hf;
+            const float* vrow = L.v + (size_t)(c0 + j) * 64 + 4 * hf;
 #pragma unroll
             for (int s = 0; s < 8; ++s) { kA[s] = *(const f32x4*)(krow + 8 * s); vA[s] = *(const f32x4*)(vrow + 8 * s); }
+        }
+        auto tile = [&](int kt, const f32x4 (&kc)[8], const f32x4 (&vc)[8], f32x4 (&kn)[8], f32x4 (&vn)[8]) {
+            const int key0 = c0 + 32 * kt;
+            f32x4 kf[2][4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 kf[0][g] = *(const f32x4*)(L.kT + (size_t)j * np + key0 + 8 * g + 4 * hf);
                 kf[1][g] = *(const f32x4*)(L.kT + (size_t)(j + 32) * np + key0 + 8 * g + 4 * hf);
             }
+            f32x16 mk;
+            if (use_mask) mk = ld_mask_row(mrow, 32 * kt, n, hf);
+            if (kt + 1 < ntile) {
+                const float* krow = L.k + (size_t)(key0 + 32 + j) * 64 + 4 * hf;
+                const float* vrow = L.v + (size_t)(key0 + 32 + j) * 64 + 4 * hf;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { kn[s] = *(const f32x4*)(krow + 8 * s); vn[s] = *(const f32x4*)(vrow + 8 * s); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 sT = zero16(), dpT = zero16();                  // rows = keys, columns = queries
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    sT = mfma32(kA[s][kk], qf[s][kk], sT);
-                    dpT = mfma32(vA[s][kk], cf[s][kk], dpT);
+                    sT = mfma32(kc[s][kk], qf[s][kk], sT);
+                    dpT = mfma32(vc[s][kk], cf[s][kk], dpT);
                 }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * kt + NQ_DROW(r, hf);
                 const float p = key < n ? expf(sT[r] - lse) : 0.f;
                 float dp = dpT[r];
-                if (mbase && valid && key < n) dp *= mbase[(int64_t)kq * n + key];
+                if (use_mask) dp *= mk[r];
                 sT[r] = p * (dp - dd);                               // d S^T
             }
 #pragma unroll
@@ -619,6 +692,10 @@ __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_laye
                     dq[0] = mfma32(kf[0][g][kk], sT[4 * g + kk], dq[0]);
                     dq[1] = mfma32(kf[1][g][kk], sT[4 * g + kk], dq[1]);
                 }
+        };
+        for (int kt = 0; kt < ntile; kt += 2) {
+            tile(kt, kA, vA, kB, vB);
+            if (kt + 1 < ntile) tile(kt + 1, kB, vB, kA, vA);
         }
         st_vec<2>(L.dqkv + (size_t)ptok * 192, dq, hf, valid ? 0.125f : 0.f);      // q entered the scores as q / 8
     } else {
@@ -628,16 +705,20 @@ __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_laye
             kf[s] = *(const f32x4*)(L.k + (size_t)ptok * 64 + 8 * s + 4 * hf);
             vf[s] = *(const f32x4*)(L.v + (size_t)ptok * 64 + 8 * s + 4 * hf);
         }
+        const bool use_mask = mbase != nullptr && valid;
         f32x16 dk[2], dv[2];
         zero_t<2>(dk);
         zero_t<2>(dv);
-        for (int qt = 0; qt < ntile; ++qt) {
-            const int q0 = c0 + 32 * qt;
-            f32x4 qA[8], cA[8], qT[2][4], cT[2][4];
-            const float* qrow = L.qs + (size_t)(q0 + j) * 64 + 4 * hf;
-            const float* crow = L.dctx + (size_t)(q0 + j) * 64 + 4 * hf;
+        f32x4 qA[8], cA[8], qB[8], cB[8];
+        {
+            const float* qrow = L.qs + (size_t)(c0 + j) * 64 + 4 * hf;
+            const float* crow = L.dctx + (size_t)(c0 + j) * 64 + 4 * hf;
 #pragma unroll
             for (int s = 0; s < 8; ++s) { qA[s] = *(const f32x4*)(qrow + 8 * s); cA[s] = *(const f32x4*)(crow + 8 * s); }
+        }
+        auto tile = [&](int qt, const f32x4 (&qc)[8], const f32x4 (&cc)[8], f32x4 (&qn)[8], f32x4 (&cn)[8]) {
+            const int q0 = c0 + 32 * qt;
+            f32x4 qT[2][4], cT[2][4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 qT[0][g] = *(const f32x4*)(L.qsT + (size_t)j * np + q0 + 8 * g + 4 * hf);
@@ -646,22 +727,36 @@ __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_laye
                 cT[1][g] = *(const f32x4*)(L.dctxT + (size_t)(j + 32) * np + q0 + 8 * g + 4 * hf);
             }
             const f32x16 lse = ld_row16(L.lse + q0, hf), dd = ld_row16(L.dd + q0, hf);
+            f32x16 mk;
+            if (use_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int qi = 32 * qt + NQ_DROW(r, hf);
+                    mk[r] = qi < n ? mbase[(int64_t)qi * n + kq] : 1.f;
+                }
+            }
+            if (qt + 1 < ntile) {
+                const float* qrow = L.qs + (size_t)(q0 + 32 + j) * 64 + 4 * hf;
+                const float* crow = L.dctx + (size_t)(q0 + 32 + j) * 64 + 4 * hf;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) { qn[s] = *(const f32x4*)(qrow + 8 * s); cn[s] = *(const f32x4*)(crow + 8 * s); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 s_ = zero16(), dp = zero16();                   // rows = queries, columns = keys
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    s_ = mfma32(qA[s][kk], kf[s][kk], s_);
-                    dp = mfma32(cA[s][kk], vf[s][kk], dp);
+                    s_ = mfma32(qc[s][kk], kf[s][kk], s_);
+                    dp = mfma32(cc[s][kk], vf[s][kk], dp);
                 }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qi = 32 * qt + NQ_DROW(r, hf);
-                const bool ok = valid && qi < n;
-                const float p = ok ? expf(s_[r] - lse[r]) : 0.f;
-                const float mk = (mbase && ok) ? mbase[(int64_t)qi * n + kq] : 1.f;
-                s_[r] = p * (dp[r] * mk - dd[r]);                    // d S
-                dp[r] = p * mk;                                      // P after dropout
+                const float p = (valid && qi < n) ? expf(s_[r] - lse[r]) : 0.f;
+                const float mkr = use_mask ? mk[r] : 1.f;
+                s_[r] = p * (dp[r] * mkr - dd[r]);                   // d S
+                dp[r] = p * mkr;                                     // P after dropout
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -672,6 +767,10 @@ __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_laye
                     dv[0] = mfma32(cT[0][g][kk], dp[4 * g + kk], dv[0]);
                     dv[1] = mfma32(cT[1][g][kk], dp[4 * g + kk], dv[1]);
                 }
+        };
+        for (int qt = 0; qt < ntile; qt += 2) {
+            tile(qt, qA, cA, qB, cB);
+            if (qt + 1 < ntile) tile(qt + 1, qB, cB, qA, cA);
         }
         st_vec<2>(L.dqkv + (size_t)ptok * 192 + 64, dk, hf, 1.f);
         st_vec<2>(L.dqkv + (size_t)ptok * 192 + 128, dv, hf, 1.f);
