@@ -127,7 +127,8 @@ int nisqa_col_dot(const float* a, const float* b, int64_t rows, int32_t c, doubl
 
 /* BatchNorm2d (batch statistics) + ReLU + adaptive_max_pool2d + Dropout2d (NISQA_lib.py:690-705, train mode).
  * sums = nisqa_col_dot(z, z) over rows = S*H*W.  Writes mean_rstd[2C], updates running_mean / running_var
- * (momentum 0.1, unbiased variance), y[S][Ho*Wo][C] and the arg-max pixel of every output (int32, for backward).
+ * (momentum 0.1, unbiased variance), y[S][Ho*Wo][C] and the arg-max pixel of every output (int32, for backward; NOT written
+ * when Ho == H and Wo == W -- the identity "pooling" of layers 3, 5, 6, whose backward never reads it).
  * drop (may be NULL): [S][C] multipliers (0 or 1/(1-p)). */
 int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const float* gamma, const float* beta,
                           float* running_mean, float* running_var, float* mean_rstd, int32_t n_segments, int32_t h,

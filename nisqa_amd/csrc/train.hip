@@ -1329,26 +1329,62 @@ NQ_DEV void bn_affine4(const float* __restrict__ gamma, const float* __restrict_
     b = be - mu * g;
 }
 
-// One thread = four consecutive channels of one output pixel (c % 4 == 0): 128-bit accesses throughout.
+// the same constants straight from the float64 column sums (sum z, sum z^2 over m_rows rows): what bn_finalize_kernel would
+// have left in mean_rstd, bit for bit
+NQ_DEV void bn_affine4_sums(const float* __restrict__ gamma, const float* __restrict__ beta, const double* __restrict__ sums, int c,
+                            double m_rows, int ch, f32x4& g, f32x4& b) {
+    const f32x4 ga = *(const f32x4*)(gamma + ch), be = *(const f32x4*)(beta + ch);
+    f32x4 mu, rs;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        double var;
+        float m_, r_;
+        bn_stats(sums, c, ch + e, m_rows, m_, r_, var);
+        mu[e] = m_;
+        rs[e] = r_;
+    }
+    g = ga * rs;
+    b = be - mu * g;
+}
+
+// One thread = four consecutive channels of one output pixel (c % 4 == 0): 128-bit accesses throughout.  The batch statistics
+// are finalised HERE (every thread derives its channels' mean / rstd from the float64 sums; block 0 also writes mean_rstd for
+// the backward kernels and updates the running statistics): no separate bn_finalize launch in front of each layer.
 template <int H, int W, int C, int HO, int WO>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(
     const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const float* __restrict__ mean_rstd, int64_t total4, int h_, int w_, int c_, int ho_, int wo_,
+    const double* __restrict__ sums, float* __restrict__ running_mean, float* __restrict__ running_var,
+    float* __restrict__ mean_rstd, int64_t total4, int h_, int w_, int c_, int ho_, int wo_,
     const float* __restrict__ drop, float* __restrict__ y, int32_t* __restrict__ arg) {
     const int h = H ? H : h_, w = H ? W : w_, c = H ? C : c_, ho = H ? HO : ho_, wo = H ? WO : wo_;
     const int c4 = c / 4;
+    const int64_t m_rows = (total4 / c4) / (ho * wo) * (h * w);
+    if (blockIdx.x == 0 && (int)threadIdx.x < c) {            // what bn_finalize_kernel did
+        const int ch = threadIdx.x;
+        float mean, rstd;
+        double var;
+        bn_stats(sums, c, ch, (double)m_rows, mean, rstd, var);
+        mean_rstd[ch] = mean;
+        mean_rstd[c + ch] = rstd;
+        const double unb = m_rows > 1 ? var * ((double)m_rows / (double)(m_rows - 1)) : var;
+        running_mean[ch] = 0.9f * running_mean[ch] + 0.1f * mean;
+        running_var[ch] = 0.9f * running_var[ch] + 0.1f * (float)unb;
+    }
     // compiled shapes: c / 4 divides the 256-thread stride, so a thread meets the SAME four channels in every iteration and
     // their constants are computed once (the generic instantiation recomputes them per element)
     constexpr bool INV = H != 0 && 256 % ((C ? C : 4) / 4) == 0;
+    // identity pooling (layers 3, 5, 6): the winning pixel is the cell itself -- no backward kernel reads arg there, and not
+    // writing it saves a tensor-sized store
+    const bool identity = h == ho && w == wo;
     f32x4 g, bsh;
-    if (INV) bn_affine4(gamma, beta, mean_rstd, c, 4 * ((int)threadIdx.x % c4), g, bsh);
+    if (INV) bn_affine4_sums(gamma, beta, sums, c, (double)m_rows, 4 * ((int)threadIdx.x % c4), g, bsh);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
         const int ch = 4 * (int)(i % c4);
         const int64_t op = i / c4;
         const int64_t s = op / (ho * wo);
         const int o = (int)(op - s * (ho * wo));
         const int oy = o / wo, ox = o % wo;
-        if (!INV) bn_affine4(gamma, beta, mean_rstd, c, ch, g, bsh);
+        if (!INV) bn_affine4_sums(gamma, beta, sums, c, (double)m_rows, ch, g, bsh);
         f32x4 best = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
         i32x4 bp = {0, 0, 0, 0};
         for (int yy = win_lo(oy, h, ho); yy < win_hi(oy, h, ho); ++yy)
@@ -1363,7 +1399,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(
             }
         if (drop) best *= *(const f32x4*)(drop + s * c + ch);
         ((f32x4*)y)[i] = best;
-        ((i32x4*)arg)[i] = bp;
+        if (!identity) ((i32x4*)arg)[i] = bp;
     }
 }
 
@@ -1387,10 +1423,8 @@ extern "C" int nisqa_bn_act_pool_fwd(const float* z, const double* sums, const f
         return NISQA_ERR_ARG;
     const int64_t total = (int64_t)n_segments * ho * wo * c / 4;
     NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, c,
-                       (int64_t)n_segments * h * w, running_mean, running_var, mean_rstd);
-    NQ_POOL_DISPATCH(bn_act_pool_fwd_kernel, dim3(grid_resident(total)), (hipStream_t)stream, z, gamma, beta,
-                     (const float*)mean_rstd, total, h, w, c, ho, wo, drop, y, arg);
+    NQ_POOL_DISPATCH(bn_act_pool_fwd_kernel, dim3(grid_resident(total)), (hipStream_t)stream, z, gamma, beta, sums, running_mean,
+                     running_var, mean_rstd, total, h, w, c, ho, wo, drop, y, arg);
     return NQ_LAUNCH_STATUS();
 }
 
