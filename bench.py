@@ -174,12 +174,48 @@ def cpu_baseline(args, sd, bs=BATCH):
             o += n
     t_net = time.perf_counter() - t1
     dt = t_mel + t_net
-    return {'value': round(bs / dt, 3), 'unit': 'clips/s', 'cores': nthr, 'kind': 'port',
+    port = {'value': round(bs / dt, 3), 'unit': 'clips/s', 'cores': nthr, 'kind': 'port',
             'network_only': round(bs / t_net, 3), 'mel_only': round(bs / t_mel, 3),
             'sample': 'one bs = %d batch of 10 s clips (8 distinct): oracle.mel (numpy restatement of librosa 0.8.1, FFT '
                       'on 1 thread like the reference dataset at num_workers = 0) %.1f s + oracle.net (torch CPU fp32, %d '
                       'threads, CNN on the packed %d segments) %.1f s; host has %d cores'
                       % (bs, t_mel, nthr, int(sum(n for _, n in segs)), t_net, os.cpu_count())}
+    # The reference's OWN loop beside it: NISQA_lib.py as shipped (staged by build() under oracle/_ref,
+    # git-ignored) -- SpeechQualityDataset -> get_librosa_melspec -> segment_specs padded to [B, 1300, 1, 48, 15] -> DataLoader
+    # (num_workers 0) -> Framewise pack -> model on the CPU -- with librosa's three entry points served by oracle/mel.py
+    # (the only part of the path that is not the reference's code: librosa is not installable here; parity unpinned there)
+    try:
+        from oracle import ref_shim
+        if not ref_shim.reference_available():
+            raise RuntimeError('NISQA_lib.py not staged under oracle/_ref (run __graft_entry__.build() where /root/reference exists)')
+        import shutil
+        import tempfile
+        d = tempfile.mkdtemp(prefix='nisqa_cpu_ref_')
+        try:
+            names = []
+            for i in range(bs):
+                names.append('c%03d.wav' % i)
+                synth.write_wav(os.path.join(d, names[-1]), synth.synth_pcm16(2000 + i % 8, SECONDS), SR)
+            synth.write_wav(os.path.join(d, 'warm.wav'), synth.synth_pcm16(1, 1.0), SR)
+            ck = os.path.join(d, 'model.tar')
+            torch.save({'args': dict(args), 'model_state_dict': {k: torch.as_tensor(np.asarray(v)) if not torch.is_tensor(v) else v
+                                                                  for k, v in sd.items()}}, ck)
+            ref_shim.reference_predict(ck, d, ['warm.wav'], bs=1)
+            tm = {}
+            y_ref = ref_shim.reference_predict(ck, d, names, bs=bs, timings=tm)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        assert y_ref.shape[0] == bs and np.isfinite(y_ref).all()
+        return {'value': round(bs / tm['predict_s'], 3), 'unit': 'clips/s', 'cores': nthr, 'kind': 'reference-torch + oracle-mel',
+                'sample': 'the reference\'s predict_dim (NISQA_lib.py:1441-1467, its own DataLoader / SpeechQualityDataset / '
+                          'segment_specs padding to [%d, 1300, 1, 48, 15] / Framewise pack / modules) on ONE bs = %d batch of 10 s WAV '
+                          'files, device cpu, num_workers 0, %d torch threads, %.1f s; librosa.load / melspectrogram / amplitude_to_db '
+                          'served by oracle/mel.py (librosa 0.8.1 is not installable: mel stage parity unpinned); host has %d cores'
+                          % (bs, bs, nthr, tm['predict_s'], os.cpu_count()),
+                'port': port}
+    except Exception as e:                                            # the port alone, and why
+        port['reference_loop_error'] = repr(e)[:300]
+        return port
 
 
 def init_dist(a):
@@ -299,20 +335,54 @@ def _stage_events(n):
     return ev
 
 
+def link_only_probe(dev, nbytes_per_copy=245_760_000, copies=24):
+    """H2D rate of the predict loop's own transport with nothing else going on: page-locked buffers of one batch's size
+    (256 clips x 10 s x 48 kHz x 2 bytes) copied on the loop's copy stream (high priority, carries no kernels -> SDMA engine),
+    three buffers in rotation like the staging ring.  What the link itself allows on this box; the loop's loss is measured
+    against it, the roofline fraction against the 63 GB/s of the data sheet."""
+    from nisqa_amd import NISQA_lib as NL
+    copy_stream, _ = NL._loop_streams(dev)
+    host = [torch.empty(nbytes_per_copy, dtype=torch.uint8, pin_memory=True) for _ in range(3)]
+    dst = [torch.empty(nbytes_per_copy, dtype=torch.uint8, device=dev) for _ in range(2)]
+    for h in host:
+        h.numpy()[::4096] = 1                                         # touch every page
+    with torch.cuda.stream(copy_stream):
+        for i in range(3):
+            dst[i % 2].copy_(host[i % 3], non_blocking=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(copy_stream)
+        for i in range(copies):
+            dst[i % 2].copy_(host[i % 3], non_blocking=True)
+        e1.record(copy_stream)
+    e1.synchronize()
+    return nbytes_per_copy * copies / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def side_predict_csv(dev, cpu):
-    """configs[2] on ONE GPU, bounded: 24 576 rows / 64 distinct 10 s WAV files, bs 256, through nisqaModel.predict()
-    (file list -> native ingest -> pinned ring -> H2D -> kernels -> DataFrame).  PCIe-inclusive: the bound is the host
-    link (2 bytes per sample cross it), not the kernels."""
-    clips, bs = 24576, 256
+    """configs[2] on ONE GPU: 98 304 rows / 64 distinct 10 s WAV files, bs 256, through nisqaModel.predict() (file list ->
+    native ingest -> pinned ring -> H2D -> kernels -> DataFrame -> the printed table): a ~2 s job, so that start-up (engine,
+    first batch, page-locking) is not what is measured.  PCIe-inclusive: the bound is the host link (2 bytes per sample
+    cross it), not the kernels.  link_only_GBps: the same transport with no loop around it (link_only_probe), so that loop
+    loss and link loss separate; print_s: what formatting the 98 304-row table costs inside the timed call."""
+    clips, bs = 98304, 256
     from nisqa_amd import ingest as _ing
-    dt, _, _ = predict_csv_job(0, 1, dev, None, clips, bs, 64, 0, 2, tag='side_csv')
+    from nisqa_amd import NISQA_lib as NL
+    link = link_only_probe(dev)
+    dt, df, _ = predict_csv_job(0, 1, dev, None, clips, bs, 64, 0, 2, tag='side_csv')
+    loop = dict(NL.LOOP_STATS)
+    from nisqa_amd.NISQA_model import frame_to_string
+    t0 = time.perf_counter()
+    frame_to_string(df)
+    t_print = time.perf_counter() - t0
     gbs = clips * SECONDS * SR * 2 / dt / 1e9
     return {'config': 'configs[2] predict_csv nisqa.tar bs=256, 1 GPU, %d rows (64 distinct 10 s WAV files in the page cache), '
                       'nisqaModel.predict() end to end incl. file listing, DataFrame and the printed table; reader threads: '
                       'the CPU budget (%d) - 3' % (clips, _ing.cpu_budget()),
             'value': round(clips / dt, 1), 'unit': 'clips/s', 'seconds': round(dt, 3), 'pcie_inclusive': True,
             'roofline': {'bound': 'pcie', 'kernel': 'H2D copy of the int16 PCM (SDMA, copy-only stream)', 'achieved': round(gbs, 2),
-                         'peak': PEAK_PCIE, 'unit': 'GB/s', 'frac': round(gbs / PEAK_PCIE, 4)},
+                         'peak': PEAK_PCIE, 'unit': 'GB/s', 'frac': round(gbs / PEAK_PCIE, 4),
+                         'link_only_GBps': round(link, 2), 'frac_of_link_only': round(gbs / link, 4)},
+            'print_s': round(t_print, 3), 'loop_host_s': {k: round(v, 3) for k, v in loop.items()},
             'cpu_baseline': cpu and {k: cpu[k] for k in ('value', 'unit', 'cores', 'kind')}}
 
 
@@ -416,63 +486,57 @@ def side_tts(dev, reps, cpu_baseline_on, pmc):
 
 def side_train(dev, steps, cpu_baseline_on, pmc):
     """configs[4]: train_nisqa_cnn_sa_ap.yaml's step (NISQA_model.py:131-152) at bs 32 x 10 s: mel front end, forward in
-    train mode, bias-aware loss, backward, BatchNorm buffers, Adam -- HipTrainer, default precision mode."""
+    train mode, bias-aware loss, backward, BatchNorm buffers, Adam -- HipTrainer.  The PRIMARY number of the leg is the
+    'f32' mode (every convolution on exact fp32 MFMA: the reference's arithmetic); 'mixed' (HipTrainer's default: fp32
+    forward, split-bf16 gradient convolutions) and 'bf16x3' (split-bf16 forward too) are reported beside it."""
     from nisqa_amd.train import HipTrainer
     bs = 32
     args = dict(synth.MOS_ARGS)                               # model NISQA, cnn_dropout 0.2, td_sa_dropout 0.1 (the yaml's values)
     sd = synth.random_state_dict(8, 'NISQA')
-    tr = HipTrainer(args, sd, dev, lr=1e-3)
     pcm = np.concatenate([synth.synth_pcm16(i % 8, SECONDS) for i in range(bs)])
-    plan = tr.eng.plan([int(SECONDS * SR)] * bs, SR)
-    x = tr.eng.pcm16_to_f32(torch.from_numpy(pcm).to(dev))
     y = np.random.default_rng(9).uniform(1, 5, (bs, 1)).astype(np.float32)
-    for _ in range(3):
-        tr.step_pcm(x, plan, SR, y)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = tr.step_pcm(x, plan, SR, y)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    assert np.isfinite(float(loss))
     flop = 3.0 * FLOP_NET_CLIP * bs                            # forward + input gradients + weight gradients
-    ach = flop / dt / 1e12
-    # the ideal time of this precision mode: forward convolutions on fp32 MFMA ('mixed', 'f32') or split-bf16 ('bf16x3'),
-    # the two gradient passes on split-bf16 ('mixed', 'bf16x3') or fp32 ('f32'); attention / pooling / projection fp32
     cnn = (FLOP_CONV1_4 + FLOP_CONV5_6) * bs
     rest = FLOP_NET_CLIP * bs - cnn
-    pk_f, pk_b = (PEAK_BF16_MFMA if tr.precision == 'bf16x3' else PEAK_F32), (PEAK_F32 if tr.precision == 'f32' else PEAK_BF16_MFMA)
-    ideal = (cnn / pk_f + 2 * cnn / pk_b + 3 * rest / PEAK_F32) / 1e12
-    res = {'config': 'configs[4] train_nisqa_cnn_sa_ap.yaml step (forward + backward + Adam, mel front end inside the step), '
-                     'bs=32 x 10 s, %d segments, model NISQA random-init, dropout on; precision mode %r' % (int(plan.n_wins.sum()), tr.precision),
-           'value': round(bs / dt, 1), 'unit': 'clips/s', 'ms_per_step': round(dt * 1e3, 3), 'steps': steps, 'loss': round(float(loss), 5),
-           'roofline': {'kernel': 'whole step (~%s launches; no single kernel dominates)' % 'see profiles/rNN_train_kernel_stats.csv',
-                        'bound': 'mfma', 'achieved': round(ach, 2), 'unit': 'TFLOP/s',
-                        'flop_per_step': flop, 'flop_rule': '3 x forward network FLOPs (2.598 GFLOP per 10 s clip)',
-                        'peak': PEAK_F32, 'frac': round(ach / PEAK_F32, 4),
-                        'peak_note': 'fp32 MFMA peak (the reference trains in fp32); frac_of_mode_ideal prices the forward / '
-                                     'gradient convolutions at the MFMA peak of the operand type each runs on in this mode',
-                        'frac_of_bf16_peak': round(ach / PEAK_BF16_MFMA, 4),
-                        'frac_of_mode_ideal': round(ideal / dt, 4), 'mode_ideal_ms': round(ideal * 1e3, 4)},
-           'peak_mem_GB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}
-    # the same step in the other precision modes (train.py: 'f32' everything exact, 'bf16x3' forward convolutions on
-    # split-bf16 too -- within 1e-4 of y_hat, gradients of a fine-tuning step from nisqa.tar within 2.2 %, DESIGN.md 4.7)
-    other = {}
-    for mode in ('f32', 'bf16x3'):
-        if mode == tr.precision:
-            continue
-        tr2 = HipTrainer(args, sd, dev, lr=1e-3, precision=mode)
+    modes, segments, peak_mem = {}, 0, 0.0
+    for mode in ('f32', 'mixed', 'bf16x3'):
+        tr = HipTrainer(args, sd, dev, lr=1e-3, precision=mode)
+        plan = tr.eng.plan([int(SECONDS * SR)] * bs, SR)
+        x = tr.eng.pcm16_to_f32(torch.from_numpy(pcm).to(dev))
         for _ in range(3):
-            tr2.step_pcm(x, plan, SR, y)
+            tr.step_pcm(x, plan, SR, y)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            tr2.step_pcm(x, plan, SR, y)
+            loss = tr.step_pcm(x, plan, SR, y)
         torch.cuda.synchronize()
-        d2 = (time.perf_counter() - t0) / steps
-        other[mode] = {'ms_per_step': round(d2 * 1e3, 3), 'value': round(bs / d2, 1), 'frac_of_fp32_peak': round(flop / d2 / 1e12 / PEAK_F32, 4)}
-        del tr2
-    res['other_precision_modes'] = other
+        dt = (time.perf_counter() - t0) / steps
+        assert np.isfinite(float(loss))
+        # the ideal time of this precision mode: forward convolutions on fp32 MFMA ('mixed', 'f32') or split-bf16 ('bf16x3'),
+        # the two gradient passes on split-bf16 ('mixed', 'bf16x3') or fp32 ('f32'); attention / pooling / projection fp32
+        pk_f, pk_b = (PEAK_BF16_MFMA if mode == 'bf16x3' else PEAK_F32), (PEAK_F32 if mode == 'f32' else PEAK_BF16_MFMA)
+        ideal = (cnn / pk_f + 2 * cnn / pk_b + 3 * rest / PEAK_F32) / 1e12
+        ach = flop / dt / 1e12
+        modes[mode] = {'ms_per_step': round(dt * 1e3, 3), 'value': round(bs / dt, 1), 'achieved_TFLOPs': round(ach, 2),
+                       'frac_of_fp32_peak': round(ach / PEAK_F32, 4), 'frac_of_mode_ideal': round(ideal / dt, 4),
+                       'mode_ideal_ms': round(ideal * 1e3, 4), 'loss': round(float(loss), 5)}
+        segments = int(plan.n_wins.sum())
+        peak_mem = max(peak_mem, torch.cuda.max_memory_allocated() / 2 ** 30)
+        del tr
+    p = modes['f32']
+    res = {'config': 'configs[4] train_nisqa_cnn_sa_ap.yaml step (forward + backward + Adam, mel front end inside the step), '
+                     'bs=32 x 10 s, %d segments, model NISQA random-init, dropout on; precision mode \'f32\' (exact fp32 MFMA '
+                     'everywhere: the reference\'s arithmetic); HipTrainer\'s default mode \'mixed\' and \'bf16x3\' beside it' % segments,
+           'value': p['value'], 'unit': 'clips/s', 'ms_per_step': p['ms_per_step'], 'steps': steps, 'loss': p['loss'],
+           'roofline': {'kernel': 'whole step (~65 launches, profiles/rNN_train_*_kernel_stats.csv; no single kernel dominates)',
+                        'bound': 'mfma', 'achieved': p['achieved_TFLOPs'], 'unit': 'TFLOP/s',
+                        'flop_per_step': flop, 'flop_rule': '3 x forward network FLOPs (2.598 GFLOP per 10 s clip)',
+                        'peak': PEAK_F32, 'frac': p['frac_of_fp32_peak'],
+                        'peak_note': 'fp32 MFMA peak (the reference trains in fp32); frac_of_mode_ideal prices the forward / '
+                                     'gradient convolutions at the MFMA peak of the operand type each runs on in that mode',
+                        'frac_of_mode_ideal': p['frac_of_mode_ideal'], 'mode_ideal_ms': p['mode_ideal_ms']},
+           'other_precision_modes': {k: v for k, v in modes.items() if k != 'f32'},
+           'peak_mem_GB': round(peak_mem, 2)}
     if cpu_baseline_on:
         from oracle import mel as omel, net as onet, train as otrain
         nb = 8

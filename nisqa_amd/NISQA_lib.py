@@ -400,9 +400,16 @@ def _predict(model, ds, bs, dev, num_workers):
     # do not overlap at all, tools/probe_overlap.py: 7.5 ms per 256-clip batch against 4.5), two streams take the
     # kernels of alternate batches behind an event, a staging slot is recycled as soon as ITS copy is done, and the D2H
     # of batch i's [B, heads] rows is waited for one batch late (no device-wide sync in the loop)
-    ing = _ingest.Ingest(ds, batches, pin=on_gpu, num_workers=num_workers, device=eng.device if on_gpu else None)
+    # three batches staged ahead (four page-locked slots): the consumer below keeps TWO batches in flight, so the copy of
+    # batch k + 1 is queued a whole batch time before the link needs it, not 0.8 ms before (kernels 3 ms + enqueue 0.5 ms
+    # against a 4.3 ms copy: with one batch in flight any jitter left the link idle, 89 % of its rate over 98 304 rows)
+    ing = _ingest.Ingest(ds, batches, pin=on_gpu, num_workers=num_workers, depth=int(os.environ.get('NISQA_LOOP_DEPTH', '3')),
+                         device=eng.device if on_gpu else None)
     copy_stream, streams = _loop_streams(eng.device) if on_gpu else (None, [None, None])
     inflight = []                                                   # (ids, host rows, event behind them)
+    keep_inflight = max(1, int(os.environ.get('NISQA_LOOP_INFLIGHT', '2')))
+    time_copies = on_gpu and os.environ.get('NISQA_LOOP_TIME_COPIES') == '1'     # tools: HIP events around every batch's H2D copies
+    copy_events = []
 
     T = {'queue_wait': 0.0, 'enqueue': 0.0, 'result_wait': 0.0}
     clock = time.perf_counter
@@ -430,6 +437,9 @@ def _predict(model, ds, bs, dev, num_workers):
             sent, ev = [], None
             try:
                 with (torch.cuda.stream(copy_stream) if on_gpu else _nullcontext()):
+                    if time_copies:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record(copy_stream)
                     for g in staged.groups:                          # files of one rate share the mel tables
                         plan = eng.plan(g.lengths, g.sr, names=g.names)
                         tables = plan.to(eng.device)
@@ -437,8 +447,10 @@ def _predict(model, ds, bs, dev, num_workers):
                         pcm = host.to(eng.device, non_blocking=True)     # PCM16 stays int16: 2 bytes/sample over PCIe
                         sent.append((g, plan, tables, pcm))
                     if on_gpu:
-                        ev = torch.cuda.Event()
+                        ev = torch.cuda.Event(enable_timing=time_copies)
                         ev.record(copy_stream)
+                        if time_copies:
+                            copy_events.append((e0, ev))
             finally:
                 ing.ring.release_after(staged.slot, ev)
             if on_gpu:
@@ -457,13 +469,19 @@ def _predict(model, ds, bs, dev, num_workers):
                     else:
                         inflight.append((g.ids, out, None))
             T['enqueue'] += clock() - t_got
-            drain(keep=len(staged.groups))                           # results of the previous batch
+            drain(keep=keep_inflight * len(staged.groups))           # results of the batch before the previous one
             t_it = clock()
         drain(keep=0)
     finally:
         ing.close()
         LOOP_STATS.clear()
         LOOP_STATS.update(T)
+        LOOP_STATS.update({'producer_' + k: v for k, v in ing.stats.items()})
+        LOOP_STATS['readers'] = ing.workers
+        if copy_events:
+            torch.cuda.synchronize()
+            LOOP_STATS['copy_busy_s'] = sum(a.elapsed_time(b) for a, b in copy_events) * 1e-3
+            LOOP_STATS['copy_span_s'] = copy_events[0][0].elapsed_time(copy_events[-1][1]) * 1e-3
     return _dist.gather_rows(y_local, n, lo, hi, dev, bounds)
 
 

@@ -232,29 +232,32 @@ class LengthAware(object):
         tokens = np.maximum(1, np.asarray(self.tokens_of(frames, srs), dtype=np.int64))
         order = np.lexsort((np.arange(n), frames, widths, srs))        # by rate, then int16-before-float, then length, then input order
         out, cur, ct = [], [], 0
-        grp = {}                                                       # rate -> [int16 frames, float frames] of the open batch
+        grp, cost = {}, 0                                              # rate -> [int16 frames, float frames] of the open batch; its staged bytes
         need = max(self.bs, self.min_clips)
+        cap, min_tokens = self.byte_cap, self.min_tokens
+        fr_l, sr_l, w_l, tk_l = frames.tolist(), srs.tolist(), widths.tolist(), tokens.tolist()   # (plain ints: this loop runs per item)
 
-        def cost(g):
-            return sum(4 * (a + b) if b else 2 * a for a, b in g.values())
+        def rate_cost(a, b):
+            return 4 * (a + b) if b else 2 * a
 
         for k in order.tolist():
-            sr, slot = int(srs[k]), 0 if widths[k] == 2 else 1
-            if cur:
-                trial = dict(grp)
-                a = list(trial.get(sr, (0, 0)))
-                a[slot] += int(frames[k])
-                trial[sr] = a
-                if cost(trial) > self.byte_cap or srs[k] != srs[cur[-1]] and len(cur) >= need:
-                    out.append(cur)
-                    cur, ct, grp = [], 0, {}
-            cur.append(k)
-            a = grp.setdefault(sr, [0, 0])
-            a[slot] += int(frames[k])
-            ct += int(tokens[k])
-            if len(cur) >= need and ct >= self.min_tokens:
+            sr, f = sr_l[k], fr_l[k]
+            slow = w_l[k] != 2
+            a, b = grp.get(sr, (0, 0))
+            a2, b2 = (a, b + f) if slow else (a + f, b)
+            add = rate_cost(a2, b2) - rate_cost(a, b)
+            if cur and (cost + add > cap or sr != sr_l[cur[-1]] and len(cur) >= need):
                 out.append(cur)
-                cur, ct, grp = [], 0, {}
+                cur, ct, grp, cost = [], 0, {}, 0
+                a2, b2 = (0, f) if slow else (f, 0)
+                add = rate_cost(a2, b2)
+            cur.append(k)
+            grp[sr] = (a2, b2)
+            cost += add
+            ct += tk_l[k]
+            if len(cur) >= need and ct >= min_tokens:
+                out.append(cur)
+                cur, ct, grp, cost = [], 0, {}, 0
         if cur:
             out.append(cur)
         # a small remainder does not get a launch chain of its own when the batch before it can take it (the byte cap is a
@@ -403,7 +406,12 @@ class Ingest(object):
                 if self.stop.is_set():
                     box[w] = ('stop', None, loc)
                     return
-                box[w] = ('ok', self._probe(wins[w], loc), loc)
+                names, enc, info = self._probe(wins[w], loc)
+                # the window's batches are cut HERE, on the helper thread: sorting and walking 16 384 items in Python is
+                # 10-20 ms during which the producer staged nothing and the link ran dry once per window
+                fast = (info['tag'] == 1) & (info['bits'] == 16) & (info['channels'] == 1)
+                cuts = pol.cut(info['n_frames'].astype(np.int64), info['sample_rate'].astype(np.int64), np.where(fast, 2, 4))
+                box[w] = ('ok', (names, enc, info, cuts), loc)
             except BaseException as e:
                 box[w] = ('err', e, loc)
 
@@ -426,9 +434,7 @@ class Ingest(object):
                 helper.start()
             else:
                 helper = None
-            names, enc, info = val
-            fast = (info['tag'] == 1) & (info['bits'] == 16) & (info['channels'] == 1)
-            cuts = pol.cut(info['n_frames'].astype(np.int64), info['sample_rate'].astype(np.int64), np.where(fast, 2, 4))
+            names, enc, info, cuts = val
             for pos in cuts:
                 yield [wins[w][k] for k in pos], ([names[k] for k in pos], [enc[k] for k in pos], info[pos])
 
