@@ -148,6 +148,20 @@ int nisqa_bn_act_pool_bwd1(const float* dy, const int32_t* arg, const float* dro
 int nisqa_bn_act_pool_bwd(const float* dy, const int32_t* arg, const float* drop, const float* z, const float* mean_rstd,
                           const float* gamma, const float* beta, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t ho,
                           int32_t wo, double* sums2, float* dz, float* dgamma, float* dbeta, void* stream);
+/* The first launch of nisqa_bn_act_pool_bwd on its own (sums2 += sum dyb, sum dyb * z over the pooled values), and the weight
+ * gradient of the segment-resident convolutions with the REST of that backward folded into its staging: it is handed z and the
+ * pooled gradient dy (+ arg, drop) instead of dz, computes dz = gamma rstd (dyb - mean(dyb) - xhat mean(dyb xhat)) per element
+ * while it stages a group of segments, writes dz (for the input-gradient kernel that runs next), dgamma and dbeta, and adds dw
+ * like nisqa_segconv_wgrad_bf16.  The dense z -> dz pass of layers 2..6 (memory-bound, 0.29 ms of a 3.4 ms step) disappears.
+ * Shapes: the five nisqa_segconv_supported layers with their pooling sizes (ho, wo) = (12,5) (12,5) (6,3) (6,3) (6,1); anything
+ * else returns NISQA_ERR_ARG (run nisqa_bn_act_pool_bwd + nisqa_segconv_wgrad_bf16 instead). */
+int nisqa_bn_pool_bwd_sums(const float* dy, const int32_t* arg, const float* drop, const float* z, const float* mean_rstd,
+                           const float* gamma, const float* beta, int32_t n_segments, int32_t h, int32_t w, int32_t c, int32_t ho,
+                           int32_t wo, double* sums2, void* stream);
+int nisqa_segconv_wgrad_bn_bf16(const float* x, const float* z, const float* dy, const int32_t* arg, const float* drop,
+                                const float* mean_rstd, const float* gamma, const float* beta, const double* sums2, float* dz_out,
+                                float* dgamma, float* dbeta, float* dw, int32_t n_segments, int32_t h, int32_t w, int32_t ci,
+                                int32_t co, int32_t pad_w, int32_t ho, int32_t wo, void* stream);
 int nisqa_bn_bwd2(float* dyb_to_dz, const float* z, const double* sums2, const float* mean_rstd, const float* gamma,
                   int64_t rows, int32_t c, float* dgamma, float* dbeta, double* sum_dz_opt, void* stream);
 

@@ -1637,6 +1637,23 @@ extern "C" int nisqa_bn_act_pool_bwd(const float* dy, const int32_t* arg, const 
     return NQ_LAUNCH_STATUS();
 }
 
+// only the first of the two launches above: sums2 [2c] += sum dyb, sum dyb z over the pooled values -- for callers that fold the
+// dense pass into a consumer of dz (nisqa_segconv_wgrad_bn_bf16)
+extern "C" int nisqa_bn_pool_bwd_sums(const float* dy, const int32_t* arg, const float* drop, const float* z, const float* mean_rstd,
+                                      const float* gamma, const float* beta, int32_t n_segments, int32_t h, int32_t w, int32_t c,
+                                      int32_t ho, int32_t wo, double* sums2, void* stream) {
+    if (!dy || !arg || !z || !mean_rstd || !gamma || !beta || !sums2 || n_segments <= 0 || h <= 0 || w <= 0 || c <= 0 || ho <= 0 ||
+        wo <= 0 || ho > h || wo > w || (c & 3) || (1024 % c) != 0)
+        return NISQA_ERR_ARG;
+    const int64_t cells = (int64_t)n_segments * ho * wo * c / 4;
+    hipStream_t st = (hipStream_t)stream;
+    NQ_LAUNCH_BEGIN();
+    int64_t g1 = (cells + 2047) / 2048;
+    g1 = g1 < 1 ? 1 : (g1 > 1024 ? 1024 : g1);
+    NQ_POOL_DISPATCH(pool_bwd_sums_kernel, dim3((unsigned)g1), st, dy, arg, drop, z, mean_rstd, gamma, beta, cells, h, w, c, ho, wo, sums2);
+    return NQ_LAUNCH_STATUS();
+}
+
 __global__ __launch_bounds__(256) void bn_bwd2_kernel(float* __restrict__ d, const float* __restrict__ z,
                                                       const double* __restrict__ sums2, const float* __restrict__ mean_rstd,
                                                       const float* __restrict__ gamma, int64_t rows, int c,

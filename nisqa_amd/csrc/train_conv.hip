@@ -496,10 +496,27 @@ NQ_DEV void segwgrad_kloop(f32x16 (&acc)[C::MTW][C::NTW], const unsigned (&za)[C
     }
 }
 
-template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT>
+// BatchNorm backward folded into the staging (PH > 0): the kernel is handed z (the layer's convolution output) and the POOLED
+// gradient dy [S][PH * PW][CO] with the arg-max pixels of the forward pass instead of dz, computes
+//   dz = gamma rstd (gate (sum of the <= 2 pooling windows that chose this pixel) drop - mean(dyb) - xhat mean(dyb xhat))
+// per element while it deposits a group into LDS -- the arithmetic of bn_act_pool_bwd_dense_kernel (train.hip), whose dense
+// pass over z and dz (0.29 ms per step for layers 2-6, memory-bound) disappears -- and writes dz out once for the input
+// gradient kernel that runs next.  sums2 = the float64 sums over the pooled values (nisqa_bn_pool_bwd_sums).
+struct segw_bn {
+    const float* z; const float* dy; const int32_t* arg; const float* drop; const float* mean_rstd; const float* gamma;
+    const float* beta; const double* sums2; float* dz_out; float* dgamma; float* dbeta;
+};
+NQ_DEV int sc_win_lo(int i, int n_in, int n_out) { return (i * n_in) / n_out; }
+NQ_DEV int sc_win_hi(int i, int n_in, int n_out) { return ((i + 1) * n_in + n_out - 1) / n_out; }
+typedef int sc_i32x4 __attribute__((ext_vector_type(4)));
+
+template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT, int PH, int PW>
 __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __restrict__ x, const float* __restrict__ dz,
-                                                               float* __restrict__ dw, int n_segments) {
+                                                               float* __restrict__ dw, int n_segments, segw_bn bn) {
     typedef segwgrad_cfg<CI, CO, H, W, WO, PADW, SEGS, MSPLIT> C;
+    constexpr bool BN = PH > 0;
+    constexpr bool IDENT = PH == H && PW == WO;
+    static_assert(!BN || (H % PH == 0 && 512 % (CO / 4) == 0), "pooling rows are disjoint; a thread keeps its four channels");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid0 = threadIdx.x, lane0 = tid0 & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -535,11 +552,36 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
         for (int j = 0; j < C::NTW; ++j) acc[m][j] = zero16();
 
     f32x4 vx[C::NVX], vz[C::NVZ];
+    // BN: the pooled gradients (and arg-max pixels) of the <= 2 windows that contain the element's pixel
+    f32x4 vd0[BN ? C::NVZ : 1], vd1[(BN && !IDENT) ? C::NVZ : 1];
+    sc_i32x4 va0[(BN && !IDENT) ? C::NVZ : 1], va1[(BN && !IDENT) ? C::NVZ : 1];
+    // this thread's four channels are the same in every element it stages (512 * 4 % CO == 0): their constants once
+    f32x4 bn_g, bn_b, bn_mu, bn_rs, bn_m1, bn_m2;
+    f32x4 vdr[BN ? C::NVZ : 1];                                  // Dropout2d multipliers of the element's (segment, channels)
+    if (BN) {
+        const int ch = (4 * tid0) % CO;
+        const double inv = 1.0 / ((double)n_segments * C::PXZ);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float mu = bn.mean_rstd[ch + e], rs = bn.mean_rstd[CO + ch + e];
+            bn_mu[e] = mu;
+            bn_rs[e] = rs;
+            bn_g[e] = bn.gamma[ch + e] * rs;
+            bn_b[e] = bn.beta[ch + e] - mu * bn_g[e];
+            bn_m1[e] = (float)(bn.sums2[ch + e] * inv);
+            bn_m2[e] = (float)((double)rs * (bn.sums2[CO + ch + e] - (double)mu * bn.sums2[ch + e]) * inv);
+        }
+        if (blockIdx.x == 0 && tid0 < CO) {                     // the BatchNorm parameter gradients (what the dense kernel's block 0 wrote)
+            const double mean = bn.mean_rstd[tid0], rstd = bn.mean_rstd[CO + tid0];
+            bn.dbeta[tid0] = (float)bn.sums2[tid0];
+            bn.dgamma[tid0] = (float)(rstd * (bn.sums2[CO + tid0] - mean * bn.sums2[tid0]));
+        }
+    }
     auto request = [&](int grp, int tid) {
         const int seg0 = grp * SEGS;
         const int nseg = grp < n_groups ? min(SEGS, n_segments - seg0) : 0;
         const f32x4* gx = (const f32x4*)(x + (size_t)seg0 * C::PXI * CI);
-        const f32x4* gz = (const f32x4*)(dz + (size_t)seg0 * C::PXZ * CO);
+        const f32x4* gz = (const f32x4*)((BN ? bn.z : dz) + (size_t)seg0 * C::PXZ * CO);
 #pragma unroll
         for (int j = 0; j < C::NVX; ++j) {
             const int i = tid + 512 * j;
@@ -548,10 +590,32 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
 #pragma unroll
         for (int j = 0; j < C::NVZ; ++j) {
             const int i = tid + 512 * j;
-            vz[j] = i < nseg * C::PXZ * CO / 4 ? gz[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = i < nseg * C::PXZ * CO / 4;
+            vz[j] = ok ? gz[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (BN) {
+                const int pix = (4 * i) / CO, c = (4 * i) % CO;
+                const int sg = pix / C::PXZ, p = pix - sg * C::PXZ;
+                vdr[j] = (ok && bn.drop) ? *(const f32x4*)(bn.drop + (size_t)(seg0 + sg) * CO + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+                if (IDENT) {
+                    vd0[j] = ok ? *(const f32x4*)(bn.dy + ((size_t)(seg0 + sg) * C::PXZ + p) * CO + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    const int yy = p / WO, xx = p - yy * WO;
+                    const int oy = yy / (H / PH);
+                    int oa = (xx * PW) / WO;                    // the window whose floor bound is at or below xx ...
+                    if (oa > 0 && sc_win_hi(oa - 1, WO, PW) > xx) --oa;      // ... or the one before it when that still covers xx
+                    const int ob = oa + 1;
+                    const bool has_b = ob < PW && sc_win_lo(ob, WO, PW) <= xx;
+                    const size_t o0 = ((size_t)(seg0 + sg) * (PH * PW) + oy * PW + oa) * CO + c;
+                    const size_t o1 = ((size_t)(seg0 + sg) * (PH * PW) + oy * PW + ob) * CO + c;
+                    vd0[j] = ok ? *(const f32x4*)(bn.dy + o0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    va0[j] = ok ? *(const sc_i32x4*)(bn.arg + o0) : sc_i32x4{-1, -1, -1, -1};
+                    vd1[j] = (ok && has_b) ? *(const f32x4*)(bn.dy + o1) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    va1[j] = (ok && has_b) ? *(const sc_i32x4*)(bn.arg + o1) : sc_i32x4{-1, -1, -1, -1};
+                }
+            }
         }
     };
-    auto deposit = [&](unsigned buf, int tid) {                  // split and store the requested group into buffer `buf`
+    auto deposit = [&](unsigned buf, int tid, int grp) {         // split and store the requested group into buffer `buf`
 #pragma unroll
         for (int j = 0; j < C::NVX; ++j) {
             const int i = tid + 512 * j;
@@ -566,15 +630,39 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
                 lds_st32(a + C::PLX, l0); lds_st32(a + C::PLX + 4, l1);
             }
         }
+        const int seg0 = grp * SEGS;
+        const int nseg_d = grp < n_groups ? min(SEGS, n_segments - seg0) : 0;
 #pragma unroll
         for (int j = 0; j < C::NVZ; ++j) {
             const int i = tid + 512 * j;
             if (C::FZ % 512 == 0 || i < C::FZ) {
                 const int pix = (4 * i) / CO, c = (4 * i) % CO;
+                f32x4 dzv = vz[j];
+                if (BN) {
+                    const bool ok = i < nseg_d * C::PXZ * CO / 4;
+                    const int sg = pix / C::PXZ, p = pix - sg * C::PXZ;
+                    const f32x4 zi = vz[j];
+                    f32x4 acc;
+                    if (IDENT) acc = vd0[j];
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = (va0[j][e] == p ? vd0[j][e] : 0.f) + (va1[j][e] == p ? vd1[j][e] : 0.f);
+                    }
+                    acc *= vdr[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float zv = zi[e];
+                        asm volatile("" : "+v"(zv));              // scalar gates: packed, hipcc emits the op_sel form of DESIGN.md 7.1
+                        const float a_ = fmaf(zv, bn_g[e], bn_b[e]) > 0.f ? acc[e] : 0.f;
+                        const float xh = (zv - bn_mu[e]) * bn_rs[e];
+                        dzv[e] = ok ? bn_g[e] * (a_ - bn_m1[e] - xh * bn_m2[e]) : 0.f;
+                    }
+                    if (ok) *(f32x4*)(bn.dz_out + (size_t)seg0 * C::PXZ * CO + (size_t)4 * i) = dzv;
+                }
                 const unsigned a = buf + C::ZB + (unsigned)(pix * C::RSZ) + 2 * c;
-                const unsigned h0 = cvt_pk_bf16(vz[j][0], vz[j][1]), h1 = cvt_pk_bf16(vz[j][2], vz[j][3]);
-                const unsigned l0 = cvt_pk_bf16(vz[j][0] - __uint_as_float(h0 << 16), vz[j][1] - __uint_as_float(h0 & 0xffff0000u));
-                const unsigned l1 = cvt_pk_bf16(vz[j][2] - __uint_as_float(h1 << 16), vz[j][3] - __uint_as_float(h1 & 0xffff0000u));
+                const unsigned h0 = cvt_pk_bf16(dzv[0], dzv[1]), h1 = cvt_pk_bf16(dzv[2], dzv[3]);
+                const unsigned l0 = cvt_pk_bf16(dzv[0] - __uint_as_float(h0 << 16), dzv[1] - __uint_as_float(h0 & 0xffff0000u));
+                const unsigned l1 = cvt_pk_bf16(dzv[2] - __uint_as_float(h1 << 16), dzv[3] - __uint_as_float(h1 & 0xffff0000u));
                 lds_st32(a, h0); lds_st32(a + 4, h1);
                 lds_st32(a + C::PLZ, l0); lds_st32(a + C::PLZ + 4, l1);
             }
@@ -584,7 +672,7 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
     int grp = blockIdx.x;
     request(grp, tid0);
     __syncthreads();                                            // the zero fill is complete
-    deposit(0u, tid0);
+    deposit(0u, tid0, grp);
     __syncthreads();
     unsigned cur = 0u;
 #ifdef SC_CLOCK
@@ -607,7 +695,7 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
         segwgrad_kloop<C>(acc, za, xa, noff, n_own);
         __builtin_amdgcn_sched_barrier(0);
         SC_CLK(4);                                              // K loop
-        deposit(C::BUF - cur, tid);                             // the other buffer: last read before the previous barrier
+        deposit(C::BUF - cur, tid, grp + (int)gridDim.x);       // the other buffer: last read before the previous barrier
         SC_CLK(2);                                              // wait for the loads + split + store
         __syncthreads();
         SC_CLK(3);
@@ -644,20 +732,20 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
 #endif
 }
 
-template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT>
-static void segwgrad_launch(hipStream_t st, const float* x, const float* dz, float* dw, int n_segments) {
+template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT, int PH = 0, int PW = 0>
+static void segwgrad_launch(hipStream_t st, const float* x, const float* dz, float* dw, int n_segments, segw_bn bn = segw_bn{}) {
     typedef segwgrad_cfg<CI, CO, H, W, WO, PADW, SEGS, MSPLIT> C;
     static std::atomic<bool> attr[SC_MAX_DEV];
     const int dev = sc_device();
     if (!attr[dev].load(std::memory_order_relaxed)) {           // more than 64 KB of dynamic LDS, per device
-        (void)hipFuncSetAttribute((const void*)segwgrad_bf16_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT>,
+        (void)hipFuncSetAttribute((const void*)segwgrad_bf16_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, PH, PW>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
         attr[dev].store(true, std::memory_order_relaxed);
     }
     const int n_groups = (n_segments + SEGS - 1) / SEGS;
     const int grid = n_groups < sc_cu_count() ? n_groups : sc_cu_count();
-    hipLaunchKernelGGL((segwgrad_bf16_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT>), dim3(grid), dim3(512), C::LDS, st, x, dz, dw,
-                       n_segments);
+    hipLaunchKernelGGL((segwgrad_bf16_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, PH, PW>), dim3(grid), dim3(512), C::LDS, st, x, dz, dw,
+                       n_segments, bn);
 }
 
 // dw[co][9 * ci] += dz^T * patches(x)  (dw zeroed by the caller, as for nisqa_conv3x3_gemm mode 2); same five shapes
@@ -672,5 +760,28 @@ extern "C" int nisqa_segconv_wgrad_bf16(const float* x, const float* dz, float* 
     else if (key == SC_KEY(12, 5, 64, 64)) segwgrad_launch<64, 64, 12, 5, 5, 1, 1, SC_W_MSPLIT>(st, x, dz, dw, n_segments);
     else if (pad_w == 1) segwgrad_launch<64, 64, 6, 3, 3, 1, 4, SC_W_MSPLIT>(st, x, dz, dw, n_segments);
     else segwgrad_launch<64, 64, 6, 3, 1, 0, 8, SC_W_MSPLIT>(st, x, dz, dw, n_segments);
+    return NQ_LAUNCH_STATUS();
+}
+
+// The same with the BatchNorm / ReLU / max-pool / Dropout2d backward of the layer folded into the staging (see segw_bn): for
+// the five layers of the reference configuration with their pooling sizes (ho, wo) = (12, 5) (12, 5) (6, 3) (6, 3) (6, 1).
+// Returns NISQA_ERR_ARG for anything else (callers then run nisqa_bn_act_pool_bwd + nisqa_segconv_wgrad_bf16).
+extern "C" int nisqa_segconv_wgrad_bn_bf16(const float* x, const float* z, const float* dy, const int32_t* arg, const float* drop,
+                                           const float* mean_rstd, const float* gamma, const float* beta, const double* sums2,
+                                           float* dz_out, float* dgamma, float* dbeta, float* dw, int32_t n_segments, int32_t h,
+                                           int32_t w, int32_t ci, int32_t co, int32_t pad_w, int32_t ho, int32_t wo, void* stream) {
+    if (!x || !z || !dy || !arg || !mean_rstd || !gamma || !beta || !sums2 || !dz_out || !dgamma || !dbeta || !dw || n_segments <= 0 ||
+        !nisqa_segconv_supported(h, w, ci, co, pad_w))
+        return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const segw_bn bn = {z, dy, arg, drop, mean_rstd, gamma, beta, sums2, dz_out, dgamma, dbeta};
+    const int key = SC_KEY(h, w, ci, co);
+    NQ_LAUNCH_BEGIN();
+    if (key == SC_KEY(24, 7, 16, 32) && ho == 12 && wo == 5) segwgrad_launch<16, 32, 24, 7, 7, 1, 1, 1, 12, 5>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(12, 5, 32, 64) && ho == 12 && wo == 5) segwgrad_launch<32, 64, 12, 5, 5, 1, 1, 2, 12, 5>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(12, 5, 64, 64) && ho == 6 && wo == 3) segwgrad_launch<64, 64, 12, 5, 5, 1, 1, SC_W_MSPLIT, 6, 3>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1 && ho == 6 && wo == 3) segwgrad_launch<64, 64, 6, 3, 3, 1, 4, SC_W_MSPLIT, 6, 3>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0 && ho == 6 && wo == 1) segwgrad_launch<64, 64, 6, 3, 1, 0, 8, SC_W_MSPLIT, 6, 1>(st, x, nullptr, dw, n_segments, bn);
+    else return NISQA_ERR_ARG;
     return NQ_LAUNCH_STATUS();
 }

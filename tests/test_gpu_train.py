@@ -771,6 +771,39 @@ def test_fused_self_attention_block_matches_the_operator_by_operator_path(name, 
             assert (d[solid].max(initial=0) if solid is not None else d.max(initial=0) * (0 if _conv_bias(k) else 1)) < 1e-4, k
 
 
+@pytest.mark.parametrize('precision', ['mixed', 'bf16x3'])
+@pytest.mark.parametrize('use_masks', [False, True])
+def test_batchnorm_backward_folded_into_the_weight_gradient_kernel_agrees_with_the_dense_pass(precision, use_masks, monkeypatch):
+    """nisqa_segconv_wgrad_bn_bf16 (the dense z -> dz pass of layers 2..6 computed inside the weight-gradient kernel's staging,
+    dz written once for the input-gradient kernel) against the two-kernel form (nisqa_bn_act_pool_bwd, then
+    nisqa_segconv_wgrad_bf16): the same step, with and without Dropout2d masks -> every gradient to fp32 rounding."""
+    from nisqa_amd.train import HipTrainer
+    g, args, sd, specs, y = _case('dim')
+    n_wins = [int(v) for v in g['n_wins']]
+    S, mk = sum(n_wins), None
+    if use_masks:
+        rng = np.random.default_rng(4)
+        mk = {key: ((rng.random((S, c)) >= 0.2).astype(np.float32) / 0.8) for key, c in (('cnn_d1', 32), ('cnn_d2', 64), ('cnn_d3', 64), ('cnn_d4', 64))}
+    res = {}
+    for fold in ('1', '0'):
+        monkeypatch.setenv('NISQA_HIP_TRAIN_FOLD_BN_WGRAD', fold)
+        tr = HipTrainer(args, sd, DEV, lr=1e-3, precision=precision)
+        assert tr.fold_bn_wgrad == (fold == '1') and tr.segconv
+        loss = tr.step_spec(specs, y, masks=mk)
+        torch.cuda.synchronize()
+        res[fold] = (float(loss), tr.grads())
+    assert res['1'][0] == pytest.approx(res['0'][0], rel=2e-6)         # the forward pass is untouched (the loss is summed with atomics)
+    worst, wk = 0.0, None
+    for k, g0 in res['0'][1].items():
+        if _conv_bias(k):
+            continue
+        e = float(np.abs(res['1'][1][k].numpy() - g0.numpy()).max()) / max(1e-3, float(np.abs(g0.numpy()).max()))
+        if e > worst:
+            worst, wk = e, k
+    print('BatchNorm backward folded into the weight gradient,', precision, 'masks' if use_masks else 'no masks', ': worst relative gradient difference', worst, wk)
+    assert worst < 1e-5, (worst, wk)
+
+
 @pytest.mark.parametrize('name', ['mos', 'dim'])
 def test_training_step_with_split_bf16_forward_convolutions(name):
     """precision='bf16x3' also runs the FORWARD convolutions on split-bf16 MFMA.  Loss, y_hat and BatchNorm buffers stay
