@@ -162,6 +162,13 @@ int nisqa_segconv_wgrad_bn_bf16(const float* x, const float* z, const float* dy,
                                 const float* mean_rstd, const float* gamma, const float* beta, const double* sums2, float* dz_out,
                                 float* dgamma, float* dbeta, float* dw, int32_t n_segments, int32_t h, int32_t w, int32_t ci,
                                 int32_t co, int32_t pad_w, int32_t ho, int32_t wo, void* stream);
+/* The weight gradient of the same five layers, segment-resident, in EXACT fp32 (v_mfma_f32_32x32x2_f32: precision mode 'f32',
+ * the reference's arithmetic), with or without the BatchNorm backward folded in: z == NULL -> dz_out holds dz on entry (as
+ * nisqa_segconv_wgrad_bf16's dz; dy .. sums2, dgamma, dbeta unused); z != NULL -> the contract of nisqa_segconv_wgrad_bn_bf16. */
+int nisqa_segconv_wgrad_f32(const float* x, const float* z, const float* dy, const int32_t* arg, const float* drop,
+                            const float* mean_rstd, const float* gamma, const float* beta, const double* sums2, float* dz_out,
+                            float* dgamma, float* dbeta, float* dw, int32_t n_segments, int32_t h, int32_t w, int32_t ci, int32_t co,
+                            int32_t pad_w, int32_t ho, int32_t wo, void* stream);
 int nisqa_bn_bwd2(float* dyb_to_dz, const float* z, const double* sums2, const float* mean_rstd, const float* gamma,
                   int64_t rows, int32_t c, float* dgamma, float* dbeta, double* sum_dz_opt, void* stream);
 

@@ -785,3 +785,260 @@ extern "C" int nisqa_segconv_wgrad_bn_bf16(const float* x, const float* z, const
     else return NISQA_ERR_ARG;
     return NQ_LAUNCH_STATUS();
 }
+
+
+// ======================================================================================================================
+// The same weight gradient in EXACT fp32 (precision mode 'f32': the reference's arithmetic) on v_mfma_f32_32x32x2_f32:
+// M = co, N = (tap, ci), K = pixels.  The implicit GEMM of train.hip (mode 2) needs 1.57 ms per step for the five layers where
+// the forward convolutions -- the same FLOPs -- take 1.14: its K-tiles are gathered from HBM with index arithmetic and its
+// accumulators restart per 128-row chunk.  Here, as in the split-bf16 kernel above, a workgroup of eight waves stages the x
+// (zero-bordered: a tap is a constant address offset) and dz of SEGS whole segments once per group as fp32 planes
+// [pixel][channel], keeps its share of dw in registers over all the groups it walks, and adds it to dw once.  An MFMA takes
+// one dword per lane and operand: A = dz[pixel 2 s + (lane >> 5)][co], B = x[that pixel + tap][ci], both ds_read_b32 on 32
+// consecutive words per lane half (conflict-free at any row stride).  The eight waves split (M tiles) x (N tiles) x (K steps):
+// every wave holds NTW accumulator tiles of one M tile and walks every KSPLIT-th K step.  PH > 0 folds the BatchNorm backward
+// into the staging exactly like the split-bf16 kernel (segw_bn).
+// ======================================================================================================================
+template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT, int NSPLIT, int KSPLIT>
+struct segwf_cfg {
+    static constexpr int RSX = CI, RSZ = CO;                 // words per pixel row
+    static constexpr int XPW = W + 2 * PADW, XPH = H + 2;
+    static constexpr int PXX = XPH * XPW, PXI = H * W, PXZ = H * WO;
+    static constexpr int KROWS = SEGS * PXZ;
+    static constexpr int KSTEPS = (KROWS + 1) / 2;
+    static constexpr unsigned XB = 4u * SEGS * PXX * RSX;      // bytes of the x plane
+    static constexpr unsigned ZBYTES = 4u * (2 * KSTEPS) * RSZ;  // dz plane incl. the zero row behind an odd last pixel
+    static constexpr unsigned BUF = XB + ZBYTES;
+    static constexpr unsigned LDS = 2u * BUF;
+    static constexpr int MT = CO / 32, NTILES = (9 * CI + 31) / 32;
+    static constexpr int NTW = (NTILES + NSPLIT - 1) / NSPLIT;
+    static constexpr int FX = SEGS * PXI * CI / 4, FZ = SEGS * PXZ * CO / 4;
+    static constexpr int NVX = (FX + 511) / 512, NVZ = (FZ + 511) / 512;
+    static_assert(MSPLIT * NSPLIT * KSPLIT == 8 && MT == MSPLIT, "eight waves; one M tile per wave");
+    static_assert(LDS <= 160 * 1024 && BUF % 16 == 0, "LDS");
+};
+
+template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT, int NSPLIT, int KSPLIT, int PH, int PW>
+__global__ __launch_bounds__(512, 1) void segwgrad_f32_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                              float* __restrict__ dw, int n_segments, segw_bn bn) {
+    typedef segwf_cfg<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, NSPLIT, KSPLIT> C;
+    constexpr bool BN = PH > 0;
+    constexpr bool IDENT = PH == H && PW == WO;
+    static_assert(!BN || (H % PH == 0 && 512 % (CO / 4) == 0), "pooling rows are disjoint; a thread keeps its four channels");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int wm = wave % MSPLIT, wn = (wave / MSPLIT) % NSPLIT, wk = wave / (MSPLIT * NSPLIT);
+    const int n_groups = (n_segments + SEGS - 1) / SEGS;
+    for (unsigned a = 16u * tid0; a < C::LDS; a += 16u * 512u) *(f32x4*)(smem + a) = f32x4{0.f, 0.f, 0.f, 0.f};   // borders, zero rows
+    const int hf = lane0 >> 5, l31 = lane0 & 31;
+    // this wave's N tiles: wn, wn + NSPLIT, ...; byte offset of the lane's column (tap, ci) inside an x plane
+    const int n_own = (C::NTILES - wn + NSPLIT - 1) / NSPLIT;
+    unsigned noff[C::NTW];
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j) {
+        const int n = 32 * (wn + NSPLIT * j) + l31;
+        const int tap = min(n / CI, 8);                        // columns behind 9 * CI read valid memory and are never stored
+        noff[j] = 4u * (unsigned)(((tap / 3) * C::XPW + tap % 3) * C::RSX + n % CI);
+    }
+    const unsigned zlane = C::XB + 4u * (unsigned)(hf * C::RSZ + 32 * wm + l31);
+    f32x16 acc[C::NTW];
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j) acc[j] = zero16();
+
+    f32x4 vx[C::NVX], vz[C::NVZ];
+    f32x4 vd0[BN ? C::NVZ : 1], vd1[(BN && !IDENT) ? C::NVZ : 1], vdr[BN ? C::NVZ : 1];
+    sc_i32x4 va0[(BN && !IDENT) ? C::NVZ : 1], va1[(BN && !IDENT) ? C::NVZ : 1];
+    f32x4 bn_g, bn_b, bn_mu, bn_rs, bn_m1, bn_m2;
+    if (BN) {
+        const int ch = (4 * tid0) % CO;
+        const double inv = 1.0 / ((double)n_segments * C::PXZ);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float mu = bn.mean_rstd[ch + e], rs = bn.mean_rstd[CO + ch + e];
+            bn_mu[e] = mu;
+            bn_rs[e] = rs;
+            bn_g[e] = bn.gamma[ch + e] * rs;
+            bn_b[e] = bn.beta[ch + e] - mu * bn_g[e];
+            bn_m1[e] = (float)(bn.sums2[ch + e] * inv);
+            bn_m2[e] = (float)((double)rs * (bn.sums2[CO + ch + e] - (double)mu * bn.sums2[ch + e]) * inv);
+        }
+        if (blockIdx.x == 0 && tid0 < CO) {
+            const double mean = bn.mean_rstd[tid0], rstd = bn.mean_rstd[CO + tid0];
+            bn.dbeta[tid0] = (float)bn.sums2[tid0];
+            bn.dgamma[tid0] = (float)(rstd * (bn.sums2[CO + tid0] - mean * bn.sums2[tid0]));
+        }
+    }
+    auto request = [&](int grp, int tid) {
+        const int seg0 = grp * SEGS;
+        const int nseg = grp < n_groups ? min(SEGS, n_segments - seg0) : 0;
+        const f32x4* gx = (const f32x4*)(x + (size_t)seg0 * C::PXI * CI);
+        const f32x4* gz = (const f32x4*)((BN ? bn.z : dz) + (size_t)seg0 * C::PXZ * CO);
+#pragma unroll
+        for (int j = 0; j < C::NVX; ++j) {
+            const int i = tid + 512 * j;
+            vx[j] = i < nseg * C::PXI * CI / 4 ? gx[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < C::NVZ; ++j) {
+            const int i = tid + 512 * j;
+            const bool ok = i < nseg * C::PXZ * CO / 4;
+            vz[j] = ok ? gz[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (BN) {
+                const int pix = (4 * i) / CO, c = (4 * i) % CO;
+                const int sg = pix / C::PXZ, p = pix - sg * C::PXZ;
+                vdr[j] = (ok && bn.drop) ? *(const f32x4*)(bn.drop + (size_t)(seg0 + sg) * CO + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+                if (IDENT) {
+                    vd0[j] = ok ? *(const f32x4*)(bn.dy + ((size_t)(seg0 + sg) * C::PXZ + p) * CO + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    const int yy = p / WO, xx = p - yy * WO;
+                    const int oy = yy / (H / PH);
+                    int oa = (xx * PW) / WO;
+                    if (oa > 0 && sc_win_hi(oa - 1, WO, PW) > xx) --oa;
+                    const int ob = oa + 1;
+                    const bool has_b = ob < PW && sc_win_lo(ob, WO, PW) <= xx;
+                    const size_t o0 = ((size_t)(seg0 + sg) * (PH * PW) + oy * PW + oa) * CO + c;
+                    const size_t o1 = ((size_t)(seg0 + sg) * (PH * PW) + oy * PW + ob) * CO + c;
+                    vd0[j] = ok ? *(const f32x4*)(bn.dy + o0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    va0[j] = ok ? *(const sc_i32x4*)(bn.arg + o0) : sc_i32x4{-1, -1, -1, -1};
+                    vd1[j] = (ok && has_b) ? *(const f32x4*)(bn.dy + o1) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    va1[j] = (ok && has_b) ? *(const sc_i32x4*)(bn.arg + o1) : sc_i32x4{-1, -1, -1, -1};
+                }
+            }
+        }
+    };
+    auto deposit = [&](unsigned buf, int tid, int grp) {
+#pragma unroll
+        for (int j = 0; j < C::NVX; ++j) {
+            const int i = tid + 512 * j;
+            if (C::FX % 512 == 0 || i < C::FX) {
+                const int pix = (4 * i) / CI, c = (4 * i) % CI;
+                const int sg = pix / C::PXI, p = pix - sg * C::PXI, y = p / W, xx = p - y * W;
+                lds_st128(buf + 4u * (unsigned)((sg * C::PXX + (y + 1) * C::XPW + xx + PADW) * C::RSX + c), vx[j]);
+            }
+        }
+        const int seg0 = grp * SEGS;
+        const int nseg_d = grp < n_groups ? min(SEGS, n_segments - seg0) : 0;
+#pragma unroll
+        for (int j = 0; j < C::NVZ; ++j) {
+            const int i = tid + 512 * j;
+            if (C::FZ % 512 == 0 || i < C::FZ) {
+                const int pix = (4 * i) / CO, c = (4 * i) % CO;
+                f32x4 dzv = vz[j];
+                if (BN) {
+                    const bool ok = i < nseg_d * C::PXZ * CO / 4;
+                    const int sg = pix / C::PXZ, p = pix - sg * C::PXZ;
+                    const f32x4 zi = vz[j];
+                    f32x4 a4;
+                    if (IDENT) a4 = vd0[j];
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a4[e] = (va0[j][e] == p ? vd0[j][e] : 0.f) + (va1[j][e] == p ? vd1[j][e] : 0.f);
+                    }
+                    a4 *= vdr[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float zv = zi[e];
+                        asm volatile("" : "+v"(zv));
+                        const float a_ = fmaf(zv, bn_g[e], bn_b[e]) > 0.f ? a4[e] : 0.f;
+                        const float xh = (zv - bn_mu[e]) * bn_rs[e];
+                        dzv[e] = ok ? bn_g[e] * (a_ - bn_m1[e] - xh * bn_m2[e]) : 0.f;
+                    }
+                    if (ok) *(f32x4*)(bn.dz_out + (size_t)seg0 * C::PXZ * CO + (size_t)4 * i) = dzv;
+                }
+                lds_st128(buf + C::XB + 4u * (unsigned)(pix * C::RSZ + c), dzv);
+            }
+        }
+    };
+
+    int grp = blockIdx.x;
+    request(grp, tid0);
+    __syncthreads();                                            // the zero fill is complete
+    deposit(0u, tid0, grp);
+    __syncthreads();
+    unsigned cur = 0u;
+    for (; grp < n_groups; grp += gridDim.x) {
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        request(grp + gridDim.x, tid);                          // the next group travels while this one is multiplied
+        __builtin_amdgcn_sched_barrier(0);
+        // K steps wk, wk + KSPLIT, ...: the pixel pair 2 s + (lane >> 5); its dz row is linear in s, its x row is not (rows of
+        // the padded plane are XPW pixels apart): two constant divisions per step
+#pragma unroll 2
+        for (int s = wk; s < C::KSTEPS; s += KSPLIT) {
+            const int r = min(2 * s + hf, C::KROWS - 1);        // (the row behind an odd last pixel: dz reads zeros, x anything valid)
+            const int sg = r / C::PXZ, p = r - sg * C::PXZ, y = p / WO, xo = p - y * WO;
+            const unsigned xa = cur + 4u * (unsigned)((sg * C::PXX + y * C::XPW + xo) * C::RSX);
+            const float av = __uint_as_float(lds_ld32(cur + zlane + 4u * (unsigned)(2 * s * C::RSZ)));
+            float bv[C::NTW];
+#pragma unroll
+            for (int j = 0; j < C::NTW; ++j) bv[j] = j < n_own ? __uint_as_float(lds_ld32(xa + noff[j])) : 0.f;
+#pragma unroll
+            for (int j = 0; j < C::NTW; ++j)
+                if (j < n_own) acc[j] = mfma32(av, bv[j], acc[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        deposit(C::BUF - cur, tid, grp + (int)gridDim.x);
+        __syncthreads();
+        cur = C::BUF - cur;
+    }
+    // ---- this workgroup's share of dw
+#pragma unroll
+    for (int j = 0; j < C::NTW; ++j) {
+        const int nt = wn + NSPLIT * j;
+        const int col = 32 * nt + l31;
+        if (nt < C::NTILES && col < 9 * CI) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * wm + NQ_DROW(r, hf);
+                atomicAdd(dw + (size_t)row * (9 * CI) + col, acc[j][r]);
+            }
+        }
+    }
+}
+
+template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT, int NSPLIT, int KSPLIT, int PH = 0, int PW = 0>
+static void segwgrad_f32_launch(hipStream_t st, const float* x, const float* dz, float* dw, int n_segments, segw_bn bn = segw_bn{}) {
+    typedef segwf_cfg<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, NSPLIT, KSPLIT> C;
+    static std::atomic<bool> attr[SC_MAX_DEV];
+    const int dev = sc_device();
+    if (!attr[dev].load(std::memory_order_relaxed)) {
+        (void)hipFuncSetAttribute((const void*)segwgrad_f32_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, NSPLIT, KSPLIT, PH, PW>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+        attr[dev].store(true, std::memory_order_relaxed);
+    }
+    const int n_groups = (n_segments + SEGS - 1) / SEGS;
+    const int grid = n_groups < sc_cu_count() ? n_groups : sc_cu_count();
+    hipLaunchKernelGGL((segwgrad_f32_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, NSPLIT, KSPLIT, PH, PW>), dim3(grid), dim3(512), C::LDS, st,
+                       x, dz, dw, n_segments, bn);
+}
+
+// exact fp32, same five shapes and the same contract as nisqa_segconv_wgrad_bf16 / nisqa_segconv_wgrad_bn_bf16 (z == NULL: dz_out
+// holds dz on entry and nothing is folded; otherwise the BatchNorm backward runs inside and dz_out, dgamma, dbeta are written)
+extern "C" int nisqa_segconv_wgrad_f32(const float* x, const float* z, const float* dy, const int32_t* arg, const float* drop,
+                                       const float* mean_rstd, const float* gamma, const float* beta, const double* sums2,
+                                       float* dz_out, float* dgamma, float* dbeta, float* dw, int32_t n_segments, int32_t h, int32_t w,
+                                       int32_t ci, int32_t co, int32_t pad_w, int32_t ho, int32_t wo, void* stream) {
+    if (!x || !dz_out || !dw || n_segments <= 0 || !nisqa_segconv_supported(h, w, ci, co, pad_w)) return NISQA_ERR_ARG;
+    const bool fold = z != nullptr;
+    if (fold && (!dy || !arg || !mean_rstd || !gamma || !beta || !sums2 || !dgamma || !dbeta)) return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const segw_bn bn = {z, dy, arg, drop, mean_rstd, gamma, beta, sums2, dz_out, dgamma, dbeta};
+    const int key = SC_KEY(h, w, ci, co);
+    NQ_LAUNCH_BEGIN();
+    if (!fold) {
+        if (key == SC_KEY(24, 7, 16, 32)) segwgrad_f32_launch<16, 32, 24, 7, 7, 1, 1, 1, 1, 8>(st, x, dz_out, dw, n_segments);
+        else if (key == SC_KEY(12, 5, 32, 64)) segwgrad_f32_launch<32, 64, 12, 5, 5, 1, 1, 2, 1, 4>(st, x, dz_out, dw, n_segments);
+        else if (key == SC_KEY(12, 5, 64, 64)) segwgrad_f32_launch<64, 64, 12, 5, 5, 1, 1, 2, 2, 2>(st, x, dz_out, dw, n_segments);
+        else if (pad_w == 1) segwgrad_f32_launch<64, 64, 6, 3, 3, 1, 4, 2, 2, 2>(st, x, dz_out, dw, n_segments);
+        else segwgrad_f32_launch<64, 64, 6, 3, 1, 0, 8, 2, 2, 2>(st, x, dz_out, dw, n_segments);
+        return NQ_LAUNCH_STATUS();
+    }
+    if (key == SC_KEY(24, 7, 16, 32) && ho == 12 && wo == 5) segwgrad_f32_launch<16, 32, 24, 7, 7, 1, 1, 1, 1, 8, 12, 5>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(12, 5, 32, 64) && ho == 12 && wo == 5) segwgrad_f32_launch<32, 64, 12, 5, 5, 1, 1, 2, 1, 4, 12, 5>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(12, 5, 64, 64) && ho == 6 && wo == 3) segwgrad_f32_launch<64, 64, 12, 5, 5, 1, 1, 2, 2, 2, 6, 3>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1 && ho == 6 && wo == 3) segwgrad_f32_launch<64, 64, 6, 3, 3, 1, 4, 2, 2, 2, 6, 3>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0 && ho == 6 && wo == 1) segwgrad_f32_launch<64, 64, 6, 3, 1, 0, 8, 2, 2, 2, 6, 1>(st, x, nullptr, dw, n_segments, bn);
+    else return NISQA_ERR_ARG;
+    return NQ_LAUNCH_STATUS();
+}

@@ -108,6 +108,7 @@ TRAIN_SYMBOLS = {
     'nisqa_bn_act_pool_bwd': (ctypes.c_int, [c_p] * 7 + [c_i32] * 6 + [c_p] * 5),
     'nisqa_bn_pool_bwd_sums': (ctypes.c_int, [c_p] * 7 + [c_i32] * 6 + [c_p] * 2),
     'nisqa_segconv_wgrad_bn_bf16': (ctypes.c_int, [c_p] * 13 + [c_i32] * 8 + [c_p]),
+    'nisqa_segconv_wgrad_f32': (ctypes.c_int, [c_p] * 13 + [c_i32] * 8 + [c_p]),
     'nisqa_bn_bwd2': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_layernorm_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
     'nisqa_layernorm_bwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),

@@ -104,6 +104,9 @@ class HipTrainer(object):
         self.fused_bn_bwd = os.environ.get('NISQA_HIP_TRAIN_FUSED_BN_BWD', '1') != '0'
         self.fused_fwd_stats = os.environ.get('NISQA_HIP_TRAIN_FUSED_FWD_STATS', '1') != '0'
         self.fold_bn_wgrad = os.environ.get('NISQA_HIP_TRAIN_FOLD_BN_WGRAD', '1') != '0'
+        # precision 'f32': the weight gradients of layers 2..6 segment-resident on exact fp32 MFMA (csrc/train_conv.hip,
+        # nisqa_segconv_wgrad_f32) instead of the implicit GEMM with split-K atomics
+        self.segconv_f32 = os.environ.get('NISQA_HIP_TRAIN_SEGCONV_F32', '1') != '0' and self.precision == 'f32'
         self._conv_fwd = fast if self.precision == 'bf16x3' else exact
         self._conv_bwd = exact if self.precision == 'f32' else fast
         # split-bf16 forward / input-gradient convolutions segment-resident (csrc/train_conv.hip) where the layer shape is
@@ -737,7 +740,22 @@ class HipTrainer(object):
             dz = self._new(rows, co)
             wk, bk = 'cnn.model.conv%d.weight' % i, 'cnn.model.conv%d.bias' % i
             fold = self.fused_bn_bwd and self.fold_bn_wgrad and i > 1 and (1, i) in self._sc_frags
-            if fold:
+            seg32 = self.segconv_f32 and i > 1 and bool(L_.nisqa_segconv_supported(geo[i - 2][2][0], geo[i - 2][2][1], ci, co, 0 if i == 6 else 1))
+            fold32 = seg32 and self.fused_bn_bwd and self.fold_bn_wgrad
+            if fold32:
+                hi, wi = geo[i - 2][2]
+                s2 = self._sums[self._sum_i]
+                self._sum_i += 1
+                dp = _ptr(c['drop']) if c['drop'] is not None else None
+                self._ck(L_.nisqa_bn_pool_bwd_sums(_ptr(da), c['arg'].data_ptr(), dp, _ptr(c['z']), _ptr(c['mr']), _ptr(g), _ptr(b_), S,
+                                                   c['h'], c['w'], co, c['ho'], c['wo'], s2.data_ptr(), st), 'nisqa_bn_pool_bwd_sums')
+                self._ck(L_.nisqa_segconv_wgrad_f32(_ptr(c['x']), _ptr(c['z']), _ptr(da), c['arg'].data_ptr(), dp, _ptr(c['mr']),
+                                                    _ptr(g), _ptr(b_), s2.data_ptr(), _ptr(dz),
+                                                    _ptr(self.G['cnn.model.bn%d.weight' % i]), _ptr(self.G['cnn.model.bn%d.bias' % i]),
+                                                    _ptr(self.G[wk]), S, hi, wi, ci, co, 0 if i == 6 else 1, c['ho'], c['wo'], st),
+                         'nisqa_segconv_wgrad_f32 (BatchNorm backward inside)')
+                sb = None
+            elif fold:
                 # BatchNorm / ReLU / pool / dropout backward folded into the weight-gradient kernel's staging: the sums over the
                 # pooled values first, then nisqa_segconv_wgrad_bn_bf16 computes dz on the fly (and writes it for the dgrad)
                 hi, wi = geo[i - 2][2]
@@ -783,8 +801,12 @@ class HipTrainer(object):
             else:
                 hi, wi = geo[i - 2][2]
                 pad = 0 if i == 6 else 1
-                if fold:
+                if fold or fold32:
                     pass                                                       # the weight gradient ran with the BatchNorm backward
+                elif seg32:
+                    self._ck(L_.nisqa_segconv_wgrad_f32(_ptr(c['x']), None, None, None, None, None, None, None, None, _ptr(dz), None, None,
+                                                        _ptr(self.G[wk]), S, hi, wi, ci, co, pad, c['ho'], c['wo'], st),
+                             'nisqa_segconv_wgrad_f32')
                 elif (1, i) in self._sc_frags:
                     self._ck(L_.nisqa_segconv_wgrad_bf16(_ptr(c['x']), _ptr(dz), _ptr(self.G[wk]), S, hi, wi, ci, co, pad, st),
                              'nisqa_segconv_wgrad_bf16')

@@ -240,6 +240,60 @@ def test_segment_resident_convolutions_forward_dgrad_wgrad(h, w, ci, co, pad_w, 
     assert L.nisqa_segconv_bf16(1, _p(dz), fr[1].data_ptr(), _p(dx), S, h, w, ci, co, pad_w, _p(b), None, _st()) == 1
 
 
+@pytest.mark.parametrize('S', [1, 9, 37, 300])
+@pytest.mark.parametrize('h,w,ci,co,pad_w,ho,wo', [(24, 7, 16, 32, 1, 12, 5), (12, 5, 32, 64, 1, 12, 5), (12, 5, 64, 64, 1, 6, 3),
+                                                   (6, 3, 64, 64, 1, 6, 3), (6, 3, 64, 64, 0, 6, 1)])
+def test_segment_resident_fp32_weight_gradient_with_and_without_the_batchnorm_backward(h, w, ci, co, pad_w, ho, wo, S):
+    """nisqa_segconv_wgrad_f32 (exact fp32 MFMA, precision mode 'f32'): (i) handed dz, against autograd's weight gradient;
+    (ii) handed z and the pooled gradient (BatchNorm / ReLU / max-pool / Dropout2d backward folded into its staging), against
+    autograd through batch_norm -> relu -> adaptive_max_pool2d -> dropout: dw, dz, dgamma, dbeta.  Segment counts that are
+    not multiples of a group; 300 segments = more groups than a 256-CU grid has workgroups."""
+    lib, L = _L()
+    wc = w + 2 * pad_w - 2                                            # width of the convolution output
+    x = _r(S, h * w, ci, seed=21)
+    dz = _r(S, h * wc, co, seed=22) * 0.1
+    xt = x.view(S, h, w, ci).permute(0, 3, 1, 2).double()
+    wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    F.conv2d(xt, wt, None, padding=(1, pad_w)).backward(dz.view(S, h, wc, co).permute(0, 3, 1, 2).double())
+    want = wt.grad.permute(0, 2, 3, 1).reshape(co, 9 * ci).float()
+    dw = torch.zeros(co, 9 * ci, device=DEV)
+    lib.check(L.nisqa_segconv_wgrad_f32(_p(x), None, None, None, None, None, None, None, None, _p(dz), None, None, _p(dw), S, h, w, ci, co,
+                                        pad_w, ho, wo, _st()), 'wgrad f32')
+    torch.cuda.synchronize()
+    assert (dw - want).abs().max() < 2e-5 * max(1.0, float(want.abs().max()))
+    # (ii) with the BatchNorm backward inside
+    z = (_r(S, h * wc, co, seed=23) * 1.5 + 0.2).requires_grad_(True)
+    gamma, beta = (_r(co, seed=24) * 0.5 + 1).requires_grad_(True), _r(co, seed=25).requires_grad_(True)
+    drop = (torch.rand(S, co, device=DEV) > 0.25).float() / 0.75
+    zn = z.view(S, h, wc, co).permute(0, 3, 1, 2)
+    y_t = F.adaptive_max_pool2d(F.relu(F.batch_norm(zn, None, None, gamma, beta, True, 0.1, 1e-5)), (ho, wo)) * drop[:, :, None, None]
+    dy = _r(S, ho * wo, co, seed=26)
+    (y_t.permute(0, 2, 3, 1).reshape(S, ho * wo, co) * dy).sum().backward()
+    zd = z.detach()
+    sums = torch.zeros(2 * co, dtype=torch.float64, device=DEV)
+    lib.check(L.nisqa_col_dot(_p(zd), _p(zd), S * h * wc, co, sums.data_ptr(), _st()), 'col_dot')
+    yk, arg = torch.empty(S, ho * wo, co, device=DEV), torch.zeros(S, ho * wo, co, dtype=torch.int32, device=DEV)
+    mr, rm, rv = torch.empty(2 * co, device=DEV), torch.zeros(co, device=DEV), torch.ones(co, device=DEV)
+    lib.check(L.nisqa_bn_act_pool_fwd(_p(zd), sums.data_ptr(), _p(gamma), _p(beta), _p(rm), _p(rv), _p(mr), S, h, wc, co, ho, wo, _p(drop),
+                                      _p(yk), arg.data_ptr(), _st()), 'bn fwd')
+    s2 = torch.zeros(2 * co, dtype=torch.float64, device=DEV)
+    lib.check(L.nisqa_bn_pool_bwd_sums(_p(dy), arg.data_ptr(), _p(drop), _p(zd), _p(mr), _p(gamma), _p(beta), S, h, wc, co, ho, wo,
+                                       s2.data_ptr(), _st()), 'sums')
+    for entry in ('nisqa_segconv_wgrad_f32', 'nisqa_segconv_wgrad_bn_bf16'):
+        dz2, dg, db, dw2 = torch.empty(S, h * wc, co, device=DEV), torch.empty(co, device=DEV), torch.empty(co, device=DEV), torch.zeros(co, 9 * ci, device=DEV)
+        lib.check(getattr(L, entry)(_p(x), _p(zd), _p(dy), arg.data_ptr(), _p(drop), _p(mr), _p(gamma), _p(beta), s2.data_ptr(), _p(dz2),
+                                    _p(dg), _p(db), _p(dw2), S, h, w, ci, co, pad_w, ho, wo, _st()), entry)
+        torch.cuda.synchronize()
+        assert (dz2 - z.grad).abs().max() < 2e-4 * max(1.0, float(z.grad.abs().max())), entry
+        assert (dg - gamma.grad).abs().max() < 2e-4 * max(1.0, float(gamma.grad.abs().max())), entry
+        assert (db - beta.grad).abs().max() < 2e-4 * max(1.0, float(beta.grad.abs().max())), entry
+        wt2 = torch.zeros(co, ci, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+        F.conv2d(xt, wt2, None, padding=(1, pad_w)).backward(z.grad.view(S, h, wc, co).permute(0, 3, 1, 2).double())
+        want2 = wt2.grad.permute(0, 2, 3, 1).reshape(co, 9 * ci).float()
+        tol = (2e-4 if entry.endswith('f32') else 5e-4) * max(1.0, float(want2.abs().max()))
+        assert (dw2 - want2).abs().max() < tol, (entry, float((dw2 - want2).abs().max()), float(want2.abs().max()))
+
+
 def test_im2col_mel_segments_and_floor():
     lib, L = _L()
     T = [40, 15]
