@@ -112,6 +112,16 @@ int nisqa_segconv_pack_many(int32_t n_jobs, const int32_t* modes, const float* c
                             uint16_t* const* frags, void* stream);
 int nisqa_segconv_bf16(int32_t mode, const float* src, const uint16_t* frags, float* out, int32_t n_segments, int32_t h,
                        int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c, void* stream);
+/* The same two products in EXACT fp32 (v_mfma_f32_32x32x2_f32; fp32 planes in LDS, fp32 fragments): the forward convolutions of
+ * the precision modes 'f32' and 'mixed' and the input gradients of 'f32'.  The implicit GEMMs (nisqa_conv3x3_gemm) reach the
+ * fp32-MFMA peak on none of these shapes but the 64 -> 64 one at 12 x 5 (narrow outputs, gathers per K-tile); here every
+ * activation is fetched once.  nisqa_segconv_frag_bytes_f32 / nisqa_segconv_pack_f32_many / nisqa_segconv_f32 mirror
+ * nisqa_segconv_frag_bytes / nisqa_segconv_pack_many / nisqa_segconv_bf16 argument for argument (frags are floats). */
+int64_t nisqa_segconv_frag_bytes_f32(int32_t mode, int32_t ci, int32_t co);
+int nisqa_segconv_pack_f32_many(int32_t n_jobs, const int32_t* modes, const float* const* w, const int32_t* ci, const int32_t* co,
+                                float* const* frags, void* stream);
+int nisqa_segconv_f32(int32_t mode, const float* src, const float* frags, float* out, int32_t n_segments, int32_t h, int32_t w,
+                      int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c, void* stream);
 /* Weight gradient of the same layers, segment-resident: dw[co][9*ci] += dz^T * patches(x) (dw zeroed by the caller, like
  * nisqa_conv3x3_gemm mode 2); x[S][h*w][ci], dz[S][h*wo][co].  A workgroup keeps its part of dw in registers over all the
  * segments it walks over and adds it to dw once (fp32 atomics). */

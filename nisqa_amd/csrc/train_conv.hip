@@ -144,28 +144,110 @@ extern "C" int nisqa_segconv_pack_many(int32_t n_jobs, const int32_t* modes, con
     return NQ_LAUNCH_STATUS();
 }
 
+// ---- exact fp32 variant (precision modes 'f32' and 'mixed' forward, 'f32' input gradient): the same kernel with fp32 planes
+// (pixel rows of CIN floats padded by 16 bytes: a lane group of a ds_read_b128 lands on 16 distinct 16-byte slots for CIN =
+// 16, 32, 64), v_mfma_f32_32x32x2_f32 and fp32 fragments [step g = (tap, 8-channel group)][NT][64 lanes][4]: lane l holds
+// column n = 32 nt + (l & 31) and reduction channels 8 (g % S8) + 4 (l >> 5) .. + 3 of that tap.  A K-step is 8 channels =
+// 4 MFMAs per (M tile, N tile): one ds_read_b128 per M tile, one 16-byte buffer load per N tile.
+#define SCF_ZADDR 4096u                    /* 256-byte zero block above the largest tap offset ((2 W + 2) rows of 272 bytes) */
+#define SCF_BASE 4352u
+template <int CIN, int MT, int NT, int W, int RS, unsigned ZADDR, int RING>
+NQ_DEV void conv_k_f32(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, unsigned lane16, const unsigned (&base)[MT],
+                       const unsigned (&m9)[MT]) {
+    constexpr int S8 = CIN / 8, TOTAL = 9 * S8;
+    static_assert(ZADDR >= (2 * W + 2) * RS + 32 * S8, "zero block must sit above the largest tap offset");
+    f32x4 b[RING][NT], a[2][MT];
+    unsigned a_ad[MT];
+    auto load_b = [&](int g, int slot) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[slot][nt] = wfrag_load(rsrc, lane16, (g * NT + nt) * 1024);
+    };
+    auto load_a = [&](int g, int slot) {
+        const int tap = g / S8, s = g - tap * S8;
+        const int tapoff = ((tap / 3) * W + tap % 3) * RS;
+        if (s == 0) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a_ad[t] = ((m9[t] >> tap) & 1u) ? base[t] : ZADDR - tapoff;
+        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t) a[slot][t] = lds_ld128(a_ad[t] + tapoff + 32 * s);
+    };
+#pragma unroll
+    for (int g = 0; g < RING - 1; ++g) load_b(g, g);
+    load_a(0, 0);
+#pragma unroll
+    for (int g = 0; g < TOTAL; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + RING - 1 < TOTAL) load_b(g + RING - 1, (g + RING - 1) % RING);
+        if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1);
+        const int sa = g & 1, sb = g % RING;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma32(a[sa][t][kk], b[sb][nt][kk], acc[t][nt]);
+    }
+}
+
+struct segconv_pack_f32_jobs { const float* w[10]; float* out[10]; int ci[10], co[10], mode[10]; };
+__global__ __launch_bounds__(256) void segconv_pack_f32_many_kernel(segconv_pack_f32_jobs jobs) {
+    const int j = blockIdx.y;
+    const float* __restrict__ w = jobs.w[j];
+    float* __restrict__ out = jobs.out[j];
+    const int ci = jobs.ci[j], co = jobs.co[j], mode = jobs.mode[j];
+    const int kc = mode ? co : ci, n_real = mode ? ci : co;
+    const int s8 = kc / 8, nt_n = (n_real + 31) / 32;
+    const int total = 9 * s8 * nt_n * 256;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int kk = i & 3, lane = (i >> 2) & 63, nt = (i >> 8) % nt_n, g = (i >> 8) / nt_n;
+        const int tap = g / s8, c = 8 * (g % s8) + 4 * (lane >> 5) + kk, n = 32 * nt + (lane & 31);
+        float v = 0.f;
+        if (n < n_real) v = mode ? w[(size_t)c * (9 * ci) + (8 - tap) * ci + n] : w[(size_t)n * (9 * ci) + tap * ci + c];
+        out[i] = v;
+    }
+}
+extern "C" int64_t nisqa_segconv_frag_bytes_f32(int32_t mode, int32_t ci, int32_t co) {
+    if (mode < 0 || mode > 1 || ci < 16 || co < 16 || (ci & 15) || (co & 15)) return -1;
+    const int kc = mode ? co : ci, n_real = mode ? ci : co;
+    return (int64_t)9 * (kc / 8) * ((n_real + 31) / 32) * 1024;
+}
+extern "C" int nisqa_segconv_pack_f32_many(int32_t n_jobs, const int32_t* modes, const float* const* w, const int32_t* ci,
+                                           const int32_t* co, float* const* frags, void* stream) {
+    if (n_jobs < 1 || n_jobs > 10 || !modes || !w || !ci || !co || !frags) return NISQA_ERR_ARG;
+    segconv_pack_f32_jobs jobs = {};
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!w[j] || !frags[j] || nisqa_segconv_frag_bytes_f32(modes[j], ci[j], co[j]) < 0) return NISQA_ERR_ARG;
+        jobs.w[j] = w[j]; jobs.out[j] = frags[j]; jobs.ci[j] = ci[j]; jobs.co[j] = co[j]; jobs.mode[j] = modes[j];
+    }
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(segconv_pack_f32_many_kernel, dim3(36, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return NQ_LAUNCH_STATUS();
+}
+
 // CIN: channels of the staged tensor (the reduction runs over 9 x CIN); NT: 32-column tiles of the output channels
 // HR x WR: output pixels of a segment (the rows); HS x WS: pixels of the staged tensor; source pixel of row (y, x) and
 // tap (ty, tx) is (y + ty - 1, x + tx - PADX)
-template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD>
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false>
 struct segconv_cfg {
-    static constexpr int RS = 2 * CIN + 16;
+    static constexpr int RS = F32 ? 4 * CIN + 16 : 2 * CIN + 16;
     static constexpr int PXS = HS * WS, PXR = HR * WR;
     static constexpr int PLANE = SEGS * PXS * RS;
-    static constexpr unsigned LDS = SC_BASE + 2 * PLANE;
+    static constexpr unsigned BASE = F32 ? SCF_BASE : SC_BASE, ZADDR = F32 ? SCF_ZADDR : SC_ZADDR;
+    static constexpr unsigned LDS = F32 ? BASE + PLANE : BASE + 2 * PLANE;
     static constexpr int ROWS = SEGS * PXR;
     static constexpr int F4 = SEGS * PXS * CIN / 4;          // 128-bit groups of the workgroup's activations
     static constexpr int NV = (F4 + 255) / 256;
     static_assert(ROWS <= 4 * MT * 32, "rows of the workgroup's segments must fit its tiles");
-    static_assert(SC_BASE >= (unsigned)((WS + PADX) * RS), "tap (-1, -PADX) of pixel 0 must not address below 0");
+    static_assert(BASE >= (unsigned)((WS + PADX) * RS), "tap (-1, -PADX) of pixel 0 must not address below 0");
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
 };
 
-template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD>
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false>
 __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
     const float* __restrict__ src, const unsigned short* __restrict__ frags, float* __restrict__ out, int n_segments,
     const float* __restrict__ bias, double* __restrict__ stats) {
-    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD> C;
+    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid0 = threadIdx.x, lane0 = tid0 & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -186,11 +268,11 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
             m |= (valid && (unsigned)ys < (unsigned)HS && (unsigned)xs < (unsigned)WS) ? (1u << tap) : 0u;
         }
         m9[t] = m;
-        base[t] = valid ? SC_BASE + (unsigned)(((sg * HS + y - 1) * WS + (x - PADX)) * C::RS) + 16u * (lane0 >> 5)
-                        : SC_BASE + 16u * (lane0 >> 5);
+        base[t] = valid ? C::BASE + (unsigned)(((sg * HS + y - 1) * WS + (x - PADX)) * C::RS) + 16u * (lane0 >> 5)
+                        : C::BASE + 16u * (lane0 >> 5);
     }
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)frags, 0, 9 * (CIN / 16) * NT * 2048, 0x00020000);
-    if (tid0 < 32) *(unsigned*)(smem + SC_ZADDR + 4 * tid0) = 0u;  // through the symbol: the kernel must be seen to use LDS
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)frags, 0, F32 ? 9 * (CIN / 8) * NT * 1024 : 9 * (CIN / 16) * NT * 2048, 0x00020000);
+    if (tid0 < (F32 ? 64 : 32)) *(unsigned*)(smem + C::ZADDR + 4 * tid0) = 0u;  // through the symbol: the kernel must be seen to use LDS
     const bool with_stats = FWD && stats != nullptr;
     double s1[NT], s2[NT];                                       // this lane's column sums over all groups of the workgroup
     float bv[NT];
@@ -238,6 +320,10 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
                 const int i = tid + 256 * j;
                 if (C::F4 % 256 == 0 || i < C::F4) {
                     const int pix = (4 * i) / CIN, c = (4 * i) % CIN;
+                    if (F32) {
+                        lds_st128(C::BASE + pix * C::RS + 4 * c, v[j]);
+                        continue;
+                    }
                     const unsigned a = SC_BASE + pix * C::RS + 2 * c;
                     const unsigned h0 = cvt_pk_bf16(v[j][0], v[j][1]), h1 = cvt_pk_bf16(v[j][2], v[j][3]);
                     const unsigned l0 = cvt_pk_bf16(v[j][0] - __uint_as_float(h0 << 16), v[j][1] - __uint_as_float(h0 & 0xffff0000u));
@@ -272,7 +358,10 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
         for (int t = 0; t < MT; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[t][nt] = zero16();
-        if (active) conv_k_bf16<CIN, MT, NT, WS, C::RS, C::PLANE, SC_ZADDR, (MT * NT <= 4), SC_RING>(acc, rsrc, 0, lane0 * 16, base, m9);
+        if (active) {
+            if constexpr (F32) conv_k_f32<CIN, MT, NT, WS, C::RS, C::ZADDR, SC_RING>(acc, rsrc, lane0 * 16, base, m9);
+            else conv_k_bf16<CIN, MT, NT, WS, C::RS, C::PLANE, SC_ZADDR, (MT * NT <= 4), SC_RING>(acc, rsrc, 0, lane0 * 16, base, m9);
+        }
 
         SC_CLK(4);                                              // K loop
         // the next group's real loads go out BEFORE this group's output stores (they would queue behind 64 stores per lane
@@ -315,7 +404,7 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
 
     // ---- BatchNorm statistics of the workgroup's rows: lane pairs, the four waves through LDS, one atomic per channel
     if (with_stats) {
-        double* red = (double*)(smem + SC_BASE);
+        double* red = (double*)(smem + C::BASE);
         __syncthreads();                                        // the planes are dead
         for (int q = tid0; q < 2 * 32 * NT; q += 256) red[q] = 0.0;
         __syncthreads();
@@ -359,19 +448,19 @@ static int sc_cu_count() {
     return v;
 }
 
-template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD>
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false>
 static void segconv_launch(hipStream_t st, const float* src, const uint16_t* frags, float* out, int n_segments,
                            const float* bias, double* stats) {
-    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD> C;
+    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32> C;
     static std::atomic<int> per_cu_dev[SC_MAX_DEV];             // resident workgroups per CU (registers and LDS), asked once per device
     const int dev = sc_device();
     int per_cu = per_cu_dev[dev].load(std::memory_order_relaxed);
     if (!per_cu) {
         // 50-80 KB of dynamic LDS: opt in explicitly (a runtime that enforces the 64 KB default would refuse the launch)
-        (void)hipFuncSetAttribute((const void*)segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD>,
+        (void)hipFuncSetAttribute((const void*)segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD>, 256,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32>, 256,
                                                          C::LDS) != hipSuccess || nb < 1)
             nb = 2;
         per_cu = nb;
@@ -379,7 +468,7 @@ static void segconv_launch(hipStream_t st, const float* src, const uint16_t* fra
     }
     const int n_groups = (n_segments + SEGS - 1) / SEGS;
     const int grid = n_groups < per_cu * sc_cu_count() ? n_groups : per_cu * sc_cu_count();
-    hipLaunchKernelGGL((segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD>), dim3(grid), dim3(256), C::LDS, st, src,
+    hipLaunchKernelGGL((segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32>), dim3(grid), dim3(256), C::LDS, st, src,
                        frags, out, n_segments, bias, stats);
 }
 
@@ -416,6 +505,35 @@ extern "C" int nisqa_segconv_bf16(int32_t mode, const float* src, const uint16_t
         else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, false>(st, src, frags, out, n, nullptr, nullptr);
         else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 14, 2, false>(st, src, frags, out, n, nullptr, nullptr);
         else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 3, 6, 1, 2, 14, 2, false>(st, src, frags, out, n, nullptr, nullptr);
+        else return NISQA_ERR_ARG;
+    }
+    return NQ_LAUNCH_STATUS();
+}
+
+// the same two products in exact fp32 (frags = nisqa_segconv_pack_f32_many of the same mode)
+extern "C" int nisqa_segconv_f32(int32_t mode, const float* src, const float* frags, float* out, int32_t n_segments, int32_t h,
+                                 int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c, void* stream) {
+    if (mode < 0 || mode > 1 || !src || !frags || !out || n_segments <= 0 || (mode == 1 && (bias || stats2c)) ||
+        !nisqa_segconv_supported(h, w, ci, co, pad_w))
+        return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const uint16_t* fr = (const uint16_t*)frags;
+    NQ_LAUNCH_BEGIN();
+    const int key = ((h * 100 + w) * 100 + ci) * 100 + co;
+    const int n = n_segments;
+    if (mode == 0) {
+        if (key == SC_KEY(24, 7, 16, 32) && pad_w == 1) segconv_launch<16, 1, 32, 24, 7, 24, 7, 1, 3, 4, true, true>(st, src, fr, out, n, bias, stats2c);
+        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<32, 2, 64, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, true, true>(st, src, fr, out, n, bias, stats2c);
+        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, true, true>(st, src, fr, out, n, bias, stats2c);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 14, 2, true, true>(st, src, fr, out, n, bias, stats2c);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 1, 6, 3, 0, 15, 1, true, true>(st, src, fr, out, n, bias, stats2c);
+        else return NISQA_ERR_ARG;
+    } else {
+        if (key == SC_KEY(24, 7, 16, 32) && pad_w == 1) segconv_launch<32, 1, 16, 24, 7, 24, 7, 1, 2, 3, false, true>(st, src, fr, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<64, 1, 32, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, false, true>(st, src, fr, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, false, true>(st, src, fr, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 14, 2, false, true>(st, src, fr, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 3, 6, 1, 2, 14, 2, false, true>(st, src, fr, out, n, nullptr, nullptr);
         else return NISQA_ERR_ARG;
     }
     return NQ_LAUNCH_STATUS();
@@ -964,18 +1082,33 @@ __global__ __launch_bounds__(512, 1) void segwgrad_f32_kernel(const float* __res
         __builtin_amdgcn_sched_barrier(0);
         // K steps wk, wk + KSPLIT, ...: the pixel pair 2 s + (lane >> 5); its dz row is linear in s, its x row is not (rows of
         // the padded plane are XPW pixels apart): two constant divisions per step
-#pragma unroll 2
-        for (int s = wk; s < C::KSTEPS; s += KSPLIT) {
+        constexpr int NFULL = C::NTILES / NSPLIT;               // tiles every wave owns: no guard around their MFMAs (only a last, odd one)
+        float av[2], bv[2][C::NTW];
+        auto fetch = [&](int s, int slot) {                      // operands of K step s (one dword per lane and MFMA)
             const int r = min(2 * s + hf, C::KROWS - 1);        // (the row behind an odd last pixel: dz reads zeros, x anything valid)
             const int sg = r / C::PXZ, p = r - sg * C::PXZ, y = p / WO, xo = p - y * WO;
             const unsigned xa = cur + 4u * (unsigned)((sg * C::PXX + y * C::XPW + xo) * C::RSX);
-            const float av = __uint_as_float(lds_ld32(cur + zlane + 4u * (unsigned)(2 * s * C::RSZ)));
-            float bv[C::NTW];
+            av[slot] = __uint_as_float(lds_ld32(cur + zlane + 4u * (unsigned)(2 * s * C::RSZ)));
 #pragma unroll
-            for (int j = 0; j < C::NTW; ++j) bv[j] = j < n_own ? __uint_as_float(lds_ld32(xa + noff[j])) : 0.f;
+            for (int j = 0; j < C::NTW; ++j) bv[slot][j] = (j < NFULL || j < n_own) ? __uint_as_float(lds_ld32(xa + noff[j])) : 0.f;
+        };
+        fetch(wk, 0);
+        int s = wk;
+        // two steps per trip so that the operand slots are compile-time; the next step's reads are issued ahead of this step's MFMAs
+        for (; s + KSPLIT < C::KSTEPS; s += 2 * KSPLIT) {
+            fetch(s + KSPLIT, 1);
 #pragma unroll
             for (int j = 0; j < C::NTW; ++j)
-                if (j < n_own) acc[j] = mfma32(av, bv[j], acc[j]);
+                if (j < NFULL || j < n_own) acc[j] = mfma32(av[0], bv[0][j], acc[j]);
+            if (s + 2 * KSPLIT < C::KSTEPS) fetch(s + 2 * KSPLIT, 0);
+#pragma unroll
+            for (int j = 0; j < C::NTW; ++j)
+                if (j < NFULL || j < n_own) acc[j] = mfma32(av[1], bv[1][j], acc[j]);
+        }
+        if (s < C::KSTEPS) {                                     // an odd number of steps: the last one sits in slot 0
+#pragma unroll
+            for (int j = 0; j < C::NTW; ++j)
+                if (j < NFULL || j < n_own) acc[j] = mfma32(av[0], bv[0][j], acc[j]);
         }
         __builtin_amdgcn_sched_barrier(0);
         deposit(C::BUF - cur, tid, grp + (int)gridDim.x);
@@ -1028,17 +1161,17 @@ extern "C" int nisqa_segconv_wgrad_f32(const float* x, const float* z, const flo
     NQ_LAUNCH_BEGIN();
     if (!fold) {
         if (key == SC_KEY(24, 7, 16, 32)) segwgrad_f32_launch<16, 32, 24, 7, 7, 1, 1, 1, 1, 8>(st, x, dz_out, dw, n_segments);
-        else if (key == SC_KEY(12, 5, 32, 64)) segwgrad_f32_launch<32, 64, 12, 5, 5, 1, 1, 2, 1, 4>(st, x, dz_out, dw, n_segments);
-        else if (key == SC_KEY(12, 5, 64, 64)) segwgrad_f32_launch<64, 64, 12, 5, 5, 1, 1, 2, 2, 2>(st, x, dz_out, dw, n_segments);
-        else if (pad_w == 1) segwgrad_f32_launch<64, 64, 6, 3, 3, 1, 4, 2, 2, 2>(st, x, dz_out, dw, n_segments);
-        else segwgrad_f32_launch<64, 64, 6, 3, 1, 0, 8, 2, 2, 2>(st, x, dz_out, dw, n_segments);
+        else if (key == SC_KEY(12, 5, 32, 64)) segwgrad_f32_launch<32, 64, 12, 5, 5, 1, 1, 2, 2, 2>(st, x, dz_out, dw, n_segments);
+        else if (key == SC_KEY(12, 5, 64, 64)) segwgrad_f32_launch<64, 64, 12, 5, 5, 1, 1, 2, 4, 1>(st, x, dz_out, dw, n_segments);
+        else if (pad_w == 1) segwgrad_f32_launch<64, 64, 6, 3, 3, 1, 4, 2, 4, 1>(st, x, dz_out, dw, n_segments);
+        else segwgrad_f32_launch<64, 64, 6, 3, 1, 0, 8, 2, 4, 1>(st, x, dz_out, dw, n_segments);
         return NQ_LAUNCH_STATUS();
     }
     if (key == SC_KEY(24, 7, 16, 32) && ho == 12 && wo == 5) segwgrad_f32_launch<16, 32, 24, 7, 7, 1, 1, 1, 1, 8, 12, 5>(st, x, nullptr, dw, n_segments, bn);
-    else if (key == SC_KEY(12, 5, 32, 64) && ho == 12 && wo == 5) segwgrad_f32_launch<32, 64, 12, 5, 5, 1, 1, 2, 1, 4, 12, 5>(st, x, nullptr, dw, n_segments, bn);
-    else if (key == SC_KEY(12, 5, 64, 64) && ho == 6 && wo == 3) segwgrad_f32_launch<64, 64, 12, 5, 5, 1, 1, 2, 2, 2, 6, 3>(st, x, nullptr, dw, n_segments, bn);
-    else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1 && ho == 6 && wo == 3) segwgrad_f32_launch<64, 64, 6, 3, 3, 1, 4, 2, 2, 2, 6, 3>(st, x, nullptr, dw, n_segments, bn);
-    else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0 && ho == 6 && wo == 1) segwgrad_f32_launch<64, 64, 6, 3, 1, 0, 8, 2, 2, 2, 6, 1>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(12, 5, 32, 64) && ho == 12 && wo == 5) segwgrad_f32_launch<32, 64, 12, 5, 5, 1, 1, 2, 2, 2, 12, 5>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(12, 5, 64, 64) && ho == 6 && wo == 3) segwgrad_f32_launch<64, 64, 12, 5, 5, 1, 1, 2, 4, 1, 6, 3>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1 && ho == 6 && wo == 3) segwgrad_f32_launch<64, 64, 6, 3, 3, 1, 4, 2, 4, 1, 6, 3>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0 && ho == 6 && wo == 1) segwgrad_f32_launch<64, 64, 6, 3, 1, 0, 8, 2, 4, 1, 6, 1>(st, x, nullptr, dw, n_segments, bn);
     else return NISQA_ERR_ARG;
     return NQ_LAUNCH_STATUS();
 }

@@ -98,6 +98,9 @@ TRAIN_SYMBOLS = {
     'nisqa_segconv_pack': (ctypes.c_int, [c_i32, c_p, c_i32, c_i32, c_p, c_p]),
     'nisqa_segconv_pack_many': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nisqa_segconv_bf16': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
+    'nisqa_segconv_frag_bytes_f32': (ctypes.c_int64, [c_i32, c_i32, c_i32]),
+    'nisqa_segconv_pack_f32_many': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'nisqa_segconv_f32': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_segconv_wgrad_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     'nisqa_col2im3x3': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     'nisqa_col_dot': (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_p]),

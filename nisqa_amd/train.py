@@ -107,6 +107,10 @@ class HipTrainer(object):
         # precision 'f32': the weight gradients of layers 2..6 segment-resident on exact fp32 MFMA (csrc/train_conv.hip,
         # nisqa_segconv_wgrad_f32) instead of the implicit GEMM with split-K atomics
         self.segconv_f32 = os.environ.get('NISQA_HIP_TRAIN_SEGCONV_F32', '1') != '0' and self.precision == 'f32'
+        # ... and the fp32 FORWARD convolutions of 'f32' and 'mixed' / the fp32 input gradients of 'f32' segment-resident too
+        # (nisqa_segconv_f32) instead of the implicit GEMMs
+        self.segconv_f32_fwd = os.environ.get('NISQA_HIP_TRAIN_SEGCONV_F32_FWD', '1') != '0' and self.precision in ('f32', 'mixed')
+        self._sc32_frags, self._sc32_bufs = {}, {}
         self._conv_fwd = fast if self.precision == 'bf16x3' else exact
         self._conv_bwd = exact if self.precision == 'f32' else fast
         # split-bf16 forward / input-gradient convolutions segment-resident (csrc/train_conv.hip) where the layer shape is
@@ -226,7 +230,27 @@ class HipTrainer(object):
         """Weight fragments of this step for every layer / direction csrc/train_conv.hip takes (mode 0 forward -- 'bf16x3'
         only --, mode 1 input gradient): ONE launch (nisqa_segconv_pack_many).  self._sc_frags[(mode, i)] is absent where the
         layer shape is not instantiated; the implicit GEMM stays there."""
-        self._sc_frags = {}
+        self._sc_frags, self._sc32_frags = {}, {}
+        if self.segconv_f32_fwd:                                # fp32 fragments: forward ('f32', 'mixed'), input gradient ('f32')
+            jobs = []
+            for i in range(2, 7):
+                ci, co = _CONV[i - 1]
+                hi, wi = geo[i - 2][2]
+                if not self.lib.nisqa_segconv_supported(hi, wi, ci, co, 0 if i == 6 else 1):
+                    continue
+                for mode in ((0, 1) if self.precision == 'f32' else (0,)):
+                    buf = self._sc32_bufs.get((mode, i))
+                    if buf is None:
+                        buf = self._sc32_bufs[(mode, i)] = torch.empty(self.lib.nisqa_segconv_frag_bytes_f32(mode, ci, co) // 4,
+                                                                       dtype=torch.float32, device=self.device)
+                    jobs.append((mode, self.P['cnn.model.conv%d.weight' % i].data_ptr(), ci, co, buf.data_ptr()))
+                    self._sc32_frags[(mode, i)] = buf
+            if jobs:
+                n = len(jobs)
+                arr_i = lambda k: (ctypes.c_int32 * n)(*[j[k] for j in jobs])
+                arr_p = lambda k: (ctypes.c_void_p * n)(*[j[k] for j in jobs])
+                self._ck(self.lib.nisqa_segconv_pack_f32_many(n, arr_i(0), arr_p(1), arr_i(2), arr_i(3), arr_p(4), self._st()),
+                         'nisqa_segconv_pack_f32_many')
         if not self.segconv:
             return
         jobs = []
@@ -686,7 +710,16 @@ class HipTrainer(object):
             else:                                                              # implicit GEMM: patches gathered by the loaders
                 hi, wi = geo[i - 2][2]
                 fr = self._sc_frags.get((0, i))
-                if fr is not None:
+                fr32 = self._sc32_frags.get((0, i))
+                if fr is None and fr32 is not None:                              # exact fp32, segment-resident
+                    sums = None
+                    if self.fused_fwd_stats:
+                        sums = self._sums[self._sum_i]
+                        self._sum_i += 1
+                    self._ck(L_.nisqa_segconv_f32(0, _ptr(act), _ptr(fr32), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
+                                                  _ptr(self.P[bk]), sums.data_ptr() if sums is not None else None, st),
+                             'nisqa_segconv_f32 fwd')
+                elif fr is not None:
                     sums = None
                     if self.fused_fwd_stats:
                         sums = self._sums[self._sum_i]
@@ -815,7 +848,11 @@ class HipTrainer(object):
                                             self._ksplit(rows, co, 9 * ci), st), 'nisqa_conv3x3_gemm wgrad')
                 da = self._new(S, hi * wi, ci)
                 fr = self._sc_frags.get((1, i))
-                if fr is not None:
+                fr32 = self._sc32_frags.get((1, i))
+                if fr is None and fr32 is not None:
+                    self._ck(L_.nisqa_segconv_f32(1, _ptr(dz), _ptr(fr32), _ptr(da), S, hi, wi, ci, co, pad, None, None, st),
+                             'nisqa_segconv_f32 dgrad')
+                elif fr is not None:
                     self._ck(L_.nisqa_segconv_bf16(1, _ptr(dz), fr.data_ptr(), _ptr(da), S, hi, wi, ci, co, pad, None, None, st),
                              'nisqa_segconv_bf16 dgrad')
                 else:

@@ -3,6 +3,7 @@
 Operators are checked one by one against plain PyTorch fp32 (autograd for the backward passes), the whole step against
 the fixtures written by the reference's own modules in train mode (tests/golden/make_golden_train.py) and against
 the oracle restatement (oracle/train.py) with explicit dropout masks and the bias-mapped loss."""
+import ctypes
 import math
 import os
 import sys
@@ -292,6 +293,44 @@ def test_segment_resident_fp32_weight_gradient_with_and_without_the_batchnorm_ba
         want2 = wt2.grad.permute(0, 2, 3, 1).reshape(co, 9 * ci).float()
         tol = (2e-4 if entry.endswith('f32') else 5e-4) * max(1.0, float(want2.abs().max()))
         assert (dw2 - want2).abs().max() < tol, (entry, float((dw2 - want2).abs().max()), float(want2.abs().max()))
+
+
+@pytest.mark.parametrize('S', [1, 14, 37, 61, 600])
+@pytest.mark.parametrize('h,w,ci,co,pad_w', [(24, 7, 16, 32, 1), (12, 5, 32, 64, 1), (12, 5, 64, 64, 1), (6, 3, 64, 64, 1), (6, 3, 64, 64, 0)])
+def test_segment_resident_fp32_convolutions_forward_and_input_gradient(h, w, ci, co, pad_w, S):
+    """nisqa_segconv_f32 (exact fp32 MFMA, segment-resident; the forward convolutions of 'f32' / 'mixed' and the input gradient
+    of 'f32') against float64 autograd: z (+ bias), the BatchNorm sums riding along, dx; segment counts that are not multiples
+    of a group and more groups than one resident round of workgroups."""
+    lib, L = _L()
+    wo = w + 2 * pad_w - 2
+    x, wt, b = _r(S, h * w, ci, seed=71), _r(co, ci, 3, 3, seed=72) * 0.2, _r(co, seed=73)
+    xd = x.double().view(S, h, w, ci).permute(0, 3, 1, 2).requires_grad_(True)
+    z_t = F.conv2d(xd, wt.double(), b.double(), padding=(1, pad_w))
+    dz = _r(S, h * wo, co, seed=74)
+    (z_t.permute(0, 2, 3, 1).reshape(S, h * wo, co) * dz.double()).sum().backward()
+    wk = wt.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+    fr = []
+    for mode in (0, 1):
+        nb = L.nisqa_segconv_frag_bytes_f32(mode, ci, co)
+        assert nb > 0
+        fr.append(torch.empty(nb // 4, device=DEV))
+    n = 2
+    lib.check(L.nisqa_segconv_pack_f32_many(n, (ctypes.c_int32 * n)(0, 1), (ctypes.c_void_p * n)(wk.data_ptr(), wk.data_ptr()),
+                                            (ctypes.c_int32 * n)(ci, ci), (ctypes.c_int32 * n)(co, co),
+                                            (ctypes.c_void_p * n)(fr[0].data_ptr(), fr[1].data_ptr()), _st()), 'pack f32')
+    z = torch.full((S * h * wo, co), float('nan'), device=DEV)
+    st2 = torch.zeros(2 * co, dtype=torch.float64, device=DEV)
+    lib.check(L.nisqa_segconv_f32(0, _p(x), _p(fr[0]), _p(z), S, h, w, ci, co, pad_w, _p(b), st2.data_ptr(), _st()), 'segconv f32 fwd')
+    dx = torch.full((S, h * w, ci), float('nan'), device=DEV)
+    lib.check(L.nisqa_segconv_f32(1, _p(dz), _p(fr[1]), _p(dx), S, h, w, ci, co, pad_w, None, None, _st()), 'segconv f32 dgrad')
+    torch.cuda.synchronize()
+    want_z = z_t.detach().permute(0, 2, 3, 1).reshape(S * h * wo, co)
+    want_dx = xd.grad.permute(0, 2, 3, 1).reshape(S, h * w, ci)
+    assert (z.double() - want_z).abs().max() < 2e-6 * max(1.0, float(want_z.abs().max())) * math.sqrt(9 * ci)
+    assert (dx.double() - want_dx).abs().max() < 2e-6 * max(1.0, float(want_dx.abs().max())) * math.sqrt(9 * co)
+    assert (st2[:co] - z.double().sum(0)).abs().max() < 1e-9 * max(1.0, float(z.abs().sum()))
+    assert (st2[co:] - (z.double() ** 2).sum(0)).abs().max() < 1e-9 * max(1.0, float((z.double() ** 2).sum()))
+    assert L.nisqa_segconv_f32(1, _p(dz), _p(fr[1]), _p(dx), S, h, w, ci, co, pad_w, _p(b), None, _st()) == lib.NISQA_ERR_ARG
 
 
 def test_im2col_mel_segments_and_floor():
