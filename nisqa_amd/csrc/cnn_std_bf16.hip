@@ -38,6 +38,48 @@ NQ_DEV float row16_sum_dpp(float v) {
     return v;
 }
 
+// conv2's K loop, second generation (round 4; before: the generic-pointer conv3x3_bf16 with per-tap bounds / swizzle / row
+// arithmetic on every tile).  Its input planes are the chunk-swizzled 16-channel A1 planes conv1 writes (32 bytes per pixel,
+// 16-byte chunk (c >> 3) ^ (image row & 1) at W = 8), so a tap's address is one of TWO lane-static bases -- the centre
+// pixel's chunk for taps in its own image row, the flipped chunk for the rows above and below -- plus a compile-time tap
+// offset; validity is a lane-static 9-bit mask, out-of-image taps read the workgroup's zero block, fragments come through
+// the buffer descriptor.  One K-step per tap (16 channels), A rows one tap ahead, B fragments two.
+template <int MT>
+NQ_DEV void conv_k_bf16_c16(f32x16 (&acc)[MT][1], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
+                            const unsigned (&a_same)[MT], const unsigned (&a_flip)[MT], const unsigned (&m9)[MT]) {
+    f32x4 bh[3], bl[3], ah[2][MT], al[2][MT];
+    auto load_b = [&](int g, int slot) {
+        bh[slot] = wfrag_load(rsrc, lane16, wbyte + (g * 2 + 0) * 1024);
+        bl[slot] = wfrag_load(rsrc, lane16, wbyte + (g * 2 + 1) * 1024);
+    };
+    auto load_a = [&](int g, int slot) {
+        const int dy = g / 3, dx = g % 3;
+        const int tapoff = ((dy - 1) * 8 + (dx - 1)) * 32;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const bool ok = (m9[t] >> g) & 1u;
+            const unsigned a = (unsigned)((int)(dy == 1 ? a_same[t] : a_flip[t]) + tapoff);
+            ah[slot][t] = lds_ld128_a(ok ? a : SS_ZADDR);
+            al[slot][t] = lds_ld128_a(ok ? a + SS_A1PLANE : SS_ZADDR);
+        }
+    };
+    load_b(0, 0);
+    load_b(1, 1);
+    load_a(0, 0);
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+        if (g + 2 < 9) load_b(g + 2, (g + 2) % 3);
+        if (g + 1 < 9) load_a(g + 1, (g + 1) & 1);
+        const int sa = g & 1, sb = g % 3;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t][0] = mfma_bf(ah[sa][t], bl[sb], acc[t][0]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t][0] = mfma_bf(al[sa][t], bh[sb], acc[t][0]);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t][0] = mfma_bf(ah[sa][t], bh[sb], acc[t][0]);
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
@@ -174,15 +216,17 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
         f32x16 acc[6][1];
 #pragma unroll
         for (int t = 0; t < 6; ++t) acc[t][0] = zero16();
-        int py[6], px[6];
-        bool pv[6];
+        unsigned a_same[6], a_flip[6], m2[6];
 #pragma unroll
         for (int t = 0; t < 6; ++t) {
-            pv[t] = true;
-            py[t] = 2 * (6 * hfi + t) + (qi >> 3);
-            px[t] = qi & 7;
+            const int py = 2 * (6 * hfi + t) + (qi >> 3), px = qi & 7;
+            m2[t] = tap_mask(true, py, px, 24, 8);
+            const unsigned row = R + (unsigned)((py * 8 + px) * 32);
+            a_same[t] = row + (unsigned)((h ^ (py & 1)) << 4);
+            a_flip[t] = row + (unsigned)((h ^ (~py & 1)) << 4);
         }
-        conv3x3_bf16<16, 6, 1, 24, 8, false>(acc, act, zero, wb + CNNB_W2, py, px, pv, lane);
+        const __amdgpu_buffer_rsrc_t wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
+        conv_k_bf16_c16<6>(acc, wrs2, CNNB_W2 * 2, lane * 16, a_same, a_flip, m2);
         const float tn = cw[CNN_T2 + n];
         const unsigned wr = R + (6 * hf * 4) * SS_RS2 + n * 2;
 #pragma unroll

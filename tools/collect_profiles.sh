@@ -2,7 +2,7 @@
 # Round profiles (run on the GPU box from the repo root): bench lines, rocprofv3 kernel stats and PMC passes for the
 # predict path (both precisions), the nisqa_tts.tar leg and the training step.  Output: gpurun_out/prof_rNN/ -> copy into profiles/.
 #   tools/collect_profiles.sh r03
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/prof_$R
 mkdir -p $O
 export TMPDIR=/tmp
@@ -30,10 +30,15 @@ for P in bf16x3 f32; do
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$P -o ks -- python bench.py --no-cpu-baseline --no-extras --precision $P > /tmp/ks_$P.log 2>&1
   cp /tmp/ks_$P/ks_kernel_stats.csv $O/${R}_bench_${P}_kernel_stats.csv
 done
-for L in tts train; do
-  rm -rf /tmp/ks_$L
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_$L -o ks -- python bench.py --no-cpu-baseline --leg $L --steps 8 > /tmp/ks_$L.log 2>&1
-  cp /tmp/ks_$L/ks_kernel_stats.csv $O/${R}_${L}_kernel_stats.csv
+rm -rf /tmp/ks_tts
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_tts -o ks -- python bench.py --no-cpu-baseline --leg tts --steps 40 > /tmp/ks_tts.log 2>&1
+cp /tmp/ks_tts/ks_kernel_stats.csv $O/${R}_tts_kernel_stats.csv
+tail -1 /tmp/ks_tts.log > $O/${R}_tts_leg_under_rocprof.json      # the same run's stage events, next to the kernel statistics
+# the training step per precision mode (bench.py --leg train runs all three in one process: its statistics would mix them)
+for P in f32 mixed bf16x3; do
+  rm -rf /tmp/ks_train_$P
+  NISQA_HIP_TRAIN_PRECISION=$P rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_train_$P -o ks -- python tools/bench_train.py 32 20 > /tmp/ks_train_$P.log 2>&1
+  cp /tmp/ks_train_$P/ks_kernel_stats.csv $O/${R}_train_${P}_kernel_stats.csv
 done
 for P in f32 mixed bf16x3; do NISQA_HIP_TRAIN_PRECISION=$P python tools/bench_train.py 32 20 2>/dev/null | tail -1; done > $O/${R}_train_bench.json
 python tools/bench_extra.py 2>/dev/null | tail -1 > $O/${R}_side_tts_pcie.json
