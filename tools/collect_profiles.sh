@@ -33,7 +33,7 @@ done
 rm -rf /tmp/ks_tts
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_tts -o ks -- python bench.py --no-cpu-baseline --leg tts --steps 40 > /tmp/ks_tts.log 2>&1
 cp /tmp/ks_tts/ks_kernel_stats.csv $O/${R}_tts_kernel_stats.csv
-tail -1 /tmp/ks_tts.log > $O/${R}_tts_leg_under_rocprof.json      # the same run's stage events, next to the kernel statistics
+grep '^{' /tmp/ks_tts.log | tail -1 > $O/${R}_tts_leg_under_rocprof.json      # the same run's stage events, next to the kernel statistics
 # the training step per precision mode (bench.py --leg train runs all three in one process: its statistics would mix them)
 for P in f32 mixed bf16x3; do
   rm -rf /tmp/ks_train_$P
