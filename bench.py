@@ -528,7 +528,7 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
                      'bs=32 x 10 s, %d segments, model NISQA random-init, dropout on; precision mode \'f32\' (exact fp32 MFMA '
                      'everywhere: the reference\'s arithmetic); HipTrainer\'s default mode \'mixed\' and \'bf16x3\' beside it' % segments,
            'value': p['value'], 'unit': 'clips/s', 'ms_per_step': p['ms_per_step'], 'steps': steps, 'loss': p['loss'],
-           'roofline': {'kernel': 'whole step (~65 launches, profiles/rNN_train_*_kernel_stats.csv; no single kernel dominates)',
+           'roofline': {'kernel': 'whole step (~59 launches, profiles/rNN_train_*_kernel_stats.csv; no single kernel dominates)',
                         'bound': 'mfma', 'achieved': p['achieved_TFLOPs'], 'unit': 'TFLOP/s',
                         'flop_per_step': flop, 'flop_rule': '3 x forward network FLOPs (2.598 GFLOP per 10 s clip)',
                         'peak': PEAK_F32, 'frac': p['frac_of_fp32_peak'],

@@ -298,3 +298,28 @@ def test_mel_oracle_against_librosa_fixture_or_report_unpinned():
                 continue
             got = omel.melspec_db_from_audio(pcm.astype(np.float32) / np.float32(32768.0), 48000, fmax=fmax)
             np.testing.assert_allclose(got, g['%s_%d' % (tag, i)], rtol=0, atol=1e-3)
+
+
+def test_reference_loop_through_the_functional_librosa_stand_in_matches_the_oracle(tmp_path):
+    """oracle/ref_shim.reference_predict: the reference's OWN predict path (SpeechQualityDataset -> get_librosa_melspec ->
+    segment_specs padded to [B, 1300, 1, 48, 15] -> DataLoader -> Framewise pack -> modules; NISQA_lib.py:1420-1467, 2129-2330)
+    with librosa's three entry points served by oracle/mel.py -- what the `-m gpu` live-reference test and bench.py's
+    cpu_baseline run on the GPU box -- against oracle.net on oracle.mel spectrograms of the same files: mono, stereo (lb.load
+    averages the channels), and one channel picked by ms_channel (mono=False + row select, NISQA_lib.py:2300-2302)."""
+    from oracle import ref_shim
+    path = helpers.find_weights('nisqa.tar')
+    if path is None or not ref_shim.reference_available():
+        pytest.skip('reference checkpoint / NISQA_lib.py not on this machine (staged under oracle/_ref by build())')
+    from nisqa_amd import synth
+    st = np.stack([synth.synth_pcm16(61, 1.1), synth.synth_pcm16(62, 1.1)], 1)
+    synth.write_wav(str(tmp_path / 'a.wav'), synth.synth_pcm16(60, 1.6), 48000)
+    synth.write_wav(str(tmp_path / 'b_stereo.wav'), st, 48000)
+    args, sd = helpers.load_checkpoint(path)
+    y = ref_shim.reference_predict(path, str(tmp_path), ['a.wav', 'b_stereo.wav'], bs=2)
+    for row, name in zip(y, ['a.wav', 'b_stereo.wav']):
+        want = onet.predict_from_melspec(sd, args, omel.get_melspec(str(tmp_path / name)))
+        assert np.abs(row - want).max() < 5e-6
+    y1 = ref_shim.reference_predict(path, str(tmp_path), ['b_stereo.wav'], bs=1, ms_channel=1)
+    mono = st[:, 1].astype(np.float32) / np.float32(32768.0)
+    want = onet.predict_from_melspec(sd, args, omel.melspec_db_from_audio(mono, 48000))
+    assert np.abs(y1[0] - want).max() < 5e-6 and np.abs(y1[0] - y[1]).max() > 1e-4
