@@ -776,7 +776,7 @@ def main():
             # BASELINE.json configs[2], [3], [4]: bounded side legs (a failure in one must not cost the contract line)
             res['side'] = {}
             for name, fn in (('tts_mixed', lambda: side_tts(dev, 3, not a.no_cpu_baseline, pmc)),
-                             ('train_step', lambda: side_train(dev, 10, not a.no_cpu_baseline, pmc)),
+                             ('train_step', lambda: side_train(dev, 30, not a.no_cpu_baseline, pmc)),
                              ('predict_csv_1gpu', lambda: side_predict_csv(dev, res.get('cpu_baseline')))):
                 t_leg = time.perf_counter()
                 try:
