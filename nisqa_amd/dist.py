@@ -92,10 +92,11 @@ def all_reduce_sum_(t):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return t
-    if dist.get_backend() == 'nccl' or not t.is_cuda:
+    nccl = dist.get_backend() == 'nccl'
+    if nccl == t.is_cuda:                                   # RCCL takes device tensors, gloo host tensors
         dist.all_reduce(t)
-    else:
-        c = t.cpu()
+    else:                                                   # a host tensor under RCCL (label counts), a device tensor under gloo
+        c = t.cuda() if nccl else t.cpu()
         dist.all_reduce(c)
         t.copy_(c)
     return t
@@ -106,10 +107,11 @@ def broadcast_(t, src=0):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return t
-    if dist.get_backend() == 'nccl' or not t.is_cuda:
+    nccl = dist.get_backend() == 'nccl'
+    if nccl == t.is_cuda:
         dist.broadcast(t, src)
     else:
-        c = t.cpu()
+        c = t.cuda() if nccl else t.cpu()
         dist.broadcast(c, src)
         t.copy_(c)
     return t
