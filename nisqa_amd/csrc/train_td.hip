@@ -195,7 +195,7 @@ struct tdt_layer_p {
     const float *f_qkv, *f_out, *f_ff1, *f_ff2, *t_qkv, *t_out, *t_ff1, *t_ff2;     // fragments: forward order, transposed
     const float *b_qkv, *b_out, *g1, *be1, *b_ff1, *b_ff2, *g2, *be2;               // vectors in the flat parameter buffer
     float *qs, *qsT, *k, *kT, *v, *vT, *lse, *ctx, *x1, *xh1, *rs1, *hd, *xh2, *rs2;  // kept by the forward pass
-    float *dx, *df, *dh, *dx1, *datt, *dctx, *dctxT, *dd, *dr1, *dqkv;               // written by the backward pass
+    float *dx, *df, *dh, *dx1, *datt, *dctx, *dctxT, *dd, *dr1, *dqkv, *dqkvp;       // written by the backward pass (dqkvp: shares 1.. of d qkv)
     const float *mP, *m1, *mf, *m2;                                                  // dropout multipliers (NULL: none)
 };
 struct tdt_head_p {
@@ -620,11 +620,19 @@ __global__ __launch_bounds__(64) void tdt_bwd_tail_kernel(tdt_common c, tdt_laye
 
 // ---------------------------------------------------------------------------------------------------------
 // Attention backward (the gradient of softmax(q k^T / 8) with dropout, times v), P recomputed from q, k and the saved
-// log-sum-exp.  blockIdx.y = 0: a 32-QUERY tile in the lanes, all key tiles in a loop -> d q;
-// blockIdx.y = 1: a 32-KEY tile in the lanes, all query tiles in a loop -> d k, d v.
+// log-sum-exp.  blockIdx.y = 0: a 32-QUERY tile in the lanes, key tiles in a loop -> d q;
+// blockIdx.y = 1: a 32-KEY tile in the lanes, query tiles in a loop -> d k, d v.
+// blockIdx.z = one of TDT_ASPLIT interleaved shares of the loop's tiles: a wave is a serial chain of ~128 MFMAs per tile, and
+// with one wave per (tile, pass) only 512 waves ran on 1 024 SIMDs for 8 dependent tiles each.  Share 0 writes its partial
+// d q / d k / d v into d qkv, share s > 0 into plane s - 1 of dqkvp; tdt_bwd_mid sums the planes and stores the total where the
+// parameter-gradient launches read it.  (A first version added the shares with fp32 atomics: a lane's row is 768 bytes from its
+// neighbour's, 64 separate L2 transactions per instruction -- 261 us instead of 56.)
 // ---------------------------------------------------------------------------------------------------------
+#define TDT_ASPLIT 2
 __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_layer_p L) {
     const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
+    const int share = blockIdx.z, nshare = gridDim.z;
+    float* __restrict__ part = share == 0 ? L.dqkv : L.dqkvp + (size_t)(share - 1) * c.np * 192;
     const int b = c.tile_clip[blockIdx.x];
     const int n = c.seg_off[b + 1] - c.seg_off[b], c0 = c.ptok_off[b];
     const int ptok = blockIdx.x * 32 + j, kq = ptok - c0;           // this lane's token: a query (y = 0) or a key (y = 1)
@@ -646,9 +654,13 @@ __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_laye
         // K / V rows of tile kt + 1 are requested while tile kt is multiplied; K^T and the dropout multipliers of tile kt at
         // its start, used behind its 64 MFMAs
         f32x4 kA[8], vA[8], kB[8], vB[8];
+        if (share >= ntile) {                                    // fewer key tiles than shares: this share's plane holds zeros
+            st_vec<2>(part + (size_t)ptok * 192, dq, hf, 0.f);
+            return;
+        }
         {
-            const float* krow = L.k + (size_t)(c0 + j) * 64 + 4 * hf;
-            const float* vrow = L.v + (size_t)(c0 + j) * 64 + 4 * hf;
+            const float* krow = L.k + (size_t)(c0 + 32 * share + j) * 64 + 4 * hf;
+            const float* vrow = L.v + (size_t)(c0 + 32 * share + j) * 64 + 4 * hf;
 #pragma unroll
             for (int s = 0; s < 8; ++s) { kA[s] = *(const f32x4*)(krow + 8 * s); vA[s] = *(const f32x4*)(vrow + 8 * s); }
         }
@@ -662,9 +674,9 @@ __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_laye
             }
             f32x16 mk;
             if (use_mask) mk = ld_mask_row(mrow, 32 * kt, n, hf);
-            if (kt + 1 < ntile) {
-                const float* krow = L.k + (size_t)(key0 + 32 + j) * 64 + 4 * hf;
-                const float* vrow = L.v + (size_t)(key0 + 32 + j) * 64 + 4 * hf;
+            if (kt + nshare < ntile) {
+                const float* krow = L.k + (size_t)(key0 + 32 * nshare + j) * 64 + 4 * hf;
+                const float* vrow = L.v + (size_t)(key0 + 32 * nshare + j) * 64 + 4 * hf;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) { kn[s] = *(const f32x4*)(krow + 8 * s); vn[s] = *(const f32x4*)(vrow + 8 * s); }
             }
@@ -693,11 +705,11 @@ __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_laye
                     dq[1] = mfma32(kf[1][g][kk], sT[4 * g + kk], dq[1]);
                 }
         };
-        for (int kt = 0; kt < ntile; kt += 2) {
+        for (int kt = share; kt < ntile; kt += 2 * nshare) {
             tile(kt, kA, vA, kB, vB);
-            if (kt + 1 < ntile) tile(kt + 1, kB, vB, kA, vA);
+            if (kt + nshare < ntile) tile(kt + nshare, kB, vB, kA, vA);
         }
-        st_vec<2>(L.dqkv + (size_t)ptok * 192, dq, hf, valid ? 0.125f : 0.f);      // q entered the scores as q / 8
+        st_vec<2>(part + (size_t)ptok * 192, dq, hf, valid ? 0.125f : 0.f);      // q entered the scores as q / 8
     } else {
         f32x4 kf[8], vf[8];
 #pragma unroll
@@ -710,9 +722,14 @@ __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_laye
         zero_t<2>(dk);
         zero_t<2>(dv);
         f32x4 qA[8], cA[8], qB[8], cB[8];
+        if (share >= ntile) {
+            st_vec<2>(part + (size_t)ptok * 192 + 64, dk, hf, 0.f);
+            st_vec<2>(part + (size_t)ptok * 192 + 128, dv, hf, 0.f);
+            return;
+        }
         {
-            const float* qrow = L.qs + (size_t)(c0 + j) * 64 + 4 * hf;
-            const float* crow = L.dctx + (size_t)(c0 + j) * 64 + 4 * hf;
+            const float* qrow = L.qs + (size_t)(c0 + 32 * share + j) * 64 + 4 * hf;
+            const float* crow = L.dctx + (size_t)(c0 + 32 * share + j) * 64 + 4 * hf;
 #pragma unroll
             for (int s = 0; s < 8; ++s) { qA[s] = *(const f32x4*)(qrow + 8 * s); cA[s] = *(const f32x4*)(crow + 8 * s); }
         }
@@ -735,9 +752,9 @@ __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_laye
                     mk[r] = qi < n ? mbase[(int64_t)qi * n + kq] : 1.f;
                 }
             }
-            if (qt + 1 < ntile) {
-                const float* qrow = L.qs + (size_t)(q0 + 32 + j) * 64 + 4 * hf;
-                const float* crow = L.dctx + (size_t)(q0 + 32 + j) * 64 + 4 * hf;
+            if (qt + nshare < ntile) {
+                const float* qrow = L.qs + (size_t)(q0 + 32 * nshare + j) * 64 + 4 * hf;
+                const float* crow = L.dctx + (size_t)(q0 + 32 * nshare + j) * 64 + 4 * hf;
 #pragma unroll
                 for (int s = 0; s < 8; ++s) { qn[s] = *(const f32x4*)(qrow + 8 * s); cn[s] = *(const f32x4*)(crow + 8 * s); }
             }
@@ -768,12 +785,12 @@ __global__ __launch_bounds__(64) void tdt_attn_bwd_kernel(tdt_common c, tdt_laye
                     dv[1] = mfma32(cT[1][g][kk], dp[4 * g + kk], dv[1]);
                 }
         };
-        for (int qt = 0; qt < ntile; qt += 2) {
+        for (int qt = share; qt < ntile; qt += 2 * nshare) {
             tile(qt, qA, cA, qB, cB);
-            if (qt + 1 < ntile) tile(qt + 1, qB, cB, qA, cA);
+            if (qt + nshare < ntile) tile(qt + nshare, qB, cB, qA, cA);
         }
-        st_vec<2>(L.dqkv + (size_t)ptok * 192 + 64, dk, hf, 1.f);
-        st_vec<2>(L.dqkv + (size_t)ptok * 192 + 128, dv, hf, 1.f);
+        st_vec<2>(part + (size_t)ptok * 192 + 64, dk, hf, 1.f);
+        st_vec<2>(part + (size_t)ptok * 192 + 128, dv, hf, 1.f);
     }
 }
 
@@ -795,6 +812,18 @@ __global__ __launch_bounds__(64) void tdt_bwd_mid_kernel(tdt_common c, tdt_layer
     const int utok = c.seg_off[b] + (valid ? kq : 0);
     f32x16 dqkv[6], dx[2];
     ld_vec<6>(Lup.dqkv + (size_t)ptok * 192, dqkv, hf);
+    {                                                            // + the other shares of the attention backward; the total goes back
+        f32x16 pp[6];                                            // to d qkv for the weight-gradient GEMM and the bias column sums
+#pragma unroll 1
+        for (int sh = 1; sh < TDT_ASPLIT; ++sh) {
+            ld_vec<6>(Lup.dqkvp + ((size_t)(sh - 1) * c.np + ptok) * 192, pp, hf);
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dqkv[mt][r] += pp[mt][r];
+        }
+        st_vec<6>(Lup.dqkv + (size_t)ptok * 192, dqkv, hf, 1.f);
+    }
     ld_vec<2>(Lup.dr1 + (size_t)ptok * 64, dx, hf);
     chain_gemm<6, 2>((const f32x4*)Lup.t_qkv, dqkv, dx, lane);
     if (has_lower) {
@@ -881,7 +910,7 @@ __global__ __launch_bounds__(256) void tdt_colsum_kernel(const int64_t* __restri
 // ---------------------------------------------------------------------------------------------------------
 struct tdt_layout {
     int64_t feat, dfeat, yhat, loss, x[TDT_MAX_LAYERS + 1], xh0, rs0, dxl0, dx0, dx0u;
-    struct { int64_t qs, qsT, k, kT, v, vT, lse, ctx, x1, xh1, rs1, hd, xh2, rs2, dx, df, dh, dx1, datt, dctx, dctxT, dd, dr1, dqkv; } L[TDT_MAX_LAYERS];
+    struct { int64_t qs, qsT, k, kT, v, vT, lse, ctx, x1, xh1, rs1, hd, xh2, rs2, dx, df, dh, dx1, datt, dctx, dctxT, dd, dr1, dqkv, dqkvp; } L[TDT_MAX_LAYERS];
     struct { int64_t u, sc, att, dsc, du, dpooled; } H[TDT_MAX_HEADS];
     int64_t total;
     // fragments
@@ -912,6 +941,7 @@ static tdt_layout tdt_make_layout(int B, int S, int NP, int nl, int nh) {
         L.lse = take(NP); L.ctx = take(t64); L.x1 = take(t64); L.xh1 = take(t64); L.rs1 = take(NP); L.hd = take(t64);
         L.xh2 = take(t64); L.rs2 = take(NP); L.dx = take(t64); L.df = take(t64); L.dh = take(t64); L.dx1 = take(t64);
         L.datt = take(t64); L.dctx = take(t64); L.dctxT = take(t64); L.dd = take(NP); L.dr1 = take(t64); L.dqkv = take(3 * t64);
+        L.dqkvp = take((TDT_ASPLIT - 1) * 3 * t64);
     }
     for (int h = 0; h < nh; ++h) {
         auto& H = y.H[h];
@@ -1022,6 +1052,7 @@ extern "C" int nisqa_tdtrain_step(const nisqa_tdtrain_args* a, void* stream) {
         L.xh2 = ws + W.xh2; L.rs2 = ws + W.rs2; L.dx = ws + W.dx; L.df = ws + W.df; L.dh = ws + W.dh; L.dx1 = ws + W.dx1;
         L.datt = ws + W.datt; L.dctx = ws + W.dctx; L.dctxT = ws + W.dctxT; L.dd = ws + W.dd; L.dr1 = ws + W.dr1;
         L.dqkv = ws + W.dqkv;
+        L.dqkvp = ws + W.dqkvp;
         L.mP = a->mask_p[l]; L.m1 = a->mask_1[l]; L.mf = a->mask_f[l]; L.m2 = a->mask_2[l];
     }
     tdt_heads hs;
@@ -1077,7 +1108,7 @@ extern "C" int nisqa_tdtrain_step(const nisqa_tdtrain_args* a, void* stream) {
     // backward
     hipLaunchKernelGGL(tdt_bwd_tail_kernel, dim3(tiles), dim3(64), 0, st, c, Lp[nl - 1], hs, (const float*)(ws + y.x[nl]));
     for (int l = nl - 1; l >= 0; --l) {
-        hipLaunchKernelGGL(tdt_attn_bwd_kernel, dim3(tiles, 2), dim3(64), 0, st, c, Lp[l]);
+        hipLaunchKernelGGL(tdt_attn_bwd_kernel, dim3(tiles, 2, TDT_ASPLIT), dim3(64), 0, st, c, Lp[l]);
         const int has_lower = l > 0;
         hipLaunchKernelGGL(tdt_bwd_mid_kernel, dim3(tiles), dim3(64), 0, st, c, Lp[l], Lp[has_lower ? l - 1 : l], has_lower,
                            (const float*)(ws + y.xh0), (const float*)(ws + y.rs0), P + po[2], (const float*)(fr + y.t_w0), ws + y.dxl0,
