@@ -394,7 +394,7 @@ def tts_weights():
     return dict(synth.TTS_ARGS), synth.random_state_dict(9, 'NISQA_TTS'), 'random-init nisqa_tts.tar architecture'
 
 
-def side_tts(dev, reps, cpu_baseline_on, pmc):
+def side_tts(dev, reps, cpu_baseline_on, pmc, two_streams=True):
     """configs[3]: nisqa_tts.tar (StandardCNN + fc -> BiLSTM(128) -> last-step pooling, segment hop 1), 256 clips with
     durations rng(7).uniform(3, 30) s, int16 PCM resident in HBM, batched by the predict loop's own policy
     (NISQA_lib.batch_policy: sorted by length, >= 128 clips per batch, <= 256 MiB of PCM)."""
@@ -431,15 +431,19 @@ def side_tts(dev, reps, cpu_baseline_on, pmc):
     assert torch.isfinite(out).all()
     # the same job with the batches alternating over two streams, as the predict loop runs them (the BiLSTM of one batch --
     # one workgroup per (clip, direction), latency-bound -- under the mel + CNN of the next)
-    st2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for r in range(reps):
-        for bi, (plan, x) in enumerate(batches):
-            with torch.cuda.stream(st2[bi % 2]):
-                eng.forward_pcm(x, plan, SR)
-    torch.cuda.synchronize()
-    dt2 = (time.perf_counter() - t1) / reps
+    # (skipped under `--leg tts --no-extras`, the rocprofv3 kernel-statistics pass: kernels of two streams run concurrently and
+    # stretch each other's durations -- profiles/r03_tts_kernel_stats.csv was 18 % above the stage events because of it)
+    dt2 = None
+    if two_streams:
+        st2 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for r in range(reps):
+            for bi, (plan, x) in enumerate(batches):
+                with torch.cuda.stream(st2[bi % 2]):
+                    eng.forward_pcm(x, plan, SR)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t1) / reps
     nb = len(batches)
     segs = np.array([int(p.n_wins.sum()) for p, _ in batches], dtype=np.float64)
     steps = np.array([int(p.n_wins.max()) for p, _ in batches], dtype=np.float64)
@@ -453,7 +457,7 @@ def side_tts(dev, reps, cpu_baseline_on, pmc):
                      '(NISQA_lib.batch_policy), one stream; weights: %s'
                      % (n_clips, float(durs.sum()), int(segs.sum()), nb, '/'.join(str(p.n_clips) for p, _ in batches), wdesc),
            'value': round(n_clips / dt, 1), 'unit': 'clips/s', 'audio_seconds_per_s': round(float(durs.sum()) / dt, 1),
-           'ms_per_job': round(dt * 1e3, 3), 'value_2_streams': round(n_clips / dt2, 1),
+           'ms_per_job': round(dt * 1e3, 3), 'value_2_streams': round(n_clips / dt2, 1) if dt2 else None,
            'stage_ms': {'mel': round(float(ms[:, 0].sum()), 4), 'cnn_std': round(cnn_ms, 4), 'lstm_pool': round(lstm_ms, 4)},
            'roofline': {'kernel': 'cnn_std_bf16_kernel (StandardCNN conv1-6 + fc, split-bf16 MFMA: 3 products per term)',
                         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA, 'unit': 'TFLOP/s',
@@ -584,7 +588,7 @@ def main():
     rank, world, dev, backend = init_dist(a)
     if a.leg in ('tts', 'train', 'csv'):                      # one side leg alone (rocprofv3 runs)
         pmc, _ = pmc_kernels()
-        r = (side_tts(dev, max(1, a.steps // 4), not a.no_cpu_baseline, pmc) if a.leg == 'tts' else
+        r = (side_tts(dev, max(1, a.steps // 4), not a.no_cpu_baseline, pmc, two_streams=not a.no_extras) if a.leg == 'tts' else
              side_train(dev, a.steps, not a.no_cpu_baseline, pmc) if a.leg == 'train' else side_predict_csv(dev, None))
         print(json.dumps({'leg': a.leg, **r}))
         return

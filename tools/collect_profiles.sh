@@ -31,7 +31,7 @@ for P in bf16x3 f32; do
   cp /tmp/ks_$P/ks_kernel_stats.csv $O/${R}_bench_${P}_kernel_stats.csv
 done
 rm -rf /tmp/ks_tts
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_tts -o ks -- python bench.py --no-cpu-baseline --leg tts --steps 40 > /tmp/ks_tts.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_tts -o ks -- python bench.py --no-cpu-baseline --no-extras --leg tts --steps 40 > /tmp/ks_tts.log 2>&1
 cp /tmp/ks_tts/ks_kernel_stats.csv $O/${R}_tts_kernel_stats.csv
 grep '^{' /tmp/ks_tts.log | tail -1 > $O/${R}_tts_leg_under_rocprof.json      # the same run's stage events, next to the kernel statistics
 # the training step per precision mode (bench.py --leg train runs all three in one process: its statistics would mix them)
