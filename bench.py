@@ -567,7 +567,7 @@ def main():
     ap.add_argument('--steps', type=int, default=400)
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', default=None, choices=['bf16x3', 'f32'])
+    ap.add_argument('--precision', default=None, choices=['bf16x3', 'f32', 'bf16x6'])
     ap.add_argument('--no-extras', action='store_true', help='skip the alt-precision and 3-stream passes (profiling runs)')
     ap.add_argument('--streams', type=int, default=1, help='HIP streams the steps alternate over')
     ap.add_argument('--workload', default='predict_dir', choices=['predict_dir', 'predict_csv'])
@@ -663,6 +663,9 @@ def main():
             if prec == 'bf16x3':
                 flop, peak, kname, kern = (FLOP_CONV1_4 + FLOP_CONV5_6) * BATCH, PEAK_BF16_MFMA, 'cnn_front_bf16_kernel', \
                     'cnn_front_bf16_kernel (AdaptCNN conv1-6 + pools, split-bf16 MFMA: 3 products per term)'
+            elif prec == 'bf16x6':
+                flop, peak, kname, kern = (FLOP_CONV1_4 + FLOP_CONV5_6) * BATCH, PEAK_BF16_MFMA, 'cnn_front_bf16x6_kernel', \
+                    'cnn_front_bf16x6_kernel (AdaptCNN conv1-6 + pools, three exact bf16 terms per fp32 operand: 6 MFMA products per term pair)'
             else:
                 flop, peak, kname, kern = FLOP_CONV1_4 * BATCH, PEAK_F32, 'cnn_front_kernel', 'cnn_front_kernel (conv1-4 + pools, fp32 MFMA)'
             ach = flop / (ms_front * 1e-3) / 1e12

@@ -125,6 +125,15 @@ int nisqa_cnn_adapt_bf16(const float* mel_tm, const int32_t* frame_off, const in
 int nisqa_cnn_adapt_segments_bf16(const float* x, int32_t seg_len_padded, const int32_t* tok_off,
                                   const int32_t* n_wins, int32_t n_clips, int32_t total_tok_padded,
                                   const float* cnn_w, const uint16_t* cnn_wb, float* feat, void* stream);
+/* The whole AdaptCNN at fp32 OPERAND precision on the bf16 matrix pipe ("bf16x6"): each fp32 operand = three bf16 terms
+ * (hi + mid + lo, an exact split of the 24-bit mantissa), six products per term pair (hh, hm, mh, hl, lh, mm; the dropped
+ * ones are below 2^-24 of the product, an fp32 multiply-add's own rounding step), fp32 accumulation.  Same inputs and feat
+ * output as nisqa_cnn_adapt (replaces NISQA_lib.py:688-710 like it); cnn_wx = the three-term fragment blob from
+ * nisqa_amd.weights.pack_adapt_cnn_bf16(terms=3), biases are read from cnn_w. */
+int nisqa_cnn_adapt_bf16x6(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                           const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                           int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
+                           const uint16_t* cnn_wx, float* feat, void* stream);
 /* Segment-tensor input mode: the reference's inner operator model.forward(x, n_wins)
  * (NISQA_lib.py:137-142, 260-268) hands over x[B][L][1][48][15] (zero-padded to L segments per clip).
  * Same outputs as nisqa_cnn_adapt; no dB floor is applied (x is already clamped). */
@@ -209,7 +218,9 @@ typedef struct {
      * [3] after the conv5-6 kernel, [4] after self-attention, [5] after pooling */
     void* const* stage_events;
     const uint16_t* cnn_wb;  /* split-bf16 conv fragments, or NULL */
-    int32_t cnn_mode;        /* 0 = exact fp32 MFMA kernels, 1 = split-bf16 kernels (needs cnn_wb, td_wb, pool_wb) */
+    int32_t cnn_mode;        /* 0 = exact fp32 MFMA kernels, 1 = split-bf16 kernels (needs cnn_wb, td_wb, pool_wb),
+                              * 2 = arch 0 only: AdaptCNN on three-term bf16 (nisqa_cnn_adapt_bf16x6; cnn_wb = its three-term
+                              * fragments), self-attention and pooling on the exact fp32 kernels */
     const uint16_t* td_wb;   /* split-bf16 self-attention fragments, or NULL */
     const uint16_t* pool_wb; /* split-bf16 pooling fragments, or NULL */
     int32_t arch;            /* 0 = CNN-SA-AP (nisqa.tar, nisqa_mos_only.tar); 1 = StandardCNN + BiLSTM + last-step

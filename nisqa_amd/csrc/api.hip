@@ -60,7 +60,7 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
                                   mel, cmax, stream);
     if (rc) return rc;
     // the split-bf16 AdaptCNN kernel derives the top_db floor from cmax itself; the other CNN kernels take clip_floor
-    const bool floor_in_cnn = model->arch == 0 && model->cnn_mode == 1;
+    const bool floor_in_cnn = model->arch == 0 && (model->cnn_mode == 1 || model->cnn_mode == 2);
     if (!floor_in_cnn) {
         rc = nisqa_mel_finalize(mel, frame_off, n_clips, total_frames, cmax, cfg->top_db, cfloor, 0, stream);
         if (rc) return rc;
@@ -86,6 +86,12 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
     if (model->cnn_mode == 1) {
         rc = nq_cnn_adapt_bf16_from_max(mel, frame_off, tok_off, n_wins, cmax, cfg->top_db, n_clips, total_tok_padded,
                                         model->seg_hop, model->cnn_w, model->cnn_wb, feat, stream);
+        if (rc) return rc;
+        NQ_STAGE(2);
+    } else if (model->cnn_mode == 2) {
+        // fp32-grade AdaptCNN on three-term bf16 operands (cnn_wb = the three-term fragments); attention and pooling exact fp32
+        rc = nq_cnn_adapt_bf16x6_from_max(mel, frame_off, tok_off, n_wins, cmax, cfg->top_db, n_clips, total_tok_padded,
+                                          model->seg_hop, model->cnn_w, model->cnn_wb, feat, stream);
         if (rc) return rc;
         NQ_STAGE(2);
     } else {

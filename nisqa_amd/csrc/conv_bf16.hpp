@@ -295,3 +295,91 @@ NQ_DEV void conv_k_bf16(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int 
     }
 }
 
+
+// ======================================================================================================================
+// T terms per operand (cnn_bf16x6.hip: T = 3, bf16 hi + mid + lo = the fp32 operand EXACTLY, 24 mantissa bits): the products
+// (i, j) with i + j <= T - 1 are formed, smallest first -- for T = 3 the six products hh, hm, mh, hl, lh, mm; what is dropped
+// (ml, lm, ll) is below 2^-24 of the product, fp32's own rounding step.  T = 2 is the shipped hi/lo form (three products).
+// ======================================================================================================================
+// v0, v1 -> T bf16 terms each, plane t `t * plane` bytes behind the first; the halves of the packed conversions are stored
+// with ds_write_b16 / ds_write_b16_d16_hi as in lds_store_split2
+template <int T>
+NQ_DEV void lds_store_terms2(unsigned a0, unsigned a1, int plane, float v0, float v1, bool st0 = true, bool st1 = true) {
+    f32x2_t r = {v0, v1};
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const unsigned pk = cvt_pk_bf16(r[0], r[1]);
+        if (st0) lds_st16(a0 + t * plane, pk);
+        if (st1) lds_st16_hi(a1 + t * plane, pk);
+        if (t + 1 < T) {
+            const f32x2_t part = {__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
+            r = r - part;
+        }
+    }
+}
+template <int T>
+NQ_DEV void lds_store_terms(unsigned a, int plane, float v) {
+    float r = v;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const unsigned pk = cvt_pk_bf16(r, 0.f);
+        lds_st16(a + t * plane, pk);
+        if (t + 1 < T) r -= __uint_as_float(pk << 16);
+    }
+}
+// acc[m][nt] += sum over the kept term products of a[m][i] x b[nt][j]; smallest products first, consecutive MFMAs on
+// different accumulators
+template <int T, int MT, int NT>
+NQ_DEV void mma_terms(f32x16 (&acc)[MT][NT], const f32x4 (&a)[MT][T], const f32x4 (&b)[NT][T]) {
+#pragma unroll
+    for (int order = T - 1; order >= 0; --order)
+#pragma unroll
+        for (int i = order; i >= 0; --i) {                 // (i, order - i): within an order the term with the smaller A part first
+            const int j = order - i;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[m][nt] = mfma_bf(a[m][i], b[nt][j], acc[m][nt]);
+        }
+}
+// conv_k_bf16 for T terms: fragments [step][NT][T][64 lanes][8 bf16], activation planes PLANE bytes apart; A rows always
+// one step ahead (this form runs one wave per SIMD on the 512-register budget)
+template <int T, int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZADDR, int RING = 3>
+NQ_DEV void conv_k_terms(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
+                         const unsigned (&base)[MT], const unsigned (&m9)[MT]) {
+    constexpr int S16 = CIN / 16, TOTAL = 9 * S16;
+    static_assert(ZADDR >= (2 * W + 2) * RS + 32 * S16, "zero block must sit above the largest tap offset");
+    f32x4 b[RING][NT][T], a[2][MT][T];
+    unsigned a_ad[MT][T];
+    auto load_b = [&](int g, int slot) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int t = 0; t < T; ++t) b[slot][nt][t] = wfrag_load(rsrc, lane16, wbyte + ((g * NT + nt) * T + t) * 1024);
+    };
+    auto load_a = [&](int g, int slot) {
+        const int tap = g / S16, s = g - tap * S16;
+        const int tapoff = ((tap / 3) * W + tap % 3) * RS;
+        if (s == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const bool ok = (m9[m] >> tap) & 1u;
+#pragma unroll
+                for (int t = 0; t < T; ++t) a_ad[m][t] = ok ? base[m] + t * PLANE : ZADDR - tapoff;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < T; ++t) a[slot][m][t] = lds_ld128_a(a_ad[m][t] + tapoff + 32 * s);
+    };
+#pragma unroll
+    for (int g = 0; g < RING - 1; ++g) load_b(g, g);
+    load_a(0, 0);
+#pragma unroll
+    for (int g = 0; g < TOTAL; ++g) {
+        if (g + RING - 1 < TOTAL) load_b(g + RING - 1, (g + RING - 1) % RING);
+        if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1);
+        mma_terms<T, MT, NT>(acc, a[g & 1], b[g % RING]);
+    }
+}

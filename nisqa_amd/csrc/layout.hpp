@@ -51,6 +51,14 @@
 #define CNNB_W5 (CNNB_W4 + 36 * 2 * 2 * 512)
 #define CNNB_W6 (CNNB_W5 + 36 * 2 * 2 * 512)
 #define CNNB_U16S (CNNB_W6 + 36 * 2 * 2 * 512)
+// three-term fragments of cnn_bf16x6.hip (bf16 hi + mid + lo = the fp32 weight exactly): as above with [3] terms per fragment
+#define CNNX_W1 0
+#define CNNX_W2 (CNNX_W1 + 3 * 512)
+#define CNNX_W3 (CNNX_W2 + 9 * 1 * 3 * 512)
+#define CNNX_W4 (CNNX_W3 + 18 * 2 * 3 * 512)
+#define CNNX_W5 (CNNX_W4 + 36 * 2 * 3 * 512)
+#define CNNX_W6 (CNNX_W5 + 36 * 2 * 3 * 512)
+#define CNNX_U16S (CNNX_W6 + 36 * 2 * 3 * 512)
 
 // ---- split-bf16 fragments of the self-attention / pooling weights ("td_wb", "pool_wb"; uint16 units) --------
 // A-fragment [step][mtile][hl][64 lanes][8]; lane (i = l&31, h = l>>5), element e:

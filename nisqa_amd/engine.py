@@ -101,8 +101,10 @@ class HipNisqa(object):
     """nisqa.tar / nisqa_mos_only.tar (CNN-SA-AP) on one MI355X."""
 
     def __init__(self, args, state_dict, device=None, precision=None):
-        """precision: 'bf16x3' (default: AdaptCNN on split-bf16 MFMA, fp32-class accuracy, |dMOS| <= 3e-5) or
-        'f32' (every GEMM on exact fp32 MFMA); the environment variable NISQA_HIP_PRECISION sets the default."""
+        """precision: 'bf16x3' (default: AdaptCNN on split-bf16 MFMA, fp32-class accuracy, |dMOS| <= 3e-5), 'f32'
+        (every GEMM on exact fp32 MFMA) or 'bf16x6' (CNN-SA-AP models only: the AdaptCNN with every fp32 operand as three
+        bf16 terms -- an exact split -- and six MFMA products per term pair, self-attention and pooling on the exact fp32
+        kernels: the accuracy of 'f32' at 1.6 x its rate); the environment variable NISQA_HIP_PRECISION sets the default."""
         if not torch.cuda.is_available():
             raise RuntimeError('nisqa_amd: no GPU visible (torch.cuda.is_available() is False); '
                                'the HIP engine has no CPU fallback')
@@ -134,8 +136,11 @@ class HipNisqa(object):
         self.dim = a['model'] == 'NISQA_DIM'
         up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
         self.precision = precision or os.environ.get('NISQA_HIP_PRECISION', 'bf16x3')
-        if self.precision not in ('f32', 'bf16x3'):
-            raise ValueError('precision must be f32 or bf16x3, got {}'.format(self.precision))
+        if self.precision not in ('f32', 'bf16x3', 'bf16x6'):
+            raise ValueError('precision must be f32, bf16x3 or bf16x6, got {}'.format(self.precision))
+        if self.precision == 'bf16x6' and self.arch == 1:
+            raise NotImplementedError("precision 'bf16x6' is implemented for the CNN-SA-AP models (AdaptCNN); "
+                                      "nisqa_tts.tar runs 'bf16x3' or 'f32'")
         if self.arch == 1:
             # StandardCNN (split-bf16 or exact-fp32 MFMA) + BiLSTM + last-step pooling (fp32 VALU)
             self.n_layers, self.n_heads = 0, 1
@@ -153,6 +158,8 @@ class HipNisqa(object):
         self.cnn_w = up(_w.pack_adapt_cnn(state_dict))
         bf = self.precision == 'bf16x3'
         self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict, conv1_pairs=True).view(np.int16)) if bf else None
+        if self.precision == 'bf16x6':
+            self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict, conv1_pairs=True, terms=3).view(np.int16))
         self.td_w = up(_w.pack_self_att(state_dict, self.n_layers))
         self.pool_w = up(_w.pack_pool_att(state_dict, heads))
         self.td_wb = up(_w.pack_self_att_bf16(state_dict, self.n_layers).view(np.int16)) if bf else None
@@ -174,7 +181,7 @@ class HipNisqa(object):
                                        _ptr(d['band_woff']), _ptr(d['band_w']), _ptr(self.cnn_w), _ptr(self.td_w),
                                        _ptr(self.pool_w), self.n_layers, self.n_heads, self.seg_hop, None,
                                        _ptr(self.cnn_wb) if self.cnn_wb is not None else None,
-                                       1 if self.precision == 'bf16x3' else 0,
+                                       {'bf16x3': 1, 'bf16x6': 2}.get(self.precision, 0),
                                        _ptr(self.td_wb) if self.td_wb is not None else None,
                                        _ptr(self.pool_wb) if self.pool_wb is not None else None, self.arch)
             self._mel[sr] = d
@@ -247,6 +254,12 @@ class HipNisqa(object):
                                                      _ptr(d['n_wins']), _ptr(clip_floor), plan.n_clips, plan.total_tok,
                                                      self.seg_hop, _ptr(self.cnn_w), _ptr(self.cnn_wb), _ptr(p3),
                                                      _ptr(feat), self._stream()), 'nisqa_cnn_adapt_bf16')
+        elif self.precision == 'bf16x6':
+            _lib.check(self.lib.nisqa_cnn_adapt_bf16x6(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']),
+                                                       _ptr(d['n_wins']), _ptr(clip_floor), plan.n_clips, plan.total_tok,
+                                                       self.seg_hop, _ptr(self.cnn_w), _ptr(self.cnn_wb), _ptr(feat),
+                                                       self._stream()), 'nisqa_cnn_adapt_bf16x6')
+            p3 = None                      # (the one-launch kernel has no pooled conv4 tensor in memory)
         else:
             _lib.check(self.lib.nisqa_cnn_adapt(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']),
                                                 _ptr(clip_floor), plan.n_clips, plan.total_tok, self.seg_hop,
@@ -268,6 +281,8 @@ class HipNisqa(object):
         d = plan.to(self.device)
         p3 = torch.empty((plan.total_tok, 18, 64), dtype=torch.float32, device=self.device)
         feat = torch.empty((plan.total_tok, 384), dtype=torch.float32, device=self.device)
+        if self.precision == 'bf16x6':
+            raise NotImplementedError("segment-tensor forward: precision 'bf16x6' has no segment-tensor kernel; use 'f32' or 'bf16x3'")
         if self.precision == 'bf16x3':
             _lib.check(self.lib.nisqa_cnn_adapt_segments_bf16(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B,
                                                               plan.total_tok, _ptr(self.cnn_w), _ptr(self.cnn_wb),

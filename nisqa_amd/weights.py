@@ -66,6 +66,14 @@ CNNB_W4 = CNNB_W3 + 18 * 2 * 2 * 512
 CNNB_W5 = CNNB_W4 + 36 * 2 * 2 * 512
 CNNB_W6 = CNNB_W5 + 36 * 2 * 2 * 512
 CNNB_U16S = CNNB_W6 + 36 * 2 * 2 * 512
+# three-term fragments (csrc/cnn_bf16x6.hip): [3] terms per fragment
+CNNX_W1 = 0
+CNNX_W2 = CNNX_W1 + 3 * 512
+CNNX_W3 = CNNX_W2 + 9 * 1 * 3 * 512
+CNNX_W4 = CNNX_W3 + 18 * 2 * 3 * 512
+CNNX_W5 = CNNX_W4 + 36 * 2 * 3 * 512
+CNNX_W6 = CNNX_W5 + 36 * 2 * 3 * 512
+CNNX_U16S = CNNX_W6 + 36 * 2 * 3 * 512
 
 TDB_PROJ = 0
 TDB_LAYER0 = TDB_PROJ + 24 * 2 * 2 * 512
@@ -224,8 +232,8 @@ def bf16_split(x, terms=2):
     return out
 
 
-def conv_b_fragments_bf16(wf):
-    """wf [cout][cin][3][3] float32 (BN-scaled) -> uint16 [9*cin/16][NT][2][64][8]"""
+def conv_b_fragments_bf16(wf, terms=2):
+    """wf [cout][cin][3][3] float32 (BN-scaled) -> uint16 [9*cin/16][NT][terms][64][8]"""
     cout, cin = wf.shape[:2]
     S16, NT = cin // 16, cout // 32
     w9 = np.asarray(wf, np.float32).reshape(cout, cin, 9)
@@ -234,12 +242,11 @@ def conv_b_fragments_bf16(wf):
     lane = _LANE[None, None, :, None]
     e = np.arange(8)[None, None, None, :]
     vals = w9[(lane & 31) + 32 * nt, 16 * (g % S16) + 8 * (lane >> 5) + e, g // S16]      # [G][NT][64][8]
-    hi, lo = bf16_split(vals, 2)
-    return np.stack([hi, lo], 2).reshape(-1)                                               # [G][NT][2][64][8]
+    return np.stack(bf16_split(vals, terms), 2).reshape(-1)                                # [G][NT][terms][64][8]
 
 
-def conv_b_fragments_bf16_nsplit(wf):
-    """conv5/conv6 fragments for the N-split 16x16x32 form: uint16 [4 waves][18 steps][2][64][8],
+def conv_b_fragments_bf16_nsplit(wf, terms=2):
+    """conv5/conv6 fragments for the N-split 16x16x32 form: uint16 [4 waves][18 steps][terms][64][8],
     value = W[n = 16*w + (lane&15)][c = 32*(g&1) + 8*(lane>>4) + e][tap = g>>1]"""
     w9 = np.asarray(wf, np.float32).reshape(64, 64, 9)
     w = np.arange(4)[:, None, None, None]
@@ -247,17 +254,20 @@ def conv_b_fragments_bf16_nsplit(wf):
     lane = _LANE[None, None, :, None]
     e = np.arange(8)[None, None, None, :]
     vals = w9[16 * w + (lane & 15), 32 * (g & 1) + 8 * (lane >> 4) + e, g >> 1]             # [4][18][64][8]
-    hi, lo = bf16_split(vals, 2)
-    return np.stack([hi, lo], 2).reshape(-1)
+    return np.stack(bf16_split(vals, terms), 2).reshape(-1)
 
 
-def pack_adapt_cnn_bf16(sd, pfx='cnn.model.', conv1_pairs=False):
-    """bf16 hi/lo weight fragments for cnn_front_bf16_kernel -> uint16 [CNNB_U16S] (biases: pack_adapt_cnn).
+def pack_adapt_cnn_bf16(sd, pfx='cnn.model.', conv1_pairs=False, terms=2):
+    """bf16 hi/lo weight fragments for cnn_front_bf16_kernel -> uint16 [CNNB_U16S] (biases: pack_adapt_cnn); terms = 3:
+    hi/mid/lo fragments for cnn_front_bf16x6_kernel -> uint16 [CNNX_U16S] (three bf16 terms hold an fp32 weight exactly).
 
     conv1 B operand [k][n], lane (n = lane & 31, h = lane >> 5) holds k-slots 8h .. 8h+7.  Plain layout (StandardCNN
     kernel): k = tap ky*3 + kx, n = channel.  conv1_pairs (AdaptCNN kernel): a row is a pair of mel-adjacent output
     pixels, n = c + 16*dm, k = 4*kx + dmm over the 4 mels the pair touches: w[c][ky = dmm - dm][kx]."""
-    blob = np.zeros(CNNB_U16S, np.uint16)
+    if terms not in (2, 3):
+        raise ValueError('terms must be 2 or 3')
+    offs = [CNNB_W2, CNNB_W3, CNNB_W4, CNNB_W5, CNNB_W6] if terms == 2 else [CNNX_W2, CNNX_W3, CNNX_W4, CNNX_W5, CNNX_W6]
+    blob = np.zeros(CNNB_U16S if terms == 2 else CNNX_U16S, np.uint16)
     w, _ = fold_bn(sd, pfx, 1)
     w1 = w.reshape(16, 9).astype(np.float32)
     full = np.zeros((64, 8), np.float32)
@@ -273,9 +283,9 @@ def pack_adapt_cnn_bf16(sd, pfx='cnn.model.', conv1_pairs=False):
                 full[lane, e] = w1[j, k]
     for t, part in enumerate(bf16_split(full, 3)):
         blob[CNNB_W1 + t * 512: CNNB_W1 + (t + 1) * 512] = part.reshape(-1)
-    for i, off in zip(range(2, 7), [CNNB_W2, CNNB_W3, CNNB_W4, CNNB_W5, CNNB_W6]):
+    for i, off in zip(range(2, 7), offs):
         w, _ = fold_bn(sd, pfx, i)
-        fr = conv_b_fragments_bf16_nsplit(w.astype(np.float32)) if i >= 5 else conv_b_fragments_bf16(w.astype(np.float32))
+        fr = conv_b_fragments_bf16_nsplit(w.astype(np.float32), terms) if i >= 5 else conv_b_fragments_bf16(w.astype(np.float32), terms)
         blob[off:off + fr.size] = fr
     return blob
 
