@@ -127,7 +127,7 @@ int nisqa_cnn_adapt_segments_bf16(const float* x, int32_t seg_len_padded, const 
                                   const float* cnn_w, const uint16_t* cnn_wb, float* feat, void* stream);
 /* The whole AdaptCNN at fp32 OPERAND precision on the bf16 matrix pipe ("bf16x6"): each fp32 operand = three bf16 terms
  * (hi + mid + lo, an exact split of the 24-bit mantissa), six products per term pair (hh, hm, mh, hl, lh, mm; the dropped
- * ones are below 2^-24 of the product, an fp32 multiply-add's own rounding step), fp32 accumulation.  Same inputs and feat
+ * ones are <= 2 x 2^-24 of the product, typically 0.5 x 2^-24: an fp32 multiply-add's own rounding step), fp32 accumulation.  Same inputs and feat
  * output as nisqa_cnn_adapt (replaces NISQA_lib.py:688-710 like it); cnn_wx = the three-term fragment blob from
  * nisqa_amd.weights.pack_adapt_cnn_bf16(terms=3), biases are read from cnn_w. */
 int nisqa_cnn_adapt_bf16x6(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,

@@ -2,18 +2,19 @@
 // ("bf16x6") -- same role, inputs and outputs as cnn_front_kernel + cnn_back_kernel in cnn.hip (reference
 // nisqa/NISQA_lib.py:2239-2282, 487-502, 688-710).
 //
-// Every fp32 operand x is carried as THREE bf16 terms x = hi + mid + lo (8 + 8 + 8 mantissa bits: the split is EXACT, no
-// bit of the fp32 value is lost) and a product is formed as the six MFMA products hh + hm + mh + hl + lh + mm on
-// v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three dropped products (ml, lm, ll) are below 2^-24 of the product,
-// i.e. below the rounding step of an fp32 multiply-add.  Against float64 the results are as close as the exact-fp32 MFMA
-// kernels' (tests/test_gpu_parity.py; DESIGN.md 4.5 "bf16x6"), at 16 / 6 = 2.7 x their matrix-pipe rate.
+// Every fp32 operand x is carried as THREE bf16 terms x = hi + mid + lo (8 + 8 + 8 significant bits, each rounded to nearest:
+// the split is EXACT, no bit of the fp32 value is lost) and a product is formed as the six MFMA products hh + hm + mh + hl +
+// lh + mm on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The three dropped products (ml, lm, ll) are at most 2 x 2^-24 of
+// the product and typically 0.5 x 2^-24 rms -- the size of the rounding an fp32 multiply-add applies to the same product.
+// Against float64 the results are as close as the exact-fp32 MFMA kernels' (tests/test_gpu_parity.py:
+// test_rounding_error_of_the_precision_modes_against_float64; DESIGN.md 4.5 "bf16x6"), at 16 / 6 = 2.7 x their matrix-pipe rate.
 //
 // Structure: cnn_bf16.hip's (a workgroup is four waves = four consecutive segments; conv1..conv4 wave-private and
 // barrier-free over LDS planes, pixel-major, rows padded by 16 bytes; conv1 on the matrix pipe with two mel-adjacent output
 // pixels per MFMA row; conv5 / conv6 batched over the four segments with the output channels split over the waves) with
 // three planes per activation tensor.  117 KB of LDS per workgroup: ONE workgroup per CU, one wave per SIMD on the
 // 512-register budget -- the K loops keep the A rows of the next step and two steps of weight fragments in flight themselves
-// (tools/micro/klx6.hip: 82 % matrix-pipe duty at 1.89 GHz in the conv3 + conv4 loops, the chip's power envelope).
+// (conv_k_terms; tools/micro/klx6.hip: 96 % matrix-pipe duty at 1.79 GHz in the conv3 + conv4 loops, the chip's power envelope).
 #include "common.hpp"
 #include "layout.hpp"
 #include <stdlib.h>
@@ -43,6 +44,31 @@ __device__ constexpr int xwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b =
 __device__ constexpr int xwin53_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : 3; }
 __device__ constexpr int xwin53_hi(int b) { return b == 0 ? 2 : b == 1 ? 4 : 5; }
 
+// -DNQ_PHASE_CLOCK (tools/ab_build_multi.sh clock6 "-DNQ_PHASE_CLOCK" cnn_bf16x6; tools/phase_clock.py with NQ_PRECISION=bf16x6):
+// shader-clock stamps at the layer boundaries, every wave writes its numbers to its own slot (cnn_bf16.hip)
+#ifdef NQ_PHASE_CLOCK
+#define X_CLK_SLOTS 32768
+__device__ unsigned long long g_phase_clk6[X_CLK_SLOTS * 16];
+#define X_CLK(i) clk[i] = clock64()
+extern "C" int nisqa_debug_phase_clock6(unsigned long long* out16, int reset) {
+    if (out16) {
+        unsigned long long* h = (unsigned long long*)malloc(sizeof(g_phase_clk6));
+        if (!h || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk6), sizeof(g_phase_clk6)) != hipSuccess) { free(h); return -1; }
+        for (int q = 0; q < 16; ++q) out16[q] = 0;
+        for (int w = 0; w < X_CLK_SLOTS; ++w)
+            for (int q = 0; q < 16; ++q) out16[q] += h[(size_t)w * 16 + q];
+        free(h);
+    }
+    if (reset) {
+        void* d = nullptr;
+        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_phase_clk6)) != hipSuccess || hipMemset(d, 0, sizeof(g_phase_clk6)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define X_CLK(i)
+#endif
+
 // 16x16x32 products of T-term operands for conv5 / conv6 (smallest first)
 template <int MT>
 NQ_DEV void mma16_terms(f32x4 (&acc)[MT], const f32x4 (&a)[MT][XT], const f32x4 (&b)[XT]) {
@@ -63,6 +89,10 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
     const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ feat,
     const uint32_t* __restrict__ clip_max_enc, float top_db) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef NQ_PHASE_CLOCK
+    const long long clk_top = clock64(), wall_top = wall_clock64();
+    long long clk[13];
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p0 = blockIdx.x * 4;                      // tok_off is a multiple of 32: no clip straddling
@@ -72,6 +102,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
     if (nvalid <= 0) return;                             // whole workgroup is padding
     const bool valid = wave < nvalid;                    // padding waves still walk the barriers (on zeros)
     const int k = k0 + wave;
+    X_CLK(0);
     const unsigned R = X_BASE + wave * X_WAVE;           // this wave's LDS region
     const unsigned lane16 = lane * 16;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNX_U16S * 2, 0x00020000);
@@ -115,6 +146,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
         }
     }
     __builtin_amdgcn_wave_barrier();
+    X_CLK(1);
 
     const int i = lane & 31, hfi = (i >> 2) & 1, qi = (i & 3) + 4 * (i >> 3);
     const int n = lane & 31, hf = lane >> 5, h = lane >> 5;
@@ -171,6 +203,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
         }
     }
 
+    X_CLK(2);
     // ---- conv2 16->32 on 24x7, pool -> 12x5
     {
         f32x16 acc[6][1];
@@ -185,6 +218,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             base[t] = R + ((py - 1) * 7 + (px - 1)) * X_RS1 + (h << 4);
         }
         conv_k_terms<XT, 16, 6, 1, 7, X_RS1, X_P1, X_ZADDR, 3>(acc, wrs, CNNX_W2 * 2, lane16, base, m9);
+        X_CLK(3);
         const unsigned wr = R + (6 * hf * 5) * X_RS2 + n * 2;
 #pragma unroll
         for (int k2 = 0; k2 < 30; k2 += 2) {              // pooled pixel k = gl * 5 + bb, two per packed split
@@ -206,6 +240,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
         }
     }
 
+    X_CLK(4);
     unsigned base34[2], m34[2];                           // conv3 and conv4 share the 12 x 5 geometry
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -227,6 +262,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             base[t] = R + base34[t] * X_RS2 + (h << 4);
         }
         conv_k_terms<XT, 32, 2, 2, 5, X_RS2, X_P2, X_ZADDR, 3>(acc, wrs, CNNX_W3 * 2, lane16, base, m34);
+        X_CLK(5);
         const unsigned wr = R + (6 * hf * 5) * X_RS3 + n * 2;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -243,6 +279,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
 
     // ---- conv4 64->64 on 12x5, pool -> 6x3.  The pooled outputs of the workgroup's four segments go to SHARED planes
     //      S4[72 px][64 ch] (row = 18 * wave + pixel) for the N-split conv5 / conv6.
+    X_CLK(6);
     const unsigned S4 = X_BASE;                           // XT planes x X_PS (wave 0/1 regions; their A3 is dead by then)
     const unsigned S5 = X_BASE + 2 * X_WAVE;              // conv5 output, same shape (wave 2/3 regions)
     const int w5b = __builtin_amdgcn_readfirstlane((CNNX_W5 + wave * (18 * XT * 512)) * 2);
@@ -258,6 +295,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             base[t] = R + base34[t] * X_RS3 + (h << 4);
         }
         conv_k_terms<XT, 64, 2, 2, 5, X_RS3, X_P3, X_ZADDR, 3>(acc, wrs, CNNX_W4 * 2, lane16, base, m34);
+        X_CLK(7);
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -285,6 +323,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             }
     }
     __syncthreads();
+    X_CLK(8);
 
     // ---- conv5 / conv6 with N split over the waves: wave w owns output channels 16w..16w+15 of ALL four segments (72 / 24
     //      output rows in 16-row tiles of v_mfma_f32_16x16x32_bf16); fragments [wave][step][term][lane][8]
@@ -327,8 +366,10 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
                 for (int q = 0; q < XT; ++q) b5[(g + 3) & 3][q] = wfrag_load(wrs, lane16, w5b + ((g + 3) * XT + q) * 1024);
             }
             if (g + 1 < 18) load_a5(g + 1);
+            __builtin_amdgcn_sched_barrier(0);             // requests stay ahead of the step's MFMAs (conv_k_terms: FENCE)
             mma16_terms<5>(acc5, a5[g & 1], b5[g & 3]);
         }
+        X_CLK(9);
 #pragma unroll
         for (int g = 0; g < 7; ++g)
 #pragma unroll
@@ -344,6 +385,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
                                              fmaxf(acc5[t][r] + tn5, 0.f), fmaxf(acc5[t][r + 1] + tn5, 0.f));
         }
         __syncthreads();
+        X_CLK(10);
 
         // conv6 (3 x 3 kernel, padding (1,0)) = padding-1 conv at the centre column: rows (slot, y), 24 of 32
         f32x4 acc6[2], acc6b[2];            // even / odd K-steps accumulate separately
@@ -383,9 +425,11 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
                 for (int q = 0; q < XT; ++q) b6[(g + 7) & 7][q] = wfrag_load(wrs, lane16, w6b + ((g + 7) * XT + q) * 1024);
             }
             if (g + 1 < 18) load_a6(g + 1);
+            __builtin_amdgcn_sched_barrier(0);
             if (g & 1) mma16_terms<2>(acc6b, a6[1], b6[g & 7]);
             else mma16_terms<2>(acc6, a6[0], b6[g & 7]);
         }
+        X_CLK(11);
         // this wave's 4 x 96 outputs (slot, channel * 6 + y) go through S4 (dead since the barrier above) so that the
         // feature rows leave as 16-byte stores: 384 contiguous bytes per slot
         const unsigned fo = S4 + wave * 2048;
@@ -406,6 +450,17 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
                 *(f32x4*)(feat + (size_t)(p0 + slot) * 384 + 96 * wave + 4 * (q - 24 * slot)) = lds_ld128(fo + 16 * q);
         }
     }
+#ifdef NQ_PHASE_CLOCK
+    clk[12] = clock64();
+    if (lane == 0) {                                      // the LAST launch's numbers stay (slots are overwritten)
+        unsigned long long* slot = g_phase_clk6 + (size_t)((((blockIdx.y * gridDim.x + blockIdx.x) << 2) + wave) & (X_CLK_SLOTS - 1)) * 16;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) slot[q] = (unsigned long long)(clk[q + 1] - clk[q]);
+        slot[12] = 1ull;
+        slot[13] = (unsigned long long)(wall_clock64() - wall_top);
+        slot[14] = (unsigned long long)(clk[0] - clk_top);
+    }
+#endif
 }
 
 static int x6_launch(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off, const int32_t* n_wins,

@@ -299,13 +299,29 @@ NQ_DEV void conv_k_bf16(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int 
 // ======================================================================================================================
 // T terms per operand (cnn_bf16x6.hip: T = 3, bf16 hi + mid + lo = the fp32 operand EXACTLY, 24 mantissa bits): the products
 // (i, j) with i + j <= T - 1 are formed, smallest first -- for T = 3 the six products hh, hm, mh, hl, lh, mm; what is dropped
-// (ml, lm, ll) is below 2^-24 of the product, fp32's own rounding step.  T = 2 is the shipped hi/lo form (three products).
+// (ml, lm, ll) is at most 2 x 2^-24 of the product, typically 0.5 x 2^-24 rms: the size of an fp32 multiply-add's own rounding of
+// that product.  T = 2 is the shipped hi/lo form (three products).
 // ======================================================================================================================
-// v0, v1 -> T bf16 terms each, plane t `t * plane` bytes behind the first; the halves of the packed conversions are stored
-// with ds_write_b16 / ds_write_b16_d16_hi as in lds_store_split2
+// v0, v1 -> T bf16 terms each (round to nearest: |term t+1| <= 2^-8 |term t|), plane t `t * plane` bytes behind the first; the halves of the packed conversions are stored with
+// ds_write_b16 / ds_write_b16_d16_hi as in lds_store_split2.
+// -DNQ_X6_TRUNC (A/B, tools/gpu_r04_q.sh): terms by truncation -- the upper half of an fp32 register IS its truncated bf16, so
+// a term is stored straight from the running remainder and costs one v_and + one subtraction (6 VALU instructions per pair
+// instead of 9).  Also an exact split, 2 % faster, but |term t+1| < 2^-7 |term t| makes the dropped products up to eight times
+// larger: the kernel's distance from float64 grows from 1.0 x to 1.4 x the fp32 kernels'.  Not used.
 template <int T>
 NQ_DEV void lds_store_terms2(unsigned a0, unsigned a1, int plane, float v0, float v1, bool st0 = true, bool st1 = true) {
     f32x2_t r = {v0, v1};
+#ifdef NQ_X6_TRUNC
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        if (st0) lds_st16_hi(a0 + t * plane, __float_as_uint(r[0]));
+        if (st1) lds_st16_hi(a1 + t * plane, __float_as_uint(r[1]));
+        if (t + 1 < T) {
+            const f32x2_t part = {__uint_as_float(__float_as_uint(r[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(r[1]) & 0xffff0000u)};
+            r = r - part;
+        }
+    }
+#else
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const unsigned pk = cvt_pk_bf16(r[0], r[1]);
@@ -316,15 +332,21 @@ NQ_DEV void lds_store_terms2(unsigned a0, unsigned a1, int plane, float v0, floa
             r = r - part;
         }
     }
+#endif
 }
 template <int T>
 NQ_DEV void lds_store_terms(unsigned a, int plane, float v) {
     float r = v;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
+#ifdef NQ_X6_TRUNC
+        lds_st16_hi(a + t * plane, __float_as_uint(r));
+        if (t + 1 < T) r -= __uint_as_float(__float_as_uint(r) & 0xffff0000u);
+#else
         const unsigned pk = cvt_pk_bf16(r, 0.f);
         lds_st16(a + t * plane, pk);
         if (t + 1 < T) r -= __uint_as_float(pk << 16);
+#endif
     }
 }
 // acc[m][nt] += sum over the kept term products of a[m][i] x b[nt][j]; smallest products first, consecutive MFMAs on
@@ -343,8 +365,11 @@ NQ_DEV void mma_terms(f32x16 (&acc)[MT][NT], const f32x4 (&a)[MT][T], const f32x
         }
 }
 // conv_k_bf16 for T terms: fragments [step][NT][T][64 lanes][8 bf16], activation planes PLANE bytes apart; A rows always
-// one step ahead (this form runs one wave per SIMD on the 512-register budget)
-template <int T, int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZADDR, int RING = 3>
+// one step ahead (this form runs one wave per SIMD on the 512-register budget).  FENCE: a sched_barrier behind the step's
+// requests -- hipcc's scheduler otherwise sinks them to just before their use, and with ONE wave per SIMD nobody fills the
+// stall (tools/micro/klx6.hip: matrix-pipe duty 0.82 -> 0.96 in the conv3 + conv4 loops; with two waves per SIMD the same
+// fence made the two-term kernel slower)
+template <int T, int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZADDR, int RING = 3, bool FENCE = true>
 NQ_DEV void conv_k_terms(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
                          const unsigned (&base)[MT], const unsigned (&m9)[MT]) {
     constexpr int S16 = CIN / 16, TOTAL = 9 * S16;
@@ -380,6 +405,7 @@ NQ_DEV void conv_k_terms(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int
     for (int g = 0; g < TOTAL; ++g) {
         if (g + RING - 1 < TOTAL) load_b(g + RING - 1, (g + RING - 1) % RING);
         if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1);
+        if (FENCE) __builtin_amdgcn_sched_barrier(0);
         mma_terms<T, MT, NT>(acc, a[g & 1], b[g % RING]);
     }
 }

@@ -163,14 +163,17 @@ def pool_last_step_bi(sd, x, pfx='pool.model.'):
 
 # -- whole network on one clip -----------------------------------------------------
 
-def predict_from_melspec(sd, args, spec, return_stages=False):
+def predict_from_melspec(sd, args, spec, return_stages=False, dtype=torch.float32):
     """model.forward on one clip's [n_mels,T] dB spectrogram (NL:137-142 / NL:260-268).
 
     Returns float32 numpy [5] (NISQA_DIM: mos, noi, dis, col, loud; NL:1461-1465) or [1] (NISQA).
+    dtype=torch.float64: the same operators in double precision (stages come back as float64) -- the yardstick the tests use
+    to compare the ROUNDING error of the GPU precision modes; the reference itself computes in float32.
     """
-    sd = {k: _t(v).float() for k, v in sd.items() if k.split('.')[-1] != 'num_batches_tracked'}
+    sd = {k: _t(v).to(dtype) for k, v in sd.items() if k.split('.')[-1] != 'num_batches_tracked'}
     with torch.no_grad():
         x, n_wins = segment_specs(spec, args['ms_seg_length'], args['ms_seg_hop_length'], None)
+        x = x.to(dtype)
         if n_wins > args['ms_max_segments']:
             raise ValueError('n_wins {} > max_length {}. Increase max window length ms_max_segments!'.format(
                 n_wins, args['ms_max_segments']))

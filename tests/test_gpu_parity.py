@@ -280,6 +280,53 @@ def test_end_to_end_matches_reference_fixture(name, precision):
     assert err.max() < TOL[precision][1]
 
 
+@pytest.mark.parametrize('weights', ['rand', 'real'])
+def test_rounding_error_of_the_precision_modes_against_float64(weights):
+    """'bf16x6' carries every fp32 operand of the AdaptCNN as three bf16 terms -- an exact split -- and drops only the three
+    term products of the size of an fp32 multiply-add's own rounding (<= 2 x 2^-24 of the product, 0.5 x 2^-24 rms): its
+    distance from a float64 evaluation of the same network must be that of fp32 arithmetic itself.  Yardstick:
+    oracle/net.py in float64 on the GPU's own spectrogram; compared: the exact-fp32 MFMA kernels ('f32'), 'bf16x6', the default
+    'bf16x3' (16 operand bits) and the reference's float32 torch operators on the CPU."""
+    if weights == 'real':
+        path = helpers.find_weights('nisqa.tar')
+        if path is None:
+            pytest.skip('real checkpoint not on this machine')
+        args, sd = helpers.load_checkpoint(path)
+    else:
+        args, sd = dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM')
+    pcm = [clip_pcm(i) for i in (0, 1, 3)]
+    err = {}
+    ref = None
+    for prec in ('f32', 'bf16x6', 'bf16x3'):
+        eng = _engine(args, sd, prec)
+        dev_pcm, plan = _upload(eng, pcm)
+        mel, floor = eng.mel(dev_pcm, plan, 48000, clamp=False)
+        feat, _ = eng.cnn(mel, floor, plan)
+        out = eng.pool(eng.td(feat, plan), plan)
+        torch.cuda.synchronize()
+        if ref is None:                                        # (the mel stage is the same kernel in every mode)
+            mel_h = torch.maximum(mel, floor[torch.from_numpy(np.repeat(np.arange(plan.n_clips), plan.T)).to(mel.device)][:, None]).cpu().numpy()
+            ref, e32 = [], [0.0, 0.0]
+            for n in range(plan.n_clips):
+                spec = mel_h[plan.frame_off[n]:plan.frame_off[n + 1]].T
+                o64, st64 = onet.predict_from_melspec(sd, args, spec, return_stages=True, dtype=torch.float64)
+                o32, st32 = onet.predict_from_melspec(sd, args, spec, return_stages=True)
+                ref.append((o64, st64))
+                e32 = [max(e32[0], np.abs(st32['feat'] - st64['feat']).max()), max(e32[1], np.abs(o32 - o64).max())]
+            err['reference float32 (CPU torch)'] = e32
+        e = [0.0, 0.0]
+        fh, oh = feat.cpu().numpy().astype(np.float64), out.cpu().numpy().astype(np.float64)
+        for n in range(plan.n_clips):
+            t0, nw = int(plan.tok_off[n]), int(plan.n_wins[n])
+            e = [max(e[0], np.abs(fh[t0:t0 + nw] - ref[n][1]['feat']).max()), max(e[1], np.abs(oh[n] - ref[n][0]).max())]
+        err[prec] = e
+    print('max |x - float64| (CNN features, outputs):', {k: ['%.3g' % v for v in e] for k, e in err.items()})
+    floor32 = max(err['f32'][0], err['reference float32 (CPU torch)'][0])
+    assert err['bf16x6'][0] <= 1.5 * floor32                   # features: within fp32 arithmetic's own distance from float64
+    assert err['bf16x6'][1] <= 1.5 * max(err['f32'][1], err['reference float32 (CPU torch)'][1]) + 2.4e-7   # outputs (+ one ulp at |4|)
+    assert err['bf16x3'][0] > 2 * err['bf16x6'][0]             # (and the 16-bit-operand default is visibly further away)
+
+
 def test_batch_composition_independence(eng_rand):
     """Per-clip result must not depend on what else is in the batch."""
     p = [clip_pcm(0), clip_pcm(3), clip_pcm(1)]
@@ -367,7 +414,7 @@ def test_predict_dir_drop_in_surface(tmp_path):
     assert np.abs(np.array([df2[c].iloc[0] for c in cols], np.float32) - ref).max() < 1e-3
 
 
-@pytest.mark.parametrize('ckpt,precision', [('nisqa.tar', 'bf16x3'), ('nisqa.tar', 'f32'), ('nisqa_mos_only.tar', 'bf16x3'),
+@pytest.mark.parametrize('ckpt,precision', [('nisqa.tar', 'bf16x3'), ('nisqa.tar', 'f32'), ('nisqa.tar', 'bf16x6'), ('nisqa_mos_only.tar', 'bf16x3'),
                                             ('nisqa_tts.tar', 'bf16x3')])
 def test_against_the_live_reference_loop_on_fresh_random_clips(tmp_path, ckpt, precision, monkeypatch):
     """Not a committed fixture: FRESH clips every run (seed from os.urandom, printed), scored by the reference's OWN loop on

@@ -1,6 +1,6 @@
 // Round 4: would an fp32-GRADE AdaptCNN on the bf16 matrix pipe pay?  Operands carried as THREE bf16 terms (hi + mid + lo = 24
-// mantissa bits, the fp32 operand itself) and SIX products per term pair (hh, hm, mh, hl, lh, mm; what is dropped is below
-// 2^-24 of the product, fp32's own rounding step): twice the MFMAs of the shipped two-term / three-product form, against the
+// mantissa bits, the fp32 operand itself) and SIX products per term pair (hh, hm, mh, hl, lh, mm; what is dropped is of the
+// size of an fp32 multiply-add's own rounding of the product): twice the MFMAs of the shipped two-term / three-product form, against the
 // exact-fp32 kernels' 5.3 x.  Three planes per activation tensor do not leave room for two workgroups per CU, so the question is
 // what ONE wave per SIMD reaches in the conv3 + conv4 K loops (1 296 MFMAs per segment) with real operand streams -- same
 // set-up as klm4.hip: fragments through a buffer descriptor from a blob of the real size, A rows by ds_read_b128 from padded
@@ -23,8 +23,8 @@
 #define SEG_BASE 2304u
 
 // conv_k_bf16 generalised to T terms per operand; products (i, j) with i + j <= T - 1, smallest first
-template <int T, int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZA, int RING>
-NQ_DEV void conv_k_terms(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
+template <int T, int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZA, int RING, int FENCE = 0>
+NQ_DEV void conv_k_local(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
                          const unsigned (&base)[MT], const unsigned (&m9)[MT]) {
     constexpr int S16 = CIN / 16, TOTAL = 9 * S16;
     f32x4 b[RING][NT][T], a[2][MT][T];
@@ -57,7 +57,9 @@ NQ_DEV void conv_k_terms(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int
 #pragma unroll
     for (int g = 0; g < TOTAL; ++g) {
         if (g + RING - 1 < TOTAL) load_b(g + RING - 1, (g + RING - 1) % RING);
+        if (FENCE & 1) __builtin_amdgcn_sched_barrier(0);
         if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1);
+        if (FENCE & 2) __builtin_amdgcn_sched_barrier(0);
         const int sa = g & 1, sb = g % RING;
 #pragma unroll
         for (int order = 2 * (T - 1); order >= 0; --order)            // smallest products first
@@ -73,7 +75,7 @@ NQ_DEV void conv_k_terms(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int
     }
 }
 
-template <int T, int RING, int WAVES>
+template <int T, int RING, int WAVES, int FENCE = 0>
 __global__ __launch_bounds__(WAVES * 64, 1) void kern(const unsigned short* __restrict__ wb, const unsigned* __restrict__ rnd,
                                                       float* __restrict__ out, long long* __restrict__ clk, int reps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,8 +108,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void kern(const unsigned short* __re
         for (int t = 0; t < MT; ++t) { acc[t][0] = zero16(); acc[t][1] = zero16(); }
 #pragma unroll
         for (int t = 0; t < MT; ++t) asm volatile("" : "+v"(base3[t]), "+v"(base4[t]), "+v"(m9[t]));
-        conv_k_terms<T, 32, MT, 2, W_, RS3, PL3, ZADDR, RING>(acc, rsrc, 0, lane16, base3, m9);
-        conv_k_terms<T, 64, MT, 2, W_, RS4, PL4, ZADDR, RING>(acc, rsrc, 18 * 2 * T * 1024, lane16, base4, m9);
+        conv_k_local<T, 32, MT, 2, W_, RS3, PL3, ZADDR, RING, FENCE>(acc, rsrc, 0, lane16, base3, m9);
+        conv_k_local<T, 64, MT, 2, W_, RS4, PL4, ZADDR, RING, FENCE>(acc, rsrc, 18 * 2 * T * 1024, lane16, base4, m9);
 #pragma unroll
         for (int t = 0; t < MT; ++t) sink += acc[t][0][rep & 15] + acc[t][1][(rep + 3) & 15];
     }
@@ -120,17 +122,17 @@ __global__ __launch_bounds__(WAVES * 64, 1) void kern(const unsigned short* __re
     out[(blockIdx.x * WAVES + wave) * 64 + lane] = sink;
 }
 
-template <int T, int RING, int WAVES>
+template <int T, int RING, int WAVES, int FENCE = 0>
 static void run(const char* name, const unsigned short* wb, const unsigned* rnd, float* out, long long* clk, int reps) {
     const unsigned lds = SEG_BASE + WAVES * T * PL4;
-    hipFuncSetAttribute((const void*)kern<T, RING, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)kern<T, RING, WAVES, FENCE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int blocks = 256;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float ms = 0.f;
     for (int it = 0; it < 3; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((kern<T, RING, WAVES>), dim3(blocks), dim3(WAVES * 64), lds, 0, wb, rnd, out, clk, reps);
+        hipLaunchKernelGGL((kern<T, RING, WAVES, FENCE>), dim3(blocks), dim3(WAVES * 64), lds, 0, wb, rnd, out, clk, reps);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
@@ -174,5 +176,8 @@ int main(int argc, char** argv) {
     run<3, 3, 4>("3 terms / 6 products, 1 wave per SIMD, ring 3", wb, rnd, out, clk, reps);
     run<3, 2, 4>("3 terms / 6 products, 1 wave per SIMD, ring 2", wb, rnd, out, clk, reps);
     run<3, 4, 4>("3 terms / 6 products, 1 wave per SIMD, ring 4", wb, rnd, out, clk, reps);
+    run<3, 3, 4, 2>("3 terms, ring 3, fence behind the step's requests", wb, rnd, out, clk, reps);
+    run<3, 3, 4, 3>("3 terms, ring 3, fences between B / A requests / MFMAs", wb, rnd, out, clk, reps);
+    run<3, 4, 4, 2>("3 terms, ring 4, fence behind the step's requests", wb, rnd, out, clk, reps);
     return 0;
 }

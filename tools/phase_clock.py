@@ -9,22 +9,24 @@ from nisqa_amd import synth, lib
 from nisqa_amd.engine import HipNisqa
 
 dev = torch.device('cuda:0')
-eng = HipNisqa(dict(synth.DIM_ARGS), synth.random_state_dict(7, 'NISQA_DIM'), dev)
+PREC = os.environ.get('NQ_PRECISION', 'bf16x3')          # bf16x6: cnn_front_bf16x6_kernel (its own stamp buffer)
+eng = HipNisqa(dict(synth.DIM_ARGS), synth.random_state_dict(7, 'NISQA_DIM'), dev, precision=PREC)
 L = ctypes.CDLL(lib.LIB_PATH)
-L.nisqa_debug_phase_clock.restype = ctypes.c_int
-L.nisqa_debug_phase_clock.argtypes = [ctypes.c_void_p, ctypes.c_int]
+DBG = getattr(L, 'nisqa_debug_phase_clock6' if PREC == 'bf16x6' else 'nisqa_debug_phase_clock')
+DBG.restype = ctypes.c_int
+DBG.argtypes = [ctypes.c_void_p, ctypes.c_int]
 base = [synth.synth_pcm16(1000 + i, 10.0) for i in range(8)]
 pcm = torch.from_numpy(np.concatenate([base[i % 8] for i in range(64)])).to(dev)
 plan = eng.plan([len(base[0])] * 64, 48000)
 for _ in range(20):
     eng.forward_pcm(pcm, plan, 48000)
 torch.cuda.synchronize()
-L.nisqa_debug_phase_clock(None, 1)
+DBG(None, 1)
 for _ in range(50):                      # every wave overwrites its own slot: the last launch's numbers are read
     eng.forward_pcm(pcm, plan, 48000)
 torch.cuda.synchronize()
 out = (ctypes.c_ulonglong * 16)()
-assert L.nisqa_debug_phase_clock(out, 0) == 0
+assert DBG(out, 0) == 0
 n = out[12]
 names = ['stage patch', 'conv1+pool', 'conv2 K loop', 'conv2 epilogue', 'conv3 K loop', 'conv3 epilogue', 'conv4 K loop',
          'barrier+conv4 epilogue+barrier', 'conv5 K loop', 'conv5 epilogue+barrier', 'conv6 K loop', 'conv6 epilogue']
