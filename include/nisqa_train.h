@@ -122,6 +122,16 @@ int nisqa_segconv_pack_f32_many(int32_t n_jobs, const int32_t* modes, const floa
                                 float* const* frags, void* stream);
 int nisqa_segconv_f32(int32_t mode, const float* src, const float* frags, float* out, int32_t n_segments, int32_t h, int32_t w,
                       int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c, void* stream);
+/* The same two products at fp32 OPERAND precision on the bf16 matrix pipe (precision mode 'bf16x6'): activations and weights
+ * as three exact bf16 terms (hi + mid + lo), six MFMA products per term pair, fp32 accumulation -- the accuracy of
+ * nisqa_segconv_f32 at 2.7 x its matrix-pipe rate.  nisqa_segconv_frag_bytes_x6 / nisqa_segconv_pack_x6_many /
+ * nisqa_segconv_bf16x6 mirror nisqa_segconv_frag_bytes / nisqa_segconv_pack_many / nisqa_segconv_bf16 argument for argument
+ * (three-term fragments: 1.5 x the bytes). */
+int64_t nisqa_segconv_frag_bytes_x6(int32_t mode, int32_t ci, int32_t co);
+int nisqa_segconv_pack_x6_many(int32_t n_jobs, const int32_t* modes, const float* const* w, const int32_t* ci, const int32_t* co,
+                               uint16_t* const* frags, void* stream);
+int nisqa_segconv_bf16x6(int32_t mode, const float* src, const uint16_t* frags, float* out, int32_t n_segments, int32_t h, int32_t w,
+                         int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c, void* stream);
 /* Weight gradient of the same layers, segment-resident: dw[co][9*ci] += dz^T * patches(x) (dw zeroed by the caller, like
  * nisqa_conv3x3_gemm mode 2); x[S][h*w][ci], dz[S][h*wo][co].  A workgroup keeps its part of dw in registers over all the
  * segments it walks over and adds it to dw once (fp32 atomics). */
@@ -179,6 +189,12 @@ int nisqa_segconv_wgrad_f32(const float* x, const float* z, const float* dy, con
                             const float* mean_rstd, const float* gamma, const float* beta, const double* sums2, float* dz_out,
                             float* dgamma, float* dbeta, float* dw, int32_t n_segments, int32_t h, int32_t w, int32_t ci, int32_t co,
                             int32_t pad_w, int32_t ho, int32_t wo, void* stream);
+/* ... and at fp32 OPERAND precision on the bf16 matrix pipe (x and dz as three exact bf16 terms, six products: precision mode
+ * 'bf16x6'); the contract of nisqa_segconv_wgrad_f32. */
+int nisqa_segconv_wgrad_bf16x6(const float* x, const float* z, const float* dy, const int32_t* arg, const float* drop,
+                               const float* mean_rstd, const float* gamma, const float* beta, const double* sums2, float* dz_out,
+                               float* dgamma, float* dbeta, float* dw, int32_t n_segments, int32_t h, int32_t w, int32_t ci,
+                               int32_t co, int32_t pad_w, int32_t ho, int32_t wo, void* stream);
 int nisqa_bn_bwd2(float* dyb_to_dz, const float* z, const double* sums2, const float* mean_rstd, const float* gamma,
                   int64_t rows, int32_t c, float* dgamma, float* dbeta, double* sum_dz_opt, void* stream);
 

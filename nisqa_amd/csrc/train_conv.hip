@@ -95,12 +95,13 @@ __global__ __launch_bounds__(256) void segconv_pack_kernel(const float* __restri
 
 // the same for up to ten (layer, mode) jobs in ONE launch (blockIdx.y = job): the training step packs five layers x two
 // directions per optimiser step, and ten launches of ~5 us each were 1.3 % of it
-struct segconv_pack_jobs { const float* w[10]; unsigned short* out[10]; int ci[10], co[10], mode[10]; };
+// (terms = 3: hi / mid / lo fragments [step g][NT][3][64 lanes][8 bf16] of the three-term kernels -- an fp32 weight exactly)
+struct segconv_pack_jobs { const float* w[10]; unsigned short* out[10]; int ci[10], co[10], mode[10]; int terms; };
 __global__ __launch_bounds__(256) void segconv_pack_many_kernel(segconv_pack_jobs jobs) {
     const int j = blockIdx.y;
     const float* __restrict__ w = jobs.w[j];
     unsigned short* __restrict__ out = jobs.out[j];
-    const int ci = jobs.ci[j], co = jobs.co[j], mode = jobs.mode[j];
+    const int ci = jobs.ci[j], co = jobs.co[j], mode = jobs.mode[j], terms = jobs.terms;
     const int kc = mode ? co : ci, n_real = mode ? ci : co;
     const int s16 = kc / 16, nt_n = (n_real + 31) / 32;
     const int total = 9 * s16 * nt_n * 64 * 8;
@@ -109,11 +110,12 @@ __global__ __launch_bounds__(256) void segconv_pack_many_kernel(segconv_pack_job
         const int tap = g / s16, c = 16 * (g % s16) + 8 * (lane >> 5) + e, n = 32 * nt + (lane & 31);
         float v = 0.f;
         if (n < n_real) v = mode ? w[(size_t)c * (9 * ci) + (8 - tap) * ci + n] : w[(size_t)n * (9 * ci) + tap * ci + c];
-        const unsigned hi = bf16_bits(v);
-        const unsigned lo = bf16_bits(v - bf16_val(hi));
-        const size_t o = (((size_t)(g * nt_n + nt) * 2) * 64 + lane) * 8 + e;
-        out[o] = (unsigned short)hi;
-        out[o + 512] = (unsigned short)lo;
+        const size_t o = (((size_t)(g * nt_n + nt) * terms) * 64 + lane) * 8 + e;
+        for (int t = 0; t < terms; ++t) {
+            const unsigned b = bf16_bits(v);
+            out[o + 512 * t] = (unsigned short)b;
+            v -= bf16_val(b);
+        }
     }
 }
 
@@ -135,6 +137,26 @@ extern "C" int nisqa_segconv_pack_many(int32_t n_jobs, const int32_t* modes, con
                                        const int32_t* co, uint16_t* const* frags, void* stream) {
     if (n_jobs < 1 || n_jobs > 10 || !modes || !w || !ci || !co || !frags) return NISQA_ERR_ARG;
     segconv_pack_jobs jobs = {};
+    jobs.terms = 2;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!w[j] || !frags[j] || nisqa_segconv_frag_bytes(modes[j], ci[j], co[j]) < 0) return NISQA_ERR_ARG;
+        jobs.w[j] = w[j]; jobs.out[j] = frags[j]; jobs.ci[j] = ci[j]; jobs.co[j] = co[j]; jobs.mode[j] = modes[j];
+    }
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(segconv_pack_many_kernel, dim3(36, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return NQ_LAUNCH_STATUS();
+}
+
+// three-term fragments (nisqa_segconv_bf16x6): 1.5 x the bytes
+extern "C" int64_t nisqa_segconv_frag_bytes_x6(int32_t mode, int32_t ci, int32_t co) {
+    const int64_t b = nisqa_segconv_frag_bytes(mode, ci, co);
+    return b < 0 ? b : b / 2 * 3;
+}
+extern "C" int nisqa_segconv_pack_x6_many(int32_t n_jobs, const int32_t* modes, const float* const* w, const int32_t* ci,
+                                          const int32_t* co, uint16_t* const* frags, void* stream) {
+    if (n_jobs < 1 || n_jobs > 10 || !modes || !w || !ci || !co || !frags) return NISQA_ERR_ARG;
+    segconv_pack_jobs jobs = {};
+    jobs.terms = 3;
     for (int j = 0; j < n_jobs; ++j) {
         if (!w[j] || !frags[j] || nisqa_segconv_frag_bytes(modes[j], ci[j], co[j]) < 0) return NISQA_ERR_ARG;
         jobs.w[j] = w[j]; jobs.out[j] = frags[j]; jobs.ci[j] = ci[j]; jobs.co[j] = co[j]; jobs.mode[j] = modes[j];
@@ -225,16 +247,37 @@ extern "C" int nisqa_segconv_pack_f32_many(int32_t n_jobs, const int32_t* modes,
     return NQ_LAUNCH_STATUS();
 }
 
+// four consecutive channels of one pixel -> T bf16 terms each (round to nearest), 8 bytes per plane
+template <int T>
+NQ_DEV void sc_store_terms4(unsigned a, int plane, f32x4 v) {
+    f32x2_t r0 = {v[0], v[1]}, r1 = {v[2], v[3]};
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const unsigned p0 = cvt_pk_bf16(r0[0], r0[1]), p1 = cvt_pk_bf16(r1[0], r1[1]);
+        lds_st32(a + t * plane, p0);
+        lds_st32(a + t * plane + 4, p1);
+        if (t + 1 < T) {
+            r0 = r0 - f32x2_t{__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u)};
+            r1 = r1 - f32x2_t{__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+        }
+    }
+}
+#ifndef SC_X6_FENCE
+#define SC_X6_FENCE true     /* sched_barrier behind a K step's requests in the three-term loops (conv_k_terms) */
+#endif
+
 // CIN: channels of the staged tensor (the reduction runs over 9 x CIN); NT: 32-column tiles of the output channels
 // HR x WR: output pixels of a segment (the rows); HS x WS: pixels of the staged tensor; source pixel of row (y, x) and
 // tap (ty, tx) is (y + ty - 1, x + tx - PADX)
-template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false>
+// TERMS (split-bf16 only): 2 = hi / lo planes and three products per term pair; 3 = hi / mid / lo planes, an exact split of the
+// fp32 activations, and six products (conv_k_terms: the accuracy of the fp32 variant at 2.7 x its matrix-pipe rate)
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false, int TERMS = 2>
 struct segconv_cfg {
     static constexpr int RS = F32 ? 4 * CIN + 16 : 2 * CIN + 16;
     static constexpr int PXS = HS * WS, PXR = HR * WR;
     static constexpr int PLANE = SEGS * PXS * RS;
     static constexpr unsigned BASE = F32 ? SCF_BASE : SC_BASE, ZADDR = F32 ? SCF_ZADDR : SC_ZADDR;
-    static constexpr unsigned LDS = F32 ? BASE + PLANE : BASE + 2 * PLANE;
+    static constexpr unsigned LDS = F32 ? BASE + PLANE : BASE + TERMS * PLANE;
     static constexpr int ROWS = SEGS * PXR;
     static constexpr int F4 = SEGS * PXS * CIN / 4;          // 128-bit groups of the workgroup's activations
     static constexpr int NV = (F4 + 255) / 256;
@@ -243,11 +286,11 @@ struct segconv_cfg {
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
 };
 
-template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false>
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false, int TERMS = 2>
 __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
     const float* __restrict__ src, const unsigned short* __restrict__ frags, float* __restrict__ out, int n_segments,
     const float* __restrict__ bias, double* __restrict__ stats) {
-    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32> C;
+    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS> C;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid0 = threadIdx.x, lane0 = tid0 & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -271,7 +314,7 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
         base[t] = valid ? C::BASE + (unsigned)(((sg * HS + y - 1) * WS + (x - PADX)) * C::RS) + 16u * (lane0 >> 5)
                         : C::BASE + 16u * (lane0 >> 5);
     }
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)frags, 0, F32 ? 9 * (CIN / 8) * NT * 1024 : 9 * (CIN / 16) * NT * 2048, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)frags, 0, F32 ? 9 * (CIN / 8) * NT * 1024 : 9 * (CIN / 16) * NT * TERMS * 1024, 0x00020000);
     if (tid0 < (F32 ? 64 : 32)) *(unsigned*)(smem + C::ZADDR + 4 * tid0) = 0u;  // through the symbol: the kernel must be seen to use LDS
     const bool with_stats = FWD && stats != nullptr;
     double s1[NT], s2[NT];                                       // this lane's column sums over all groups of the workgroup
@@ -325,6 +368,10 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
                         continue;
                     }
                     const unsigned a = SC_BASE + pix * C::RS + 2 * c;
+                    if constexpr (TERMS == 3) {
+                        sc_store_terms4<3>(a, C::PLANE, v[j]);
+                        continue;
+                    }
                     const unsigned h0 = cvt_pk_bf16(v[j][0], v[j][1]), h1 = cvt_pk_bf16(v[j][2], v[j][3]);
                     const unsigned l0 = cvt_pk_bf16(v[j][0] - __uint_as_float(h0 << 16), v[j][1] - __uint_as_float(h0 & 0xffff0000u));
                     const unsigned l1 = cvt_pk_bf16(v[j][2] - __uint_as_float(h1 << 16), v[j][3] - __uint_as_float(h1 & 0xffff0000u));
@@ -360,6 +407,7 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
             for (int nt = 0; nt < NT; ++nt) acc[t][nt] = zero16();
         if (active) {
             if constexpr (F32) conv_k_f32<CIN, MT, NT, WS, C::RS, C::ZADDR, SC_RING>(acc, rsrc, lane0 * 16, base, m9);
+            else if constexpr (TERMS == 3) conv_k_terms<3, CIN, MT, NT, WS, C::RS, C::PLANE, SC_ZADDR, SC_RING, SC_X6_FENCE>(acc, rsrc, 0, lane0 * 16, base, m9);
             else conv_k_bf16<CIN, MT, NT, WS, C::RS, C::PLANE, SC_ZADDR, (MT * NT <= 4), SC_RING>(acc, rsrc, 0, lane0 * 16, base, m9);
         }
 
@@ -448,19 +496,19 @@ static int sc_cu_count() {
     return v;
 }
 
-template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false>
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false, int TERMS = 2>
 static void segconv_launch(hipStream_t st, const float* src, const uint16_t* frags, float* out, int n_segments,
                            const float* bias, double* stats) {
-    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32> C;
+    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS> C;
     static std::atomic<int> per_cu_dev[SC_MAX_DEV];             // resident workgroups per CU (registers and LDS), asked once per device
     const int dev = sc_device();
     int per_cu = per_cu_dev[dev].load(std::memory_order_relaxed);
     if (!per_cu) {
         // 50-80 KB of dynamic LDS: opt in explicitly (a runtime that enforces the 64 KB default would refuse the launch)
-        (void)hipFuncSetAttribute((const void*)segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32>,
+        (void)hipFuncSetAttribute((const void*)segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32>, 256,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS>, 256,
                                                          C::LDS) != hipSuccess || nb < 1)
             nb = 2;
         per_cu = nb;
@@ -468,7 +516,7 @@ static void segconv_launch(hipStream_t st, const float* src, const uint16_t* fra
     }
     const int n_groups = (n_segments + SEGS - 1) / SEGS;
     const int grid = n_groups < per_cu * sc_cu_count() ? n_groups : per_cu * sc_cu_count();
-    hipLaunchKernelGGL((segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32>), dim3(grid), dim3(256), C::LDS, st, src,
+    hipLaunchKernelGGL((segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS>), dim3(grid), dim3(256), C::LDS, st, src,
                        frags, out, n_segments, bias, stats);
 }
 
@@ -539,6 +587,36 @@ extern "C" int nisqa_segconv_f32(int32_t mode, const float* src, const float* fr
     return NQ_LAUNCH_STATUS();
 }
 
+// the same two products at fp32 OPERAND precision on the bf16 matrix pipe (precision mode 'bf16x6'): activations and weights
+// as three exact bf16 terms, six products per term pair (conv_k_terms; frags = nisqa_segconv_pack_x6_many of the same mode).
+// Three planes per staged tensor: fewer segments per workgroup than the two-term table above, still two workgroups per CU.
+extern "C" int nisqa_segconv_bf16x6(int32_t mode, const float* src, const uint16_t* frags, float* out, int32_t n_segments, int32_t h,
+                                    int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c, void* stream) {
+    if (mode < 0 || mode > 1 || !src || !frags || !out || n_segments <= 0 || (mode == 1 && (bias || stats2c)) ||
+        !nisqa_segconv_supported(h, w, ci, co, pad_w))
+        return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    NQ_LAUNCH_BEGIN();
+    const int key = ((h * 100 + w) * 100 + ci) * 100 + co;
+    const int n = n_segments;
+    if (mode == 0) {
+        if (key == SC_KEY(24, 7, 16, 32) && pad_w == 1) segconv_launch<16, 1, 32, 24, 7, 24, 7, 1, 3, 4, true, false, 3>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<32, 2, 64, 12, 5, 12, 5, 1, 4, 2, true, false, 3>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, 2, 1, true, false, 3>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 7, 1, true, false, 3>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 1, 6, 3, 0, 7, 1, true, false, 3>(st, src, frags, out, n, bias, stats2c);
+        else return NISQA_ERR_ARG;
+    } else {
+        if (key == SC_KEY(24, 7, 16, 32) && pad_w == 1) segconv_launch<32, 1, 16, 24, 7, 24, 7, 1, 1, 2, false, false, 3>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<64, 1, 32, 12, 5, 12, 5, 1, 2, 1, false, false, 3>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, 2, 1, false, false, 3>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 7, 1, false, false, 3>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 3, 6, 1, 2, 14, 2, false, false, 3>(st, src, frags, out, n, nullptr, nullptr);
+        else return NISQA_ERR_ARG;
+    }
+    return NQ_LAUNCH_STATUS();
+}
+
 // ======================================================================================================================
 // Weight gradient, segment-resident: dw[co][tap * CI + ci] += sum over the pixels of every segment of
 // dz[px][co] * x[px + tap][ci]  -- a GEMM with M = co, N = (tap, ci), K = pixels.  The implicit GEMM (train.hip, mode 2)
@@ -562,16 +640,18 @@ NQ_DEV f32x4 sc_tr_frag(unsigned a0, unsigned a1) {
     return __builtin_bit_cast(f32x4, both);
 }
 
-template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT>
+// TERMS: 2 = hi / lo planes of x and dz, three products; 3 = hi / mid / lo (exact splits), six products: fp32-grade ('bf16x6')
+template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT, int TERMS = 2>
 struct segwgrad_cfg {
+    static constexpr int T = TERMS;
     static constexpr int RSX = 2 * CI + 16, RSZ = 2 * CO + 16;
     static constexpr int XPW = W + 2 * PADW, XPH = H + 2;
     static constexpr int PXX = XPH * XPW, PXI = H * W, PXZ = H * WO;
     static constexpr int PLX = SEGS * PXX * RSX;
     static constexpr int KROWS = SEGS * PXZ;
     static constexpr int PLZ = (KROWS + 1) * RSZ;            // + one zero row: the k rows behind the last pixel
-    static constexpr unsigned ZB = 2u * PLX;                 // inside a buffer: x hi, x lo, dz hi, dz lo
-    static constexpr unsigned BUF = 2u * PLX + 2u * PLZ;
+    static constexpr unsigned ZB = (unsigned)TERMS * PLX;    // inside a buffer: the x planes (hi, [mid,] lo), then the dz planes
+    static constexpr unsigned BUF = (unsigned)TERMS * PLX + (unsigned)TERMS * PLZ;
     static constexpr unsigned LDS = 2u * BUF;                // two buffers: group g + 1 is staged while group g is multiplied
     static constexpr int KSTEPS = (KROWS + 15) / 16;
     static constexpr int MT = CO / 32, MTW = MT / MSPLIT;    // M tiles of the layer / of a wave
@@ -591,24 +671,27 @@ NQ_DEV void segwgrad_kloop(f32x16 (&acc)[C::MTW][C::NTW], const unsigned (&za)[C
 #pragma unroll
     for (int st = 0; st < C::KSTEPS; ++st) {
         __builtin_amdgcn_sched_barrier(0);                     // a step's reads stay in their step (register pressure)
-        f32x4 ah[C::MTW], al[C::MTW];
+        f32x4 a[C::MTW][C::T];
 #pragma unroll
-        for (int m = 0; m < C::MTW; ++m) {
-            ah[m] = sc_tr_frag(za[st][0] + 64 * m, za[st][1] + 64 * m);
-            al[m] = sc_tr_frag(za[st][0] + 64 * m + C::PLZ, za[st][1] + 64 * m + C::PLZ);
-        }
+        for (int m = 0; m < C::MTW; ++m)
+#pragma unroll
+            for (int t = 0; t < C::T; ++t) a[m][t] = sc_tr_frag(za[st][0] + 64 * m + t * C::PLZ, za[st][1] + 64 * m + t * C::PLZ);
 #pragma unroll
         for (int j = 0; j < C::NTW; ++j) {
             if (j < n_own) {                                   // wave-uniform
                 const unsigned a0 = xa[st][0] + noff[j], a1 = xa[st][1] + noff[j];
-                const f32x4 bh = sc_tr_frag(a0, a1);
-                const f32x4 bl = sc_tr_frag(a0 + C::PLX, a1 + C::PLX);
+                f32x4 b[C::T];
 #pragma unroll
-                for (int m = 0; m < C::MTW; ++m) acc[m][j] = mfma_bf(ah[m], bl, acc[m][j]);
+                for (int t = 0; t < C::T; ++t) b[t] = sc_tr_frag(a0 + t * C::PLX, a1 + t * C::PLX);
+                // the term products (i, j2) with i + j2 <= T - 1, smallest first (T = 2: hl, lh, hh as before)
 #pragma unroll
-                for (int m = 0; m < C::MTW; ++m) acc[m][j] = mfma_bf(al[m], bh, acc[m][j]);
+                for (int order = C::T - 1; order >= 0; --order)
 #pragma unroll
-                for (int m = 0; m < C::MTW; ++m) acc[m][j] = mfma_bf(ah[m], bh, acc[m][j]);
+                    for (int i = 0; i <= order; ++i) {
+                        const int j2 = order - i;
+#pragma unroll
+                        for (int m = 0; m < C::MTW; ++m) acc[m][j] = mfma_bf(a[m][i], b[j2], acc[m][j]);
+                    }
             }
         }
     }
@@ -628,10 +711,10 @@ NQ_DEV int sc_win_lo(int i, int n_in, int n_out) { return (i * n_in) / n_out; }
 NQ_DEV int sc_win_hi(int i, int n_in, int n_out) { return ((i + 1) * n_in + n_out - 1) / n_out; }
 typedef int sc_i32x4 __attribute__((ext_vector_type(4)));
 
-template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT, int PH, int PW>
+template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT, int PH, int PW, int TERMS = 2>
 __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                float* __restrict__ dw, int n_segments, segw_bn bn) {
-    typedef segwgrad_cfg<CI, CO, H, W, WO, PADW, SEGS, MSPLIT> C;
+    typedef segwgrad_cfg<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, TERMS> C;
     constexpr bool BN = PH > 0;
     constexpr bool IDENT = PH == H && PW == WO;
     static_assert(!BN || (H % PH == 0 && 512 % (CO / 4) == 0), "pooling rows are disjoint; a thread keeps its four channels");
@@ -741,11 +824,7 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
                 const int pix = (4 * i) / CI, c = (4 * i) % CI;
                 const int sg = pix / C::PXI, p = pix - sg * C::PXI, y = p / W, xx = p - y * W;
                 const unsigned a = buf + (unsigned)((sg * C::PXX + (y + 1) * C::XPW + xx + PADW) * C::RSX) + 2 * c;
-                const unsigned h0 = cvt_pk_bf16(vx[j][0], vx[j][1]), h1 = cvt_pk_bf16(vx[j][2], vx[j][3]);
-                const unsigned l0 = cvt_pk_bf16(vx[j][0] - __uint_as_float(h0 << 16), vx[j][1] - __uint_as_float(h0 & 0xffff0000u));
-                const unsigned l1 = cvt_pk_bf16(vx[j][2] - __uint_as_float(h1 << 16), vx[j][3] - __uint_as_float(h1 & 0xffff0000u));
-                lds_st32(a, h0); lds_st32(a + 4, h1);
-                lds_st32(a + C::PLX, l0); lds_st32(a + C::PLX + 4, l1);
+                sc_store_terms4<TERMS>(a, C::PLX, vx[j]);
             }
         }
         const int seg0 = grp * SEGS;
@@ -778,11 +857,7 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
                     if (ok) *(f32x4*)(bn.dz_out + (size_t)seg0 * C::PXZ * CO + (size_t)4 * i) = dzv;
                 }
                 const unsigned a = buf + C::ZB + (unsigned)(pix * C::RSZ) + 2 * c;
-                const unsigned h0 = cvt_pk_bf16(dzv[0], dzv[1]), h1 = cvt_pk_bf16(dzv[2], dzv[3]);
-                const unsigned l0 = cvt_pk_bf16(dzv[0] - __uint_as_float(h0 << 16), dzv[1] - __uint_as_float(h0 & 0xffff0000u));
-                const unsigned l1 = cvt_pk_bf16(dzv[2] - __uint_as_float(h1 << 16), dzv[3] - __uint_as_float(h1 & 0xffff0000u));
-                lds_st32(a, h0); lds_st32(a + 4, h1);
-                lds_st32(a + C::PLZ, l0); lds_st32(a + C::PLZ + 4, l1);
+                sc_store_terms4<TERMS>(a, C::PLZ, dzv);
             }
         }
     };
@@ -850,19 +925,19 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
 #endif
 }
 
-template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT, int PH = 0, int PW = 0>
+template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT, int PH = 0, int PW = 0, int TERMS = 2>
 static void segwgrad_launch(hipStream_t st, const float* x, const float* dz, float* dw, int n_segments, segw_bn bn = segw_bn{}) {
-    typedef segwgrad_cfg<CI, CO, H, W, WO, PADW, SEGS, MSPLIT> C;
+    typedef segwgrad_cfg<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, TERMS> C;
     static std::atomic<bool> attr[SC_MAX_DEV];
     const int dev = sc_device();
     if (!attr[dev].load(std::memory_order_relaxed)) {           // more than 64 KB of dynamic LDS, per device
-        (void)hipFuncSetAttribute((const void*)segwgrad_bf16_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, PH, PW>,
+        (void)hipFuncSetAttribute((const void*)segwgrad_bf16_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, PH, PW, TERMS>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
         attr[dev].store(true, std::memory_order_relaxed);
     }
     const int n_groups = (n_segments + SEGS - 1) / SEGS;
     const int grid = n_groups < sc_cu_count() ? n_groups : sc_cu_count();
-    hipLaunchKernelGGL((segwgrad_bf16_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, PH, PW>), dim3(grid), dim3(512), C::LDS, st, x, dz, dw,
+    hipLaunchKernelGGL((segwgrad_bf16_kernel<CI, CO, H, W, WO, PADW, SEGS, MSPLIT, PH, PW, TERMS>), dim3(grid), dim3(512), C::LDS, st, x, dz, dw,
                        n_segments, bn);
 }
 
@@ -904,6 +979,38 @@ extern "C" int nisqa_segconv_wgrad_bn_bf16(const float* x, const float* z, const
     return NQ_LAUNCH_STATUS();
 }
 
+
+// The weight gradient at fp32 OPERAND precision on the bf16 matrix pipe (precision mode 'bf16x6'): x and dz as three exact bf16
+// terms, six products; the contract of nisqa_segconv_wgrad_f32 (z == NULL: dz_out holds dz on entry and nothing is folded;
+// otherwise the BatchNorm backward runs inside the staging and dz_out, dgamma, dbeta are written).  Three planes per tensor
+// and two buffers: half the segments per group of the two-term table where that does not fit 160 KB.
+extern "C" int nisqa_segconv_wgrad_bf16x6(const float* x, const float* z, const float* dy, const int32_t* arg, const float* drop,
+                                          const float* mean_rstd, const float* gamma, const float* beta, const double* sums2,
+                                          float* dz_out, float* dgamma, float* dbeta, float* dw, int32_t n_segments, int32_t h, int32_t w,
+                                          int32_t ci, int32_t co, int32_t pad_w, int32_t ho, int32_t wo, void* stream) {
+    if (!x || !dz_out || !dw || n_segments <= 0 || !nisqa_segconv_supported(h, w, ci, co, pad_w)) return NISQA_ERR_ARG;
+    const bool fold = z != nullptr;
+    if (fold && (!dy || !arg || !mean_rstd || !gamma || !beta || !sums2 || !dgamma || !dbeta)) return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const segw_bn bn = {z, dy, arg, drop, mean_rstd, gamma, beta, sums2, dz_out, dgamma, dbeta};
+    const int key = SC_KEY(h, w, ci, co);
+    NQ_LAUNCH_BEGIN();
+    if (!fold) {
+        if (key == SC_KEY(24, 7, 16, 32)) segwgrad_launch<16, 32, 24, 7, 7, 1, 1, 1, 0, 0, 3>(st, x, dz_out, dw, n_segments);
+        else if (key == SC_KEY(12, 5, 32, 64)) segwgrad_launch<32, 64, 12, 5, 5, 1, 1, 2, 0, 0, 3>(st, x, dz_out, dw, n_segments);
+        else if (key == SC_KEY(12, 5, 64, 64)) segwgrad_launch<64, 64, 12, 5, 5, 1, 1, SC_W_MSPLIT, 0, 0, 3>(st, x, dz_out, dw, n_segments);
+        else if (pad_w == 1) segwgrad_launch<64, 64, 6, 3, 3, 1, 2, SC_W_MSPLIT, 0, 0, 3>(st, x, dz_out, dw, n_segments);
+        else segwgrad_launch<64, 64, 6, 3, 1, 0, 4, SC_W_MSPLIT, 0, 0, 3>(st, x, dz_out, dw, n_segments);
+        return NQ_LAUNCH_STATUS();
+    }
+    if (key == SC_KEY(24, 7, 16, 32) && ho == 12 && wo == 5) segwgrad_launch<16, 32, 24, 7, 7, 1, 1, 1, 12, 5, 3>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(12, 5, 32, 64) && ho == 12 && wo == 5) segwgrad_launch<32, 64, 12, 5, 5, 1, 1, 2, 12, 5, 3>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(12, 5, 64, 64) && ho == 6 && wo == 3) segwgrad_launch<64, 64, 12, 5, 5, 1, 1, SC_W_MSPLIT, 6, 3, 3>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1 && ho == 6 && wo == 3) segwgrad_launch<64, 64, 6, 3, 3, 1, 2, SC_W_MSPLIT, 6, 3, 3>(st, x, nullptr, dw, n_segments, bn);
+    else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0 && ho == 6 && wo == 1) segwgrad_launch<64, 64, 6, 3, 1, 0, 4, SC_W_MSPLIT, 6, 1, 3>(st, x, nullptr, dw, n_segments, bn);
+    else return NISQA_ERR_ARG;
+    return NQ_LAUNCH_STATUS();
+}
 
 // ======================================================================================================================
 // The same weight gradient in EXACT fp32 (precision mode 'f32': the reference's arithmetic) on v_mfma_f32_32x32x2_f32:

@@ -102,6 +102,9 @@ TRAIN_SYMBOLS = {
     'nisqa_segconv_frag_bytes_f32': (ctypes.c_int64, [c_i32, c_i32, c_i32]),
     'nisqa_segconv_pack_f32_many': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nisqa_segconv_f32': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
+    'nisqa_segconv_frag_bytes_x6': (ctypes.c_int64, [c_i32, c_i32, c_i32]),
+    'nisqa_segconv_pack_x6_many': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'nisqa_segconv_bf16x6': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_segconv_wgrad_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     'nisqa_col2im3x3': (ctypes.c_int, [c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     'nisqa_col_dot': (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_p]),
@@ -113,6 +116,7 @@ TRAIN_SYMBOLS = {
     'nisqa_bn_pool_bwd_sums': (ctypes.c_int, [c_p] * 7 + [c_i32] * 6 + [c_p] * 2),
     'nisqa_segconv_wgrad_bn_bf16': (ctypes.c_int, [c_p] * 13 + [c_i32] * 8 + [c_p]),
     'nisqa_segconv_wgrad_f32': (ctypes.c_int, [c_p] * 13 + [c_i32] * 8 + [c_p]),
+    'nisqa_segconv_wgrad_bf16x6': (ctypes.c_int, [c_p] * 13 + [c_i32] * 8 + [c_p]),
     'nisqa_bn_bwd2': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_layernorm_fwd': (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
     'nisqa_layernorm_bwd': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),

@@ -84,14 +84,17 @@ class HipTrainer(object):
           'mixed'  (default) forward on fp32 MFMA, dgrad and wgrad on split-bf16 MFMA (bf16 hi + lo operands, three products per term,
                    fp32 accumulation): loss, y_hat and BatchNorm buffers are those of 'f32' bit for bit, every gradient
                    stays within the same 1e-3 bound of the reference fixture (measured 7e-5);
+          'bf16x6' forward, dgrad and wgrad at fp32 OPERAND precision on the bf16 matrix pipe: activations, gradients and weights as
+                   three exact bf16 terms, six MFMA products per term pair (csrc/train_conv.hip, TERMS = 3): held to the bounds
+                   of 'f32' by the same tests, at 2.7 x its matrix-pipe rate;
           'bf16x3' the forward convolutions on split-bf16 MFMA as well (the arithmetic of the inference path's default):
                    y_hat moves by <= 1e-4.  On the random-weight fixtures that is enough to move individual gradient
                    tensors by per cent (the network's Jacobian at a random initialisation is that sensitive to its
                    activations; the backward kernels themselves agree with fp32 to 1e-5, tests/test_gpu_train.py)."""
         a = args
         self.precision = precision or os.environ.get('NISQA_HIP_TRAIN_PRECISION', 'mixed')
-        if self.precision not in ('f32', 'mixed', 'bf16x3'):
-            raise ValueError('precision must be f32, mixed or bf16x3, got {}'.format(self.precision))
+        if self.precision not in ('f32', 'mixed', 'bf16x3', 'bf16x6'):
+            raise ValueError('precision must be f32, mixed, bf16x3 or bf16x6, got {}'.format(self.precision))
         if not (a.get('cnn_model') == 'adapt' and a.get('td') == 'self_att' and a.get('pool') == 'att') \
                 or a.get('td_2') not in (None, 'skip') or a['model'] not in ('NISQA', 'NISQA_DIM'):
             raise NotImplementedError('HIP training step covers NISQA / NISQA_DIM with cnn_model=adapt, td=self_att, '
@@ -112,7 +115,13 @@ class HipTrainer(object):
         self.segconv_f32_fwd = os.environ.get('NISQA_HIP_TRAIN_SEGCONV_F32_FWD', '1') != '0' and self.precision in ('f32', 'mixed')
         self._sc32_frags, self._sc32_bufs = {}, {}
         self._conv_fwd = fast if self.precision == 'bf16x3' else exact
-        self._conv_bwd = exact if self.precision == 'f32' else fast
+        self._conv_bwd = exact if self.precision in ('f32', 'bf16x6') else fast     # (layer shapes train_conv.hip does not instantiate)
+        # 'bf16x6' walks the control flow of 'bf16x3' -- segment-resident kernels on uint16 fragments for forward, dgrad and wgrad --
+        # through the three-term entry points
+        x6 = self.precision == 'bf16x6'
+        self._sc_frag_bytes = self.lib.nisqa_segconv_frag_bytes_x6 if x6 else self.lib.nisqa_segconv_frag_bytes
+        self._sc_pack_many = self.lib.nisqa_segconv_pack_x6_many if x6 else self.lib.nisqa_segconv_pack_many
+        self._sc_conv = self.lib.nisqa_segconv_bf16x6 if x6 else self.lib.nisqa_segconv_bf16
         # split-bf16 forward / input-gradient convolutions segment-resident (csrc/train_conv.hip) where the layer shape is
         # one of the reference configuration's; weight fragments are packed once per step (_segconv_pack)
         self.segconv = os.environ.get('NISQA_HIP_TRAIN_SEGCONV', '1') != '0' and self.precision != 'f32'
@@ -259,10 +268,10 @@ class HipTrainer(object):
             hi, wi = geo[i - 2][2]
             if not self.lib.nisqa_segconv_supported(hi, wi, ci, co, 0 if i == 6 else 1):
                 continue
-            for mode in ((0, 1) if self.precision == 'bf16x3' else (1,)):
+            for mode in ((0, 1) if self.precision in ('bf16x3', 'bf16x6') else (1,)):
                 buf = self._sc_bufs.get((mode, i))
                 if buf is None:
-                    buf = self._sc_bufs[(mode, i)] = torch.empty(self.lib.nisqa_segconv_frag_bytes(mode, ci, co) // 2,
+                    buf = self._sc_bufs[(mode, i)] = torch.empty(self._sc_frag_bytes(mode, ci, co) // 2,
                                                                  dtype=torch.int16, device=self.device)
                 jobs.append((mode, self.P['cnn.model.conv%d.weight' % i].data_ptr(), ci, co, buf.data_ptr()))
                 self._sc_frags[(mode, i)] = buf
@@ -270,7 +279,7 @@ class HipTrainer(object):
             n = len(jobs)
             arr_i = lambda k: (ctypes.c_int32 * n)(*[j[k] for j in jobs])
             arr_p = lambda k: (ctypes.c_void_p * n)(*[j[k] for j in jobs])
-            self._ck(self.lib.nisqa_segconv_pack_many(n, arr_i(0), arr_p(1), arr_i(2), arr_i(3), arr_p(4), self._st()),
+            self._ck(self._sc_pack_many(n, arr_i(0), arr_p(1), arr_i(2), arr_i(3), arr_p(4), self._st()),
                      'nisqa_segconv_pack_many')
 
     def _gemm(self, A, B, C, M, N, K, lda, ldb, ldc, ta=0, tb=0, ksplit=1, ao=0, bo=0, co=0, bias=None, relu=0):
@@ -724,7 +733,7 @@ class HipTrainer(object):
                     if self.fused_fwd_stats:
                         sums = self._sums[self._sum_i]
                         self._sum_i += 1
-                    self._ck(L_.nisqa_segconv_bf16(0, _ptr(act), fr.data_ptr(), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
+                    self._ck(self._sc_conv(0, _ptr(act), fr.data_ptr(), _ptr(z), S, hi, wi, ci, co, 0 if i == 6 else 1,
                                                    _ptr(self.P[bk]), sums.data_ptr() if sums is not None else None, st),
                              'nisqa_segconv_bf16 fwd')
                 elif self.fused_fwd_stats:                                     # sum z, sum z^2 from the convolution's epilogue
@@ -797,7 +806,8 @@ class HipTrainer(object):
                 dp = _ptr(c['drop']) if c['drop'] is not None else None
                 self._ck(L_.nisqa_bn_pool_bwd_sums(_ptr(da), c['arg'].data_ptr(), dp, _ptr(c['z']), _ptr(c['mr']), _ptr(g), _ptr(b_), S,
                                                    c['h'], c['w'], co, c['ho'], c['wo'], s2.data_ptr(), st), 'nisqa_bn_pool_bwd_sums')
-                self._ck(L_.nisqa_segconv_wgrad_bn_bf16(_ptr(c['x']), _ptr(c['z']), _ptr(da), c['arg'].data_ptr(), dp, _ptr(c['mr']),
+                self._ck((L_.nisqa_segconv_wgrad_bf16x6 if self.precision == 'bf16x6' else L_.nisqa_segconv_wgrad_bn_bf16)(
+                    _ptr(c['x']), _ptr(c['z']), _ptr(da), c['arg'].data_ptr(), dp, _ptr(c['mr']),
                                                         _ptr(g), _ptr(b_), s2.data_ptr(), _ptr(dz),
                                                         _ptr(self.G['cnn.model.bn%d.weight' % i]), _ptr(self.G['cnn.model.bn%d.bias' % i]),
                                                         _ptr(self.G[wk]), S, hi, wi, ci, co, 0 if i == 6 else 1, c['ho'], c['wo'], st),
@@ -840,6 +850,10 @@ class HipTrainer(object):
                     self._ck(L_.nisqa_segconv_wgrad_f32(_ptr(c['x']), None, None, None, None, None, None, None, None, _ptr(dz), None, None,
                                                         _ptr(self.G[wk]), S, hi, wi, ci, co, pad, c['ho'], c['wo'], st),
                              'nisqa_segconv_wgrad_f32')
+                elif (1, i) in self._sc_frags and self.precision == 'bf16x6':
+                    self._ck(L_.nisqa_segconv_wgrad_bf16x6(_ptr(c['x']), None, None, None, None, None, None, None, None, _ptr(dz), None, None,
+                                                           _ptr(self.G[wk]), S, hi, wi, ci, co, pad, c['ho'], c['wo'], st),
+                             'nisqa_segconv_wgrad_bf16x6')
                 elif (1, i) in self._sc_frags:
                     self._ck(L_.nisqa_segconv_wgrad_bf16(_ptr(c['x']), _ptr(dz), _ptr(self.G[wk]), S, hi, wi, ci, co, pad, st),
                              'nisqa_segconv_wgrad_bf16')
@@ -853,7 +867,7 @@ class HipTrainer(object):
                     self._ck(L_.nisqa_segconv_f32(1, _ptr(dz), _ptr(fr32), _ptr(da), S, hi, wi, ci, co, pad, None, None, st),
                              'nisqa_segconv_f32 dgrad')
                 elif fr is not None:
-                    self._ck(L_.nisqa_segconv_bf16(1, _ptr(dz), fr.data_ptr(), _ptr(da), S, hi, wi, ci, co, pad, None, None, st),
+                    self._ck(self._sc_conv(1, _ptr(dz), fr.data_ptr(), _ptr(da), S, hi, wi, ci, co, pad, None, None, st),
                              'nisqa_segconv_bf16 dgrad')
                 else:
                     self._ck(self._conv_bwd(1, _ptr(dz), _ptr(self.P[wk]), _ptr(da), S, hi, wi, ci, co, pad, None, 1, st),

@@ -245,7 +245,8 @@ def test_segment_resident_convolutions_forward_dgrad_wgrad(h, w, ci, co, pad_w, 
 @pytest.mark.parametrize('h,w,ci,co,pad_w,ho,wo', [(24, 7, 16, 32, 1, 12, 5), (12, 5, 32, 64, 1, 12, 5), (12, 5, 64, 64, 1, 6, 3),
                                                    (6, 3, 64, 64, 1, 6, 3), (6, 3, 64, 64, 0, 6, 1)])
 def test_segment_resident_fp32_weight_gradient_with_and_without_the_batchnorm_backward(h, w, ci, co, pad_w, ho, wo, S):
-    """nisqa_segconv_wgrad_f32 (exact fp32 MFMA, precision mode 'f32'): (i) handed dz, against autograd's weight gradient;
+    """nisqa_segconv_wgrad_f32 (exact fp32 MFMA, precision mode 'f32') and nisqa_segconv_wgrad_bf16x6 (three exact bf16 terms per
+    operand, six products: mode 'bf16x6', the SAME bounds): (i) handed dz, against autograd's weight gradient;
     (ii) handed z and the pooled gradient (BatchNorm / ReLU / max-pool / Dropout2d backward folded into its staging), against
     autograd through batch_norm -> relu -> adaptive_max_pool2d -> dropout: dw, dz, dgamma, dbeta.  Segment counts that are
     not multiples of a group; 300 segments = more groups than a 256-CU grid has workgroups."""
@@ -257,11 +258,12 @@ def test_segment_resident_fp32_weight_gradient_with_and_without_the_batchnorm_ba
     wt = torch.zeros(co, ci, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
     F.conv2d(xt, wt, None, padding=(1, pad_w)).backward(dz.view(S, h, wc, co).permute(0, 3, 1, 2).double())
     want = wt.grad.permute(0, 2, 3, 1).reshape(co, 9 * ci).float()
-    dw = torch.zeros(co, 9 * ci, device=DEV)
-    lib.check(L.nisqa_segconv_wgrad_f32(_p(x), None, None, None, None, None, None, None, None, _p(dz), None, None, _p(dw), S, h, w, ci, co,
-                                        pad_w, ho, wo, _st()), 'wgrad f32')
-    torch.cuda.synchronize()
-    assert (dw - want).abs().max() < 2e-5 * max(1.0, float(want.abs().max()))
+    for entry in ('nisqa_segconv_wgrad_f32', 'nisqa_segconv_wgrad_bf16x6'):
+        dw = torch.zeros(co, 9 * ci, device=DEV)
+        lib.check(getattr(L, entry)(_p(x), None, None, None, None, None, None, None, None, _p(dz), None, None, _p(dw), S, h, w, ci, co,
+                                    pad_w, ho, wo, _st()), entry)
+        torch.cuda.synchronize()
+        assert (dw - want).abs().max() < 2e-5 * max(1.0, float(want.abs().max())), entry
     # (ii) with the BatchNorm backward inside
     z = (_r(S, h * wc, co, seed=23) * 1.5 + 0.2).requires_grad_(True)
     gamma, beta = (_r(co, seed=24) * 0.5 + 1).requires_grad_(True), _r(co, seed=25).requires_grad_(True)
@@ -280,7 +282,7 @@ def test_segment_resident_fp32_weight_gradient_with_and_without_the_batchnorm_ba
     s2 = torch.zeros(2 * co, dtype=torch.float64, device=DEV)
     lib.check(L.nisqa_bn_pool_bwd_sums(_p(dy), arg.data_ptr(), _p(drop), _p(zd), _p(mr), _p(gamma), _p(beta), S, h, wc, co, ho, wo,
                                        s2.data_ptr(), _st()), 'sums')
-    for entry in ('nisqa_segconv_wgrad_f32', 'nisqa_segconv_wgrad_bn_bf16'):
+    for entry in ('nisqa_segconv_wgrad_f32', 'nisqa_segconv_wgrad_bf16x6', 'nisqa_segconv_wgrad_bn_bf16'):
         dz2, dg, db, dw2 = torch.empty(S, h * wc, co, device=DEV), torch.empty(co, device=DEV), torch.empty(co, device=DEV), torch.zeros(co, 9 * ci, device=DEV)
         lib.check(getattr(L, entry)(_p(x), _p(zd), _p(dy), arg.data_ptr(), _p(drop), _p(mr), _p(gamma), _p(beta), s2.data_ptr(), _p(dz2),
                                     _p(dg), _p(db), _p(dw2), S, h, w, ci, co, pad_w, ho, wo, _st()), entry)
@@ -291,7 +293,7 @@ def test_segment_resident_fp32_weight_gradient_with_and_without_the_batchnorm_ba
         wt2 = torch.zeros(co, ci, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
         F.conv2d(xt, wt2, None, padding=(1, pad_w)).backward(z.grad.view(S, h, wc, co).permute(0, 3, 1, 2).double())
         want2 = wt2.grad.permute(0, 2, 3, 1).reshape(co, 9 * ci).float()
-        tol = (2e-4 if entry.endswith('f32') else 5e-4) * max(1.0, float(want2.abs().max()))
+        tol = (5e-4 if entry.endswith('bn_bf16') else 2e-4) * max(1.0, float(want2.abs().max()))
         assert (dw2 - want2).abs().max() < tol, (entry, float((dw2 - want2).abs().max()), float(want2.abs().max()))
 
 
@@ -299,7 +301,8 @@ def test_segment_resident_fp32_weight_gradient_with_and_without_the_batchnorm_ba
 @pytest.mark.parametrize('h,w,ci,co,pad_w', [(24, 7, 16, 32, 1), (12, 5, 32, 64, 1), (12, 5, 64, 64, 1), (6, 3, 64, 64, 1), (6, 3, 64, 64, 0)])
 def test_segment_resident_fp32_convolutions_forward_and_input_gradient(h, w, ci, co, pad_w, S):
     """nisqa_segconv_f32 (exact fp32 MFMA, segment-resident; the forward convolutions of 'f32' / 'mixed' and the input gradient
-    of 'f32') against float64 autograd: z (+ bias), the BatchNorm sums riding along, dx; segment counts that are not multiples
+    of 'f32') and nisqa_segconv_bf16x6 (three exact bf16 terms per operand, six products: every convolution of 'bf16x6'; the SAME
+    bounds) against float64 autograd: z (+ bias), the BatchNorm sums riding along, dx; segment counts that are not multiples
     of a group and more groups than one resident round of workgroups."""
     lib, L = _L()
     wo = w + 2 * pad_w - 2
@@ -309,28 +312,32 @@ def test_segment_resident_fp32_convolutions_forward_and_input_gradient(h, w, ci,
     dz = _r(S, h * wo, co, seed=74)
     (z_t.permute(0, 2, 3, 1).reshape(S, h * wo, co) * dz.double()).sum().backward()
     wk = wt.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
-    fr = []
-    for mode in (0, 1):
-        nb = L.nisqa_segconv_frag_bytes_f32(mode, ci, co)
-        assert nb > 0
-        fr.append(torch.empty(nb // 4, device=DEV))
-    n = 2
-    lib.check(L.nisqa_segconv_pack_f32_many(n, (ctypes.c_int32 * n)(0, 1), (ctypes.c_void_p * n)(wk.data_ptr(), wk.data_ptr()),
-                                            (ctypes.c_int32 * n)(ci, ci), (ctypes.c_int32 * n)(co, co),
-                                            (ctypes.c_void_p * n)(fr[0].data_ptr(), fr[1].data_ptr()), _st()), 'pack f32')
-    z = torch.full((S * h * wo, co), float('nan'), device=DEV)
-    st2 = torch.zeros(2 * co, dtype=torch.float64, device=DEV)
-    lib.check(L.nisqa_segconv_f32(0, _p(x), _p(fr[0]), _p(z), S, h, w, ci, co, pad_w, _p(b), st2.data_ptr(), _st()), 'segconv f32 fwd')
-    dx = torch.full((S, h * w, ci), float('nan'), device=DEV)
-    lib.check(L.nisqa_segconv_f32(1, _p(dz), _p(fr[1]), _p(dx), S, h, w, ci, co, pad_w, None, None, _st()), 'segconv f32 dgrad')
-    torch.cuda.synchronize()
     want_z = z_t.detach().permute(0, 2, 3, 1).reshape(S * h * wo, co)
     want_dx = xd.grad.permute(0, 2, 3, 1).reshape(S, h * w, ci)
-    assert (z.double() - want_z).abs().max() < 2e-6 * max(1.0, float(want_z.abs().max())) * math.sqrt(9 * ci)
-    assert (dx.double() - want_dx).abs().max() < 2e-6 * max(1.0, float(want_dx.abs().max())) * math.sqrt(9 * co)
-    assert (st2[:co] - z.double().sum(0)).abs().max() < 1e-9 * max(1.0, float(z.abs().sum()))
-    assert (st2[co:] - (z.double() ** 2).sum(0)).abs().max() < 1e-9 * max(1.0, float((z.double() ** 2).sum()))
-    assert L.nisqa_segconv_f32(1, _p(dz), _p(fr[1]), _p(dx), S, h, w, ci, co, pad_w, _p(b), None, _st()) == lib.NISQA_ERR_ARG
+    n = 2
+    for fam, nbytes, pack, conv, dt, esz in (('f32', L.nisqa_segconv_frag_bytes_f32, L.nisqa_segconv_pack_f32_many, L.nisqa_segconv_f32, torch.float32, 4),
+                                             ('bf16x6', L.nisqa_segconv_frag_bytes_x6, L.nisqa_segconv_pack_x6_many, L.nisqa_segconv_bf16x6, torch.int16, 2)):
+        fr = []
+        for mode in (0, 1):
+            nb = nbytes(mode, ci, co)
+            assert nb > 0
+            fr.append(torch.empty(nb // esz, dtype=dt, device=DEV))
+        lib.check(pack(n, (ctypes.c_int32 * n)(0, 1), (ctypes.c_void_p * n)(wk.data_ptr(), wk.data_ptr()),
+                       (ctypes.c_int32 * n)(ci, ci), (ctypes.c_int32 * n)(co, co),
+                       (ctypes.c_void_p * n)(fr[0].data_ptr(), fr[1].data_ptr()), _st()), 'pack ' + fam)
+        z = torch.full((S * h * wo, co), float('nan'), device=DEV)
+        st2 = torch.zeros(2 * co, dtype=torch.float64, device=DEV)
+        lib.check(conv(0, _p(x), fr[0].data_ptr(), _p(z), S, h, w, ci, co, pad_w, _p(b), st2.data_ptr(), _st()), 'segconv fwd ' + fam)
+        dx = torch.full((S, h * w, ci), float('nan'), device=DEV)
+        lib.check(conv(1, _p(dz), fr[1].data_ptr(), _p(dx), S, h, w, ci, co, pad_w, None, None, _st()), 'segconv dgrad ' + fam)
+        torch.cuda.synchronize()
+        ez, ex = float((z.double() - want_z).abs().max()), float((dx.double() - want_dx).abs().max())
+        print('%s: max|d| z %.2e of %.1f, dx %.2e of %.1f' % (fam, ez, float(want_z.abs().max()), ex, float(want_dx.abs().max())))
+        assert ez < 2e-6 * max(1.0, float(want_z.abs().max())) * math.sqrt(9 * ci), fam
+        assert ex < 2e-6 * max(1.0, float(want_dx.abs().max())) * math.sqrt(9 * co), fam
+        assert (st2[:co] - z.double().sum(0)).abs().max() < 1e-9 * max(1.0, float(z.abs().sum())), fam
+        assert (st2[co:] - (z.double() ** 2).sum(0)).abs().max() < 1e-9 * max(1.0, float((z.double() ** 2).sum())), fam
+        assert conv(1, _p(dz), fr[1].data_ptr(), _p(dx), S, h, w, ci, co, pad_w, _p(b), None, _st()) == lib.NISQA_ERR_ARG
 
 
 def test_im2col_mel_segments_and_floor():
@@ -603,7 +610,7 @@ def _case(name):
     return g, args, sd, specs, y
 
 
-@pytest.mark.parametrize('precision', ['f32', 'mixed'])
+@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x6'])
 @pytest.mark.parametrize('name', ['mos', 'dim'])
 def test_training_step_matches_reference_fixture(name, precision):
     from nisqa_amd.train import HipTrainer
@@ -651,7 +658,7 @@ def test_training_step_matches_reference_fixture(name, precision):
     HipNisqa(args, tr.state_dict(), DEV)
 
 
-@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x3', 'bf16x6'])
 def test_training_step_from_the_published_weights(precision):
     """Fine-tuning step from nisqa.tar (fixture: the reference's NISQA_DIM in train mode on the same seeded batch,
     tests/golden/make_golden_train.py run('dim_real')): a trained network, not a random initialisation -- the case the
@@ -703,7 +710,7 @@ def _cfg5_case(name):
     return g, args, sd, specs, y
 
 
-@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x3', 'bf16x6'])
 @pytest.mark.parametrize('name', ['cfg5_mos', 'cfg5_dim_real'])
 def test_training_step_at_configs4_size_matches_reference_fixture(name, precision):
     """BASELINE configs[4] at ITS OWN size -- bs 32 x 10 s = 7 904 segments, the size bench.py's train_step leg times --
@@ -720,7 +727,7 @@ def test_training_step_at_configs4_size_matches_reference_fixture(name, precisio
     tools/diag_cfg5.py against a float64 restatement kept with its intermediates); an independent fp32 evaluation on the CPU
     (unfold + matmul convolutions) deviates from float64 by up to 1.2e-3, the reference's own fp32 by up to 1.4e-3.
     Hence: every tensor within 1e-2 (max-abs, relative to its largest entry) AND within 3e-3 in the Frobenius norm of the
-    float64 gradients ('f32' / 'mixed'); 'bf16x3' (split-bf16 FORWARD convolutions: z moves by 5e-6 relative, more flips)
+    float64 gradients ('f32' / 'mixed' / 'bf16x6': the three-term mode is held to the bounds of exact fp32); 'bf16x3' (split-bf16 FORWARD convolutions: z moves by 5e-6 relative, more flips)
     keeps the loose 5e-2 max-abs bound of the small fixtures and 2e-2 in the norm."""
     from nisqa_amd.train import HipTrainer
     g, args, sd, specs, y = _cfg5_case(name)
