@@ -492,7 +492,9 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
     """configs[4]: train_nisqa_cnn_sa_ap.yaml's step (NISQA_model.py:131-152) at bs 32 x 10 s: mel front end, forward in
     train mode, bias-aware loss, backward, BatchNorm buffers, Adam -- HipTrainer.  The PRIMARY number of the leg is the
     'f32' mode (every convolution on exact fp32 MFMA: the reference's arithmetic); 'mixed' (HipTrainer's default: fp32
-    forward, split-bf16 gradient convolutions) and 'bf16x3' (split-bf16 forward too) are reported beside it."""
+    forward, split-bf16 gradient convolutions), 'bf16x3' (split-bf16 forward too) and 'bf16x6' (every convolution at fp32
+    OPERAND precision on the bf16 matrix pipe: three exact bf16 terms per operand, six products -- held to the bounds of 'f32'
+    by the parity tests) are reported beside it."""
     from nisqa_amd.train import HipTrainer
     bs = 32
     args = dict(synth.MOS_ARGS)                               # model NISQA, cnn_dropout 0.2, td_sa_dropout 0.1 (the yaml's values)
@@ -503,7 +505,7 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
     cnn = (FLOP_CONV1_4 + FLOP_CONV5_6) * bs
     rest = FLOP_NET_CLIP * bs - cnn
     modes, segments, peak_mem = {}, 0, 0.0
-    for mode in ('f32', 'mixed', 'bf16x3'):
+    for mode in ('f32', 'bf16x6', 'mixed', 'bf16x3'):
         tr = HipTrainer(args, sd, dev, lr=1e-3, precision=mode)
         plan = tr.eng.plan([int(SECONDS * SR)] * bs, SR)
         x = tr.eng.pcm16_to_f32(torch.from_numpy(pcm).to(dev))
@@ -518,8 +520,9 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
         assert np.isfinite(float(loss))
         # the ideal time of this precision mode: forward convolutions on fp32 MFMA ('mixed', 'f32') or split-bf16 ('bf16x3'),
         # the two gradient passes on split-bf16 ('mixed', 'bf16x3') or fp32 ('f32'); attention / pooling / projection fp32
-        pk_f, pk_b = (PEAK_BF16_MFMA if mode == 'bf16x3' else PEAK_F32), (PEAK_F32 if mode == 'f32' else PEAK_BF16_MFMA)
-        ideal = (cnn / pk_f + 2 * cnn / pk_b + 3 * rest / PEAK_F32) / 1e12
+        # ('bf16x6': all three on the bf16 pipe with six products per term pair instead of three)
+        pk_f, pk_b = (PEAK_F32 if mode in ('f32', 'mixed') else PEAK_BF16_MFMA), (PEAK_F32 if mode == 'f32' else PEAK_BF16_MFMA)
+        ideal = ((2 if mode == 'bf16x6' else 1) * (cnn / pk_f + 2 * cnn / pk_b) + 3 * rest / PEAK_F32) / 1e12
         ach = flop / dt / 1e12
         modes[mode] = {'ms_per_step': round(dt * 1e3, 3), 'value': round(bs / dt, 1), 'achieved_TFLOPs': round(ach, 2),
                        'frac_of_fp32_peak': round(ach / PEAK_F32, 4), 'frac_of_mode_ideal': round(ideal / dt, 4),
@@ -530,7 +533,7 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
     p = modes['f32']
     res = {'config': 'configs[4] train_nisqa_cnn_sa_ap.yaml step (forward + backward + Adam, mel front end inside the step), '
                      'bs=32 x 10 s, %d segments, model NISQA random-init, dropout on; precision mode \'f32\' (exact fp32 MFMA '
-                     'everywhere: the reference\'s arithmetic); HipTrainer\'s default mode \'mixed\' and \'bf16x3\' beside it' % segments,
+                     'everywhere: the reference\'s arithmetic); \'bf16x6\' (fp32-grade on the bf16 matrix pipe), HipTrainer\'s default mode \'mixed\' and \'bf16x3\' beside it' % segments,
            'value': p['value'], 'unit': 'clips/s', 'ms_per_step': p['ms_per_step'], 'steps': steps, 'loss': p['loss'],
            'roofline': {'kernel': 'whole step (~59 launches, profiles/rNN_train_*_kernel_stats.csv; no single kernel dominates)',
                         'bound': 'mfma', 'achieved': p['achieved_TFLOPs'], 'unit': 'TFLOP/s',

@@ -36,12 +36,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_tts -o ks -- pyt
 cp /tmp/ks_tts/ks_kernel_stats.csv $O/${R}_tts_kernel_stats.csv
 grep '^{' /tmp/ks_tts.log | tail -1 > $O/${R}_tts_leg_under_rocprof.json      # the same run's stage events, next to the kernel statistics
 # the training step per precision mode (bench.py --leg train runs all three in one process: its statistics would mix them)
-for P in f32 mixed bf16x3; do
+for P in f32 bf16x6 mixed bf16x3; do
   rm -rf /tmp/ks_train_$P
   NISQA_HIP_TRAIN_PRECISION=$P rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks_train_$P -o ks -- python tools/bench_train.py 32 20 > /tmp/ks_train_$P.log 2>&1
   cp /tmp/ks_train_$P/ks_kernel_stats.csv $O/${R}_train_${P}_kernel_stats.csv
 done
-for P in f32 mixed bf16x3; do NISQA_HIP_TRAIN_PRECISION=$P python tools/bench_train.py 32 20 2>/dev/null | tail -1; done > $O/${R}_train_bench.json
+for P in f32 bf16x6 mixed bf16x3; do NISQA_HIP_TRAIN_PRECISION=$P python tools/bench_train.py 32 20 2>/dev/null | tail -1; done > $O/${R}_train_bench.json
 python tools/bench_extra.py 2>/dev/null | tail -1 > $O/${R}_side_tts_pcie.json
 python tools/bench_ingest.py 2048 12 2>/dev/null | tail -1 > $O/${R}_side_ingest.json
 timeout 600 python bench.py --workload predict_csv --no-cpu-baseline 2>/dev/null | tail -1 > $O/${R}_bench_predict_csv_1gpu.json
