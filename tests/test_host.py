@@ -55,6 +55,35 @@ def test_conv_fragments_roundtrip():
     assert seen == list(range(32))
 
 
+def test_three_bf16_terms_hold_an_fp32_value_exactly_and_the_x6_fragments_are_the_weights():
+    """precision 'bf16x6' (csrc/cnn_bf16x6.hip): bf16_split(x, 3) is an EXACT split of any finite fp32 value (8 + 8 + 8 significant
+    bits, each term rounded to nearest), two terms are not; the three-term fragment blob of pack_adapt_cnn_bf16 holds every
+    BatchNorm-folded weight bit for bit at the layout offsets of layout.hpp (CNNX_*)."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(20000) * 10.0 ** rng.uniform(-6, 4, 20000), [0.0, 1.0, -1.0, 65504.0, 1e-30, -3.0e38,
+                        np.float32(1) + np.float32(2) ** -23]]).astype(np.float32)
+    val = lambda b: (b.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    t3 = W.bf16_split(x, 3)
+    assert np.array_equal((val(t3[0]) + val(t3[1]) + val(t3[2])).astype(np.float32), x)
+    assert np.all(val(t3[0]) + val(t3[1]) + val(t3[2]) == x.astype(np.float64))          # exact even before the final rounding
+    t2 = W.bf16_split(x, 2)
+    assert np.abs(val(t2[0]) + val(t2[1]) - x).max() > 0                                # 16 bits are not enough
+    nz = x != 0
+    assert np.all(np.abs(val(t3[1])[nz]) <= 2.0 ** -8 * np.abs(x[nz]) * (1 + 2.0 ** -7))  # |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|
+    assert np.all(np.abs(val(t3[2])[nz]) <= 2.0 ** -16 * np.abs(x[nz]) * (1 + 2.0 ** -6))
+    # fragments: conv3 (32 -> 64 channels), step g = (tap, 16-channel group), N tile nt, term t, lane, k-slot e
+    sd = synth.random_state_dict(7, 'NISQA_DIM')
+    blob = W.pack_adapt_cnn_bf16(sd, conv1_pairs=True, terms=3)
+    assert blob.size == W.CNNX_U16S and W.pack_adapt_cnn_bf16(sd, conv1_pairs=True).size == W.CNNB_U16S
+    w3, _ = W.fold_bn(sd, 'cnn.model.', 3)
+    fr = blob[W.CNNX_W3:W.CNNX_W4].reshape(18, 2, 3, 64, 8)
+    for g, nt, lane, e in [(0, 0, 0, 0), (17, 1, 63, 7), (5, 1, 37, 3), (10, 0, 31, 4)]:
+        n, c, tap = (lane & 31) + 32 * nt, 16 * (g % 2) + 8 * (lane >> 5) + e, g // 2
+        want = np.float32(w3.astype(np.float32).reshape(64, 32, 9)[n, c, tap])
+        got = sum(val(fr[g, nt, t, lane, e:e + 1])[0] for t in range(3))
+        assert np.float32(got) == want and got == np.float64(want)
+
+
 def test_linear_fragments_roundtrip():
     rng = np.random.default_rng(1)
     w = rng.standard_normal((192, 64))
