@@ -310,7 +310,8 @@ def bench_predict_csv(a):
             'metric': 'clips/sec (10 s, 48 kHz)', 'value': round(a.clips / dt, 2), 'unit': 'clips/s', 'n_gpus': world,
             'steps': steps, 'warmup': max(1, a.warmup), 'ms_per_step': round(1e3 * dt / steps, 4), 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None,
-            'dtype': 'bf16x3 (bf16 hi+lo operands, 3 MFMA products per term, f32 accumulate; mel/attention/pooling f32)',
+            'dtype': {'f32': 'f32', 'bf16x6': 'bf16x6 (AdaptCNN: fp32 operands as three exact bf16 terms, 6 MFMA products per term pair; mel/attention/pooling f32)'}.get(
+                os.environ.get('NISQA_HIP_PRECISION', 'bf16x3'), 'bf16x3 (bf16 hi+lo operands, 3 MFMA products per term, f32 accumulate; mel/attention/pooling f32)'),
             'data': 'synthetic 48 kHz / 10 s PCM16 WAV files on local disk (%d distinct, reused cyclically), %s' % (a.distinct, wdesc),
             'config': {'workload': 'predict_csv nisqa.tar bs=%d per GPU, %d synthetic 10 s 48 kHz clips, clip-sharded over '
                                    '%d rank(s); WAV files -> native ingest -> H2D -> kernels -> all_gather (PCIe-inclusive)'
