@@ -134,6 +134,9 @@ int nisqa_cnn_adapt_bf16x6(const float* mel_tm, const int32_t* frame_off, const 
                            const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                            int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
                            const uint16_t* cnn_wx, float* feat, void* stream);
+int nisqa_cnn_adapt_segments_bf16x6(const float* x, int32_t seg_len_padded, const int32_t* tok_off,
+                                    const int32_t* n_wins, int32_t n_clips, int32_t total_tok_padded,
+                                    const float* cnn_w, const uint16_t* cnn_wx, float* feat, void* stream);
 /* Segment-tensor input mode: the reference's inner operator model.forward(x, n_wins)
  * (NISQA_lib.py:137-142, 260-268) hands over x[B][L][1][48][15] (zero-padded to L segments per clip).
  * Same outputs as nisqa_cnn_adapt; no dB floor is applied (x is already clamped). */

@@ -83,12 +83,15 @@ NQ_DEV void mma16_terms(f32x4 (&acc)[MT], const f32x4 (&a)[MT][XT], const f32x4 
         }
 }
 
+// SEGX: the input is the reference's segment tensor x[B][L][1][48][15] (inner-operator mode, NISQA_lib.py:260-268) instead of the
+// spectrogram; no dB floor is applied (x is already clamped)
+template <bool SEGX>
 __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
     const float* __restrict__ clip_floor, int n_clips, int seg_hop,
     const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ feat,
-    const uint32_t* __restrict__ clip_max_enc, float top_db) {
+    const uint32_t* __restrict__ clip_max_enc, float top_db, const float* __restrict__ seg_x, int seg_L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef NQ_PHASE_CLOCK
     const long long clk_top = clock64(), wall_top = wall_clock64();
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNX_U16S * 2, 0x00020000);
 
     // ---- stage the 15-frame window as XT zero-bordered bf16 planes [frame j + 1][mel m + 1]
-    const float fl = clip_max_enc ? dec_ordered(clip_max_enc[b]) - top_db : clip_floor[b];
-    const float* src = mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
+    const float fl = SEGX ? -3.0e38f : clip_max_enc ? dec_ordered(clip_max_enc[b]) - top_db : clip_floor[b];
+    const float* src = SEGX ? seg_x + ((size_t)b * seg_L + k) * 720 : mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
     float vraw[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
@@ -131,19 +134,29 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
         // as one that uses no LDS at all)
         if (lane < 32) ((unsigned*)(smem + X_ZADDR))[lane] = 0u;
         __builtin_amdgcn_wave_barrier();
-        // element i0 = lane + 64 q of the [15][48] window is (frame j, mel m) = divmod(i0, 48); with q = 3 t + u that is
-        // j = q + t + (lane + 16 u) / 48, m = (lane + 16 u) % 48: three lane-dependent store bases, the rest are immediates
-        unsigned ob[3];
+        if (!SEGX) {
+            // element i0 = lane + 64 q of the [15][48] window is (frame j, mel m) = divmod(i0, 48); with q = 3 t + u that is
+            // j = q + t + (lane + 16 u) / 48, m = (lane + 16 u) % 48: three lane-dependent store bases, the rest are immediates
+            unsigned ob[3];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int e = lane + 16 * u, j0 = e >= 48 ? 1 : 0, m = e - 48 * j0;
-            ob[u] = pb + ((j0 + 1) * 50 + m + 1) * 2;
-        }
+            for (int u = 0; u < 3; ++u) {
+                const int e = lane + 16 * u, j0 = e >= 48 ? 1 : 0, m = e - 48 * j0;
+                ob[u] = pb + ((j0 + 1) * 50 + m + 1) * 2;
+            }
 #pragma unroll
-        for (int q = 0; q < 12; q += 2) {
-            const float v0 = valid ? fmaxf(vraw[q], fl) : 0.f, v1 = valid ? fmaxf(vraw[q + 1], fl) : 0.f;
-            lds_store_terms2<XT>(ob[q % 3] + (q + q / 3) * 100, ob[(q + 1) % 3] + (q + 1 + (q + 1) / 3) * 100, X_PPLANE, v0, v1,
-                                 true, q + 1 < 11 || lane < 16);
+            for (int q = 0; q < 12; q += 2) {
+                const float v0 = valid ? fmaxf(vraw[q], fl) : 0.f, v1 = valid ? fmaxf(vraw[q + 1], fl) : 0.f;
+                lds_store_terms2<XT>(ob[q % 3] + (q + q / 3) * 100, ob[(q + 1) % 3] + (q + 1 + (q + 1) / 3) * 100, X_PPLANE, v0, v1,
+                                     true, q + 1 < 11 || lane < 16);
+            }
+        } else {
+            // the segment tensor is [mel m][frame j]: element i0 = (m, j) = divmod(i0, 15)
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const int i0 = lane + 64 * q;
+                const int m = i0 / 15, j = i0 - 15 * m;
+                if (i0 < 720) lds_store_terms<XT>(pb + ((j + 1) * 50 + (m + 1)) * 2, X_PPLANE, valid ? vraw[q] : 0.f);
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -464,12 +477,13 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
 #endif
 }
 
+template <bool SEGX>
 static int x6_launch(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off, const int32_t* n_wins,
                      const float* clip_floor, const uint32_t* clip_max_enc, float top_db, int32_t n_clips,
                      int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w, const uint16_t* cnn_wx, float* feat,
-                     void* stream) {
+                     void* stream, const float* seg_x = nullptr, int32_t seg_L = 0) {
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wx || !feat ||
-        (!clip_floor && !clip_max_enc))
+        (!SEGX && !clip_floor && !clip_max_enc) || (SEGX && (!seg_x || seg_L <= 0)))
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
     // 117 KB of dynamic LDS is above the 64 KB default: opted in once per device ordinal (a process may drive several GPUs)
@@ -477,12 +491,12 @@ static int x6_launch(const float* mel_tm, const int32_t* frame_off, const int32_
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr[dev].load(std::memory_order_relaxed)) {
-        if (hipFuncSetAttribute((const void*)cnn_front_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)cnn_front_bf16x6_kernel<SEGX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS) != hipSuccess)
             return 2;
         attr[dev].store(true, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(cnn_front_bf16x6_kernel, dim3(total_tok_padded / 4), dim3(256), X_LDS, (hipStream_t)stream, mel_tm,
-                       frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wx, feat, clip_max_enc, top_db);
+    hipLaunchKernelGGL(cnn_front_bf16x6_kernel<SEGX>, dim3(total_tok_padded / 4), dim3(256), X_LDS, (hipStream_t)stream, mel_tm,
+                       frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wx, feat, clip_max_enc, top_db, seg_x, seg_L);
     return NQ_LAUNCH_STATUS();
 }
 
@@ -490,8 +504,8 @@ extern "C" int nisqa_cnn_adapt_bf16x6(const float* mel_tm, const int32_t* frame_
                                       const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                                       int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
                                       const uint16_t* cnn_wx, float* feat, void* stream) {
-    return x6_launch(mel_tm, frame_off, tok_off, n_wins, clip_floor, nullptr, 0.f, n_clips, total_tok_padded, seg_hop, cnn_w,
-                     cnn_wx, feat, stream);
+    return x6_launch<false>(mel_tm, frame_off, tok_off, n_wins, clip_floor, nullptr, 0.f, n_clips, total_tok_padded, seg_hop, cnn_w,
+                            cnn_wx, feat, stream);
 }
 
 // nisqa_cnn_adapt_bf16x6 with the per-clip floor derived in the kernel from the mel kernel's clip_max_enc (internal.hpp)
@@ -500,6 +514,14 @@ int nq_cnn_adapt_bf16x6_from_max(const float* mel_tm, const int32_t* frame_off, 
                                  int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w, const uint16_t* cnn_wx,
                                  float* feat, void* stream) {
     if (!clip_max_enc) return NISQA_ERR_ARG;
-    return x6_launch(mel_tm, frame_off, tok_off, n_wins, nullptr, clip_max_enc, top_db, n_clips, total_tok_padded, seg_hop,
-                     cnn_w, cnn_wx, feat, stream);
+    return x6_launch<false>(mel_tm, frame_off, tok_off, n_wins, nullptr, clip_max_enc, top_db, n_clips, total_tok_padded, seg_hop,
+                            cnn_w, cnn_wx, feat, stream);
+}
+
+// segment-tensor input mode (nisqa_cnn_adapt_segments_bf16's contract)
+extern "C" int nisqa_cnn_adapt_segments_bf16x6(const float* x, int32_t seg_len_padded, const int32_t* tok_off,
+                                               const int32_t* n_wins, int32_t n_clips, int32_t total_tok_padded,
+                                               const float* cnn_w, const uint16_t* cnn_wx, float* feat, void* stream) {
+    return x6_launch<true>(nullptr, nullptr, tok_off, n_wins, nullptr, nullptr, 0.f, n_clips, total_tok_padded, 1, cnn_w, cnn_wx, feat,
+                           stream, x, seg_len_padded);
 }

@@ -281,12 +281,10 @@ class HipNisqa(object):
         d = plan.to(self.device)
         p3 = torch.empty((plan.total_tok, 18, 64), dtype=torch.float32, device=self.device)
         feat = torch.empty((plan.total_tok, 384), dtype=torch.float32, device=self.device)
-        if self.precision == 'bf16x6':
-            raise NotImplementedError("segment-tensor forward: precision 'bf16x6' has no segment-tensor kernel; use 'f32' or 'bf16x3'")
-        if self.precision == 'bf16x3':
-            _lib.check(self.lib.nisqa_cnn_adapt_segments_bf16(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B,
-                                                              plan.total_tok, _ptr(self.cnn_w), _ptr(self.cnn_wb),
-                                                              _ptr(feat), self._stream()), 'nisqa_cnn_adapt_segments_bf16')
+        if self.precision in ('bf16x3', 'bf16x6'):
+            fn = self.lib.nisqa_cnn_adapt_segments_bf16 if self.precision == 'bf16x3' else self.lib.nisqa_cnn_adapt_segments_bf16x6
+            _lib.check(fn(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B, plan.total_tok, _ptr(self.cnn_w), _ptr(self.cnn_wb),
+                          _ptr(feat), self._stream()), 'nisqa_cnn_adapt_segments_' + self.precision)
         else:
             _lib.check(self.lib.nisqa_cnn_adapt_segments(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B,
                                                          plan.total_tok, _ptr(self.cnn_w), _ptr(p3), _ptr(feat),
