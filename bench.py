@@ -310,7 +310,7 @@ def bench_predict_csv(a):
             'metric': 'clips/sec (10 s, 48 kHz)', 'value': round(a.clips / dt, 2), 'unit': 'clips/s', 'n_gpus': world,
             'steps': steps, 'warmup': max(1, a.warmup), 'ms_per_step': round(1e3 * dt / steps, 4), 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None,
-            'dtype': {'f32': 'f32', 'bf16x6': 'bf16x6 (AdaptCNN: fp32 operands as three exact bf16 terms, 6 MFMA products per term pair; mel/attention/pooling f32)'}.get(
+            'dtype': {'f32': 'f32', 'bf16x6': 'bf16x6 (every GEMM: fp32 operands as three exact bf16 terms, 6 MFMA products per term pair; mel f32)'}.get(
                 os.environ.get('NISQA_HIP_PRECISION', 'bf16x3'), 'bf16x3 (bf16 hi+lo operands, 3 MFMA products per term, f32 accumulate; mel/attention/pooling f32)'),
             'data': 'synthetic 48 kHz / 10 s PCM16 WAV files on local disk (%d distinct, reused cyclically), %s' % (a.distinct, wdesc),
             'config': {'workload': 'predict_csv nisqa.tar bs=%d per GPU, %d synthetic 10 s 48 kHz clips, clip-sharded over '
@@ -697,8 +697,8 @@ def main():
         mtr, _ = pmc_derived(pmc.get('mel_frame_kernel'))
         kern_tab = {}
         for stage, ks in (('mel', ['mel_frame_kernel']), ('cnn', ['cnn_front_bf16_kernel'] if eng.precision == 'bf16x3' else ['cnn_front_bf16x6_kernel'] if eng.precision == 'bf16x6' else ['cnn_front_kernel', 'cnn_back_kernel']),
-                          ('selfatt', ['td_fused_bf16_kernel', 'td_proj_bf16_kernel', 'td_layer_bf16_kernel'] if eng.precision == 'bf16x3' else ['td_proj_kernel', 'td_layer_kernel']),
-                          ('pool', ['pool_score_bf16_kernel', 'pool_final_kernel'] if eng.precision == 'bf16x3' else ['pool_score_kernel', 'pool_final_kernel'])):
+                          ('selfatt', ['td_fused_bf16_kernel', 'td_proj_bf16_kernel', 'td_layer_bf16_kernel'] if eng.precision == 'bf16x3' else ['td_proj_bf16x6_kernel', 'td_layer_bf16x6_kernel'] if eng.precision == 'bf16x6' else ['td_proj_kernel', 'td_layer_kernel']),
+                          ('pool', ['pool_score_bf16_kernel', 'pool_final_kernel'] if eng.precision == 'bf16x3' else ['pool_score_bf16x6_kernel', 'pool_final_kernel'] if eng.precision == 'bf16x6' else ['pool_score_kernel', 'pool_final_kernel'])):
             for kn in ks:
                 if kn in pmc:
                     tr, mu = pmc_derived(pmc[kn])
@@ -708,8 +708,8 @@ def main():
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': {'bf16x3': 'bf16x3 (bf16 hi+lo operands, 3 MFMA products per term, f32 accumulate; mel/attention/pooling f32)',
-                      'bf16x6': 'bf16x6 (AdaptCNN: fp32 operands as three exact bf16 terms, 6 MFMA products per term pair, f32 accumulate; '
-                                'mel/attention/pooling f32)'}.get(eng.precision, 'f32'),
+                      'bf16x6': 'bf16x6 (every GEMM: fp32 operands as three exact bf16 terms, 6 MFMA products per term pair, f32 accumulate; '
+                                'mel f32)'}.get(eng.precision, 'f32'),
             'data': 'synthetic 48 kHz / 10 s PCM16 clips (SURVEY 8d generator); ' + wdesc,
             'config': {'workload': 'predict_dir nisqa.tar (NISQA_DIM CNN-SA-AP) bs=64 per GPU, 10 s synthetic 48 kHz '
                                    'clips, int16 PCM resident in HBM' + ('' if BATCH == 64 else ' [EXPERIMENT: bs=%d]' % BATCH), 'batch_clips_per_gpu': BATCH, 'streams': len(streams),
@@ -731,8 +731,8 @@ def main():
         if world == 1 and not a.no_extras:
             # the other precision path on the same workload: same --steps / --warmup, same barriers, right after the
             # primary region.  For the default run this is the exact-fp32 path -- the reference's own arithmetic.
-            # (and 'bf16x6': the AdaptCNN at fp32 operand precision on the bf16 matrix pipe -- three exact bf16 terms per operand, six
-            # products -- with attention and pooling on the fp32 kernels: the accuracy of 'f32', tests/test_gpu_parity.py)
+            # (and 'bf16x6': every GEMM at fp32 operand precision on the bf16 matrix pipe -- three exact bf16 terms per operand, six
+            # products: the accuracy of 'f32', tests/test_gpu_parity.py)
             alt_out = {}
             for other in (['f32', 'bf16x6'] if eng.precision == 'bf16x3' else ['bf16x3']):
                 eng2 = HipNisqa(margs, sd, dev, precision=other)

@@ -180,6 +180,18 @@ int nisqa_pool_att_bf16(const float* x, const int32_t* tok_off, const int32_t* n
 int nisqa_pool_score_bf16(const float* x, const int32_t* tok_off, const int32_t* n_wins,
                           int32_t n_clips, int32_t total_tok_padded, int32_t n_heads,
                           const float* pool_w, const uint16_t* pool_wb, float* ws, void* stream);
+/* The same at fp32 OPERAND precision on the bf16 matrix pipe (three exact bf16 terms per operand, six products; DESIGN.md 4.5
+ * "bf16x6"): td_wx / pool_wx are the three-term fragments from nisqa_amd.weights.pack_self_att_bf16 / pack_pool_att_bf16 with
+ * terms=3; nisqa_td_selfatt_bf16x6 needs ws of 9 * total_tok_padded * 64 floats (the others: 6 *). */
+int nisqa_td_selfatt_bf16x6(const float* feat, const int32_t* tok_off, const int32_t* n_wins,
+                            int32_t n_clips, int32_t total_tok_padded, int32_t n_layers, const float* td_w,
+                            const uint16_t* td_wx, float* ws, float* x_out, void* stream);
+int nisqa_pool_att_bf16x6(const float* x, const int32_t* tok_off, const int32_t* n_wins,
+                          int32_t n_clips, int32_t total_tok_padded, int32_t n_heads, const float* pool_w,
+                          const uint16_t* pool_wx, float* ws, float* out, void* stream);
+int nisqa_pool_score_bf16x6(const float* x, const int32_t* tok_off, const int32_t* n_wins,
+                            int32_t n_clips, int32_t total_tok_padded, int32_t n_heads, const float* pool_w,
+                            const uint16_t* pool_wx, float* ws, void* stream);
 /* second pass of the pooling (masked softmax over tokens + weighted sum) on scores left in ws */
 int nisqa_pool_final(const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
                      int32_t total_tok_padded, int32_t n_heads, const float* ws, float* out, void* stream);
@@ -222,8 +234,9 @@ typedef struct {
     void* const* stage_events;
     const uint16_t* cnn_wb;  /* split-bf16 conv fragments, or NULL */
     int32_t cnn_mode;        /* 0 = exact fp32 MFMA kernels, 1 = split-bf16 kernels (needs cnn_wb, td_wb, pool_wb),
-                              * 2 = arch 0 only: AdaptCNN on three-term bf16 (nisqa_cnn_adapt_bf16x6; cnn_wb = its three-term
-                              * fragments), self-attention and pooling on the exact fp32 kernels */
+                              * 2 = arch 0 only: every GEMM on three-term bf16 (nisqa_cnn_adapt_bf16x6, nisqa_td_selfatt_bf16x6,
+                              * nisqa_pool_att_bf16x6; cnn_wb / td_wb / pool_wb = their three-term fragments; td_wb or
+                              * pool_wb NULL: self-attention and pooling on the exact fp32 kernels) */
     const uint16_t* td_wb;   /* split-bf16 self-attention fragments, or NULL */
     const uint16_t* pool_wb; /* split-bf16 pooling fragments, or NULL */
     int32_t arch;            /* 0 = CNN-SA-AP (nisqa.tar, nisqa_mos_only.tar); 1 = StandardCNN + BiLSTM + last-step

@@ -20,7 +20,7 @@ static ws_plan plan_ws(int32_t n_clips, int32_t total_frames, int32_t np) {
     p.cfloor = o; o += align256((size_t)n_clips * 4);
     p.p3 = o;     o += align256((size_t)np * 18 * 64 * 4);
     p.feat = o;   o += align256((size_t)np * NISQA_FEAT * 4);
-    p.td = o;     o += align256((size_t)np * 64 * 6 * 4);
+    p.td = o;     o += align256((size_t)np * 64 * 9 * 4);          // (nine bf16 planes x two layer buffers in the three-term mode)
     p.x = o;      o += align256((size_t)np * 64 * 4);
     p.pool = o;   o += align256((size_t)np * 8 * 2 * 4);
     p.total = o;
@@ -89,7 +89,7 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
         if (rc) return rc;
         NQ_STAGE(2);
     } else if (model->cnn_mode == 2) {
-        // fp32-grade AdaptCNN on three-term bf16 operands (cnn_wb = the three-term fragments); attention and pooling exact fp32
+        // fp32-grade AdaptCNN on three-term bf16 operands (cnn_wb = the three-term fragments)
         rc = nq_cnn_adapt_bf16x6_from_max(mel, frame_off, tok_off, n_wins, cmax, cfg->top_db, n_clips, total_tok_padded,
                                           model->seg_hop, model->cnn_w, model->cnn_wb, feat, stream);
         if (rc) return rc;
@@ -104,13 +104,18 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
     }
     NQ_STAGE(3);
     const bool bf = model->cnn_mode == 1 && model->td_wb && model->pool_wb;
+    const bool x6 = model->cnn_mode == 2 && model->td_wb && model->pool_wb;      // three-term fragments in td_wb / pool_wb
     rc = bf ? nisqa_td_selfatt_bf16(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w,
                                     model->td_wb, td, x, stream)
+         : x6 ? nisqa_td_selfatt_bf16x6(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w,
+                                        model->td_wb, td, x, stream)
             : nisqa_td_selfatt(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w, td, x, stream);
     if (rc) return rc;
     NQ_STAGE(4);
     rc = bf ? nisqa_pool_att_bf16(x, tok_off, n_wins, n_clips, total_tok_padded, model->n_heads, model->pool_w,
                                   model->pool_wb, pool, out, stream)
+         : x6 ? nisqa_pool_att_bf16x6(x, tok_off, n_wins, n_clips, total_tok_padded, model->n_heads, model->pool_w,
+                                      model->pool_wb, pool, out, stream)
             : nisqa_pool_att(x, tok_off, n_wins, n_clips, total_tok_padded, model->n_heads, model->pool_w, pool, out, stream);
     if (rc) return rc;
     NQ_STAGE(5);

@@ -72,6 +72,15 @@
 #define TDBL_FF2 (TDBL_FF1 + 4 * 2 * 2 * 512)
 #define TDBL_U16S (TDBL_FF2 + 4 * 2 * 2 * 512)
 #define PLB_U16S (4 * 4 * 2 * 512)                   /* per head: linear1 [128][64], chain, 4 steps x 4 mtiles */
+/* three-term fragments of td_bf16x6.hip: the blocks above with [3] terms per fragment */
+#define TDX_PROJ 0
+#define TDX_LAYER0 (TDX_PROJ + 24 * 2 * 3 * 512)
+#define TDXL_QKV 0
+#define TDXL_OUT (TDXL_QKV + 4 * 6 * 3 * 512)
+#define TDXL_FF1 (TDXL_OUT + 4 * 2 * 3 * 512)
+#define TDXL_FF2 (TDXL_FF1 + 4 * 2 * 3 * 512)
+#define TDXL_U16S (TDXL_FF2 + 4 * 2 * 3 * 512)
+#define PLX_U16S (4 * 4 * 3 * 512)
 
 // ---- self-attention blob ("td_w") ----------------------------------------------------------
 // A-fragments af[step][mtile][lane][4]:

@@ -102,9 +102,8 @@ class HipNisqa(object):
 
     def __init__(self, args, state_dict, device=None, precision=None):
         """precision: 'bf16x3' (default: AdaptCNN on split-bf16 MFMA, fp32-class accuracy, |dMOS| <= 3e-5), 'f32'
-        (every GEMM on exact fp32 MFMA) or 'bf16x6' (CNN-SA-AP models only: the AdaptCNN with every fp32 operand as three
-        bf16 terms -- an exact split -- and six MFMA products per term pair, self-attention and pooling on the exact fp32
-        kernels: the accuracy of 'f32' at 1.6 x its rate); the environment variable NISQA_HIP_PRECISION sets the default."""
+        (every GEMM on exact fp32 MFMA) or 'bf16x6' (CNN-SA-AP models only: every GEMM -- AdaptCNN, self-attention, pooling -- with its fp32 operands as three
+        bf16 terms, an exact split, and six MFMA products per term pair: the accuracy of 'f32' at 1.7 x its rate); the environment variable NISQA_HIP_PRECISION sets the default."""
         if not torch.cuda.is_available():
             raise RuntimeError('nisqa_amd: no GPU visible (torch.cuda.is_available() is False); '
                                'the HIP engine has no CPU fallback')
@@ -164,6 +163,9 @@ class HipNisqa(object):
         self.pool_w = up(_w.pack_pool_att(state_dict, heads))
         self.td_wb = up(_w.pack_self_att_bf16(state_dict, self.n_layers).view(np.int16)) if bf else None
         self.pool_wb = up(_w.pack_pool_att_bf16(state_dict, heads).view(np.int16)) if bf else None
+        if self.precision == 'bf16x6':                       # three-term fragments for self-attention and pooling as well
+            self.td_wb = up(_w.pack_self_att_bf16(state_dict, self.n_layers, terms=3).view(np.int16))
+            self.pool_wb = up(_w.pack_pool_att_bf16(state_dict, heads, terms=3).view(np.int16))
         self._mel = {}
         self._ws = {}                      # one workspace per stream (batches may be in flight on several)
 
@@ -321,12 +323,12 @@ class HipNisqa(object):
 
     def td(self, feat, plan):
         d = plan.to(self.device)
-        ws = torch.empty(plan.total_tok * 64 * 6, dtype=torch.float32, device=self.device)
+        ws = torch.empty(plan.total_tok * 64 * 9, dtype=torch.float32, device=self.device)
         x = torch.zeros((plan.total_tok, 64), dtype=torch.float32, device=self.device)
-        if self.precision == 'bf16x3':
-            _lib.check(self.lib.nisqa_td_selfatt_bf16(_ptr(feat), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
-                                                      plan.total_tok, self.n_layers, _ptr(self.td_w), _ptr(self.td_wb),
-                                                      _ptr(ws), _ptr(x), self._stream()), 'nisqa_td_selfatt_bf16')
+        if self.precision in ('bf16x3', 'bf16x6'):
+            fn = self.lib.nisqa_td_selfatt_bf16 if self.precision == 'bf16x3' else self.lib.nisqa_td_selfatt_bf16x6
+            _lib.check(fn(_ptr(feat), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips, plan.total_tok, self.n_layers,
+                          _ptr(self.td_w), _ptr(self.td_wb), _ptr(ws), _ptr(x), self._stream()), 'nisqa_td_selfatt_' + self.precision)
         else:
             _lib.check(self.lib.nisqa_td_selfatt(_ptr(feat), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
                                                  plan.total_tok, self.n_layers, _ptr(self.td_w), _ptr(ws), _ptr(x),
@@ -337,10 +339,10 @@ class HipNisqa(object):
         d = plan.to(self.device)
         ws = torch.empty(plan.total_tok * 16, dtype=torch.float32, device=self.device)
         out = torch.empty((plan.n_clips, self.n_heads), dtype=torch.float32, device=self.device)
-        if self.precision == 'bf16x3':
-            _lib.check(self.lib.nisqa_pool_att_bf16(_ptr(x), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
-                                                    plan.total_tok, self.n_heads, _ptr(self.pool_w), _ptr(self.pool_wb),
-                                                    _ptr(ws), _ptr(out), self._stream()), 'nisqa_pool_att_bf16')
+        if self.precision in ('bf16x3', 'bf16x6'):
+            fn = self.lib.nisqa_pool_att_bf16 if self.precision == 'bf16x3' else self.lib.nisqa_pool_att_bf16x6
+            _lib.check(fn(_ptr(x), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips, plan.total_tok, self.n_heads,
+                          _ptr(self.pool_w), _ptr(self.pool_wb), _ptr(ws), _ptr(out), self._stream()), 'nisqa_pool_att_' + self.precision)
         else:
             _lib.check(self.lib.nisqa_pool_att(_ptr(x), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips, plan.total_tok,
                                                self.n_heads, _ptr(self.pool_w), _ptr(ws), _ptr(out), self._stream()),

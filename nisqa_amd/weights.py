@@ -83,6 +83,15 @@ TDBL_FF1 = TDBL_OUT + 4 * 2 * 2 * 512
 TDBL_FF2 = TDBL_FF1 + 4 * 2 * 2 * 512
 TDBL_U16S = TDBL_FF2 + 4 * 2 * 2 * 512
 PLB_U16S = 4 * 4 * 2 * 512
+# three-term fragments (csrc/td_bf16x6.hip)
+TDX_PROJ = 0
+TDX_LAYER0 = TDX_PROJ + 24 * 2 * 3 * 512
+TDXL_QKV = 0
+TDXL_OUT = TDXL_QKV + 4 * 6 * 3 * 512
+TDXL_FF1 = TDXL_OUT + 4 * 2 * 3 * 512
+TDXL_FF2 = TDXL_FF1 + 4 * 2 * 3 * 512
+TDXL_U16S = TDXL_FF2 + 4 * 2 * 3 * 512
+PLX_U16S = 4 * 4 * 3 * 512
 
 PL_W1_AF = 0
 PL_B1 = PL_W1_AF + 8 * 4 * 256
@@ -332,8 +341,8 @@ def pack_lstm_laststep(sd, lpfx='time_dependency.model.lstm.', ppfx='pool.model.
 
 
 # ---- split-bf16 fragments of the linear layers (csrc/td_bf16.hip) ---------------------------------------------
-def linear_a_fragments_bf16(w, chain):
-    """w [rows][K] -> uint16 [K/16][rows/32][2][64][8].  k-slot e of lane half h = column 16s + 8h + e (natural: the B
+def linear_a_fragments_bf16(w, chain, terms=2):
+    """w [rows][K] -> uint16 [K/16][rows/32][terms][64][8].  k-slot e of lane half h = column 16s + 8h + e (natural: the B
     operand is read from memory) or 16s + (e&3) + 8(e>>2) + 4h (chain: the B operand is the previous D fragment)."""
     w = np.asarray(w, np.float32)
     rows, K = w.shape
@@ -343,30 +352,35 @@ def linear_a_fragments_bf16(w, chain):
     e = np.arange(8)[None, None, None, :]
     col = 16 * s + ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) if chain else 8 * (lane >> 5) + e)
     vals = w[(lane & 31) + 32 * mt, col]
-    hi, lo = bf16_split(vals, 2)
-    return np.stack([hi, lo], 2).reshape(-1)
+    return np.stack(bf16_split(vals, terms), 2).reshape(-1)
 
 
-def pack_self_att_bf16(sd, n_layers, pfx='time_dependency.model.'):
-    blob = np.zeros(TDB_LAYER0 + n_layers * TDBL_U16S, np.uint16)
+def pack_self_att_bf16(sd, n_layers, pfx='time_dependency.model.', terms=2):
+    """terms = 2: hi / lo fragments of td_bf16.hip (TDB_* offsets); terms = 3: hi / mid / lo of td_bf16x6.hip (TDX_*)"""
+    if terms == 2:
+        PROJ, LAYER0, QKV, OUT, FF1, FF2, LSZ = TDB_PROJ, TDB_LAYER0, TDBL_QKV, TDBL_OUT, TDBL_FF1, TDBL_FF2, TDBL_U16S
+    else:
+        PROJ, LAYER0, QKV, OUT, FF1, FF2, LSZ = TDX_PROJ, TDX_LAYER0, TDXL_QKV, TDXL_OUT, TDXL_FF1, TDXL_FF2, TDXL_U16S
+    blob = np.zeros(LAYER0 + n_layers * LSZ, np.uint16)
 
     def put(off, fr):
         blob[off:off + fr.size] = fr
 
-    put(TDB_PROJ, linear_a_fragments_bf16(_np(sd, pfx + 'linear.weight'), chain=False))
+    put(PROJ, linear_a_fragments_bf16(_np(sd, pfx + 'linear.weight'), chain=False, terms=terms))
     for l in range(n_layers):
         p = pfx + 'layers.%d.' % l
-        base = TDB_LAYER0 + l * TDBL_U16S
-        put(base + TDBL_QKV, linear_a_fragments_bf16(_np(sd, p + 'self_attn.in_proj_weight'), chain=True))
-        put(base + TDBL_OUT, linear_a_fragments_bf16(_np(sd, p + 'self_attn.out_proj.weight'), chain=True))
-        put(base + TDBL_FF1, linear_a_fragments_bf16(_np(sd, p + 'linear1.weight'), chain=True))
-        put(base + TDBL_FF2, linear_a_fragments_bf16(_np(sd, p + 'linear2.weight'), chain=True))
+        base = LAYER0 + l * LSZ
+        put(base + QKV, linear_a_fragments_bf16(_np(sd, p + 'self_attn.in_proj_weight'), chain=True, terms=terms))
+        put(base + OUT, linear_a_fragments_bf16(_np(sd, p + 'self_attn.out_proj.weight'), chain=True, terms=terms))
+        put(base + FF1, linear_a_fragments_bf16(_np(sd, p + 'linear1.weight'), chain=True, terms=terms))
+        put(base + FF2, linear_a_fragments_bf16(_np(sd, p + 'linear2.weight'), chain=True, terms=terms))
     return blob
 
 
-def pack_pool_att_bf16(sd, head_prefixes):
-    blob = np.zeros(len(head_prefixes) * PLB_U16S, np.uint16)
+def pack_pool_att_bf16(sd, head_prefixes, terms=2):
+    sz = PLB_U16S if terms == 2 else PLX_U16S
+    blob = np.zeros(len(head_prefixes) * sz, np.uint16)
     for h, p in enumerate(head_prefixes):
-        fr = linear_a_fragments_bf16(_np(sd, p + 'linear1.weight'), chain=True)
-        blob[h * PLB_U16S: h * PLB_U16S + fr.size] = fr
+        fr = linear_a_fragments_bf16(_np(sd, p + 'linear1.weight'), chain=True, terms=terms)
+        blob[h * sz: h * sz + fr.size] = fr
     return blob

@@ -36,11 +36,11 @@ def _header_defines(path):
 
 def test_layout_header_matches_python():
     env = _header_defines(os.path.join(ROOT, 'nisqa_amd', 'csrc', 'layout.hpp'))
-    names = [n for n in dir(W) if re.match(r'(CNN|CNNB|CNNX|CNNS|LSTM|TD|TDL|TDB|TDBL|PL|PLB)_', n)]
+    names = [n for n in dir(W) if re.match(r'(CNN|CNNB|CNNX|CNNS|LSTM|TD|TDL|TDB|TDBL|TDX|TDXL|PL|PLB|PLX)_', n)]
     assert len(names) > 30
     for n in names:
         assert env[n] == getattr(W, n), n
-        assert getattr(W, n) % (8 if n.startswith(('CNNB', 'CNNX', 'TDB', 'PLB')) else 4) == 0, n   # 16-byte aligned
+        assert getattr(W, n) % (8 if n.startswith(('CNNB', 'CNNX', 'TDB', 'TDX', 'PLB', 'PLX')) else 4) == 0, n   # 16-byte aligned
 
 
 def test_conv_fragments_roundtrip():
