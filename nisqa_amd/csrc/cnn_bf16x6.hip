@@ -167,6 +167,10 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
 
     // ---- conv1 1->16 + pool 48x15 -> 24x7 on the matrix pipe, two output pixels per row (cnn_bf16.hip: same row / column
     //      / k-slot maps); the dB input and the weights are exact in their three terms
+    // the first two K steps of conv2's fragments travel while conv1 runs (one wave per SIMD: nobody else covers the L2 round trip
+    // a K loop otherwise opens with); conv3's are requested above conv2's epilogue, conv4's above conv3's
+    conv_k_ring<XT, 1, 3> ring2;
+    conv_k_preload(ring2, wrs, CNNX_W2 * 2, lane16);
     {
         f32x4 w1[1][XT];
 #pragma unroll
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
 
     X_CLK(2);
     // ---- conv2 16->32 on 24x7, pool -> 12x5
+    conv_k_ring<XT, 2, 3> ring34;                         // conv3's, then conv4's first fragments
     {
         f32x16 acc[6][1];
         unsigned base[6], m9[6];
@@ -231,8 +236,10 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             m9[t] = tap_mask(u < 84, py, px, 24, 7);
             base[t] = R + ((py - 1) * 7 + (px - 1)) * X_RS1 + (h << 4);
         }
-        conv_k_terms<XT, 16, 6, 1, 7, X_RS1, X_P1, X_ZADDR, 3>(acc, wrs, CNNX_W2 * 2, lane16, base, m9);
+        conv_k_terms_ring<XT, 16, 6, 1, 7, X_RS1, X_P1, X_ZADDR, 3, true, true>(acc, wrs, CNNX_W2 * 2, lane16, base, m9, ring2);
         X_CLK(3);
+        conv_k_preload(ring34, wrs, CNNX_W3 * 2, lane16);
+        __builtin_amdgcn_sched_barrier(0);                // (hipcc would sink the requests below the epilogue, to their use)
         const unsigned wr = R + (6 * hf * 5) * X_RS2 + n * 2;
 #pragma unroll
         for (int k2 = 0; k2 < 30; k2 += 2) {              // pooled pixel k = gl * 5 + bb, two per packed split
@@ -275,8 +282,10 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
             base[t] = R + base34[t] * X_RS2 + (h << 4);
         }
-        conv_k_terms<XT, 32, 2, 2, 5, X_RS2, X_P2, X_ZADDR, 3>(acc, wrs, CNNX_W3 * 2, lane16, base, m34);
+        conv_k_terms_ring<XT, 32, 2, 2, 5, X_RS2, X_P2, X_ZADDR, 3, true, true>(acc, wrs, CNNX_W3 * 2, lane16, base, m34, ring34);
         X_CLK(5);
+        conv_k_preload(ring34, wrs, CNNX_W4 * 2, lane16);
+        __builtin_amdgcn_sched_barrier(0);
         const unsigned wr = R + (6 * hf * 5) * X_RS3 + n * 2;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
             base[t] = R + base34[t] * X_RS3 + (h << 4);
         }
-        conv_k_terms<XT, 64, 2, 2, 5, X_RS3, X_P3, X_ZADDR, 3>(acc, wrs, CNNX_W4 * 2, lane16, base, m34);
+        conv_k_terms_ring<XT, 64, 2, 2, 5, X_RS3, X_P3, X_ZADDR, 3, true, true>(acc, wrs, CNNX_W4 * 2, lane16, base, m34, ring34);
         X_CLK(7);
 #pragma unroll
         for (int g = 0; g < 3; ++g)

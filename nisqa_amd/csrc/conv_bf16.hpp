@@ -369,18 +369,32 @@ NQ_DEV void mma_terms(f32x16 (&acc)[MT][NT], const f32x4 (&a)[MT][T], const f32x
 // requests -- hipcc's scheduler otherwise sinks them to just before their use, and with ONE wave per SIMD nobody fills the
 // stall (tools/micro/klx6.hip: matrix-pipe duty 0.82 -> 0.96 in the conv3 + conv4 loops; with two waves per SIMD the same
 // fence made the two-term kernel slower)
-template <int T, int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZADDR, int RING = 3, bool FENCE = true>
-NQ_DEV void conv_k_terms(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
-                         const unsigned (&base)[MT], const unsigned (&m9)[MT]) {
+// the first RING - 1 steps of a layer's fragments, requested by the caller a phase ahead (behind the previous layer's K loop,
+// above its epilogue): with one wave per SIMD nobody else covers the L2 round trip a K loop otherwise opens with
+template <int T, int NT, int RING = 3>
+struct conv_k_ring { f32x4 b[RING][NT][T]; };
+template <int T, int NT, int RING>
+NQ_DEV void conv_k_preload(conv_k_ring<T, NT, RING>& r, __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16) {
+#pragma unroll
+    for (int g = 0; g < RING - 1; ++g)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int t = 0; t < T; ++t) r.b[g][nt][t] = wfrag_load(rsrc, lane16, wbyte + ((g * NT + nt) * T + t) * 1024);
+}
+// PRE: `ring` already holds the first RING - 1 steps (conv_k_preload)
+template <int T, int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZADDR, int RING, bool FENCE, bool PRE>
+NQ_DEV void conv_k_terms_ring(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
+                              const unsigned (&base)[MT], const unsigned (&m9)[MT], conv_k_ring<T, NT, RING>& ring) {
     constexpr int S16 = CIN / 16, TOTAL = 9 * S16;
     static_assert(ZADDR >= (2 * W + 2) * RS + 32 * S16, "zero block must sit above the largest tap offset");
-    f32x4 b[RING][NT][T], a[2][MT][T];
+    f32x4 a[2][MT][T];
     unsigned a_ad[MT][T];
     auto load_b = [&](int g, int slot) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int t = 0; t < T; ++t) b[slot][nt][t] = wfrag_load(rsrc, lane16, wbyte + ((g * NT + nt) * T + t) * 1024);
+            for (int t = 0; t < T; ++t) ring.b[slot][nt][t] = wfrag_load(rsrc, lane16, wbyte + ((g * NT + nt) * T + t) * 1024);
     };
     auto load_a = [&](int g, int slot) {
         const int tap = g / S16, s = g - tap * S16;
@@ -398,14 +412,22 @@ NQ_DEV void conv_k_terms(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int
 #pragma unroll
             for (int t = 0; t < T; ++t) a[slot][m][t] = lds_ld128_a(a_ad[m][t] + tapoff + 32 * s);
     };
+    if (!PRE) {
 #pragma unroll
-    for (int g = 0; g < RING - 1; ++g) load_b(g, g);
+        for (int g = 0; g < RING - 1; ++g) load_b(g, g);
+    }
     load_a(0, 0);
 #pragma unroll
     for (int g = 0; g < TOTAL; ++g) {
         if (g + RING - 1 < TOTAL) load_b(g + RING - 1, (g + RING - 1) % RING);
         if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1);
         if (FENCE) __builtin_amdgcn_sched_barrier(0);
-        mma_terms<T, MT, NT>(acc, a[g & 1], b[g % RING]);
+        mma_terms<T, MT, NT>(acc, a[g & 1], ring.b[g % RING]);
     }
+}
+template <int T, int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZADDR, int RING = 3, bool FENCE = true>
+NQ_DEV void conv_k_terms(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
+                         const unsigned (&base)[MT], const unsigned (&m9)[MT]) {
+    conv_k_ring<T, NT, RING> ring;
+    conv_k_terms_ring<T, CIN, MT, NT, W, RS, PLANE, ZADDR, RING, FENCE, false>(acc, rsrc, wbyte, lane16, base, m9, ring);
 }
