@@ -871,7 +871,7 @@ def test_fused_self_attention_block_matches_the_operator_by_operator_path(name, 
             assert (d[solid].max(initial=0) if solid is not None else d.max(initial=0) * (0 if _conv_bias(k) else 1)) < 1e-4, k
 
 
-@pytest.mark.parametrize('precision', ['mixed', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['mixed', 'bf16x3', 'bf16x6'])
 @pytest.mark.parametrize('use_masks', [False, True])
 def test_batchnorm_backward_folded_into_the_weight_gradient_kernel_agrees_with_the_dense_pass(precision, use_masks, monkeypatch):
     """nisqa_segconv_wgrad_bn_bf16 (the dense z -> dz pass of layers 2..6 computed inside the weight-gradient kernel's staging,
@@ -1102,11 +1102,12 @@ def test_training_step_edge_shapes_match_oracle():
     assert worst < 1e-3, (worst, wk)
 
 
-@pytest.mark.parametrize('precision', ['mixed', 'bf16x3'])
+@pytest.mark.parametrize('precision', ['mixed', 'bf16x3', 'bf16x6'])
 def test_segment_resident_and_implicit_convolution_paths_agree_in_the_step(precision, monkeypatch):
     """HipTrainer with the segment-resident convolutions (default) and with NISQA_HIP_TRAIN_SEGCONV=0 (implicit GEMMs): the
     same split-bf16 arithmetic in a different summation order -- loss, y_hat and every gradient agree to 2e-4 of a tensor's
-    largest entry."""
+    largest entry.  'bf16x6': the three-term kernels against the exact-fp32 implicit GEMMs its fallback uses -- fp32-grade
+    both, the bounds of 'mixed'."""
     from nisqa_amd.train import HipTrainer
     import make_golden_train as mk
     args = dict(synth.DIM_ARGS)
@@ -1124,14 +1125,16 @@ def test_segment_resident_and_implicit_convolution_paths_agree_in_the_step(preci
 
     l1, y1, g1, fr1 = run(args, True)
     l0, y0, g0, fr0 = run(args, False)
-    assert len(fr1) == (10 if precision == 'bf16x3' else 5) and not fr0
+    assert len(fr1) == (5 if precision == 'mixed' else 10) and not fr0
     # 'mixed': identical fp32 forward; 'bf16x3': two summation orders of the split-bf16 forward, each ~7e-5 from fp32
-    assert l1 == pytest.approx(l0, rel=1e-5 if precision == 'mixed' else 1e-4)
-    assert np.abs(y1 - y0).max() < (1e-6 if precision == 'mixed' else 2e-4)
+    assert l1 == pytest.approx(l0, rel=1e-4 if precision == 'bf16x3' else 1e-5)
+    assert np.abs(y1 - y0).max() < {'mixed': 2e-6, 'bf16x6': 2e-5, 'bf16x3': 2e-4}[precision]   # (mixed: the same fp32 forward twice)
     worst = max(float(np.abs(g1[k].numpy() - g0[k].numpy()).max()) / max(1e-3, float(np.abs(g0[k].numpy()).max())) for k in g0
                 if not _conv_bias(k))
     print('segment-resident vs implicit convolutions,', precision, ': worst relative gradient difference %.2e' % worst)
-    assert worst < (2e-4 if precision == 'mixed' else 5e-2)     # 'bf16x3': forward rounding differs too (sensitivity: DESIGN.md 4.7)
+    # 'bf16x3': forward rounding differs too (sensitivity: DESIGN.md 4.7); 'bf16x6': two fp32-grade but DIFFERENT forward evaluations
+    # (y_hat 8e-6 apart): the ReLU gates behind train-mode BatchNorm that flip between them move gradient entries by ~1e-3
+    assert worst < {'mixed': 2e-4, 'bf16x6': 2e-3, 'bf16x3': 5e-2}[precision]
 
 
 @pytest.mark.parametrize('model', ['NISQA', 'NISQA_DIM'])
