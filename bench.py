@@ -492,7 +492,7 @@ def side_tts(dev, reps, cpu_baseline_on, pmc, two_streams=True):
 def side_train(dev, steps, cpu_baseline_on, pmc):
     """configs[4]: train_nisqa_cnn_sa_ap.yaml's step (NISQA_model.py:131-152) at bs 32 x 10 s: mel front end, forward in
     train mode, bias-aware loss, backward, BatchNorm buffers, Adam -- HipTrainer.  The PRIMARY number of the leg is the
-    'f32' mode (every convolution on exact fp32 MFMA: the reference's arithmetic); 'mixed' (HipTrainer's default: fp32
+    'f32' mode (every convolution on exact fp32 MFMA: the reference's arithmetic); 'mixed' (HipTrainer's default until round 4: fp32
     forward, split-bf16 gradient convolutions), 'bf16x3' (split-bf16 forward too) and 'bf16x6' (every convolution at fp32
     OPERAND precision on the bf16 matrix pipe: three exact bf16 terms per operand, six products -- held to the bounds of 'f32'
     by the parity tests) are reported beside it."""
@@ -534,7 +534,7 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
     p = modes['f32']
     res = {'config': 'configs[4] train_nisqa_cnn_sa_ap.yaml step (forward + backward + Adam, mel front end inside the step), '
                      'bs=32 x 10 s, %d segments, model NISQA random-init, dropout on; precision mode \'f32\' (exact fp32 MFMA '
-                     'everywhere: the reference\'s arithmetic); \'bf16x6\' (fp32-grade on the bf16 matrix pipe), HipTrainer\'s default mode \'mixed\' and \'bf16x3\' beside it' % segments,
+                     'everywhere: the reference\'s arithmetic); HipTrainer\'s default mode \'bf16x6\' (fp32-grade on the bf16 matrix pipe), \'mixed\' and \'bf16x3\' beside it' % segments,
            'value': p['value'], 'unit': 'clips/s', 'ms_per_step': p['ms_per_step'], 'steps': steps, 'loss': p['loss'],
            'roofline': {'kernel': 'whole step (~59 launches, profiles/rNN_train_*_kernel_stats.csv; no single kernel dominates)',
                         'bound': 'mfma', 'achieved': p['achieved_TFLOPs'], 'unit': 'TFLOP/s',
