@@ -84,6 +84,27 @@ def test_three_bf16_terms_hold_an_fp32_value_exactly_and_the_x6_fragments_are_th
         assert np.float32(got) == want and got == np.float64(want)
 
 
+def test_three_term_linear_fragments_hold_the_weights_exactly():
+    """td_bf16x6.hip: the chain-order fragments [K/16][rows/32][3][64][8] of a linear layer sum to the fp32 weight bit for bit at the
+    k-slot map of the two-term form; blob sizes follow layout.hpp (TDX_*, PLX_*)."""
+    rng = np.random.default_rng(3)
+    w = (rng.standard_normal((192, 64)) * 10.0 ** rng.uniform(-3, 1, (192, 64))).astype(np.float32)
+    val = lambda b: (b.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+    for chain in (False, True):
+        fr3 = W.linear_a_fragments_bf16(w, chain=chain, terms=3).reshape(4, 6, 3, 64, 8)
+        fr2 = W.linear_a_fragments_bf16(w, chain=chain).reshape(4, 6, 2, 64, 8)
+        assert np.array_equal(fr3[:, :, 0], fr2[:, :, 0])                                    # the same leading term, the same slots
+        total = val(fr3[:, :, 0]) + val(fr3[:, :, 1]) + val(fr3[:, :, 2])
+        for s_, mt, lane, e in [(0, 0, 0, 0), (3, 5, 63, 7), (2, 1, 37, 5)]:
+            col = 16 * s_ + ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) if chain else 8 * (lane >> 5) + e)
+            assert total[s_, mt, lane, e] == np.float64(w[(lane & 31) + 32 * mt, col])
+    sd = synth.random_state_dict(7, 'NISQA_DIM')
+    heads = ['pool_layers.%d.model.' % h for h in range(5)]
+    assert W.pack_self_att_bf16(sd, 2, terms=3).size == W.TDX_LAYER0 + 2 * W.TDXL_U16S
+    assert W.pack_self_att_bf16(sd, 2).size == W.TDB_LAYER0 + 2 * W.TDBL_U16S
+    assert W.pack_pool_att_bf16(sd, heads, terms=3).size == 5 * W.PLX_U16S and W.pack_pool_att_bf16(sd, heads).size == 5 * W.PLB_U16S
+
+
 def test_linear_fragments_roundtrip():
     rng = np.random.default_rng(1)
     w = rng.standard_normal((192, 64))
