@@ -402,7 +402,7 @@ def side_tts(dev, reps, cpu_baseline_on, pmc, two_streams=True):
     from nisqa_amd.engine import HipNisqa
     from nisqa_amd import NISQA_lib as NL, ingest as _ing
     targs, tsd, wdesc = tts_weights()
-    eng = HipNisqa(targs, tsd, dev)
+    eng = HipNisqa(targs, tsd, dev, precision=os.environ.get('NISQA_HIP_PRECISION', 'bf16x3'))
     n_clips = 256
     durs = np.random.default_rng(7).uniform(3, 30, n_clips)
     base = synth.synth_pcm16(5, 30.0)
@@ -468,6 +468,25 @@ def side_tts(dev, reps, cpu_baseline_on, pmc, two_streams=True):
                     'bound': 'latency', 'us_per_step': round(1e3 * lstm_ms / float(steps.sum()), 4),
                     'steps_per_job': int(steps.sum()), 'workgroups_per_launch': [2 * p.n_clips for p, _ in batches],
                     'achieved_tflops': round(float(segs.sum()) * FLOP_LSTM_SEG / (lstm_ms * 1e-3) / 1e12, 3)}}
+    if two_streams and eng.precision == 'bf16x3':
+        # the same job on the exact-fp32 kernels (the reference's arithmetic) and on 'bf16x6' (fp32 operands as three exact bf16
+        # terms, six products: held to the bounds of 'f32' by the parity tests); the BiLSTM is fp32 VALU in every mode
+        for prec in ('f32', 'bf16x6'):
+            e2 = HipNisqa(targs, tsd, dev, precision=prec)
+            for plan, x in batches:
+                o2 = e2.forward_pcm(x, plan, SR)
+            torch.cuda.synchronize()
+            r2 = max(1, min(reps, 8))
+            t1 = time.perf_counter()
+            for r in range(r2):
+                for plan, x in batches:
+                    o2 = e2.forward_pcm(x, plan, SR)
+            torch.cuda.synchronize()
+            d2 = (time.perf_counter() - t1) / r2
+            res['value_' + prec] = round(n_clips / d2, 1)
+            res[prec] = {'value': round(n_clips / d2, 1), 'unit': 'clips/s', 'ms_per_job': round(d2 * 1e3, 3), 'jobs_timed': r2,
+                         'max_abs_diff_vs_primary_last_batch': float((o2 - out).abs().max())}
+            del e2
     if cpu_baseline_on:
         from oracle import mel as omel, net as onet
         n_cpu = 4

@@ -214,6 +214,12 @@ int nisqa_cnn_standard_bf16(const float* mel_tm, const int32_t* frame_off, const
                             const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                             int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
                             const uint16_t* cnn_wb, float* feat20, void* stream);
+/* ... and at fp32 OPERAND precision on the bf16 matrix pipe (three exact bf16 terms per operand, six products: "bf16x6"); cnn_wx =
+ * the three-term fragment blob (nisqa_amd.weights.pack_adapt_cnn_bf16(terms=3): the conv shapes are the AdaptCNN's). */
+int nisqa_cnn_standard_bf16x6(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                              const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                              int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
+                              const uint16_t* cnn_wx, float* feat20, void* stream);
 int nisqa_lstm_laststep(const float* feat20, const int32_t* tok_off, const int32_t* n_wins,
                         int32_t n_clips, const float* lstm_w, float* hfin_ws, float* seq_opt,
                         float* out, void* stream);
@@ -234,9 +240,10 @@ typedef struct {
     void* const* stage_events;
     const uint16_t* cnn_wb;  /* split-bf16 conv fragments, or NULL */
     int32_t cnn_mode;        /* 0 = exact fp32 MFMA kernels, 1 = split-bf16 kernels (needs cnn_wb, td_wb, pool_wb),
-                              * 2 = arch 0 only: every GEMM on three-term bf16 (nisqa_cnn_adapt_bf16x6, nisqa_td_selfatt_bf16x6,
+                              * 2 = every GEMM on three-term bf16 (arch 0: nisqa_cnn_adapt_bf16x6, nisqa_td_selfatt_bf16x6,
                               * nisqa_pool_att_bf16x6; cnn_wb / td_wb / pool_wb = their three-term fragments; td_wb or
-                              * pool_wb NULL: self-attention and pooling on the exact fp32 kernels) */
+                              * pool_wb NULL: self-attention and pooling on the exact fp32 kernels; arch 1: nisqa_cnn_standard_bf16x6, the
+                              * BiLSTM is fp32 in every mode) */
     const uint16_t* td_wb;   /* split-bf16 self-attention fragments, or NULL */
     const uint16_t* pool_wb; /* split-bf16 pooling fragments, or NULL */
     int32_t arch;            /* 0 = CNN-SA-AP (nisqa.tar, nisqa_mos_only.tar); 1 = StandardCNN + BiLSTM + last-step

@@ -72,6 +72,9 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
         rc = model->cnn_mode == 1
                  ? nisqa_cnn_standard_bf16(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded,
                                            model->seg_hop, model->cnn_w, model->cnn_wb, feat, stream)
+             : model->cnn_mode == 2
+                 ? nisqa_cnn_standard_bf16x6(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded,
+                                             model->seg_hop, model->cnn_w, model->cnn_wb, feat, stream)
                  : nisqa_cnn_standard(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded,
                                       model->seg_hop, model->cnn_w, p3, feat, stream);
         if (rc) return rc;

@@ -1,0 +1,483 @@
+// StandardCNN (fixed 2x2 max-pools) + fc_out at fp32 OPERAND precision on the bf16 matrix pipe ("bf16x6") for the nisqa_tts.tar
+// architecture -- cnn_std_bf16.hip's kernel (same role, inputs and outputs as cnn_std_front_kernel + cnn_std_back_kernel in
+// cnn_std.hip; reference nisqa/NISQA_lib.py:2239-2282, 487-502, 811-836) with every fp32 operand as THREE bf16 terms (hi + mid + lo,
+// an exact split) and six MFMA products per term pair (cnn_bf16x6.hip, DESIGN.md 4.5 "bf16x6").  Three planes per activation
+// tensor: 23.7 KB of LDS per wave, ONE workgroup per CU, one wave per SIMD; the K loops carry the scheduling fence of conv_k_terms.
+#include "common.hpp"
+#include "layout.hpp"
+#include <atomic>
+#include "conv_bf16.hpp"
+#include "../../include/nisqa_hip.h"
+
+#define XT 3
+#define SS_A1PLANE 6144                    /* 192 px x 16 ch bf16 */
+#define SS_PATCH (XT * SS_A1PLANE)         /* conv1 input: three zero-bordered bf16 planes [17][50] behind the A1 planes */
+#define SS_PPLANE 1700
+#define SS_ZERO (SS_PATCH + 5120)          /* 128 B of zeros per wave (the zero block of wave 3 serves conv5 / conv6) */
+#define SS_WAVE (SS_ZERO + 128)            /* 23 680 */
+#define SS_ZADDR 2048u                     /* a zero block shared by the workgroup, above the largest tap offset (conv_k_terms) */
+#define SS_BASE 2176u                      /* first wave region */
+#define SS_LDS (SS_BASE + 4 * SS_WAVE)     /* 96 896 B: one workgroup per CU */
+#define SS_PLANE 6144                      /* S4 / S5: 48 rows x 64 ch bf16, chunk-swizzled */
+/* conv2 -> conv3 -> conv4 activations: pixel rows padded by 16 bytes, NOT swizzled (every address = lane base + immediate) */
+#define SS_RS2 80                          /* A2: 48 px x 32 ch */
+#define SS_P2 (48 * SS_RS2)
+#define SS_RS3 144                         /* A3: 48 px x 64 ch */
+#define SS_P3 (48 * SS_RS3)
+static_assert(XT * SS_P3 <= SS_ZERO && XT * SS_PLANE <= SS_WAVE && SS_LDS <= 160 * 1024 && XT * SS_PPLANE <= 5120, "LDS plan");
+
+// v -> XT bf16 terms (round to nearest) at byte offset `off` of the first plane (generic pointer: the swizzled S4 / S5 planes)
+NQ_DEV void store_terms(char* plane0, int plane_bytes, int off, float v) {
+    float r = v;
+#pragma unroll
+    for (int t = 0; t < XT; ++t) {
+        const unsigned pk = cvt_pk_bf16(r, 0.f);
+        *(unsigned short*)(plane0 + t * plane_bytes + off) = (unsigned short)pk;
+        if (t + 1 < XT) r -= __uint_as_float(pk << 16);
+    }
+}
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+NQ_DEV float row16_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+    return v;
+}
+
+// conv2's K loop (cnn_std_bf16.hip: chunk-swizzled 16-channel A1 planes, two lane-static bases per tile -- own image row / flipped
+// chunk --, 9-bit tap masks, one K-step per tap) with three terms per operand and six products; A rows one tap ahead, fragments two
+template <int MT>
+NQ_DEV void conv_k_terms_c16(f32x16 (&acc)[MT][1], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
+                             const unsigned (&a_same)[MT], const unsigned (&a_flip)[MT], const unsigned (&m9)[MT]) {
+    f32x4 b[3][1][XT], a[2][MT][XT];
+    auto load_b = [&](int g, int slot) {
+#pragma unroll
+        for (int t = 0; t < XT; ++t) b[slot][0][t] = wfrag_load(rsrc, lane16, wbyte + (g * XT + t) * 1024);
+    };
+    auto load_a = [&](int g, int slot) {
+        const int dy = g / 3, dx = g % 3;
+        const int tapoff = ((dy - 1) * 8 + (dx - 1)) * 32;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bool ok = (m9[m] >> g) & 1u;
+            const unsigned ad = (unsigned)((int)(dy == 1 ? a_same[m] : a_flip[m]) + tapoff);
+#pragma unroll
+            for (int t = 0; t < XT; ++t) a[slot][m][t] = lds_ld128_a(ok ? ad + t * SS_A1PLANE : SS_ZADDR);
+        }
+    };
+    load_b(0, 0);
+    load_b(1, 1);
+    load_a(0, 0);
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+        if (g + 2 < 9) load_b(g + 2, (g + 2) % 3);
+        if (g + 1 < 9) load_a(g + 1, (g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_terms<XT, MT, 1>(acc, a[g & 1], b[g % 3]);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void cnn_std_bf16x6_kernel(
+    const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
+    const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
+    const float* __restrict__ clip_floor, int n_clips, int seg_hop,
+    const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ feat20) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p0 = blockIdx.x * 4;                      // tok_off is a multiple of 32: no clip straddling
+    const int b = __builtin_amdgcn_readfirstlane(find_segment_wave(tok_off, n_clips, p0, lane));   // one vector load + ballot, not a chain of log2(n) scalar loads
+    const int k0 = p0 - tok_off[b];
+    const int nvalid = min(4, n_wins[b] - k0);
+    if (nvalid <= 0) return;
+    const bool valid = wave < nvalid;                    // padding waves still walk the barriers (on zeros)
+    const int k = k0 + wave;
+    char* act = smem + SS_BASE + wave * SS_WAVE;
+    char* zero = act + SS_ZERO;
+
+    // ---- the 15-frame window as three zero-bordered bf16 planes (hi, mid, lo) [frame j + 1][mel m + 1]; all 12 global loads
+    //      of the window are requested up front (one memory latency), the plane addresses are three lane-dependent bases +
+    //      immediates (element i0 = lane + 64 q = (frame, mel) = divmod(i0, 48); q = 3 t + u: frame q + t + (lane + 16 u) / 48)
+    const unsigned R = SS_BASE + (unsigned)wave * SS_WAVE; // this wave's region (the kernel has no static LDS: addresses start at 0)
+    {
+        const float fl = clip_floor[b];
+        const float* src = mel_tm + (size_t)(frame_off[b] + k * seg_hop) * 48;
+        float vraw[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) vraw[q] = (valid && (q < 11 || lane < 16)) ? src[lane + 64 * q] : 0.f;
+        const unsigned pb = R + SS_PATCH;
+#pragma unroll
+        for (int it = 0; it < 5; ++it)                      // 319 x 16 bytes of zeros (three planes)
+            if (it < 4 || lane < (3 * SS_PPLANE + 15) / 16 - 256) lds_st128(pb + (lane + 64 * it) * 16, f32x4{0.f, 0.f, 0.f, 0.f});
+        if (lane < 32) { ((float*)zero)[lane] = 0.f; ((unsigned*)(smem + SS_ZADDR))[lane] = 0u; }   // (through the dynamic-LDS symbol: see cnn_bf16.hip)
+        __builtin_amdgcn_wave_barrier();
+        unsigned ob[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = lane + 16 * u, j0 = e >= 48 ? 1 : 0, m = e - 48 * j0;
+            ob[u] = pb + ((j0 + 1) * 50 + m + 1) * 2;
+        }
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const float v = valid ? fmaxf(vraw[q], fl) : 0.f;
+            const unsigned hi = cvt_pk_bf16(v, 0.f);
+            const float r1 = v - __uint_as_float(hi << 16);
+            const unsigned mid = cvt_pk_bf16(r1, 0.f);
+            const unsigned lo = cvt_pk_bf16(r1 - __uint_as_float(mid << 16), 0.f);
+            const unsigned a = ob[q % 3] + (q + q / 3) * 100;
+            if (q < 11 || lane < 16) {
+                lds_st16(a, hi);
+                lds_st16(a + SS_PPLANE, mid);
+                lds_st16(a + 2 * SS_PPLANE, lo);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const int i = lane & 31, hfi = (i >> 2) & 1, qi = (i & 3) + 4 * (i >> 3);
+    const int n = lane & 31, hf = lane >> 5, h = lane >> 5;
+
+    // ---- conv1 1->16 on the matrix pipe + MaxPool2d(2, stride 2, padding (0,1)): 48x15 -> 24x8, TWO output pixels per MFMA
+    //      row like cnn_front_bf16_kernel (round 3; before: one pixel per row, k-slots gathered with 48 16-bit LDS reads and 24
+    //      shift-ors per tile pair).  A row = the mel pair (m0, m0 + 1) of one frame; N = 32 = (channel c, pair member dm);
+    //      K = 12 of 16 = (frame tap kx, the four mels m0 - 1 .. m0 + 2 the pair touches): contiguous in the bordered patch, so
+    //      a lane's 8 k-slots are two pairs of dwords per plane.  B[k][n] = w[c][dmm - dm][kx] (weights.py, conv1_pairs).
+    //      The input keeps THREE bf16 terms (six products): the BiLSTM head amplifies input error ten times more than the
+    //      attention head.  Pooled column bb covers frames {2 bb - 1, 2 bb} (column -1 is pool padding): in-lane; the mel
+    //      pair's maximum needs the partner 16 lanes away: lane group dm = 0 finalises the even pooled pixels of an
+    //      iteration, dm = 1 the odd ones (one ds_swizzle per pixel pair); ReLU first, maxima on non-negative floats as uints.
+    {
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNX_U16S * 2, 0x00020000);
+        f32x4 w1[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) w1[t] = wfrag_load(wrs, lane * 16, (CNNX_W1 + t * 512) * 2);
+        const float tn = cw[CNN_T1 + (n & 15)];
+        const int xq = min(qi, 14);                       // row 15 of a tile is padding (result unused)
+        unsigned rd_a = R + SS_PATCH + ((xq + (h ? 2 : 0)) * 50 + 24 * hfi) * 2;
+        unsigned rd_b = R + SS_PATCH + ((xq + (h ? 2 : 1)) * 50 + 24 * hfi) * 2;
+        const bool is_b = (n & 16) != 0;
+        const unsigned mb = is_b ? ~0u : 0u;
+        // A1 is chunk-swizzled (16-byte chunk (c >> 3) ^ ((pixel >> 3) & 1)); an iteration's 16 pixels start at a multiple of
+        // 16, so the swizzle bit of pixel 2 kk (+ 1) is kk >> 2: two lane bases, the rest are immediates
+        const int c = n & 15;
+        const unsigned wr0 = R + (12 * hf * 8) * 32 + (is_b ? 32 : 0) + (c & 7) * 2;
+        const unsigned wrA = wr0 + ((c >> 3) << 4), wrB = wr0 + (((c >> 3) ^ 1) << 4);
+        for (int g2 = 0; g2 < 6; ++g2) {
+            f32x16 acc[2];
+            f32x4 xa[2][3];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {              // dword reads (ds_read2_b32): the pairs are only 4-byte aligned
+                    const unsigned pa = rd_a + 4 * tt + t * SS_PPLANE, pq = rd_b + 4 * tt + t * SS_PPLANE;
+                    xa[tt][t] = f32x4{__uint_as_float(lds_ld32(pa)), __uint_as_float(lds_ld32(pa + 4)),
+                                      __uint_as_float(lds_ld32(pq)), __uint_as_float(lds_ld32(pq + 4))};
+                }
+            acc[0] = zero16();
+            acc[1] = zero16();
+            acc[0] = mfma_bf(xa[0][2], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][2], w1[0], acc[1]);   // smallest products first
+            acc[0] = mfma_bf(xa[0][1], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[1], acc[1]);
+            acc[0] = mfma_bf(xa[0][0], w1[2], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[2], acc[1]);
+            acc[0] = mfma_bf(xa[0][1], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[0], acc[1]);
+            acc[0] = mfma_bf(xa[0][0], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[1], acc[1]);
+            acc[0] = mfma_bf(xa[0][0], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[0], acc[1]);
+            unsigned r[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int tt = v >> 3, bb = v & 7;
+                const float mx = bb ? fmaxf(acc[tt][2 * bb - 1], acc[tt][2 * bb]) : acc[tt][0];   // frames
+                r[v] = __float_as_uint(fmaxf(mx + tn, 0.f));
+            }
+            unsigned got[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                got[kk] = (unsigned)__builtin_amdgcn_ds_swizzle((int)((r[2 * kk] & mb) | (r[2 * kk + 1] & ~mb)), 0x401F);
+            float fin[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const unsigned own = (r[2 * kk + 1] & mb) | (r[2 * kk] & ~mb);
+                fin[kk] = __uint_as_float(max(own, got[kk]));
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; kk += 2) {             // pixels 16 g2 + 2 kk (+ 1 in the dm = 1 lanes) and two further
+                const unsigned w_ = (kk < 4 ? wrA : wrB) + 512 * g2 + 64 * kk;
+                lds_store_terms2<XT>(w_, w_ + 64, SS_A1PLANE, fin[kk], fin[kk + 1]);
+            }
+            rd_a += 8; rd_b += 8;                          // mel m0 = 2 gl, gl = 12 hfi + 2 g2 + tt
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- conv2 16->32 on 24x8, pool 2x2 -> 12x4: tile t of a lane half = pooled row 6*half + t (2 rows x 8 cols)
+    {
+        f32x16 acc[6][1];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) acc[t][0] = zero16();
+        unsigned a_same[6], a_flip[6], m2[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int py = 2 * (6 * hfi + t) + (qi >> 3), px = qi & 7;
+            m2[t] = tap_mask(true, py, px, 24, 8);
+            const unsigned row = R + (unsigned)((py * 8 + px) * 32);
+            a_same[t] = row + (unsigned)((h ^ (py & 1)) << 4);
+            a_flip[t] = row + (unsigned)((h ^ (~py & 1)) << 4);
+        }
+        const __amdgpu_buffer_rsrc_t wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNX_U16S * 2, 0x00020000);
+        conv_k_terms_c16<6>(acc, wrs2, CNNX_W2 * 2, lane * 16, a_same, a_flip, m2);
+        const float tn = cw[CNN_T2 + n];
+        const unsigned wr = R + (6 * hf * 4) * SS_RS2 + n * 2;
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int bb = 0; bb < 4; bb += 2) {             // pooled pixels (6 hf + t) * 4 + bb, + 1: one packed split
+                float pvv[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int q = 2 * (bb + e);
+                    const float mx = fmaxf(fmaxf(acc[t][0][q], acc[t][0][q + 1]), fmaxf(acc[t][0][8 + q], acc[t][0][8 + q + 1]));
+                    pvv[e] = fmaxf(mx + tn, 0.f);
+                }
+                lds_store_terms2<XT>(wr + (4 * t + bb) * SS_RS2, wr + (4 * t + bb + 1) * SS_RS2, SS_P2, pvv[0], pvv[1]);
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // conv3 / conv4 on 12x4: a lane half owns 3 pooled rows = 3 groups of 8 pixels; u = 8*gl + 4*yy + x.  Second-generation
+    // K loop (conv_bf16.hpp: lane-static tap masks, one select per tap and tile, fragments through a buffer descriptor)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNX_U16S * 2, 0x00020000);
+    const unsigned lane16 = lane * 16;
+    unsigned base34[2], m34[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int u = 16 * t + qi;
+        const int py = 2 * (3 * hfi + (u >> 3)) + ((u >> 2) & 1), px = u & 3;
+        m34[t] = tap_mask(u < 24, py, px, 12, 4);
+        base34[t] = (py - 1) * 4 + (px - 1);              // pixel index of tap (-1, -1)
+    }
+    {
+        f32x16 acc[2][2];
+        unsigned base[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
+            base[t] = R + base34[t] * SS_RS2 + (h << 4);
+        }
+        conv_k_terms<XT, 32, 2, 2, 4, SS_RS2, SS_P2, SS_ZADDR, 3>(acc, wrs, CNNX_W3 * 2, lane16, base, m34);
+        const unsigned wr = R + (24 * hf) * SS_RS3 + n * 2; // pixel (2 (3 hf + (u >> 3)) + ((u >> 2) & 1)) * 4 + (u & 3) = 24 hf + u
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float tn = cw[CNN_T3 + n + 32 * nt];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int u = 16 * t + r;
+                    if (u < 24)
+                        lds_store_terms2<XT>(wr + u * SS_RS3 + 64 * nt, wr + (u + 1) * SS_RS3 + 64 * nt, SS_P3,
+                                         fmaxf(acc[t][nt][r] + tn, 0.f), fmaxf(acc[t][nt][r + 1] + tn, 0.f));
+                }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- conv4 64->64 on 12x4, pool -> 6x2.  The pooled outputs of the four segments go to a SHARED pair of
+    //      bf16 planes S4[48 rows][64 ch] (row = 12 * wave + pixel) for the N-split conv5 / conv6.
+    char* s4 = smem + SS_BASE;             // wave 0's region (its A3 is dead by then)
+    char* s5 = smem + SS_BASE + SS_WAVE;   // wave 1's region
+    float* s6 = (float*)(smem + SS_BASE);  // conv6 output, fp32 [48][64], over S4
+    {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
+        unsigned base[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) base[t] = R + base34[t] * SS_RS3 + (h << 4);
+        conv_k_terms<XT, 64, 2, 2, 4, SS_RS3, SS_P3, SS_ZADDR, 3>(acc, wrs, CNNX_W4 * 2, lane16, base, m34);
+        __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = n + 32 * nt;
+            const float tn = cw[CNN_T4 + c];
+#pragma unroll
+            for (int gl = 0; gl < 3; ++gl)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    float mx = -3.0e38f;
+#pragma unroll
+                    for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                        for (int xx = 0; xx < 2; ++xx) {
+                            const int u = 8 * gl + 4 * yy + 2 * bb + xx;
+                            mx = fmaxf(mx, acc[u >> 4][nt][u & 15]);
+                        }
+                    const int pp = 12 * wave + (3 * hf + gl) * 2 + bb;
+                    store_terms(s4, SS_PLANE, pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2,
+                                fmaxf(mx + tn, 0.f));
+                }
+        }
+    }
+    __syncthreads();
+
+    // fc_out (768 -> 20) is split over the waves like conv5 / conv6: wave w computes outputs 5 w .. 5 w + 4 of all four segments
+    // (a quarter of the weights per wave: 60 floats per lane instead of 240), and those 60 floats are requested NOW, so that
+    // they arrive under conv5 / conv6 (before: twelve exposed L2 round trips behind the last barrier)
+    struct __attribute__((packed, aligned(4))) fc5_t { float v[5]; };
+    fc5_t wfc_pre[12];
+    __builtin_amdgcn_sched_barrier(0);                     // not earlier: conv2..conv4 need the registers
+#pragma unroll
+    for (int m = 0; m < 12; ++m) wfc_pre[m] = *(const fc5_t*)(cw + CNNS_FC_W + (size_t)(m * 64 + lane) * 20 + 5 * wave);
+    // ---- conv5 / conv6 (3x3, padding 1, on 6x2) with N split over the waves: wave w owns output channels
+    //      16w..16w+15 of all four segments; rows rho = 16 t + i16 <-> (slot = rho / 12, pixel = rho % 12)
+    {
+        const int i16 = lane & 15, kg = lane >> 4;
+        const int ch = 16 * wave + i16;
+        const char* zero3 = smem + SS_BASE + 3 * SS_WAVE + SS_ZERO;  // wave 3's zero block: S4 / S5 / S6 never cover it
+        int ry[3], rx[3], rb[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int rho = 16 * t + i16;
+            const int slot = rho / 12, pix = rho - 12 * slot;
+            ry[t] = pix >> 1;
+            rx[t] = pix & 1;
+            rb[t] = slot * 12;
+        }
+        // the 9 x 3 tap addresses of a lane are static (row -> pixel map, image bounds, chunk swizzle): computed once for
+        // both layers as offsets into the S4 / S5 planes (round 3; before: per tap, tile, step and layer); K-step s = 1 is
+        // the address ^ 64 (the chunk index is (4 s + kg) ^ swizzle and the zero block is 128-byte aligned)
+        unsigned poff[9][3];
+        unsigned pok = 0;                                   // bit 3 tap + t: the tap is inside the image
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int y = ry[t] + tap / 3 - 1, x = rx[t] + tap % 3 - 1;
+                const bool ok = (unsigned)y < 6u && (unsigned)x < 2u;
+                const int pix = rb[t] + y * 2 + x;
+                poff[tap][t] = (unsigned)(pix * 128 + ((kg ^ ((pix >> 1) & 7)) << 4));
+                pok |= ok ? (1u << (3 * tap + t)) : 0u;
+            }
+        const unsigned Z3 = SS_BASE + 3 * SS_WAVE + SS_ZERO;
+        const __amdgpu_buffer_rsrc_t wrs5 = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNX_U16S * 2, 0x00020000);
+#pragma unroll 1
+        for (int layer = 0; layer < 2; ++layer) {
+            const unsigned srcA = layer ? SS_BASE + SS_WAVE : SS_BASE;
+            f32x4 acc5[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc5[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int wbyte = ((layer ? CNNX_W6 : CNNX_W5) + wave * (18 * XT * 512)) * 2;
+            f32x4 bq[4][XT], aq[2][3][XT];                 // fragments three K-steps ahead, A rows one step ahead
+            auto load_a = [&](int g) {
+                const int tap = g >> 1, sx = (g & 1) << 6;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const bool ok = (pok >> (3 * tap + t)) & 1u;
+                    const unsigned a0_ = ok ? (srcA + poff[tap][t]) ^ sx : Z3;
+#pragma unroll
+                    for (int q = 0; q < XT; ++q) aq[g & 1][t][q] = lds_ld128(ok ? a0_ + q * SS_PLANE : Z3);
+                }
+            };
+            auto load_bq = [&](int g) {
+#pragma unroll
+                for (int q = 0; q < XT; ++q) bq[g & 3][q] = wfrag_load(wrs5, lane * 16, wbyte + (g * XT + q) * 1024);
+            };
+#pragma unroll
+            for (int g = 0; g < 3; ++g) load_bq(g);
+            load_a(0);
+#pragma unroll
+            for (int g = 0; g < 18; ++g) {
+                if (g + 3 < 18) load_bq(g + 3);
+                if (g + 1 < 18) load_a(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int order = XT - 1; order >= 0; --order)
+#pragma unroll
+                    for (int i_ = order; i_ >= 0; --i_)
+#pragma unroll
+                        for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(aq[g & 1][t][i_], bq[g & 3][order - i_], acc5[t]);
+            }
+            const float tn = cw[(layer ? CNN_T6 : CNN_T5) + ch];
+            // conv6's fp32 output goes over S4, which every wave finished reading before the barrier that ended conv5
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rho = 16 * t + 4 * kg + r;
+                    const float v = fmaxf(acc5[t][r] + tn, 0.f);
+                    if (layer) s6[rho * 64 + ch] = v;
+                    else store_terms(s5, SS_PLANE, rho * 128 + (((ch >> 3) ^ ((rho >> 1) & 7)) << 4) + (ch & 7) * 2, v);
+                }
+            __syncthreads();
+        }
+    }
+
+    // ---- fc_out 768 -> 20, N split over the waves: lane takes k' = lane + 64 m (k' = pixel * 64 + c) of ALL four segments
+    //      (48 LDS reads of conv6's fp32 output) against its wave's five output columns (wfc_pre).  The 20 sums over the
+    //      wave (4 segments x 5 outputs) are a reduce-scatter -- 10 + 5 exchanges, then four DPP steps on 5 values -- instead
+    //      of 20 six-step butterflies; row r of the wave ends up holding segment r.
+    {
+        float o[4][5];
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) o[sg][j] = 0.f;
+#pragma unroll
+        for (int m = 0; m < 12; ++m)
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg) {
+                const float a = s6[(12 * sg + m) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) o[sg][j] = fmaf(a, wfc_pre[m].v[j], o[sg][j]);
+            }
+        // lanes l, l ^ 32: the lower half keeps segments 0, 1, the upper half segments 2, 3
+        float p10[2][5];
+        const bool up = lane >= 32;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const float give = up ? o[sg][j] : o[2 + sg][j], keep = up ? o[2 + sg][j] : o[sg][j];
+                p10[sg][j] = keep + __shfl_xor(give, 32);
+            }
+        // lanes l, l ^ 16: bit 4 clear keeps the first segment of its two, bit 4 set the second
+        float p5[5];
+        const bool hi16 = (lane & 16) != 0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const float give = hi16 ? p10[0][j] : p10[1][j], keep = hi16 ? p10[1][j] : p10[0][j];
+            p5[j] = keep + __shfl_xor(give, 16);
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const float t = row16_sum_dpp(p5[j]);
+            if ((lane & 15) == j) mine = t;
+        }
+        const int sg = lane >> 4, jo = 5 * wave + (lane & 15);
+        if ((lane & 15) < 5 && sg < nvalid) feat20[(size_t)(p0 + sg) * 20 + jo] = mine + cw[CNNS_FC_B + jo];
+    }
+}
+
+extern "C" int nisqa_cnn_standard_bf16x6(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                                         const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                                         int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
+                                         const uint16_t* cnn_wx, float* feat20, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wx || !feat20)
+        return NISQA_ERR_ARG;
+    NQ_LAUNCH_BEGIN();
+    static std::atomic<bool> attr[64];                       // 95 KB of dynamic LDS: opted in once per device ordinal
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr[dev].load(std::memory_order_relaxed)) {
+        if (hipFuncSetAttribute((const void*)cnn_std_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SS_LDS) != hipSuccess)
+            return 2;
+        attr[dev].store(true, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(cnn_std_bf16x6_kernel, dim3(total_tok_padded / 4), dim3(256), SS_LDS, (hipStream_t)stream, mel_tm,
+                       frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_std_w, cnn_wx, feat20);
+    return NQ_LAUNCH_STATUS();
+}

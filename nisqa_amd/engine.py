@@ -102,8 +102,8 @@ class HipNisqa(object):
 
     def __init__(self, args, state_dict, device=None, precision=None):
         """precision: 'bf16x3' (default: AdaptCNN on split-bf16 MFMA, fp32-class accuracy, |dMOS| <= 3e-5), 'f32'
-        (every GEMM on exact fp32 MFMA) or 'bf16x6' (CNN-SA-AP models only: every GEMM -- AdaptCNN, self-attention, pooling -- with its fp32 operands as three
-        bf16 terms, an exact split, and six MFMA products per term pair: the accuracy of 'f32' at 1.7 x its rate); the environment variable NISQA_HIP_PRECISION sets the default."""
+        (every GEMM on exact fp32 MFMA) or 'bf16x6' (every GEMM -- AdaptCNN / StandardCNN, self-attention, pooling -- with its fp32 operands as three bf16 terms, an
+        exact split, and six MFMA products per term pair: the accuracy of 'f32' at 1.5-1.7 x its rate); the environment variable NISQA_HIP_PRECISION sets the default."""
         if not torch.cuda.is_available():
             raise RuntimeError('nisqa_amd: no GPU visible (torch.cuda.is_available() is False); '
                                'the HIP engine has no CPU fallback')
@@ -137,9 +137,6 @@ class HipNisqa(object):
         self.precision = precision or os.environ.get('NISQA_HIP_PRECISION', 'bf16x3')
         if self.precision not in ('f32', 'bf16x3', 'bf16x6'):
             raise ValueError('precision must be f32, bf16x3 or bf16x6, got {}'.format(self.precision))
-        if self.precision == 'bf16x6' and self.arch == 1:
-            raise NotImplementedError("precision 'bf16x6' is implemented for the CNN-SA-AP models (AdaptCNN); "
-                                      "nisqa_tts.tar runs 'bf16x3' or 'f32'")
         if self.arch == 1:
             # StandardCNN (split-bf16 or exact-fp32 MFMA) + BiLSTM + last-step pooling (fp32 VALU)
             self.n_layers, self.n_heads = 0, 1
@@ -147,6 +144,8 @@ class HipNisqa(object):
             self.td_w = up(_w.pack_lstm_laststep(state_dict))
             self.pool_w = torch.zeros(4, dtype=torch.float32, device=self.device)
             self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict, conv1_pairs=True).view(np.int16)) if self.precision == 'bf16x3' else None
+            if self.precision == 'bf16x6':               # three-term fragments (the BiLSTM and the pooling are fp32 in every mode)
+                self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict, conv1_pairs=True, terms=3).view(np.int16))
             self.td_wb = self.pool_wb = None
             self._mel = {}
             self._ws = {}
@@ -298,11 +297,11 @@ class HipNisqa(object):
         """StandardCNN + fc_out -> feat20 [NP, 20]"""
         d = plan.to(self.device)
         feat = torch.zeros((plan.total_tok, 20), dtype=torch.float32, device=self.device)
-        if self.precision == 'bf16x3':
-            _lib.check(self.lib.nisqa_cnn_standard_bf16(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']),
-                                                        _ptr(d['n_wins']), _ptr(clip_floor), plan.n_clips, plan.total_tok,
-                                                        self.seg_hop, _ptr(self.cnn_w), _ptr(self.cnn_wb), _ptr(feat),
-                                                        self._stream()), 'nisqa_cnn_standard_bf16')
+        if self.precision in ('bf16x3', 'bf16x6'):
+            fn = self.lib.nisqa_cnn_standard_bf16 if self.precision == 'bf16x3' else self.lib.nisqa_cnn_standard_bf16x6
+            _lib.check(fn(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']), _ptr(clip_floor), plan.n_clips,
+                          plan.total_tok, self.seg_hop, _ptr(self.cnn_w), _ptr(self.cnn_wb), _ptr(feat), self._stream()),
+                       'nisqa_cnn_standard_' + self.precision)
             return feat
         p3 = torch.empty((plan.total_tok, 12, 64), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.nisqa_cnn_standard(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']),

@@ -30,8 +30,7 @@ def clip_pcm(i):
 
 
 PRECISIONS = ['f32', 'bf16x3']
-# the CNN-SA-AP models also run 'bf16x6' (AdaptCNN on three exact bf16 terms per fp32 operand, six products; attention and
-# pooling on the fp32 kernels): held to the SAME bounds as 'f32'
+# 'bf16x6' (every GEMM on three exact bf16 terms per fp32 operand, six products): held to the SAME bounds as 'f32'
 PRECISIONS_SA = PRECISIONS + ['bf16x6']
 MEL_TOL = 1e-3          # dB
 # stage tolerances per precision path: (CNN features / td output, final outputs)
@@ -491,7 +490,7 @@ def test_inner_operator_forward_on_segment_tensors(eng_rand, batch, monkeypatch)
 TTS_CLIPS = [0, 3, 4, 5, 6, 1]            # indices into CLIPS, same set as tests/golden/net_tts_*.npz
 
 
-@pytest.mark.parametrize('precision', PRECISIONS)
+@pytest.mark.parametrize('precision', PRECISIONS_SA)
 @pytest.mark.parametrize('name', ['tts_rand', 'tts_real'])
 def test_tts_architecture_stages_and_fixture(name, precision):
     g = helpers.golden('net_%s.npz' % name)
@@ -721,7 +720,7 @@ def test_config3_bs256_sampled_rows_match_reference_fixture(name, precision):
         assert np.abs(out[r] - ref4[r % 4]).max() < 1e-5
 
 
-@pytest.mark.parametrize('precision', PRECISIONS)
+@pytest.mark.parametrize('precision', PRECISIONS_SA)
 @pytest.mark.parametrize('name', ['tts_real', 'tts_rand'])
 def test_config4_tts_long_clips_match_reference_fixture(name, precision):
     """configs[3] lengths on the nisqa_tts.tar architecture: 30 s (2 987 sequential LSTM steps, NL:925-943), 17.3 s and
