@@ -379,55 +379,62 @@ def _predict(model, ds, bs, dev, num_workers):
         # prefix sum -- a length-sorted list of mixed 3-30 s clips otherwise gives the last rank several times the first
         # one's work.  An unreadable header counts as one segment here; the error itself is raised where the reference
         # raises it, when the file is loaded.
+        # A rank whose probe itself fails (ingest library missing, no filename column ...) still enters both collectives:
+        # the others would otherwise wait in all_reduce for ever (dist.raise_together).
         tok = np.zeros(n, dtype=np.int64)
-        if hi > lo:
-            info = _ingest.probe_headers(ds, range(lo, hi), num_workers)
-            ok = info['status'] == _lib_mod.WAV_OK
-            tok[lo:hi] = np.where(ok, tokens_of(ds, np.where(ok, info['n_frames'], 0), np.where(ok, info['sample_rate'], 48000)), 1)
+        probe_err = None
+        try:
+            if hi > lo:
+                info = _ingest.probe_headers(ds, range(lo, hi), num_workers)
+                ok = info['status'] == _lib_mod.WAV_OK
+                tok[lo:hi] = np.where(ok, tokens_of(ds, np.where(ok, info['n_frames'], 0), np.where(ok, info['sample_rate'], 48000)), 1)
+        except Exception as e:                                      # noqa: BLE001 (re-raised on every rank below)
+            probe_err = e
+            tok[lo:hi] = 0
         tok = _dist.all_reduce_sum_i64(tok)
+        _dist.raise_together(probe_err)
         bounds = _dist.balanced_bounds(tok, world)
         lo, hi = bounds[rank]
-    bs = max(1, int(bs))
-    heads = eng.n_heads
-    y_local = np.zeros((hi - lo, heads), dtype=np.float32)
-    if os.environ.get('NISQA_EXACT_BS') == '1':                     # the reference's batches: index order, exactly bs clips
-        batches = [list(range(s, min(s + bs, hi))) for s in range(lo, hi, bs)]
-    else:
-        batches = batch_policy(eng, ds, range(lo, hi), bs)
-    # host side (ingest.py): a producer thread + num_workers readers stage batches two ahead in page-locked buffers;
-    # device side: ONE stream carries nothing but the H2D copies (a stream that also carries kernels gets its copies done
-    # by a shader blit that competes with them instead of the SDMA engine: copy and kernels of neighbouring batches then
-    # do not overlap at all, tools/probe_overlap.py: 7.5 ms per 256-clip batch against 4.5), two streams take the
-    # kernels of alternate batches behind an event, a staging slot is recycled as soon as ITS copy is done, and the D2H
-    # of batch i's [B, heads] rows is waited for one batch late (no device-wide sync in the loop)
-    # three batches staged ahead (four page-locked slots): the consumer below keeps TWO batches in flight, so the copy of
-    # batch k + 1 is queued a whole batch time before the link needs it, not 0.8 ms before (kernels 3 ms + enqueue 0.5 ms
-    # against a 4.3 ms copy: with one batch in flight any jitter left the link idle, 89 % of its rate over 98 304 rows)
-    ing = _ingest.Ingest(ds, batches, pin=on_gpu, num_workers=num_workers, depth=int(os.environ.get('NISQA_LOOP_DEPTH', '3')),
-                         device=eng.device if on_gpu else None)
-    copy_stream, streams = _loop_streams(eng.device) if on_gpu else (None, [None, None])
-    inflight = []                                                   # (ids, host rows, event behind them)
-    keep_inflight = max(1, int(os.environ.get('NISQA_LOOP_INFLIGHT', '2')))
-    time_copies = on_gpu and os.environ.get('NISQA_LOOP_TIME_COPIES') == '1'     # tools: HIP events around every batch's H2D copies
-    copy_events = []
-
+    loop_err, ing, copy_events = None, None, []
     T = {'queue_wait': 0.0, 'enqueue': 0.0, 'result_wait': 0.0}
-    clock = time.perf_counter
-
-    def drain(keep):
-        # waits on the EVENT behind a batch's rows, never on its stream: hipStreamSynchronize also waits for whatever was
-        # queued on the stream (or on another stream that shares its hardware queue) after that batch, i.e. for the batch
-        # just enqueued -- the loop then runs copy and kernels strictly one after the other (8.2 instead of 4.6 ms per
-        # 256 clips; which it was depended on the order streams were created in)
-        t0 = clock()
-        while len(inflight) > keep:
-            ids, rows, done = inflight.pop(0)
-            if done is not None:
-                done.synchronize()
-            y_local[np.asarray(ids) - lo] = rows.numpy()
-        T['result_wait'] += clock() - t0
-
     try:
+        bs = max(1, int(bs))
+        heads = eng.n_heads
+        y_local = np.zeros((hi - lo, heads), dtype=np.float32)
+        if os.environ.get('NISQA_EXACT_BS') == '1':                     # the reference's batches: index order, exactly bs clips
+            batches = [list(range(s, min(s + bs, hi))) for s in range(lo, hi, bs)]
+        else:
+            batches = batch_policy(eng, ds, range(lo, hi), bs)
+        # host side (ingest.py): a producer thread + num_workers readers stage batches two ahead in page-locked buffers;
+        # device side: ONE stream carries nothing but the H2D copies (a stream that also carries kernels gets its copies done
+        # by a shader blit that competes with them instead of the SDMA engine: copy and kernels of neighbouring batches then
+        # do not overlap at all, tools/probe_overlap.py: 7.5 ms per 256-clip batch against 4.5), two streams take the
+        # kernels of alternate batches behind an event, a staging slot is recycled as soon as ITS copy is done, and the D2H
+        # of batch i's [B, heads] rows is waited for one batch late (no device-wide sync in the loop)
+        # three batches staged ahead (four page-locked slots): the consumer below keeps TWO batches in flight, so the copy of
+        # batch k + 1 is queued a whole batch time before the link needs it, not 0.8 ms before (kernels 3 ms + enqueue 0.5 ms
+        # against a 4.3 ms copy: with one batch in flight any jitter left the link idle, 89 % of its rate over 98 304 rows)
+        ing = _ingest.Ingest(ds, batches, pin=on_gpu, num_workers=num_workers, depth=int(os.environ.get('NISQA_LOOP_DEPTH', '3')),
+                             device=eng.device if on_gpu else None)
+        copy_stream, streams = _loop_streams(eng.device) if on_gpu else (None, [None, None])
+        inflight = []                                                   # (ids, host rows, event behind them)
+        keep_inflight = max(1, int(os.environ.get('NISQA_LOOP_INFLIGHT', '2')))
+        time_copies = on_gpu and os.environ.get('NISQA_LOOP_TIME_COPIES') == '1'     # tools: HIP events around every batch's H2D copies
+        clock = time.perf_counter
+
+        def drain(keep):
+            # waits on the EVENT behind a batch's rows, never on its stream: hipStreamSynchronize also waits for whatever was
+            # queued on the stream (or on another stream that shares its hardware queue) after that batch, i.e. for the batch
+            # just enqueued -- the loop then runs copy and kernels strictly one after the other (8.2 instead of 4.6 ms per
+            # 256 clips; which it was depended on the order streams were created in)
+            t0 = clock()
+            while len(inflight) > keep:
+                ids, rows, done = inflight.pop(0)
+                if done is not None:
+                    done.synchronize()
+                y_local[np.asarray(ids) - lo] = rows.numpy()
+            T['result_wait'] += clock() - t0
+
         t_it = clock()
         for bi, staged in enumerate(ing):
             t_got = clock()
@@ -472,16 +479,23 @@ def _predict(model, ds, bs, dev, num_workers):
             drain(keep=keep_inflight * len(staged.groups))           # results of the batch before the previous one
             t_it = clock()
         drain(keep=0)
+    except Exception as e:                                          # noqa: BLE001
+        # the reference's errors (unreadable file, too short, too many segments: NL:2305-2306, 2259-2263, 2276-2277) are
+        # raised on EVERY rank below, not only on the one whose shard holds the file -- the others would block in the
+        # closing all_gather
+        loop_err = e
     finally:
-        ing.close()
         LOOP_STATS.clear()
         LOOP_STATS.update(T)
-        LOOP_STATS.update({'producer_' + k: v for k, v in ing.stats.items()})
-        LOOP_STATS['readers'] = ing.workers
+        if ing is not None:
+            ing.close()
+            LOOP_STATS.update({'producer_' + k: v for k, v in ing.stats.items()})
+            LOOP_STATS['readers'] = ing.workers
         if copy_events:
             torch.cuda.synchronize()
             LOOP_STATS['copy_busy_s'] = sum(a.elapsed_time(b) for a, b in copy_events) * 1e-3
             LOOP_STATS['copy_span_s'] = copy_events[0][0].elapsed_time(copy_events[-1][1]) * 1e-3
+    _dist.raise_together(loop_err)
     return _dist.gather_rows(y_local, n, lo, hi, dev, bounds)
 
 

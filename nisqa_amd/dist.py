@@ -63,6 +63,46 @@ def all_reduce_sum_i64(a):
     return t.cpu().numpy()
 
 
+_RAISABLE = {'ValueError': ValueError, 'RuntimeError': RuntimeError, 'NotImplementedError': NotImplementedError,
+             'FileNotFoundError': FileNotFoundError, 'OSError': OSError, 'KeyError': KeyError, 'TypeError': TypeError,
+             'MemoryError': MemoryError}
+
+
+def raise_together(err):
+    """Fail together: every rank calls this at the same point with the exception it caught on its shard (or None).
+    One all_reduce(MIN) names the first rank that failed, one broadcast carries its exception (type name + message), and
+    EVERY rank raises it -- the rank that caught it raises the original object.  The reference is one process and fails at
+    once with ValueError('Could not load file ...') / ('Sample too short ...') / ('n_wins ... > max_length ...')
+    (NISQA_lib.py:2305-2306, 2259-2263, 2276-2277); without this exchange the rank that raised would leave _predict while
+    the others block in the closing all_gather until the RCCL watchdog fires.  No-op (plain raise) without a process group."""
+    r, w = world()
+    if w == 1:
+        if err is not None:
+            raise err
+        return
+    import torch.distributed as dist
+    nccl = dist.get_backend() == 'nccl'
+    tdev = torch.device('cuda', torch.cuda.current_device()) if nccl else torch.device('cpu')
+    first = torch.tensor([r if err is not None else w], dtype=torch.int64, device=tdev)
+    dist.all_reduce(first, op=dist.ReduceOp.MIN)
+    first = int(first.item())
+    if first >= w:
+        return
+    payload = b''
+    if r == first:
+        payload = (type(err).__name__ + '\0' + (str(err.args[0]) if len(err.args) == 1 else str(err))).encode('utf-8', 'replace')[:1 << 16]
+    size = torch.tensor([len(payload)], dtype=torch.int64, device=tdev)
+    dist.broadcast(size, first)
+    buf = torch.zeros(int(size.item()), dtype=torch.uint8, device=tdev)
+    if r == first:
+        buf.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
+    dist.broadcast(buf, first)
+    if r == first:
+        raise err
+    name, _, msg = bytes(buf.cpu().numpy().tobytes()).decode('utf-8', 'replace').partition('\0')
+    raise _RAISABLE.get(name, RuntimeError)(msg if name in _RAISABLE else '{}: {}'.format(name, msg))
+
+
 def gather_rows(local, n, lo, hi, dev, bounds=None):
     """All ranks get the full [n, C] array assembled from every rank's [hi-lo, C] rows.  bounds: the [lo, hi) of every
     rank when the shards are not shard_bounds(n, k, world) (work-balanced shards)."""

@@ -745,6 +745,123 @@ def test_predict_loop_shards_by_work_on_a_length_sorted_list(tmp_path, world):
     assert (np.diff(y[:, 0]) != 0).any()
 
 
+_WORKER_FAIL = r"""
+import os, sys, json, time
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+import numpy as np, torch, pandas as pd
+import test_host as T
+from nisqa_amd import NISQA_lib as NL, synth
+rank = int(sys.argv[1]); world = int(sys.argv[2])
+torch.distributed.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=rank, world_size=world)
+files = %(files)r
+ds = NL.SpeechQualityDataset(pd.DataFrame(files, columns=['deg']), data_dir=%(wavs)r, filename_column='deg',
+                             mos_column='predict_only', dim=True, seg_length=15, seg_hop_length=4, ms_hop_length=0.01)
+model = NL.NISQA_DIM(**{k: v for k, v in synth.DIM_ARGS.items() if k.startswith(('cnn_', 'td', 'pool', 'ms_seg_length', 'ms_n_mels'))})
+model._engine = T.FakeEngine(5)
+t0 = time.time()
+res = {'raised': None}
+try:
+    NL.predict_dim(model, ds, 2, 'cpu', 0)
+except Exception as e:
+    res = {'raised': type(e).__name__, 'msg': str(e), 'seconds': time.time() - t0}
+json.dump(res, open(os.path.join(%(out)r, 'r%%d.json' %% rank), 'w'))
+torch.distributed.destroy_process_group()
+"""
+
+
+def _run_ranks(tmp_path, script_text, world, timeout=300):
+    import json
+    script = tmp_path / 'worker.py'
+    script.write_text(script_text)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', OMP_NUM_THREADS='1', MKL_NUM_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world)], env=env) for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=timeout) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return [json.load(open(tmp_path / ('r%d.json' % r))) for r in range(world)]
+
+
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+@pytest.mark.parametrize('bad', ['unreadable', 'too_short', 'too_long'])
+def test_a_bad_file_in_one_ranks_shard_fails_every_rank_with_the_reference_error(tmp_path, bad):
+    """the rank whose shard holds an unreadable / too-short (0.1 s: 11 frames < 15) / too-long (60 s: 1497
+    segments > 1300) clip raises the reference's ValueError (NL:2305-2306, 2259-2263, 2276-2277); the other rank used to
+    block in the closing all_gather.  Now both ranks raise, within seconds, with the message one process gives."""
+    d = tmp_path / 'w'
+    d.mkdir()
+    names = _mixed_wavs(d, [0.4] * 6)
+    if bad == 'unreadable':
+        (d / 'bad.wav').write_bytes(b'not a wav file at all')
+        match = 'Could not load file'
+    elif bad == 'too_short':
+        synth.write_wav(str(d / 'bad.wav'), synth.synth_pcm16(1, 0.1), 48000)
+        match = 'Sample too short'
+    else:
+        synth.write_wav(str(d / 'bad.wav'), np.zeros(60 * 48000, np.int16), 48000)
+        match = 'Increase max window length'
+    names = names + ['bad.wav']                           # last item: rank 1's shard under any split
+    res = _run_ranks(tmp_path, _WORKER_FAIL % {'root': ROOT, 'port': _free_port(), 'wavs': str(d), 'out': str(tmp_path),
+                                               'files': names}, 2, timeout=120)
+    from nisqa_amd import NISQA_lib as NL
+    ds = NL.SpeechQualityDataset(pd.DataFrame(names, columns=['deg']), data_dir=str(d), filename_column='deg',
+                                 mos_column='predict_only', dim=True, seg_length=15, seg_hop_length=4, ms_hop_length=0.01)
+    model = NL.NISQA_DIM(**{k: v for k, v in synth.DIM_ARGS.items()
+                            if k.startswith(('cnn_', 'td', 'pool', 'ms_seg_length', 'ms_n_mels'))})
+    model._engine = FakeEngine(5)
+    with pytest.raises(ValueError, match=match) as one:
+        NL.predict_dim(model, ds, 2, 'cpu', 0)
+    for r in res:
+        assert r['raised'] == 'ValueError' and r['msg'] == str(one.value) and 'bad.wav' in r['msg'], r
+        assert r['seconds'] < 30
+
+
+def test_raise_together_is_a_plain_raise_without_a_process_group():
+    from nisqa_amd import dist
+    dist.raise_together(None)
+    with pytest.raises(ValueError, match='x'):
+        dist.raise_together(ValueError('x'))
+
+
+def test_predict_loop_at_world_eight_matches_one_process(tmp_path):
+    """The real loop (header probe, work-balanced contiguous shards, length-aware batches, fail-together exchange, closing
+    all_gather) on eight gloo ranks with a counting engine: a length-sorted list of 0.2 ... 2.4 s clips, every rank ends with
+    the full frame in input order, equal to a one-process run; segment counts per rank within 25 % of the mean (96 clips
+    over 8 ranks: the granularity of a clip is 2-3 % of a rank's share)."""
+    d = tmp_path / 'w'
+    d.mkdir()
+    durs = np.sort(np.concatenate((np.random.default_rng(5).uniform(0.2, 2.4, 94), [0.2, 2.4])))
+    names = _mixed_wavs(d, durs.tolist())
+    res = _run_ranks(tmp_path, _WORKER_BAL % {'root': ROOT, 'port': _free_port(), 'wavs': str(d), 'out': str(tmp_path),
+                                              'files': names}, 8, timeout=600)
+    assert all(r['y'] == res[0]['y'] for r in res)
+    tok = np.array([r['tokens'] for r in res], dtype=np.float64)
+    assert np.abs(tok / tok.mean() - 1).max() < 0.25, tok
+    from nisqa_amd import NISQA_lib as NL
+    ds = NL.SpeechQualityDataset(pd.DataFrame(names, columns=['deg']), data_dir=str(d), filename_column='deg',
+                                 mos_column='predict_only', dim=True, seg_length=15, seg_hop_length=4, ms_hop_length=0.01)
+    model = NL.NISQA_DIM(**{k: v for k, v in synth.DIM_ARGS.items()
+                            if k.startswith(('cnn_', 'td', 'pool', 'ms_seg_length', 'ms_n_mels'))})
+    seen = []
+
+    class Eng(FakeEngine):
+        def forward_pcm(self, pcm, plan, sr):
+            seen.append(int(np.sum(plan.n_wins)))
+            return super().forward_pcm(pcm, plan, sr)
+    model._engine = Eng(5)
+    y, _ = NL.predict_dim(model, ds, 2, 'cpu', 0)
+    np.testing.assert_allclose(np.array(res[0]['y']), y, rtol=0, atol=1e-6)
+    assert int(tok.sum()) == sum(seen)
+
+
 def test_byte_cap_charges_what_staging_lays_out_for_mixed_sample_widths():
     """one stereo / 24-bit / float file widens its whole sample-rate group to float32 in Ingest._stage; the
     batch policy charges the byte cap with exactly that (LengthAware.staged_bytes) and sorts int16 clips before float ones
