@@ -75,8 +75,18 @@ def _salvage_pickle_module():
                 got = getattr(torch, name)
             return _Inert if got is None else got
 
+    # EVERY pickle stream goes through the allow-listing find_class: torch's legacy (non-zip) reader pulls the magic number,
+    # the protocol version and sys_info through pickle_module.load, which with the stock pickle.load is the unrestricted
+    # unpickler (a file whose first pickle is a __reduce__ ran its callable here)
+    def load(f, **kw):
+        return Unpickler(f, **kw).load()
+
+    def loads(b, **kw):
+        import io
+        return Unpickler(io.BytesIO(b), **kw).load()
+
     mod = types.ModuleType('nisqa_salvage_pickle')
-    mod.Unpickler, mod.load, mod.loads = Unpickler, pickle.load, pickle.loads
+    mod.Unpickler, mod.load, mod.loads = Unpickler, load, loads
     mod.__name__ = 'pickle'                       # torch.load consults the module's name in one branch
     return mod
 

@@ -1220,6 +1220,34 @@ def test_checkpoint_with_pickled_objects_is_refused_unless_opted_in(tmp_path, mo
     assert 'args' in ck and 'code ran at load time' in capsys.readouterr().out
 
 
+def test_legacy_format_checkpoint_cannot_run_code_through_the_salvage_pass(tmp_path, monkeypatch):
+    """torch's legacy (non-zip) reader reads the magic number / protocol / sys_info with
+    pickle_module.load; the salvage module used to hand it the stock pickle.load, so a file whose FIRST pickle is a
+    __reduce__ ran its callable although weights_only=True had refused it.  Every stream now goes through the allow-list."""
+    import pickle
+    from nisqa_amd.NISQA_model import _load_checkpoint
+    trap = tmp_path / 'ran.txt'
+
+    class Boom(object):
+        def __reduce__(self):
+            return (open, (str(trap), 'w'))
+    evil = tmp_path / 'legacy.tar'
+    with open(evil, 'wb') as f:
+        pickle.dump(Boom(), f, protocol=2)                       # where the legacy reader expects the magic number
+        pickle.dump(1001, f, protocol=2)
+        pickle.dump({}, f, protocol=2)
+    # a genuine legacy-format checkpoint with an object in it: refused by weights_only, salvaged through the allow-list
+    legacy = tmp_path / 'legacy_ok.tar'
+    torch.save({'args': {'a': 1}, 'model_state_dict': {'w': torch.arange(4.)}, 'trap': Boom()}, legacy,
+               _use_new_zipfile_serialization=False)
+    monkeypatch.delenv('NISQA_ALLOW_UNSAFE_CHECKPOINT', raising=False)
+    with pytest.raises(Exception):
+        _load_checkpoint(str(evil))
+    assert not trap.exists()
+    ck = _load_checkpoint(str(legacy))
+    assert not trap.exists() and ck['args'] == {'a': 1} and torch.equal(ck['model_state_dict']['w'], torch.arange(4.))
+
+
 def test_checkpoint_written_by_the_reference_trainer_is_salvaged_without_running_it(tmp_path, monkeypatch, capsys):
     """the reference's trainer saves db_results DataFrames and numpy scalars next to the tensors (reference
     NISQA_model.py:1096-1108); the restricted unpickler rejects such a file.  It is loaded through the salvage unpickler:
