@@ -78,6 +78,30 @@ FLOP_NET_CLIP = (51.2 + 382.4 + 546.3 + 1092.6 + 327.8 + 109.3 + 12.1 + 55.5 + 2
 PEAK_PCIE = 63.0                                             # GB/s host -> device, PCIe Gen5 x16
 
 
+# what `dtype` says for each precision mode of the engine (arithmetic of EVERY GEMM of the path: AdaptCNN / StandardCNN, the 384 -> 64
+# projection, self-attention, pooling; the mel front end is fp32 VALU in all of them)
+DTYPE_TEXT = {
+    'f32': 'f32 (every GEMM on v_mfma_f32_32x32x2_f32, fp32 operands and accumulation: the reference\'s own arithmetic; mel f32)',
+    'bf16x6': 'bf16x6 (every GEMM -- CNN, projection, self-attention, pooling: fp32 operands as three exact bf16 terms, 6 MFMA products per '
+              'term pair, f32 accumulate: all 24 operand mantissa bits; mel f32)',
+    'bf16x3': 'bf16x3 (every GEMM -- CNN, projection, self-attention, pooling: fp32 operands as bf16 hi + lo, 3 MFMA products per term pair, '
+              'f32 accumulate: 16 of the 24 operand mantissa bits, NARROWER than the reference; mel f32)',
+    'f16x4': 'f16x4 (AdaptCNN: fp32 operands as f16 hi + lo of the power-of-two-scaled tensors -- 11 + 11 bits and the low term\'s sign: the fp32 '
+             'value for ~75 % of the operands, one fp32 ulp off otherwise -- all 4 MFMA products per term pair, f32 accumulate; projection, '
+             'self-attention, pooling as bf16x6; mel f32)',
+    'f16x3': 'f16x3 (AdaptCNN: fp32 operands as f16 hi + lo of the power-of-two-scaled tensors, 3 MFMA products per term pair (lo*lo dropped: <= 2^-22 '
+             'of a product), f32 accumulate; projection, self-attention, pooling as bf16x6; mel f32)',
+}
+ALL_PRECISIONS = ('f32', 'bf16x6', 'f16x4', 'f16x3', 'bf16x3')
+CNN_KERNEL = {'f32': 'cnn_front_kernel', 'bf16x3': 'cnn_front_bf16_kernel', 'bf16x6': 'cnn_front_bf16x6_kernel', 'f16x4': 'cnn_front_f16_kernel',
+              'f16x3': 'cnn_front_f16_kernel'}
+
+
+def default_precision():
+    from nisqa_amd.engine import DEFAULT_PRECISION
+    return os.environ.get('NISQA_HIP_PRECISION') or DEFAULT_PRECISION
+
+
 def find_weights(name='nisqa.tar'):
     for d in (os.environ.get('NISQA_WEIGHTS_DIR', ''), os.path.join(ROOT, 'oracle', '_ref', 'weights')):
         p = os.path.join(d, name) if d else ''
@@ -310,8 +334,7 @@ def bench_predict_csv(a):
             'metric': 'clips/sec (10 s, 48 kHz)', 'value': round(a.clips / dt, 2), 'unit': 'clips/s', 'n_gpus': world,
             'steps': steps, 'warmup': max(1, a.warmup), 'ms_per_step': round(1e3 * dt / steps, 4), 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None,
-            'dtype': {'f32': 'f32', 'bf16x6': 'bf16x6 (every GEMM: fp32 operands as three exact bf16 terms, 6 MFMA products per term pair; mel f32)'}.get(
-                os.environ.get('NISQA_HIP_PRECISION', 'bf16x3'), 'bf16x3 (bf16 hi+lo operands, 3 MFMA products per term, f32 accumulate; mel/attention/pooling f32)'),
+            'dtype': DTYPE_TEXT[default_precision()],
             'data': 'synthetic 48 kHz / 10 s PCM16 WAV files on local disk (%d distinct, reused cyclically), %s' % (a.distinct, wdesc),
             'config': {'workload': 'predict_csv nisqa.tar bs=%d per GPU, %d synthetic 10 s 48 kHz clips, clip-sharded over '
                                    '%d rank(s); WAV files -> native ingest -> H2D -> kernels -> all_gather (PCIe-inclusive)'
@@ -402,7 +425,7 @@ def side_tts(dev, reps, cpu_baseline_on, pmc, two_streams=True):
     from nisqa_amd.engine import HipNisqa
     from nisqa_amd import NISQA_lib as NL, ingest as _ing
     targs, tsd, wdesc = tts_weights()
-    eng = HipNisqa(targs, tsd, dev, precision=os.environ.get('NISQA_HIP_PRECISION', 'bf16x3'))
+    eng = HipNisqa(targs, tsd, dev, precision=default_precision())
     n_clips = 256
     durs = np.random.default_rng(7).uniform(3, 30, n_clips)
     base = synth.synth_pcm16(5, 30.0)
@@ -452,7 +475,11 @@ def side_tts(dev, reps, cpu_baseline_on, pmc, two_streams=True):
                    for bi in range(nb)])                     # [batch][mel, cnn, (unused), lstm + pool]
     cnn_ms, lstm_ms = float(ms[:, 1].sum()), float(ms[:, 3].sum())
     ach = float(segs.sum()) * FLOP_STD_SEG / (cnn_ms * 1e-3) / 1e12
-    tr, mu = pmc_derived(pmc.get('tts:cnn_std_bf16_kernel'))
+    kname = {'bf16x3': 'cnn_std_bf16_kernel', 'bf16x6': 'cnn_std_bf16x6_kernel'}.get(eng.precision, 'cnn_std_kernel')
+    kdesc = {'bf16x3': 'split-bf16 MFMA: 3 products per term pair', 'bf16x6': 'three exact bf16 terms per fp32 operand: 6 MFMA products per term pair',
+             'f32': 'fp32 MFMA'}[eng.precision]
+    kpeak = PEAK_F32 if eng.precision == 'f32' else PEAK_BF16_MFMA
+    tr, mu = pmc_derived(pmc.get('tts:' + kname))
     res = {'config': 'configs[3] predict_dir nisqa_tts.tar (Naturalness head), %d clips, durations rng(7).uniform(3, 30) s '
                      '(%.0f s of audio, %d segments at hop 1), int16 PCM resident in HBM, %d length-sorted batches of %s clips '
                      '(NISQA_lib.batch_policy), one stream; weights: %s'
@@ -460,18 +487,20 @@ def side_tts(dev, reps, cpu_baseline_on, pmc, two_streams=True):
            'value': round(n_clips / dt, 1), 'unit': 'clips/s', 'audio_seconds_per_s': round(float(durs.sum()) / dt, 1),
            'ms_per_job': round(dt * 1e3, 3), 'value_2_streams': round(n_clips / dt2, 1) if dt2 else None,
            'stage_ms': {'mel': round(float(ms[:, 0].sum()), 4), 'cnn_std': round(cnn_ms, 4), 'lstm_pool': round(lstm_ms, 4)},
-           'roofline': {'kernel': 'cnn_std_bf16_kernel (StandardCNN conv1-6 + fc, split-bf16 MFMA: 3 products per term)',
-                        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_BF16_MFMA, 'unit': 'TFLOP/s',
-                        'frac': round(ach / PEAK_BF16_MFMA, 4), 'flop_per_job': float(segs.sum()) * FLOP_STD_SEG,
+           'precision': eng.precision, 'dtype': DTYPE_TEXT[eng.precision] + '; BiLSTM and last-step pooling fp32 VALU',
+           'roofline': {'kernel': '%s (StandardCNN conv1-6 + fc, %s)' % (kname, kdesc),
+                        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': kpeak, 'unit': 'TFLOP/s',
+                        'frac': round(ach / kpeak, 4), 'flop_per_job': float(segs.sum()) * FLOP_STD_SEG,
                         'avg_launch_ms': round(cnn_ms / nb, 4), 'launches_per_job': nb, 'traffic': tr, 'mfma_util': mu},
            'lstm': {'kernel': 'lstm_dir_kernel + pool_last_kernel: one 512-thread workgroup per (clip, direction), sequential in time',
                     'bound': 'latency', 'us_per_step': round(1e3 * lstm_ms / float(steps.sum()), 4),
                     'steps_per_job': int(steps.sum()), 'workgroups_per_launch': [2 * p.n_clips for p, _ in batches],
                     'achieved_tflops': round(float(segs.sum()) * FLOP_LSTM_SEG / (lstm_ms * 1e-3) / 1e12, 3)}}
-    if two_streams and eng.precision == 'bf16x3':
-        # the same job on the exact-fp32 kernels (the reference's arithmetic) and on 'bf16x6' (fp32 operands as three exact bf16
-        # terms, six products: held to the bounds of 'f32' by the parity tests); the BiLSTM is fp32 VALU in every mode
-        for prec in ('f32', 'bf16x6'):
+    if two_streams:
+        # the same job in the other precision modes: the exact-fp32 kernels (the reference's arithmetic), 'bf16x6' (fp32 operands as
+        # three exact bf16 terms, six products: held to the bounds of 'f32' by the parity tests), 'bf16x3' (two terms: the fast mode);
+        # the BiLSTM is fp32 VALU in every mode
+        for prec in [q for q in ('f32', 'bf16x6', 'bf16x3') if q != eng.precision]:
             e2 = HipNisqa(targs, tsd, dev, precision=prec)
             for plan, x in batches:
                 o2 = e2.forward_pcm(x, plan, SR)
@@ -590,7 +619,7 @@ def main():
     ap.add_argument('--steps', type=int, default=400)
     ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--precision', default=None, choices=['bf16x3', 'f32', 'bf16x6'])
+    ap.add_argument('--precision', default=None, choices=list(ALL_PRECISIONS))
     ap.add_argument('--no-extras', action='store_true', help='skip the alt-precision and 3-stream passes (profiling runs)')
     ap.add_argument('--streams', type=int, default=1, help='HIP streams the steps alternate over')
     ap.add_argument('--workload', default='predict_dir', choices=['predict_dir', 'predict_csv'])
@@ -689,6 +718,10 @@ def main():
             elif prec == 'bf16x6':
                 flop, peak, kname, kern = (FLOP_CONV1_4 + FLOP_CONV5_6) * BATCH, PEAK_BF16_MFMA, 'cnn_front_bf16x6_kernel', \
                     'cnn_front_bf16x6_kernel (AdaptCNN conv1-6 + pools, three exact bf16 terms per fp32 operand: 6 MFMA products per term pair)'
+            elif prec in ('f16x4', 'f16x3'):
+                flop, peak, kname, kern = (FLOP_CONV1_4 + FLOP_CONV5_6) * BATCH, PEAK_BF16_MFMA, 'cnn_front_f16_kernel<%s>' % prec, \
+                    'cnn_front_f16_kernel (AdaptCNN conv1-6 + pools, two f16 terms per fp32 operand of the scaled tensors: %s MFMA products per term pair; ' \
+                    'the f16 matrix peak is the bf16 one)' % prec[-1]
             else:
                 flop, peak, kname, kern = FLOP_CONV1_4 * BATCH, PEAK_F32, 'cnn_front_kernel', 'cnn_front_kernel (conv1-4 + pools, fp32 MFMA)'
             ach = flop / (ms_front * 1e-3) / 1e12
@@ -696,17 +729,17 @@ def main():
             r = {'kernel': kern, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                  'frac': round(ach / peak, 4), 'traffic': tr, 'traffic_unit': 'HBM bytes/launch (rocprofv3 PMC of this build: %s)' % pmc_file,
                  'mfma_util': mu, 'flop_per_launch': flop, 'avg_launch_ms': round(ms_front, 4)}
-            if prec == 'bf16x6':     # fp32-grade results: also against the fp32 matrix peak the exact-fp32 kernels are priced on
+            if prec in ('bf16x6', 'f16x4', 'f16x3'):     # fp32-grade results: also against the fp32 matrix peak the exact-fp32 kernels are priced on
                 r['achieved_vs_fp32_mfma_peak'] = round(ach / PEAK_F32, 4)
             return r
 
         clips = BATCH * a.steps * world
         roof = roofline_of(eng.precision, stage_ms['cnn_front'])
         roof['whole_path_tflops'] = round(FLOP_TOTAL * clips / dt / 1e12 / world, 2)
-        k = pmc.get({'bf16x3': 'cnn_front_bf16_kernel', 'bf16x6': 'cnn_front_bf16x6_kernel'}.get(eng.precision, 'cnn_front_kernel')) or {}
+        k = pmc.get(CNN_KERNEL[eng.precision]) or {}
         if k.get('GRBM_GUI_ACTIVE') and k.get('_ms'):
             roof['shader_clock_mhz_profiled'] = round(k['GRBM_GUI_ACTIVE'] / 8.0 / (k['_ms'] * 1e-3) / 1e6, 0)
-        if world == 1 and not a.no_extras and eng.precision == 'bf16x3':
+        if world == 1 and not a.no_extras and eng.precision != 'f32':
             sus = sus or mfma_sustained(dev)
             roof['peak_sustained'] = {'what': 'dense v_mfma_f32_32x32x16_bf16 on register operands, measured on this GPU just now: '
                                               'zero operands reach the data-sheet peak, random operands are power-limited',
@@ -715,9 +748,10 @@ def main():
         mel_ach = mel_flop / (stage_ms['mel'] * 1e-3) / 1e12
         mtr, _ = pmc_derived(pmc.get('mel_frame_kernel'))
         kern_tab = {}
-        for stage, ks in (('mel', ['mel_frame_kernel']), ('cnn', ['cnn_front_bf16_kernel'] if eng.precision == 'bf16x3' else ['cnn_front_bf16x6_kernel'] if eng.precision == 'bf16x6' else ['cnn_front_kernel', 'cnn_back_kernel']),
-                          ('selfatt', ['td_fused_bf16_kernel', 'td_proj_bf16_kernel', 'td_layer_bf16_kernel'] if eng.precision == 'bf16x3' else ['td_proj_bf16x6_kernel', 'td_layer_bf16x6_kernel'] if eng.precision == 'bf16x6' else ['td_proj_kernel', 'td_layer_kernel']),
-                          ('pool', ['pool_score_bf16_kernel', 'pool_final_kernel'] if eng.precision == 'bf16x3' else ['pool_score_bf16x6_kernel', 'pool_final_kernel'] if eng.precision == 'bf16x6' else ['pool_score_kernel', 'pool_final_kernel'])):
+        tdp = eng.td_precision
+        for stage, ks in (('mel', ['mel_frame_kernel']), ('cnn', ['cnn_front_kernel', 'cnn_back_kernel'] if eng.precision == 'f32' else [CNN_KERNEL[eng.precision]]),
+                          ('selfatt', ['td_fused_bf16_kernel', 'td_proj_bf16_kernel', 'td_layer_bf16_kernel'] if tdp == 'bf16x3' else ['td_proj_bf16x6_kernel', 'td_layer_bf16x6_kernel'] if tdp == 'bf16x6' else ['td_proj_kernel', 'td_layer_kernel']),
+                          ('pool', ['pool_score_bf16_kernel', 'pool_final_kernel'] if tdp == 'bf16x3' else ['pool_score_bf16x6_kernel', 'pool_final_kernel'] if tdp == 'bf16x6' else ['pool_score_kernel', 'pool_final_kernel'])):
             for kn in ks:
                 if kn in pmc:
                     tr, mu = pmc_derived(pmc[kn])
@@ -726,9 +760,7 @@ def main():
             'metric': 'clips/sec (10 s, 48 kHz)', 'value': round(clips / dt, 2), 'unit': 'clips/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': {'bf16x3': 'bf16x3 (bf16 hi+lo operands, 3 MFMA products per term, f32 accumulate; mel/attention/pooling f32)',
-                      'bf16x6': 'bf16x6 (every GEMM: fp32 operands as three exact bf16 terms, 6 MFMA products per term pair, f32 accumulate; '
-                                'mel f32)'}.get(eng.precision, 'f32'),
+            'dtype': DTYPE_TEXT[eng.precision],
             'data': 'synthetic 48 kHz / 10 s PCM16 clips (SURVEY 8d generator); ' + wdesc,
             'config': {'workload': 'predict_dir nisqa.tar (NISQA_DIM CNN-SA-AP) bs=64 per GPU, 10 s synthetic 48 kHz '
                                    'clips, int16 PCM resident in HBM' + ('' if BATCH == 64 else ' [EXPERIMENT: bs=%d]' % BATCH), 'batch_clips_per_gpu': BATCH, 'streams': len(streams),
@@ -753,7 +785,7 @@ def main():
             # (and 'bf16x6': every GEMM at fp32 operand precision on the bf16 matrix pipe -- three exact bf16 terms per operand, six
             # products: the accuracy of 'f32', tests/test_gpu_parity.py)
             alt_out = {}
-            for other in (['f32', 'bf16x6'] if eng.precision == 'bf16x3' else ['bf16x3']):
+            for other in [q for q in ALL_PRECISIONS if q != eng.precision]:
                 eng2 = HipNisqa(margs, sd, dev, precision=other)
                 for _ in range(max(2, a.warmup)):
                     o2 = eng2.forward_pcm(pcm, plan, SR)
@@ -773,7 +805,9 @@ def main():
                               'stage_ms': {k: round(v, 4) for k, v in st2.items()}, 'roofline': r2,
                               'max_abs_diff_vs_primary': float((o2 - outs[-1]).abs().max())}
                 alt_out[other] = o2
-                if other == 'bf16x6' and 'f32' in alt_out:
+                if other == 'f32':           # how far every path is from the exact-fp32 kernels on this batch
+                    res['max_abs_diff_vs_f32'] = res[other]['max_abs_diff_vs_primary']
+                elif 'f32' in alt_out:
                     res[other]['max_abs_diff_vs_f32'] = float((o2 - alt_out['f32']).abs().max())
                 if other == 'f32':
                     trb, mub = pmc_derived(pmc.get('cnn_back_kernel'))

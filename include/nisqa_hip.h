@@ -137,6 +137,19 @@ int nisqa_cnn_adapt_bf16x6(const float* mel_tm, const int32_t* frame_off, const 
 int nisqa_cnn_adapt_segments_bf16x6(const float* x, int32_t seg_len_padded, const int32_t* tok_off,
                                     const int32_t* n_wins, int32_t n_clips, int32_t total_tok_padded,
                                     const float* cnn_w, const uint16_t* cnn_wx, float* feat, void* stream);
+/* nisqa_cnn_adapt on the f16 matrix pipe: every fp32 operand as TWO f16 terms of the power-of-two-scaled tensor (11 + 11
+ * significand bits and the low term's sign: the fp32 value itself for ~75 % of the values, one fp32 ulp off otherwise; the
+ * scale of every activation tensor follows the measured maximum of the layer's input, so no finite input leaves f16's range),
+ * products = 4: hi*hi + hi*lo + lo*hi + lo*lo ('f16x4'), products = 3: without lo*lo ('f16x3').  Measured against float64
+ * both are as close as the exact-fp32 kernels (fewer accumulator roundings; tools/micro/f16probe.hip).
+ * cnn_wh: nisqa_amd.weights.pack_adapt_cnn_f16 (CNNH_U16S uint16, csrc/layout.hpp: fragments of W * 2^kw + per-layer constants).
+ * Replaces the same reference lines as nisqa_cnn_adapt (NISQA_lib.py:2239-2282, 487-502, 688-710). */
+int nisqa_cnn_adapt_f16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off, const int32_t* n_wins,
+                        const float* clip_floor, int32_t n_clips, int32_t total_tok_padded, int32_t seg_hop,
+                        const float* cnn_w, const uint16_t* cnn_wh, int32_t products, float* feat, void* stream);
+int nisqa_cnn_adapt_segments_f16(const float* x, int32_t seg_len_padded, const int32_t* tok_off, const int32_t* n_wins,
+                                 int32_t n_clips, int32_t total_tok_padded, const float* cnn_w, const uint16_t* cnn_wh,
+                                 int32_t products, float* feat, void* stream);
 /* Segment-tensor input mode: the reference's inner operator model.forward(x, n_wins)
  * (NISQA_lib.py:137-142, 260-268) hands over x[B][L][1][48][15] (zero-padded to L segments per clip).
  * Same outputs as nisqa_cnn_adapt; no dB floor is applied (x is already clamped). */
@@ -243,7 +256,9 @@ typedef struct {
                               * 2 = every GEMM on three-term bf16 (arch 0: nisqa_cnn_adapt_bf16x6, nisqa_td_selfatt_bf16x6,
                               * nisqa_pool_att_bf16x6; cnn_wb / td_wb / pool_wb = their three-term fragments; td_wb or
                               * pool_wb NULL: self-attention and pooling on the exact fp32 kernels; arch 1: nisqa_cnn_standard_bf16x6, the
-                              * BiLSTM is fp32 in every mode) */
+                              * BiLSTM is fp32 in every mode),
+                              * 3 / 4 = arch 0 only: AdaptCNN on two-term f16 operands with 3 / 4 products (nisqa_cnn_adapt_f16, cnn_wb =
+                              * its CNNH blob); self-attention and pooling as in mode 2 (td_wb / pool_wb = three-term fragments) */
     const uint16_t* td_wb;   /* split-bf16 self-attention fragments, or NULL */
     const uint16_t* pool_wb; /* split-bf16 pooling fragments, or NULL */
     int32_t arch;            /* 0 = CNN-SA-AP (nisqa.tar, nisqa_mos_only.tar); 1 = StandardCNN + BiLSTM + last-step

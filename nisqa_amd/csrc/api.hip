@@ -60,7 +60,8 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
                                   mel, cmax, stream);
     if (rc) return rc;
     // the split-bf16 AdaptCNN kernel derives the top_db floor from cmax itself; the other CNN kernels take clip_floor
-    const bool floor_in_cnn = model->arch == 0 && (model->cnn_mode == 1 || model->cnn_mode == 2);
+    if (model->cnn_mode < 0 || model->cnn_mode > 4 || (model->arch == 1 && model->cnn_mode > 2)) return NISQA_ERR_ARG;
+    const bool floor_in_cnn = model->arch == 0 && model->cnn_mode >= 1;
     if (!floor_in_cnn) {
         rc = nisqa_mel_finalize(mel, frame_off, n_clips, total_frames, cmax, cfg->top_db, cfloor, 0, stream);
         if (rc) return rc;
@@ -97,6 +98,12 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
                                           model->seg_hop, model->cnn_w, model->cnn_wb, feat, stream);
         if (rc) return rc;
         NQ_STAGE(2);
+    } else if (model->cnn_mode == 3 || model->cnn_mode == 4) {
+        // AdaptCNN on two-term f16 operands of the scaled tensors, three / four products (cnn_wb = the CNNH blob)
+        rc = nq_cnn_adapt_f16_from_max(mel, frame_off, tok_off, n_wins, cmax, cfg->top_db, n_clips, total_tok_padded,
+                                       model->seg_hop, model->cnn_w, model->cnn_wb, model->cnn_mode, feat, stream);
+        if (rc) return rc;
+        NQ_STAGE(2);
     } else {
         rc = nisqa_cnn_front(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded, model->seg_hop,
                              model->cnn_w, p3, stream);
@@ -107,7 +114,7 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
     }
     NQ_STAGE(3);
     const bool bf = model->cnn_mode == 1 && model->td_wb && model->pool_wb;
-    const bool x6 = model->cnn_mode == 2 && model->td_wb && model->pool_wb;      // three-term fragments in td_wb / pool_wb
+    const bool x6 = model->cnn_mode >= 2 && model->td_wb && model->pool_wb;      // three-term fragments in td_wb / pool_wb
     rc = bf ? nisqa_td_selfatt_bf16(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w,
                                     model->td_wb, td, x, stream)
          : x6 ? nisqa_td_selfatt_bf16x6(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w,

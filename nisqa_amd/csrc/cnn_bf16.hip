@@ -26,6 +26,7 @@
 #include "common.hpp"
 #include "layout.hpp"
 #include <stdlib.h>
+#include <atomic>
 #include "conv_bf16.hpp"
 #include "internal.hpp"
 #include "../../include/nisqa_hip.h"
@@ -97,10 +98,24 @@ extern "C" int nisqa_debug_phase_clock(unsigned long long* out16, int reset) {
 #define NQ_CLK(i)
 #endif
 
+// the per-row scale tables of the f16 formats' conv5 / conv6 epilogues (the LDS below the zero block is otherwise unused)
+#define FB_TAB5 0u                         /* [72 rows] {2^(e5 - e4 - kw5), 2^e5} of the row's segment */
+#define FB_TAB6 1024u                      /* [24 rows] 2^-(e5 + kw6) */
+NQ_DEV f32x2_t lds_ld64(unsigned a) { return *(NQ_AS3 const f32x2_t*)(a); }
+// bias + ReLU of an epilogue value; the f16 formats fold the power-of-two scales in: relu(v * c + t) with c = 2^(e_out - e_in - kw),
+// t = shift * 2^e_out -- exact scalings, so the result is 2^e_out times what the unscaled arithmetic rounds to
+template <int FMT>
+NQ_DEV float epi_fmt(float v, float c, float t) { return FMT == NQ_FMT_BF16X3 ? fmaxf(v + t, 0.f) : fmaxf(fmaf(v, c, t), 0.f); }
+
+// FMT: operand format (conv_bf16.hpp): bf16 hi + lo / three products, or f16 hi + lo of the power-of-two-scaled tensors with three or
+//      all four products.  For the f16 formats wb is the CNNH_ blob (fragments of W * 2^kw + per-layer constants) and every activation
+//      tensor is stored as y * 2^e with e = 15 - ceil(log2(m_in * G + T)): m_in the MEASURED maximum of the layer's input for this
+//      segment, G = max_c sum |W_c| and T = max |shift| of the layer -- |y| <= m_in * G + T, so the scaled tensor stays below 2^15 for
+//      any finite input and any weights (no calibration, no clamping), 5-6 bits below it for the shipped weights.
 // SEGX: the input is the reference's segment tensor x[B][L][1][48][15] (inner-operator mode) instead of the spectrogram
 // P3: also write the pooled conv4 output as fp32 (debug / parity callers of nisqa_cnn_adapt_bf16 that pass p3_opt)
-template <bool SEGX, bool P3>
-__global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
+template <int FMT, bool SEGX, bool P3>
+NQ_DEV void cnn_front_split_body(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
     const float* __restrict__ clip_floor, int n_clips, int seg_hop,
@@ -108,6 +123,12 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
     float* __restrict__ feat, const float* __restrict__ seg_x, int seg_L,
     const uint32_t* __restrict__ clip_max_enc, float top_db) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool F16 = FMT != NQ_FMT_BF16X3;
+    static_assert(!(F16 && P3), "the fp32 copy of the pooled conv4 tensor is a bf16x3 debug output");
+    // F16: per-layer constants behind the fragments (layout.hpp CNNH_META): kw[l], G[l], T[l] for l = 1..6 at index l - 1
+    const int* __restrict__ meta_i = (const int*)(wb + CNNH_META);
+    const float* __restrict__ meta_f = (const float*)(wb + CNNH_META);
+    float dummy_mx = 0.f;
 #ifdef NQ_PHASE_CLOCK
     const long long clk_top = clock64(), wall_top = wall_clock64();
     long long clk[13];
@@ -153,6 +174,21 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
     const float tn3[2] = {cw[CNN_T3 + (lane & 31)], cw[CNN_T3 + 32 + (lane & 31)]};
     const float tn4[2] = {cw[CNN_T4 + (lane & 31)], cw[CNN_T4 + 32 + (lane & 31)]};
     const float tn5 = cw[CNN_T5 + 16 * wave + (lane & 15)], tn6 = cw[CNN_T6 + 16 * wave + (lane & 15)];
+    // the window's values (floored at the clip's top_db level); F16: scaled by 2^e0, e0 from the window's own largest magnitude
+    float vin[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) vin[q] = !valid ? 0.f : SEGX ? vraw[q] : fmaxf(vraw[q], fl);
+    int e_in = 0;                                        // scale exponent of the tensor the next layer reads (F16)
+    float m_in = 0.f;                                    // its largest magnitude, unscaled
+    float s0 = 1.f;
+    if (F16) {
+        float mr = 0.f;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) mr = fmaxf(mr, __builtin_fabsf(vin[q]));
+        m_in = wave_max_nonneg(mr);
+        e_in = f16_scale_exp(m_in);
+        s0 = pow2_f32(e_in);
+    }
     {
         const unsigned pb = R + FB_PATCH;
         // zero the patch planes (213 x 16 bytes) and the shared zero block (every wave writes the same zeros)
@@ -175,23 +211,16 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
             }
 #pragma unroll
             for (int q = 0; q < 12; q += 2) {
-                const float v0 = valid ? fmaxf(vraw[q], fl) : 0.f, v1 = valid ? fmaxf(vraw[q + 1], fl) : 0.f;
-                lds_store_split2<false>(ob[q % 3] + (q + q / 3) * 100, ob[(q + 1) % 3] + (q + 1 + (q + 1) / 3) * 100, FB_PPLANE, v0, v1,
-                                 true, q + 1 < 11 || lane < 16);
+                const float v0 = vin[q] * s0, v1 = vin[q + 1] * s0;
+                lds_store_pair_fmt<FMT, false>(ob[q % 3] + (q + q / 3) * 100, ob[(q + 1) % 3] + (q + 1 + (q + 1) / 3) * 100, FB_PPLANE, v0, v1,
+                                               dummy_mx, true, q + 1 < 11 || lane < 16);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < 12; ++q) {
                 const int i0 = lane + 64 * q;
                 const int m = i0 / 15, j = i0 - 15 * m;
-                const float v = valid ? vraw[q] : 0.f;
-                const unsigned hi = cvt_pk_bf16(v, 0.f);
-                const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
-                const unsigned a = pb + ((j + 1) * 50 + (m + 1)) * 2;
-                if (i0 < 720) {
-                    lds_st16(a, hi);
-                    lds_st16(a + FB_PPLANE, lo);
-                }
+                if (i0 < 720) lds_store_one_fmt<FMT>(pb + ((j + 1) * 50 + (m + 1)) * 2, FB_PPLANE, vin[q] * s0, dummy_mx);
             }
         }
     }
@@ -210,7 +239,14 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
         f32x4 w1[2];                                      // weights hi and the first residual term (16 mantissa bits)
 #pragma unroll
         for (int t = 0; t < 2; ++t) w1[t] = wfrag_load(wrs, lane16, (CNNB_W1 + t * 512) * 2);
-        const float tn = tn1;
+        // F16: |y1| <= m0 * G1 + T1 fixes the scale of conv1's output before its first store
+        float tn = tn1, c1 = 1.f, ms1 = 0.f;
+        int e1 = 0;
+        if (F16) {
+            e1 = f16_scale_exp(fmaf(m_in, meta_f[8], meta_f[16]));
+            c1 = pow2_f32(e1 - e_in - meta_i[0]);
+            tn = tn1 * pow2_f32(e1);
+        }
         // lane half 0: k-slots 0..7 = (kx 0, kx 1); half 1: k-slots 8..11 = kx 2 (12..15 meet zero weights: kx 2 again)
         const int xq = min(qi, 14);                       // row 15 of a tile is padding (result unused)
         unsigned rd_a = R + FB_PATCH + ((xq + (h ? 2 : 0)) * 50 + 24 * hfi) * 2;
@@ -237,9 +273,10 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
             acc[1] = zero16();
             // x = hi + lo carries 16 mantissa bits: 6e-4 dB at |80| dB, the size of the mel stage's own deviation from
             // the oracle (2.6e-4 dB) and three orders below what moves a MOS by 1e-3; smallest products first
-            acc[0] = mfma_bf(xa[0][1], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[0], acc[1]);
-            acc[0] = mfma_bf(xa[0][0], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[1], acc[1]);
-            acc[0] = mfma_bf(xa[0][0], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[0], acc[1]);
+            if (FMT == NQ_FMT_F16X4) { acc[0] = mfma32_fmt<FMT>(xa[0][1], w1[1], acc[0]); acc[1] = mfma32_fmt<FMT>(xa[1][1], w1[1], acc[1]); }
+            acc[0] = mfma32_fmt<FMT>(xa[0][1], w1[0], acc[0]); acc[1] = mfma32_fmt<FMT>(xa[1][1], w1[0], acc[1]);
+            acc[0] = mfma32_fmt<FMT>(xa[0][0], w1[1], acc[0]); acc[1] = mfma32_fmt<FMT>(xa[1][0], w1[1], acc[1]);
+            acc[0] = mfma32_fmt<FMT>(xa[0][0], w1[0], acc[0]); acc[1] = mfma32_fmt<FMT>(xa[1][0], w1[0], acc[1]);
             // ReLU(. + shift) is monotone, so it is applied before the pair maximum, which is then taken on non-negative
             // floats -- as unsigned integers
             unsigned r[14];
@@ -247,7 +284,7 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
             for (int v = 0; v < 14; ++v) {
                 const int tt = v / 7, bb = v - 7 * tt;
                 const float mx = fmaxf(fmaxf(acc[tt][2 * bb], acc[tt][2 * bb + 1]), acc[tt][2 * bb + 2]);   // frames
-                r[v] = __float_as_uint(fmaxf(mx + tn, 0.f));
+                r[v] = __float_as_uint(epi_fmt<FMT>(mx, c1, tn));
             }
             unsigned got[7];
 #pragma unroll
@@ -260,11 +297,12 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
                 fin[kk] = __uint_as_float(max(own, got[kk]));
             }
 #pragma unroll
-            for (int kk = 0; kk < 6; kk += 2) lds_store_split2(wr + 2 * kk * FB_RS1, wr + 2 * (kk + 1) * FB_RS1, FB_P1, fin[kk], fin[kk + 1]);
-            lds_store_split(wr + 12 * FB_RS1, FB_P1, fin[6]);
+            for (int kk = 0; kk < 6; kk += 2) lds_store_pair_fmt<FMT>(wr + 2 * kk * FB_RS1, wr + 2 * (kk + 1) * FB_RS1, FB_P1, fin[kk], fin[kk + 1], ms1);
+            lds_store_one_fmt<FMT>(wr + 12 * FB_RS1, FB_P1, fin[6], ms1);
             rd_a += 8; rd_b += 8;                          // mel m0 = 2 gl, gl = 12 hfi + 2 g2 + tt
             wr += 14 * FB_RS1;
         }
+        if (F16) { m_in = wave_max_nonneg(ms1) * pow2_f32(-e1); e_in = e1; }
     }
 
     NQ_CLK(2);
@@ -281,8 +319,15 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
             m9[t] = tap_mask(u < 84, py, px, 24, 7);
             base[t] = R + ((py - 1) * 7 + (px - 1)) * FB_RS1 + (h << 4);
         }
-        conv_k_bf16<16, 6, 1, 7, FB_RS1, FB_P1, FB_ZADDR, false, NQ_RING2>(acc, wrs, CNNB_W2 * 2, lane16, base, m9);
+        conv_k_bf16<16, 6, 1, 7, FB_RS1, FB_P1, FB_ZADDR, false, NQ_RING2, FMT>(acc, wrs, CNNB_W2 * 2, lane16, base, m9);
         NQ_CLK(3);
+        float tn = tn2, c2 = 1.f, ms2 = 0.f;
+        int e2 = 0;
+        if (F16) {
+            e2 = f16_scale_exp(fmaf(m_in, meta_f[9], meta_f[17]));
+            c2 = pow2_f32(e2 - e_in - meta_i[1]);
+            tn = tn2 * pow2_f32(e2);
+        }
         const unsigned wr = R + (6 * hf * 5) * FB_RS2 + n * 2;
 #pragma unroll
         for (int k2 = 0; k2 < 30; k2 += 2) {              // pooled pixel k = gl * 5 + bb, two per packed split
@@ -298,10 +343,11 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
                         const int u = 14 * gl + 7 * yy + x;
                         mx = fmaxf(mx, acc[u >> 4][0][u & 15]);
                     }
-                pv[e] = fmaxf(mx + tn2, 0.f);
+                pv[e] = epi_fmt<FMT>(mx, c2, tn);
             }
-            lds_store_split2(wr + k2 * FB_RS2, wr + (k2 + 1) * FB_RS2, FB_P2, pv[0], pv[1]);
+            lds_store_pair_fmt<FMT>(wr + k2 * FB_RS2, wr + (k2 + 1) * FB_RS2, FB_P2, pv[0], pv[1], ms2);
         }
+        if (F16) { m_in = wave_max_nonneg(ms2) * pow2_f32(-e2); e_in = e2; }
     }
 
     NQ_CLK(4);
@@ -325,8 +371,16 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
             base[t] = R + base34[t] * FB_RS2 + (h << 4);
         }
-        conv_k_bf16<32, 2, 2, 5, FB_RS2, FB_P2, FB_ZADDR, true, NQ_RING34>(acc, wrs, CNNB_W3 * 2, lane16, base, m34);
+        conv_k_bf16<32, 2, 2, 5, FB_RS2, FB_P2, FB_ZADDR, true, NQ_RING34, FMT>(acc, wrs, CNNB_W3 * 2, lane16, base, m34);
         NQ_CLK(5);
+        float tn[2] = {tn3[0], tn3[1]}, c3 = 1.f, ms3 = 0.f;
+        int e3 = 0;
+        if (F16) {
+            e3 = f16_scale_exp(fmaf(m_in, meta_f[10], meta_f[18]));
+            c3 = pow2_f32(e3 - e_in - meta_i[2]);
+            tn[0] *= pow2_f32(e3);
+            tn[1] *= pow2_f32(e3);
+        }
         const unsigned wr = R + (6 * hf * 5) * FB_RS3 + n * 2;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -336,9 +390,10 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
                 for (int r = 0; r < 16; r += 2) {
                     const int u = 16 * t + r;                  // rows u, u + 1: pixel (2 gl + yy) * 5 + x = u (same order)
                     if (u < 30)
-                        lds_store_split2(wr + u * FB_RS3 + 64 * nt, wr + (u + 1) * FB_RS3 + 64 * nt, FB_P3,
-                                         fmaxf(acc[t][nt][r] + tn3[nt], 0.f), fmaxf(acc[t][nt][r + 1] + tn3[nt], 0.f));
+                        lds_store_pair_fmt<FMT>(wr + u * FB_RS3 + 64 * nt, wr + (u + 1) * FB_RS3 + 64 * nt, FB_P3,
+                                                epi_fmt<FMT>(acc[t][nt][r], c3, tn[nt]), epi_fmt<FMT>(acc[t][nt][r + 1], c3, tn[nt]), ms3);
                 }
+        if (F16) { m_in = wave_max_nonneg(ms3) * pow2_f32(-e3); e_in = e3; }
     }
 
     // ---- conv4 64->64 on 12x5, pool -> 6x3.  The pooled outputs of the workgroup's four segments go to a
@@ -361,8 +416,16 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
             base[t] = R + base34[t] * FB_RS3 + (h << 4);
         }
-        conv_k_bf16<64, 2, 2, 5, FB_RS3, FB_P3, FB_ZADDR, true, NQ_RING34>(acc, wrs, CNNB_W4 * 2, lane16, base, m34);
+        conv_k_bf16<64, 2, 2, 5, FB_RS3, FB_P3, FB_ZADDR, true, NQ_RING34, FMT>(acc, wrs, CNNB_W4 * 2, lane16, base, m34);
         NQ_CLK(7);
+        float tn[2] = {tn4[0], tn4[1]}, c4 = 1.f, ms4 = 0.f;
+        int e4 = 0;
+        if (F16) {
+            e4 = f16_scale_exp(fmaf(m_in, meta_f[11], meta_f[19]));
+            c4 = pow2_f32(e4 - e_in - meta_i[3]);
+            tn[0] *= pow2_f32(e4);
+            tn[1] *= pow2_f32(e4);
+        }
 #pragma unroll
         for (int g = 0; g < 3; ++g) { b5[g][0] = wfrag_load(wrs, lane16, w5b + g * 2048); b5[g][1] = wfrag_load(wrs, lane16, w5b + g * 2048 + 1024); }
         NQ_SYNC();                   // every wave has consumed its A3: the regions may be re-used
@@ -383,11 +446,22 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
                             const int u = 10 * gl + 5 * yy + x;
                             mx = fmaxf(mx, acc[u >> 4][nt][u & 15]);
                         }
-                    pv[nt] = fmaxf(mx + tn4[nt], 0.f);
+                    pv[nt] = epi_fmt<FMT>(mx, c4, tn[nt]);
                     if (P3 && valid) dst[((3 * hf + gl) * 3 + bb) * 64 + n + 32 * nt] = pv[nt];   // optional fp32 copy (debug / parity)
                 }
-                lds_store_split2(wr + (gl * 3 + bb) * FB_RS3, wr + (gl * 3 + bb) * FB_RS3 + 64, FB_PS, pv[0], pv[1]);
+                lds_store_pair_fmt<FMT>(wr + (gl * 3 + bb) * FB_RS3, wr + (gl * 3 + bb) * FB_RS3 + 64, FB_PS, pv[0], pv[1], ms4);
             }
+        if (F16) {
+            // conv5 / conv6 run over the four segments' rows at once: every row carries its own segment's scales.  conv5's output
+            // scale comes from this segment's measured conv4 maximum; conv6 writes fp32 features and needs only its input's scale.
+            const float m4 = wave_max_nonneg(ms4) * pow2_f32(-e4);
+            const int e5 = f16_scale_exp(fmaf(m4, meta_f[12], meta_f[20]));
+            if (lane < 18) {
+                lds_st32(FB_TAB5 + (18 * wave + lane) * 8, __float_as_uint(pow2_f32(e5 - e4 - meta_i[4])));
+                lds_st32(FB_TAB5 + (18 * wave + lane) * 8 + 4, __float_as_uint(pow2_f32(e5)));
+            }
+            if (lane < 6) lds_st32(FB_TAB6 + (6 * wave + lane) * 4, __float_as_uint(pow2_f32(-(e5 + meta_i[5]))));
+        }
     }
     NQ_SYNC();
     NQ_CLK(8);
@@ -433,12 +507,7 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
         for (int g = 0; g < 18; ++g) {
             if (g + 3 < 18) { b5[(g + 3) & 3][0] = wfrag_load(wrs, lane16, w5b + (g + 3) * 2048); b5[(g + 3) & 3][1] = wfrag_load(wrs, lane16, w5b + (g + 3) * 2048 + 1024); }
             if (g + 1 < 18) load_a5(g + 1);
-#pragma unroll
-            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(a5[g & 1][t][0], b5[g & 3][1], acc5[t]);
-#pragma unroll
-            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(a5[g & 1][t][1], b5[g & 3][0], acc5[t]);
-#pragma unroll
-            for (int t = 0; t < 5; ++t) acc5[t] = mfma_bf16x16(a5[g & 1][t][0], b5[g & 3][0], acc5[t]);
+            mma16_pair_fmt<FMT, 5>(acc5, a5[g & 1], b5[g & 3]);
         }
         NQ_CLK(9);
 #pragma unroll
@@ -449,9 +518,12 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
             for (int t = 0; t < 5; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; r += 2)
-                    if (t < 4 || kg < 2)                       // rho = 16 t + 4 kg + r < 72
-                        lds_store_split2(wr + (16 * t + r) * FB_RS3, wr + (16 * t + r + 1) * FB_RS3, FB_PS,
-                                         fmaxf(acc5[t][r] + tn5, 0.f), fmaxf(acc5[t][r + 1] + tn5, 0.f));
+                    if (t < 4 || kg < 2) {                     // rho = 16 t + 4 kg + r < 72
+                        f32x2_t cs0 = {1.f, 1.f}, cs1 = {1.f, 1.f};      // F16: {2^(e5 - e4 - kw5), 2^e5} of the rows' segments
+                        if (F16) { cs0 = lds_ld64(FB_TAB5 + (16 * t + r) * 8 + kg * 32); cs1 = lds_ld64(FB_TAB5 + (16 * t + r + 1) * 8 + kg * 32); }
+                        lds_store_pair_fmt<FMT>(wr + (16 * t + r) * FB_RS3, wr + (16 * t + r + 1) * FB_RS3, FB_PS,
+                                                epi_fmt<FMT>(acc5[t][r], cs0[0], tn5 * cs0[1]), epi_fmt<FMT>(acc5[t][r + 1], cs1[0], tn5 * cs1[1]), dummy_mx);
+                    }
         }
         NQ_SYNC();
         NQ_CLK(10);
@@ -492,21 +564,8 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
         for (int g = 0; g < 18; ++g) {
             if (g + 7 < 18) { b6[(g + 7) & 7][0] = wfrag_load(wrs, lane16, w6b + (g + 7) * 2048); b6[(g + 7) & 7][1] = wfrag_load(wrs, lane16, w6b + (g + 7) * 2048 + 1024); }
             if (g + 1 < 18) load_a6(g + 1);
-            if (g & 1) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(a6[1][t][0], b6[g & 7][1], acc6b[t]);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(a6[1][t][1], b6[g & 7][0], acc6b[t]);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc6b[t] = mfma_bf16x16(a6[1][t][0], b6[g & 7][0], acc6b[t]);
-            } else {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(a6[0][t][0], b6[g & 7][1], acc6[t]);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(a6[0][t][1], b6[g & 7][0], acc6[t]);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) acc6[t] = mfma_bf16x16(a6[0][t][0], b6[g & 7][0], acc6[t]);
-            }
+            if (g & 1) mma16_pair_fmt<FMT, 2>(acc6b, a6[1], b6[g & 7]);
+            else mma16_pair_fmt<FMT, 2>(acc6, a6[0], b6[g & 7]);
         }
         NQ_CLK(11);
         // this wave's 4 x 96 outputs (slot, channel * 6 + y) go through S4 (dead since the barrier above) so that the
@@ -518,7 +577,10 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
             for (int r = 0; r < 4; ++r) {
                 const int rho = 16 * t + 4 * kg + r;
                 const int slot = rho / 6, y = rho - 6 * slot;
-                if (rho < 24) lds_st32(fo + (slot * 96 + i16 * 6 + y) * 4, __float_as_uint(fmaxf(acc6[t][r] + acc6b[t][r] + tn6, 0.f)));
+                if (rho < 24) {
+                    const float c6 = F16 ? __uint_as_float(lds_ld32(FB_TAB6 + (16 * t + r) * 4 + kg * 16)) : 1.f;   // 2^-(e5 + kw6) of the row's segment
+                    lds_st32(fo + (slot * 96 + i16 * 6 + y) * 4, __float_as_uint(epi_fmt<FMT>(acc6[t][r] + acc6b[t][r], c6, tn6)));
+                }
             }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -542,22 +604,62 @@ __global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
 #endif
 }
 
+// ---- kernels: one body, three operand formats -------------------------------------------------------------------------------------
+template <bool SEGX, bool P3>
+__global__ __launch_bounds__(256, FB_WGS) void cnn_front_bf16_kernel(
+    const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off, const int32_t* __restrict__ tok_off,
+    const int32_t* __restrict__ n_wins, const float* __restrict__ clip_floor, int n_clips, int seg_hop,
+    const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ p3, float* __restrict__ feat,
+    const float* __restrict__ seg_x, int seg_L, const uint32_t* __restrict__ clip_max_enc, float top_db) {
+    cnn_front_split_body<NQ_FMT_BF16X3, SEGX, P3>(mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cw, wb, p3, feat, seg_x, seg_L,
+                                                  clip_max_enc, top_db);
+}
+// fp32 operands as two f16 terms of the power-of-two-scaled tensors; P4: all four term products ('f16x4'), else hh + hl + lh ('f16x3')
+template <bool P4, bool SEGX>
+__global__ __launch_bounds__(256, FB_WGS) void cnn_front_f16_kernel(
+    const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off, const int32_t* __restrict__ tok_off,
+    const int32_t* __restrict__ n_wins, const float* __restrict__ clip_floor, int n_clips, int seg_hop,
+    const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ p3, float* __restrict__ feat,
+    const float* __restrict__ seg_x, int seg_L, const uint32_t* __restrict__ clip_max_enc, float top_db) {
+    cnn_front_split_body<P4 ? NQ_FMT_F16X4 : NQ_FMT_F16X3, SEGX, false>(mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cw, wb, p3,
+                                                                       feat, seg_x, seg_L, clip_max_enc, top_db);
+}
+
+typedef void (*fb_kernel_t)(const float*, const int32_t*, const int32_t*, const int32_t*, const float*, int, int, const float*,
+                            const unsigned short*, float*, float*, const float*, int, const uint32_t*, float);
+// fmt: 0 bf16x3, 1 f16x3, 2 f16x4.  80.5 KB of dynamic LDS is above the 64 KB default: every instantiation is opted in once per
+// device ordinal (a process may drive several GPUs), like the three-term kernel's launcher
+static int fb_launch(int fmt, bool segx, bool p3, const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                     const int32_t* n_wins, const float* clip_floor, const uint32_t* clip_max_enc, float top_db, int32_t n_clips,
+                     int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w, const uint16_t* cnn_wb, float* p3_opt, float* feat,
+                     const float* seg_x, int32_t seg_L, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat || fmt < 0 || fmt > 2 ||
+        (p3 && fmt != 0) || (segx && (!seg_x || seg_L <= 0)) || (!segx && !clip_floor && !clip_max_enc))
+        return NISQA_ERR_ARG;
+    static const fb_kernel_t kernels[7] = {
+        cnn_front_bf16_kernel<false, false>, cnn_front_bf16_kernel<false, true>, cnn_front_bf16_kernel<true, false>,
+        cnn_front_f16_kernel<false, false>, cnn_front_f16_kernel<false, true>, cnn_front_f16_kernel<true, false>, cnn_front_f16_kernel<true, true>};
+    const int which = fmt == 0 ? (segx ? 2 : p3 ? 1 : 0) : 3 + 2 * (fmt - 1) + (segx ? 1 : 0);
+    NQ_LAUNCH_BEGIN();
+    static std::atomic<bool> attr[7][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr[which][dev].load(std::memory_order_relaxed)) {
+        if (hipFuncSetAttribute((const void*)kernels[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS) != hipSuccess) return 2;
+        attr[which][dev].store(true, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kernels[which], dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream, mel_tm, frame_off, tok_off, n_wins,
+                       clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat, seg_x, seg_L, clip_max_enc, top_db);
+    return NQ_LAUNCH_STATUS();
+}
+
 extern "C" int nisqa_cnn_adapt_bf16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
                                     const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                                     int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w,
                                     const uint16_t* cnn_wb, float* p3_opt, float* feat, void* stream) {
-    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat)
-        return NISQA_ERR_ARG;
-    NQ_LAUNCH_BEGIN();
-    if (p3_opt)
-        hipLaunchKernelGGL((cnn_front_bf16_kernel<false, true>), dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
-                           mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat,
-                           (const float*)nullptr, 0, (const uint32_t*)nullptr, 0.f);
-    else
-        hipLaunchKernelGGL((cnn_front_bf16_kernel<false, false>), dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
-                           mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat,
-                           (const float*)nullptr, 0, (const uint32_t*)nullptr, 0.f);
-    return NQ_LAUNCH_STATUS();
+    if (!clip_floor) return NISQA_ERR_ARG;
+    return fb_launch(0, false, p3_opt != nullptr, mel_tm, frame_off, tok_off, n_wins, clip_floor, nullptr, 0.f, n_clips, total_tok_padded, seg_hop,
+                     cnn_w, cnn_wb, p3_opt, feat, nullptr, 0, stream);
 }
 
 // nisqa_cnn_adapt_bf16 with the per-clip floor derived in the kernel from the mel kernel's clip_max_enc (internal.hpp)
@@ -565,23 +667,37 @@ int nq_cnn_adapt_bf16_from_max(const float* mel_tm, const int32_t* frame_off, co
                                const int32_t* n_wins, const uint32_t* clip_max_enc, float top_db, int32_t n_clips,
                                int32_t total_tok_padded, int32_t seg_hop, const float* cnn_w, const uint16_t* cnn_wb,
                                float* feat, void* stream) {
-    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat || !clip_max_enc)
-        return NISQA_ERR_ARG;
-    NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL((cnn_front_bf16_kernel<false, false>), dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
-                       mel_tm, frame_off, tok_off, n_wins, (const float*)nullptr, n_clips, seg_hop, cnn_w, cnn_wb,
-                       (float*)nullptr, feat, (const float*)nullptr, 0, clip_max_enc, top_db);
-    return NQ_LAUNCH_STATUS();
+    if (!clip_max_enc) return NISQA_ERR_ARG;
+    return fb_launch(0, false, false, mel_tm, frame_off, tok_off, n_wins, nullptr, clip_max_enc, top_db, n_clips, total_tok_padded, seg_hop, cnn_w,
+                     cnn_wb, nullptr, feat, nullptr, 0, stream);
 }
 
 extern "C" int nisqa_cnn_adapt_segments_bf16(const float* x, int32_t seg_len_padded, const int32_t* tok_off,
                                              const int32_t* n_wins, int32_t n_clips, int32_t total_tok_padded,
                                              const float* cnn_w, const uint16_t* cnn_wb, float* feat, void* stream) {
-    if (!x || seg_len_padded <= 0 || n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || !cnn_wb || !feat)
-        return NISQA_ERR_ARG;
-    NQ_LAUNCH_BEGIN();
-    hipLaunchKernelGGL((cnn_front_bf16_kernel<true, false>), dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream,
-                       (const float*)nullptr, (const int32_t*)nullptr, tok_off, n_wins, (const float*)nullptr, n_clips, 1,
-                       cnn_w, cnn_wb, (float*)nullptr, feat, x, seg_len_padded, (const uint32_t*)nullptr, 0.f);
-    return NQ_LAUNCH_STATUS();
+    return fb_launch(0, true, false, nullptr, nullptr, tok_off, n_wins, nullptr, nullptr, 0.f, n_clips, total_tok_padded, 1, cnn_w, cnn_wb, nullptr,
+                     feat, x, seg_len_padded, stream);
+}
+
+// ---- the f16 formats (cnn_wh: nisqa_amd.weights.pack_adapt_cnn_f16, CNNH_U16S uint16) -------------------------------------------------
+extern "C" int nisqa_cnn_adapt_f16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off, const int32_t* n_wins,
+                                   const float* clip_floor, int32_t n_clips, int32_t total_tok_padded, int32_t seg_hop,
+                                   const float* cnn_w, const uint16_t* cnn_wh, int32_t products, float* feat, void* stream) {
+    if (!clip_floor || (products != 3 && products != 4)) return NISQA_ERR_ARG;
+    return fb_launch(products - 2, false, false, mel_tm, frame_off, tok_off, n_wins, clip_floor, nullptr, 0.f, n_clips, total_tok_padded, seg_hop,
+                     cnn_w, cnn_wh, nullptr, feat, nullptr, 0, stream);
+}
+int nq_cnn_adapt_f16_from_max(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off, const int32_t* n_wins,
+                              const uint32_t* clip_max_enc, float top_db, int32_t n_clips, int32_t total_tok_padded, int32_t seg_hop,
+                              const float* cnn_w, const uint16_t* cnn_wh, int32_t products, float* feat, void* stream) {
+    if (!clip_max_enc || (products != 3 && products != 4)) return NISQA_ERR_ARG;
+    return fb_launch(products - 2, false, false, mel_tm, frame_off, tok_off, n_wins, nullptr, clip_max_enc, top_db, n_clips, total_tok_padded,
+                     seg_hop, cnn_w, cnn_wh, nullptr, feat, nullptr, 0, stream);
+}
+extern "C" int nisqa_cnn_adapt_segments_f16(const float* x, int32_t seg_len_padded, const int32_t* tok_off, const int32_t* n_wins,
+                                            int32_t n_clips, int32_t total_tok_padded, const float* cnn_w, const uint16_t* cnn_wh,
+                                            int32_t products, float* feat, void* stream) {
+    if (products != 3 && products != 4) return NISQA_ERR_ARG;
+    return fb_launch(products - 2, true, false, nullptr, nullptr, tok_off, n_wins, nullptr, nullptr, 0.f, n_clips, total_tok_padded, 1, cnn_w, cnn_wh,
+                     nullptr, feat, x, seg_len_padded, stream);
 }

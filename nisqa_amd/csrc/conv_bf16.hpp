@@ -25,6 +25,92 @@ NQ_DEV f32x4 mfma_bf16x16(f32x4 a, f32x4 b, f32x4 c) {     // 16x16x32: A[i = l&
 #endif
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+// ---- operand formats of the two-term kernels (cnn_bf16.hip) ---------------------------------------------------------------------
+//   NQ_FMT_BF16X3: x = hi + lo in bf16 (8 + 8 significand bits), products hh + hl + lh: 16 of an fp32 operand's 24 bits
+//   NQ_FMT_F16X3 / NQ_FMT_F16X4: x * 2^e = hi + lo in f16 (11 + 11 significand bits and lo's sign: the residual x - hi is a
+//     multiple of ulp32(x) of magnitude <= 4096 ulp32, and f16 holds every such integer up to 2048 and every even one up to 4096 --
+//     the pair is the fp32 value itself for ~75 % of the values and one fp32 ulp off for the rest), e a power-of-two scale that keeps
+//     the tensor inside f16's range (cnn_bf16.hip: from the measured maximum of the layer's input and the layer's weight norm);
+//     products hh + hl + lh (+ ll for F16X4).  v_mfma_*_f16 honours f16 subnormals (tools/micro/f16probe.hip), so small values lose
+//     absolute, not relative, precision: 2^-25 of the scaled range.  Measured against float64 on K = 576 dot products
+//     (profiles/r05_micro_f16probe.txt): rms error 0.85 x (F16X4) / 0.87 x (F16X3) the fp32-MFMA kernels' -- fewer accumulator
+//     roundings than their 288 K-steps -- against 0.97 x for bf16x6 and 14.6 x for BF16X3.
+#define NQ_FMT_BF16X3 0
+#define NQ_FMT_F16X3 1
+#define NQ_FMT_F16X4 2
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <int FMT>
+NQ_DEV f32x16 mfma32_fmt(f32x4 a, f32x4 b, f32x16 c) {
+    if (FMT == NQ_FMT_BF16X3) return mfma_bf(a, b, c);
+#ifdef NQ_KO
+    if (NQ_KO & 8) { c[0] += a[0] * b[0]; return c; }
+#endif
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+template <int FMT>
+NQ_DEV f32x4 mfma16_fmt(f32x4 a, f32x4 b, f32x4 c) {
+    if (FMT == NQ_FMT_BF16X3) return mfma_bf16x16(a, b, c);
+#ifdef NQ_KO
+    if (NQ_KO & 8) { c[0] += a[0] * b[0]; return c; }
+#endif
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// the term products of one (A, B) fragment pair, smallest first: ll (F16X4 only), hl, lh, hh
+template <int FMT, int MT, int NT>
+NQ_DEV void mma_pair_fmt(f32x16 (&acc)[MT][NT], const f32x4 (&ah)[MT], const f32x4 (&al)[MT], const f32x4 (&bh)[NT], const f32x4 (&bl)[NT]) {
+    if (FMT == NQ_FMT_F16X4) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma32_fmt<FMT>(al[t], bl[nt], acc[t][nt]);
+    }
+    // product-major: consecutive MFMAs go to DIFFERENT accumulators (no dependent-accumulate bubbles)
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma32_fmt<FMT>(ah[t], bl[nt], acc[t][nt]);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma32_fmt<FMT>(al[t], bh[nt], acc[t][nt]);
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma32_fmt<FMT>(ah[t], bh[nt], acc[t][nt]);
+}
+template <int FMT, int MT>
+NQ_DEV void mma16_pair_fmt(f32x4 (&acc)[MT], const f32x4 (&a)[MT][2], const f32x4 (&b)[2]) {
+    if (FMT == NQ_FMT_F16X4) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = mfma16_fmt<FMT>(a[t][1], b[1], acc[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = mfma16_fmt<FMT>(a[t][0], b[1], acc[t]);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = mfma16_fmt<FMT>(a[t][1], b[0], acc[t]);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = mfma16_fmt<FMT>(a[t][0], b[0], acc[t]);
+}
+// ---- power-of-two scales of the f16 formats (wave-uniform integer exponents) -------------------------------------------------
+// e with bound * 2^e in [2^14, 2^15) (f16's largest finite value is 2^16 - 32), clamped to +-60; bound >= 0
+NQ_DEV int f16_scale_exp(float bound) {
+    const int be = (int)((__float_as_uint(bound) >> 23) & 0xffu);       // bound = f * 2^(be - 126), f in [0.5, 1)
+    return min(max(15 - (be - 126), -60), 60);
+}
+NQ_DEV float pow2_f32(int e) { return __uint_as_float((unsigned)(min(max(e, -126), 127) + 127) << 23); }
+// maximum of a non-negative float over the wave (four DPP steps inside the rows of 16 lanes, then the four row results through SGPRs)
+NQ_DEV float wave_max_nonneg(float v) {
+    int x = (int)__float_as_uint(v);
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));      // quad_perm [1, 0, 3, 2]
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));      // quad_perm [2, 3, 0, 1]
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));     // row_half_mirror
+    x = max(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false));     // row_mirror
+    const unsigned m = max(max((unsigned)__builtin_amdgcn_readlane(x, 0), (unsigned)__builtin_amdgcn_readlane(x, 16)),
+                           max((unsigned)__builtin_amdgcn_readlane(x, 32), (unsigned)__builtin_amdgcn_readlane(x, 48)));
+    return __uint_as_float(m);
+}
+
 // round-to-nearest-even fp32 -> bf16 (finite inputs)
 NQ_DEV unsigned bf16_bits(float v) {
     const unsigned u = __float_as_uint(v);
@@ -208,6 +294,35 @@ NQ_DEV void lds_store_split2(unsigned a0, unsigned a1, int plane, float v0, floa
     if (st0) { lds_st16(a0, hi2); lds_st16(a0 + plane, lo2); }
     if (st1) { lds_st16_hi(a1, hi2); lds_st16_hi(a1 + plane, lo2); }
 }
+// fp32 pair -> packed f16 pair (v_cvt_pk_f16_f32, round to nearest even)
+NQ_DEV unsigned cvt_pk_f16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+}
+// lds_store_split2 for either format; `mx` (F16 formats) gathers the maximum of the stored values (they are >= 0 behind a ReLU; the
+// conv1 input passes |v|): the next layer's scale comes from it
+template <int FMT, bool KO_DW = true>
+NQ_DEV void lds_store_pair_fmt(unsigned a0, unsigned a1, int plane, float v0, float v1, float& mx, bool st0 = true, bool st1 = true) {
+    if (FMT == NQ_FMT_BF16X3) { lds_store_split2<KO_DW>(a0, a1, plane, v0, v1, st0, st1); return; }
+    const unsigned hi2 = cvt_pk_f16(v0, v1);
+    const f32x2_t vv = {v0, v1};
+    const f32x2_t hf = __builtin_convertvector(__builtin_bit_cast(f16x2_t, hi2), f32x2_t);
+    const f32x2_t r = vv - hf;
+    const unsigned lo2 = cvt_pk_f16(r[0], r[1]);
+    mx = fmaxf(fmaxf(mx, __builtin_fabsf(v0)), __builtin_fabsf(v1));
+    if (st0) { lds_st16(a0, hi2); lds_st16(a0 + plane, lo2); }
+    if (st1) { lds_st16_hi(a1, hi2); lds_st16_hi(a1 + plane, lo2); }
+}
+template <int FMT>
+NQ_DEV void lds_store_one_fmt(unsigned a, int plane, float v, float& mx) {
+    if (FMT == NQ_FMT_BF16X3) { lds_store_split(a, plane, v); return; }
+    const unsigned hi = cvt_pk_f16(v, 0.f);
+    const float hf = (float)__builtin_bit_cast(f16x2_t, hi)[0];
+    const unsigned lo = cvt_pk_f16(v - hf, 0.f);
+    mx = fmaxf(mx, __builtin_fabsf(v));
+    lds_st16(a, hi);
+    lds_st16(a + plane, lo);
+}
 NQ_DEV f32x16 splat16(float v) { f32x16 r; for (int q = 0; q < 16; ++q) r[q] = v; return r; }
 typedef int nq_i32x4 __attribute__((ext_vector_type(4)));
 // NQ_KO: knock-out bits for timing experiments (results are WRONG): 32 weight fragments read from LDS instead, 1 no weight loads, 2 no A-operand LDS reads,
@@ -238,7 +353,7 @@ NQ_DEV unsigned tap_mask(bool valid, int y, int x, int H, int W) {
 //             (dy, dx = 0..2), channel step s 32 s bytes further: both ride on the ds_read offset field.
 //   m9[t]   : tap_mask of the row; a cleared bit sends both reads to the zero block at ZADDR (a kernel-wide constant).
 //   wbyte   : byte offset of the layer's fragments [step][NT][hi, lo][64 lanes][8 bf16] in the weight blob
-template <int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZADDR, bool APF, int RING = 3>
+template <int CIN, int MT, int NT, int W, int RS, int PLANE, unsigned ZADDR, bool APF, int RING = 3, int FMT = NQ_FMT_BF16X3>
 NQ_DEV void conv_k_bf16(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
                         const unsigned (&base)[MT], const unsigned (&m9)[MT]) {
     constexpr int S16 = CIN / 16, TOTAL = 9 * S16, AB = APF ? 2 : 1;
@@ -279,19 +394,7 @@ NQ_DEV void conv_k_bf16(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int 
         if (APF) { if (g + 1 < TOTAL) load_a(g + 1, (g + 1) & 1); } else load_a(g, 0);
         NQ_ISSUE_FENCE();
         const int sa = APF ? (g & 1) : 0, sb = g % RING;
-        // product-major: consecutive MFMAs go to DIFFERENT accumulators (no dependent-accumulate bubbles)
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bl[sb][nt], acc[t][nt]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(al[sa][t], bh[sb][nt], acc[t][nt]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bh[sb][nt], acc[t][nt]);
+        mma_pair_fmt<FMT, MT, NT>(acc, ah[sa], al[sa], bh[sb], bl[sb]);
     }
 }
 

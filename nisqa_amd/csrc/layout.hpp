@@ -59,6 +59,11 @@
 #define CNNX_W5 (CNNX_W4 + 36 * 2 * 3 * 512)
 #define CNNX_W6 (CNNX_W5 + 36 * 2 * 3 * 512)
 #define CNNX_U16S (CNNX_W6 + 36 * 2 * 3 * 512)
+/* two-term f16 fragments (cnn_bf16.hip, formats F16X3 / F16X4): the CNNB_ blocks with f16 bit patterns of W * 2^kw (kw per layer:
+   max |W| * 2^kw in [2^14, 2^15)), followed by 32 dwords of per-layer constants: int kw[1..6] at dword 0..5, float G[1..6] =
+   max over output channels of sum |W| (BatchNorm folded) at dword 8..13, float T[1..6] = max |shift| at dword 16..21 */
+#define CNNH_META CNNB_U16S
+#define CNNH_U16S (CNNB_U16S + 64)
 
 // ---- split-bf16 fragments of the self-attention / pooling weights ("td_wb", "pool_wb"; uint16 units) --------
 // A-fragment [step][mtile][hl][64 lanes][8]; lane (i = l&31, h = l>>5), element e:

@@ -17,6 +17,19 @@ from .melbank import MelTables
 
 SEG_LEN = 15
 TOK_PAD = 32
+# The precision every GEMM of the path runs in unless the caller (or NISQA_HIP_PRECISION) says otherwise.  'bf16x6' carries the
+# reference's fp32 operands EXACTLY (three bf16 terms, six MFMA products per term pair, fp32 accumulation): reference-grade
+# arithmetic, as far from a float64 evaluation as the exact-fp32 kernels and the reference's own CPU float32
+# (tests/test_gpu_parity.py::test_rounding_error_of_the_precision_modes_against_float64).  'bf16x3' (16 of the 24 operand mantissa
+# bits, |dMOS| <= 5e-5, 1.5 x faster) was the default until round 4 and stays selectable; 'f32' is the exact fp32-MFMA path.
+#
+# Round 5 added 'f16x4' / 'f16x3': the AdaptCNN with every fp32 operand as TWO f16 terms of the power-of-two-scaled tensor (11 + 11
+# significand bits and the low term's sign: the fp32 value itself for ~75 % of the values, one fp32 ulp off for the rest) and all four /
+# three term products; self-attention and pooling run as in 'bf16x6'.  Measured against float64 they are as close as 'f32' and 'bf16x6'
+# (the same test), at 4 / 3 instead of 6 MFMA products -- but an operand may lose its last bit, so they are opt-in, not the default.
+DEFAULT_PRECISION = 'bf16x6'
+PRECISIONS = ('f32', 'bf16x3', 'bf16x6', 'f16x3', 'f16x4')
+CNN_MODE = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2, 'f16x3': 3, 'f16x4': 4}
 
 
 class BatchPlan(object):
@@ -101,9 +114,10 @@ class HipNisqa(object):
     """nisqa.tar / nisqa_mos_only.tar (CNN-SA-AP) on one MI355X."""
 
     def __init__(self, args, state_dict, device=None, precision=None):
-        """precision: 'bf16x3' (default: AdaptCNN on split-bf16 MFMA, fp32-class accuracy, |dMOS| <= 3e-5), 'f32'
-        (every GEMM on exact fp32 MFMA) or 'bf16x6' (every GEMM -- AdaptCNN / StandardCNN, self-attention, pooling -- with its fp32 operands as three bf16 terms, an
-        exact split, and six MFMA products per term pair: the accuracy of 'f32' at 1.5-1.7 x its rate); the environment variable NISQA_HIP_PRECISION sets the default."""
+        """precision: 'bf16x6' (DEFAULT_PRECISION: every GEMM -- AdaptCNN / StandardCNN, self-attention, pooling -- with its fp32
+        operands as three bf16 terms, an exact split, and six MFMA products per term pair: the accuracy of 'f32' at 1.5-1.7 x its
+        rate), 'f32' (every GEMM on exact fp32 MFMA) or 'bf16x3' (two bf16 terms, three products: 16 of the 24 operand mantissa
+        bits, |dMOS| <= 5e-5, the fast mode); the environment variable NISQA_HIP_PRECISION overrides the default."""
         if not torch.cuda.is_available():
             raise RuntimeError('nisqa_amd: no GPU visible (torch.cuda.is_available() is False); '
                                'the HIP engine has no CPU fallback')
@@ -134,9 +148,13 @@ class HipNisqa(object):
         self.max_segments = a['ms_max_segments']
         self.dim = a['model'] == 'NISQA_DIM'
         up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(self.device)
-        self.precision = precision or os.environ.get('NISQA_HIP_PRECISION', 'bf16x3')
-        if self.precision not in ('f32', 'bf16x3', 'bf16x6'):
-            raise ValueError('precision must be f32, bf16x3 or bf16x6, got {}'.format(self.precision))
+        self.precision = precision or os.environ.get('NISQA_HIP_PRECISION') or DEFAULT_PRECISION
+        if self.precision not in PRECISIONS:
+            raise ValueError('precision must be one of {}, got {}'.format(', '.join(PRECISIONS), self.precision))
+        if self.arch == 1 and self.precision in ('f16x3', 'f16x4'):
+            self.precision = 'bf16x6'           # the f16 formats are built for the AdaptCNN; nisqa_tts.tar runs its StandardCNN as 'bf16x6'
+        # the operand format of self-attention / pooling: the f16 CNN modes pair with the three-term kernels
+        self.td_precision = 'bf16x6' if self.precision in ('f16x3', 'f16x4') else self.precision
         if self.arch == 1:
             # StandardCNN (split-bf16 or exact-fp32 MFMA) + BiLSTM + last-step pooling (fp32 VALU)
             self.n_layers, self.n_heads = 0, 1
@@ -158,11 +176,13 @@ class HipNisqa(object):
         self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict, conv1_pairs=True).view(np.int16)) if bf else None
         if self.precision == 'bf16x6':
             self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict, conv1_pairs=True, terms=3).view(np.int16))
+        if self.precision in ('f16x3', 'f16x4'):
+            self.cnn_wb = up(_w.pack_adapt_cnn_f16(state_dict).view(np.int16))
         self.td_w = up(_w.pack_self_att(state_dict, self.n_layers))
         self.pool_w = up(_w.pack_pool_att(state_dict, heads))
         self.td_wb = up(_w.pack_self_att_bf16(state_dict, self.n_layers).view(np.int16)) if bf else None
         self.pool_wb = up(_w.pack_pool_att_bf16(state_dict, heads).view(np.int16)) if bf else None
-        if self.precision == 'bf16x6':                       # three-term fragments for self-attention and pooling as well
+        if self.td_precision == 'bf16x6':                    # three-term fragments for self-attention and pooling as well
             self.td_wb = up(_w.pack_self_att_bf16(state_dict, self.n_layers, terms=3).view(np.int16))
             self.pool_wb = up(_w.pack_pool_att_bf16(state_dict, heads, terms=3).view(np.int16))
         self._mel = {}
@@ -182,7 +202,7 @@ class HipNisqa(object):
                                        _ptr(d['band_woff']), _ptr(d['band_w']), _ptr(self.cnn_w), _ptr(self.td_w),
                                        _ptr(self.pool_w), self.n_layers, self.n_heads, self.seg_hop, None,
                                        _ptr(self.cnn_wb) if self.cnn_wb is not None else None,
-                                       {'bf16x3': 1, 'bf16x6': 2}.get(self.precision, 0),
+                                       CNN_MODE[self.precision],
                                        _ptr(self.td_wb) if self.td_wb is not None else None,
                                        _ptr(self.pool_wb) if self.pool_wb is not None else None, self.arch)
             self._mel[sr] = d
@@ -261,6 +281,12 @@ class HipNisqa(object):
                                                        self.seg_hop, _ptr(self.cnn_w), _ptr(self.cnn_wb), _ptr(feat),
                                                        self._stream()), 'nisqa_cnn_adapt_bf16x6')
             p3 = None                      # (the one-launch kernel has no pooled conv4 tensor in memory)
+        elif self.precision in ('f16x3', 'f16x4'):
+            _lib.check(self.lib.nisqa_cnn_adapt_f16(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']),
+                                                    _ptr(clip_floor), plan.n_clips, plan.total_tok, self.seg_hop, _ptr(self.cnn_w),
+                                                    _ptr(self.cnn_wb), int(self.precision[-1]), _ptr(feat), self._stream()),
+                       'nisqa_cnn_adapt_f16')
+            p3 = None
         else:
             _lib.check(self.lib.nisqa_cnn_adapt(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']),
                                                 _ptr(clip_floor), plan.n_clips, plan.total_tok, self.seg_hop,
@@ -286,6 +312,10 @@ class HipNisqa(object):
             fn = self.lib.nisqa_cnn_adapt_segments_bf16 if self.precision == 'bf16x3' else self.lib.nisqa_cnn_adapt_segments_bf16x6
             _lib.check(fn(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B, plan.total_tok, _ptr(self.cnn_w), _ptr(self.cnn_wb),
                           _ptr(feat), self._stream()), 'nisqa_cnn_adapt_segments_' + self.precision)
+        elif self.precision in ('f16x3', 'f16x4'):
+            _lib.check(self.lib.nisqa_cnn_adapt_segments_f16(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B, plan.total_tok,
+                                                             _ptr(self.cnn_w), _ptr(self.cnn_wb), int(self.precision[-1]), _ptr(feat),
+                                                             self._stream()), 'nisqa_cnn_adapt_segments_f16')
         else:
             _lib.check(self.lib.nisqa_cnn_adapt_segments(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B,
                                                          plan.total_tok, _ptr(self.cnn_w), _ptr(p3), _ptr(feat),
@@ -324,10 +354,10 @@ class HipNisqa(object):
         d = plan.to(self.device)
         ws = torch.empty(plan.total_tok * 64 * 9, dtype=torch.float32, device=self.device)
         x = torch.zeros((plan.total_tok, 64), dtype=torch.float32, device=self.device)
-        if self.precision in ('bf16x3', 'bf16x6'):
-            fn = self.lib.nisqa_td_selfatt_bf16 if self.precision == 'bf16x3' else self.lib.nisqa_td_selfatt_bf16x6
+        if self.td_precision in ('bf16x3', 'bf16x6'):
+            fn = self.lib.nisqa_td_selfatt_bf16 if self.td_precision == 'bf16x3' else self.lib.nisqa_td_selfatt_bf16x6
             _lib.check(fn(_ptr(feat), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips, plan.total_tok, self.n_layers,
-                          _ptr(self.td_w), _ptr(self.td_wb), _ptr(ws), _ptr(x), self._stream()), 'nisqa_td_selfatt_' + self.precision)
+                          _ptr(self.td_w), _ptr(self.td_wb), _ptr(ws), _ptr(x), self._stream()), 'nisqa_td_selfatt_' + self.td_precision)
         else:
             _lib.check(self.lib.nisqa_td_selfatt(_ptr(feat), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips,
                                                  plan.total_tok, self.n_layers, _ptr(self.td_w), _ptr(ws), _ptr(x),
@@ -338,10 +368,10 @@ class HipNisqa(object):
         d = plan.to(self.device)
         ws = torch.empty(plan.total_tok * 16, dtype=torch.float32, device=self.device)
         out = torch.empty((plan.n_clips, self.n_heads), dtype=torch.float32, device=self.device)
-        if self.precision in ('bf16x3', 'bf16x6'):
-            fn = self.lib.nisqa_pool_att_bf16 if self.precision == 'bf16x3' else self.lib.nisqa_pool_att_bf16x6
+        if self.td_precision in ('bf16x3', 'bf16x6'):
+            fn = self.lib.nisqa_pool_att_bf16 if self.td_precision == 'bf16x3' else self.lib.nisqa_pool_att_bf16x6
             _lib.check(fn(_ptr(x), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips, plan.total_tok, self.n_heads,
-                          _ptr(self.pool_w), _ptr(self.pool_wb), _ptr(ws), _ptr(out), self._stream()), 'nisqa_pool_att_' + self.precision)
+                          _ptr(self.pool_w), _ptr(self.pool_wb), _ptr(ws), _ptr(out), self._stream()), 'nisqa_pool_att_' + self.td_precision)
         else:
             _lib.check(self.lib.nisqa_pool_att(_ptr(x), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips, plan.total_tok,
                                                self.n_heads, _ptr(self.pool_w), _ptr(ws), _ptr(out), self._stream()),

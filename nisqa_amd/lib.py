@@ -46,6 +46,8 @@ SYMBOLS = {
     'nisqa_cnn_adapt_segments_bf16': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_cnn_adapt_bf16x6': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_cnn_adapt_segments_bf16x6': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    'nisqa_cnn_adapt_f16': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p]),
+    'nisqa_cnn_adapt_segments_f16': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p]),
     'nisqa_cnn_adapt_segments': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_cnn_back': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_cnn_standard': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),

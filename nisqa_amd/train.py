@@ -133,6 +133,10 @@ class HipTrainer(object):
         self.lr = float(lr)
         self.n_layers = int(a['td_sa_num_layers'])
         self.heads = ['pool_layers.%d.model.' % h for h in range(5)] if a['model'] == 'NISQA_DIM' else ['pool.model.']
+        if self.n_layers > 4 or len(self.heads) > 8:
+            # csrc/train_td.hip is laid out for TDT_MAX_LAYERS = 4 / TDT_MAX_HEADS = 8 (the reference configurations use 2 / 5);
+            # deeper stacks take the operator-by-operator path, which has no such limit
+            self.fused_td = False
         self.pools = [tuple(a['cnn_pool_1']), tuple(a['cnn_pool_2']), tuple(a['cnn_pool_3'])]
         self.p_cnn, self.p_td, self.p_pool = float(a['cnn_dropout']), float(a['td_sa_dropout']), float(a['pool_att_dropout'] or 0)
         if self.p_pool:
@@ -522,10 +526,12 @@ class HipTrainer(object):
         self._ck(self.lib.nisqa_tdtrain_step(ctypes.byref(a), self._st()), 'nisqa_tdtrain_step')
         self._td_keep = keep                            # explicit masks / the label buffer stay alive until the step has run
         ws = self._td_ws
-        y_hat = ws[pl['yhat']:pl['yhat'] + B * H].view(B, H)
-        loss = ws[pl['loss']:pl['loss'] + 1]
+        # y_hat and the loss leave the persistent workspace as fresh tensors: the next step overwrites the workspace, and a
+        # caller that collects losses over steps must not see later values
+        y_hat = ws[pl['yhat']:pl['yhat'] + B * H].view(B, H).clone()
+        loss = ws[pl['loss']:pl['loss'] + 1].clone()
         if _dist.world()[1] > 1:
-            loss = _dist.all_reduce_sum_(loss.clone())
+            loss = _dist.all_reduce_sum_(loss)
         da = ws[pl['dfeat']:pl['dfeat'] + S * 384].view(S, 6, 64)
         return y_hat, loss, da
 

@@ -74,6 +74,9 @@ CNNX_W4 = CNNX_W3 + 18 * 2 * 3 * 512
 CNNX_W5 = CNNX_W4 + 36 * 2 * 3 * 512
 CNNX_W6 = CNNX_W5 + 36 * 2 * 3 * 512
 CNNX_U16S = CNNX_W6 + 36 * 2 * 3 * 512
+# two-term f16 fragments + per-layer constants (csrc/cnn_bf16.hip, formats F16X3 / F16X4)
+CNNH_META = CNNB_U16S
+CNNH_U16S = CNNB_U16S + 64
 
 TDB_PROJ = 0
 TDB_LAYER0 = TDB_PROJ + 24 * 2 * 2 * 512
@@ -241,8 +244,8 @@ def bf16_split(x, terms=2):
     return out
 
 
-def conv_b_fragments_bf16(wf, terms=2):
-    """wf [cout][cin][3][3] float32 (BN-scaled) -> uint16 [9*cin/16][NT][terms][64][8]"""
+def conv_b_fragments_bf16(wf, terms=2, split=None):
+    """wf [cout][cin][3][3] float32 (BN-scaled) -> uint16 [9*cin/16][NT][terms][64][8]; split: bf16_split (default) or f16_split"""
     cout, cin = wf.shape[:2]
     S16, NT = cin // 16, cout // 32
     w9 = np.asarray(wf, np.float32).reshape(cout, cin, 9)
@@ -251,10 +254,10 @@ def conv_b_fragments_bf16(wf, terms=2):
     lane = _LANE[None, None, :, None]
     e = np.arange(8)[None, None, None, :]
     vals = w9[(lane & 31) + 32 * nt, 16 * (g % S16) + 8 * (lane >> 5) + e, g // S16]      # [G][NT][64][8]
-    return np.stack(bf16_split(vals, terms), 2).reshape(-1)                                # [G][NT][terms][64][8]
+    return np.stack((split or bf16_split)(vals, terms), 2).reshape(-1)                     # [G][NT][terms][64][8]
 
 
-def conv_b_fragments_bf16_nsplit(wf, terms=2):
+def conv_b_fragments_bf16_nsplit(wf, terms=2, split=None):
     """conv5/conv6 fragments for the N-split 16x16x32 form: uint16 [4 waves][18 steps][terms][64][8],
     value = W[n = 16*w + (lane&15)][c = 32*(g&1) + 8*(lane>>4) + e][tap = g>>1]"""
     w9 = np.asarray(wf, np.float32).reshape(64, 64, 9)
@@ -263,7 +266,7 @@ def conv_b_fragments_bf16_nsplit(wf, terms=2):
     lane = _LANE[None, None, :, None]
     e = np.arange(8)[None, None, None, :]
     vals = w9[16 * w + (lane & 15), 32 * (g & 1) + 8 * (lane >> 4) + e, g >> 1]             # [4][18][64][8]
-    return np.stack(bf16_split(vals, terms), 2).reshape(-1)
+    return np.stack((split or bf16_split)(vals, terms), 2).reshape(-1)
 
 
 def pack_adapt_cnn_bf16(sd, pfx='cnn.model.', conv1_pairs=False, terms=2):
@@ -296,6 +299,62 @@ def pack_adapt_cnn_bf16(sd, pfx='cnn.model.', conv1_pairs=False, terms=2):
         w, _ = fold_bn(sd, pfx, i)
         fr = conv_b_fragments_bf16_nsplit(w.astype(np.float32), terms) if i >= 5 else conv_b_fragments_bf16(w.astype(np.float32), terms)
         blob[off:off + fr.size] = fr
+    return blob
+
+
+# ---- two-term f16 fragments (csrc/cnn_bf16.hip, formats F16X3 / F16X4) ------------------------------------------------------
+def f16_split(x, terms=2):
+    """x (float32, |x| < 65504) -> list of `terms` uint16 arrays of f16 bit patterns with x ~= sum(parts): each term is the
+    round-to-nearest-even f16 of the running remainder (numpy's conversion = v_cvt_pk_f16_f32's).  Two terms hold 11 + 11
+    significand bits and the second term's sign: the fp32 value itself unless its remainder is an odd multiple of ulp32(x) beyond
+    2048 ulp32 -- then the pair is one fp32 ulp off (about a quarter of random values)."""
+    r = np.asarray(x, dtype=np.float32)
+    out = []
+    for _ in range(terms):
+        h = r.astype(np.float16)
+        out.append(h.view(np.uint16))
+        r = (r - h.astype(np.float32)).astype(np.float32)
+    return out
+
+
+def f16_val(b):
+    return np.asarray(b, dtype=np.uint16).view(np.float16).astype(np.float32)
+
+
+def pack_adapt_cnn_f16(sd, pfx='cnn.model.'):
+    """f16 hi/lo weight fragments for cnn_front_f16_kernel -> uint16 [CNNH_U16S]: the layout of pack_adapt_cnn_bf16(conv1_pairs=True,
+    terms=2) with f16 bit patterns of W_l * 2^kw_l (kw_l: the layer's largest |W| lands in [2^14, 2^15), so even weights 2^-24 of it
+    keep an absolute precision of 2^-39 of the largest), followed by the per-layer constants the kernel derives its activation
+    scales from (layout.hpp CNNH_META): int32 kw[6], float32 G[6] = max over output channels of sum |W| (BatchNorm folded, rounded
+    up), float32 T[6] = max |shift|.  |layer output| <= (largest |layer input|) * G + T."""
+    blob = np.zeros(CNNH_U16S, np.uint16)
+    meta_i = np.zeros(32, np.int32)
+    meta_f = meta_i.view(np.float32)
+    folded = [fold_bn(sd, pfx, i) for i in range(1, 7)]
+    for l, (w, t) in enumerate(folded):
+        w32 = np.asarray(w, np.float32)
+        wmax = float(np.abs(w32).max())
+        kw = 0 if wmax == 0 or not np.isfinite(wmax) else 15 - int(np.frexp(wmax)[1])        # wmax * 2^kw in [2^14, 2^15)
+        kw = int(min(max(kw, -60), 60))
+        meta_i[l] = kw
+        meta_f[8 + l] = np.float32(np.abs(w32.astype(np.float64)).reshape(w32.shape[0], -1).sum(1).max() * (1 + 1e-6))
+        meta_f[16 + l] = np.float32(np.abs(np.asarray(t, np.float32)).max() * (1 + 1e-6))
+    w1 = np.ldexp(np.asarray(folded[0][0], np.float32).reshape(16, 9), int(meta_i[0])).astype(np.float32)
+    full = np.zeros((64, 8), np.float32)
+    for lane in range(64):
+        j, h = lane & 31, lane >> 5
+        for e in range(8):
+            k = 8 * h + e
+            c, dm, kx, dmm = j & 15, j >> 4, k >> 2, k & 3
+            if k < 12 and 0 <= dmm - dm <= 2:
+                full[lane, e] = w1[c, (dmm - dm) * 3 + kx]
+    for t, part in enumerate(f16_split(full, 2)):
+        blob[CNNB_W1 + t * 512: CNNB_W1 + (t + 1) * 512] = part.reshape(-1)
+    for i, off in zip(range(2, 7), [CNNB_W2, CNNB_W3, CNNB_W4, CNNB_W5, CNNB_W6]):
+        ws = np.ldexp(np.asarray(folded[i - 1][0], np.float32), int(meta_i[i - 1])).astype(np.float32)
+        fr = conv_b_fragments_bf16_nsplit(ws, 2, split=f16_split) if i >= 5 else conv_b_fragments_bf16(ws, 2, split=f16_split)
+        blob[off:off + fr.size] = fr
+    blob[CNNH_META:CNNH_META + 64] = meta_i.view(np.uint16)
     return blob
 
 

@@ -1,8 +1,9 @@
 """GPU parity tests (run with -m gpu on an MI355X): HIP path vs the CPU oracle and the committed
 golden fixtures, stage by stage and end to end, through the C ABI (ctypes -> libnisqa_hip.so).
 
-Both precision paths of the engine are run: 'f32' (every GEMM on exact fp32 MFMA) and 'bf16x3' (default: AdaptCNN
-on split-bf16 MFMA).  Tolerances (floating point; the bar of BASELINE.json is |dMOS| <= 1e-3 end to end):
+Every precision path of the engine is run: 'f32' (every GEMM on exact fp32 MFMA), 'bf16x6' (the default: fp32 operands as three exact
+bf16 terms), 'f16x4' / 'f16x3' (two f16 terms of the scaled tensors) -- all four held to the 'f32' bounds -- and 'bf16x3' (two bf16 terms:
+16 operand bits, the fast mode).  Tolerances (floating point; the bar of BASELINE.json is |dMOS| <= 1e-3 end to end):
   mel dB        1e-3 dB   (f32 FFT vs librosa's f64 FFT; worst near the amin floor; measured <= 2.6e-4)
   CNN features  f32 2e-4 (measured 1.3e-5)   bf16x3 1e-3 (measured 1.5e-4, features reach |8|)
   td output     same bounds (measured 2e-6 / 1.6e-5)
@@ -31,10 +32,12 @@ def clip_pcm(i):
 
 PRECISIONS = ['f32', 'bf16x3']
 # 'bf16x6' (every GEMM on three exact bf16 terms per fp32 operand, six products): held to the SAME bounds as 'f32'
-PRECISIONS_SA = PRECISIONS + ['bf16x6']
+# 'f16x4' / 'f16x3' (AdaptCNN on two f16 terms of the power-of-two-scaled tensors, four / three products; self-attention and pooling as
+# in 'bf16x6'): the SAME bounds as 'f32' too
+PRECISIONS_SA = PRECISIONS + ['bf16x6', 'f16x4', 'f16x3']
 MEL_TOL = 1e-3          # dB
 # stage tolerances per precision path: (CNN features / td output, final outputs)
-TOL = {'f32': (2e-4, 1e-4), 'bf16x3': (1e-3, 2e-4), 'bf16x6': (2e-4, 1e-4)}
+TOL = {'f32': (2e-4, 1e-4), 'bf16x3': (1e-3, 2e-4), 'bf16x6': (2e-4, 1e-4), 'f16x4': (2e-4, 1e-4), 'f16x3': (2e-4, 1e-4)}
 
 
 def _engine(args, sd, precision=None):
@@ -296,7 +299,7 @@ def test_rounding_error_of_the_precision_modes_against_float64(weights):
     pcm = [clip_pcm(i) for i in (0, 1, 3)]
     err = {}
     ref = None
-    for prec in ('f32', 'bf16x6', 'bf16x3'):
+    for prec in ('f32', 'bf16x6', 'f16x4', 'f16x3', 'bf16x3'):
         eng = _engine(args, sd, prec)
         dev_pcm, plan = _upload(eng, pcm)
         mel, floor = eng.mel(dev_pcm, plan, 48000, clamp=False)
@@ -323,7 +326,11 @@ def test_rounding_error_of_the_precision_modes_against_float64(weights):
     floor32 = max(err['f32'][0], err['reference float32 (CPU torch)'][0])
     assert err['bf16x6'][0] <= 1.5 * floor32                   # features: within fp32 arithmetic's own distance from float64
     assert err['bf16x6'][1] <= 1.5 * max(err['f32'][1], err['reference float32 (CPU torch)'][1]) + 2.4e-7   # outputs (+ one ulp at |4|)
-    assert err['bf16x3'][0] > 2 * err['bf16x6'][0]             # (and the 16-bit-operand default is visibly further away)
+    assert err['bf16x3'][0] > 2 * err['bf16x6'][0]             # (and the 16-bit-operand fast mode is visibly further away)
+    # the two-term f16 formats (an operand may be one fp32 ulp off; fewer accumulator roundings than the fp32 MFMA chain): the same bounds
+    for prec in ('f16x4', 'f16x3'):
+        assert err[prec][0] <= 1.5 * floor32, (prec, err[prec], floor32)
+        assert err[prec][1] <= 1.5 * max(err['f32'][1], err['reference float32 (CPU torch)'][1]) + 2.4e-7, (prec, err[prec])
 
 
 def test_batch_composition_independence(eng_rand):
@@ -413,8 +420,9 @@ def test_predict_dir_drop_in_surface(tmp_path):
     assert np.abs(np.array([df2[c].iloc[0] for c in cols], np.float32) - ref).max() < 1e-3
 
 
-@pytest.mark.parametrize('ckpt,precision', [('nisqa.tar', 'bf16x3'), ('nisqa.tar', 'f32'), ('nisqa.tar', 'bf16x6'), ('nisqa_mos_only.tar', 'bf16x3'),
-                                            ('nisqa_tts.tar', 'bf16x3')])
+@pytest.mark.parametrize('ckpt,precision', [('nisqa.tar', 'bf16x3'), ('nisqa.tar', 'f32'), ('nisqa.tar', 'bf16x6'), ('nisqa.tar', 'f16x4'),
+                                            ('nisqa_mos_only.tar', 'bf16x3'), ('nisqa_mos_only.tar', 'bf16x6'),
+                                            ('nisqa_tts.tar', 'bf16x3'), ('nisqa_tts.tar', 'f32'), ('nisqa_tts.tar', 'bf16x6')])
 def test_against_the_live_reference_loop_on_fresh_random_clips(tmp_path, ckpt, precision, monkeypatch):
     """Not a committed fixture: FRESH clips every run (seed from os.urandom, printed), scored by the reference's OWN loop on
     the CPU -- NISQA_lib.py as shipped (staged by build() under oracle/_ref/nisqa, git-ignored): SpeechQualityDataset ->

@@ -36,11 +36,11 @@ def _header_defines(path):
 
 def test_layout_header_matches_python():
     env = _header_defines(os.path.join(ROOT, 'nisqa_amd', 'csrc', 'layout.hpp'))
-    names = [n for n in dir(W) if re.match(r'(CNN|CNNB|CNNX|CNNS|LSTM|TD|TDL|TDB|TDBL|TDX|TDXL|PL|PLB|PLX)_', n)]
+    names = [n for n in dir(W) if re.match(r'(CNN|CNNB|CNNX|CNNH|CNNS|LSTM|TD|TDL|TDB|TDBL|TDX|TDXL|PL|PLB|PLX)_', n)]
     assert len(names) > 30
     for n in names:
         assert env[n] == getattr(W, n), n
-        assert getattr(W, n) % (8 if n.startswith(('CNNB', 'CNNX', 'TDB', 'TDX', 'PLB', 'PLX')) else 4) == 0, n   # 16-byte aligned
+        assert getattr(W, n) % (8 if n.startswith(('CNNB', 'CNNX', 'CNNH', 'TDB', 'TDX', 'PLB', 'PLX')) else 4) == 0, n   # 16-byte aligned
 
 
 def test_conv_fragments_roundtrip():
@@ -82,6 +82,48 @@ def test_three_bf16_terms_hold_an_fp32_value_exactly_and_the_x6_fragments_are_th
         want = np.float32(w3.astype(np.float32).reshape(64, 32, 9)[n, c, tap])
         got = sum(val(fr[g, nt, t, lane, e:e + 1])[0] for t in range(3))
         assert np.float32(got) == want and got == np.float64(want)
+
+
+def test_two_f16_terms_hold_an_fp32_value_to_its_last_bit_or_one_ulp_and_the_f16_blob_carries_the_layer_constants():
+    """precision 'f16x4' / 'f16x3' (csrc/cnn_bf16.hip, formats F16X3 / F16X4): f16_split(x, 2) of a value scaled into f16's normal range is
+    the fp32 value itself or exactly one fp32 ulp off (an odd remainder beyond 2048 ulp32, about a quarter of random values); the CNNH
+    blob holds W * 2^kw with the layer's largest weight in [2^14, 2^15) and, behind the fragments, kw / G = max_c sum |W_c| / T = max
+    |shift| per layer -- the constants the kernel bounds every layer output with (|y| <= max|x| * G + T)."""
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(200000) * np.exp(rng.uniform(-3, 3, 200000))).astype(np.float32)
+    x = np.ldexp(x / np.abs(x).max(), 15).astype(np.float32)            # max in [2^14, 2^15) like every scaled tensor
+    x = x[np.abs(x) >= 0.25]                                             # (below 2^-2 the low term is subnormal: absolute precision 2^-25)
+    hi, lo = W.f16_split(x, 2)
+    rec = W.f16_val(hi).astype(np.float64) + W.f16_val(lo).astype(np.float64)
+    ulps = np.abs(rec - x.astype(np.float64)) / np.spacing(np.abs(x)).astype(np.float64)
+    assert set(np.unique(ulps)) <= {0.0, 1.0} and 0.70 < (ulps == 0).mean() < 0.80
+    small = np.float32(3e-4)                                              # subnormal low term: absolute error <= 2^-25
+    h2, l2 = W.f16_split(np.array([small]), 2)
+    assert abs(float(W.f16_val(h2)[0]) + float(W.f16_val(l2)[0]) - float(small)) <= 2.0 ** -25
+    sd = synth.random_state_dict(7)
+    blob = W.pack_adapt_cnn_f16(sd)
+    assert blob.dtype == np.uint16 and blob.size == W.CNNH_U16S
+    mi, mf = blob[W.CNNH_META:].view(np.int32), blob[W.CNNH_META:].view(np.float32)
+    for l in range(1, 7):
+        w, t = W.fold_bn(sd, 'cnn.model.', l)
+        w32 = w.astype(np.float32)
+        kw = int(mi[l - 1])
+        assert 2.0 ** 14 <= np.abs(w32).max() * 2.0 ** kw < 2.0 ** 15
+        assert mf[8 + l - 1] >= np.abs(w32.astype(np.float64)).reshape(w32.shape[0], -1).sum(1).max() and mf[8 + l - 1] < 1.0001 * np.abs(w).reshape(w.shape[0], -1).sum(1).max()
+        assert mf[16 + l - 1] >= np.abs(t.astype(np.float32)).max()
+    # conv3 / conv5 fragments: hi + lo = W * 2^kw to the pair's precision, in the two-term bf16 blob's layout
+    w3, _ = W.fold_bn(sd, 'cnn.model.', 3)
+    fr = blob[W.CNNB_W3:W.CNNB_W4].reshape(18, 2, 2, 64, 8)
+    val = (W.f16_val(fr[:, :, 0]).astype(np.float64) + W.f16_val(fr[:, :, 1])) * 2.0 ** -int(mi[2])
+    for g, nt, lane, e in [(0, 0, 0, 0), (17, 1, 63, 7), (9, 1, 37, 3)]:
+        ref = np.float32(w3[(lane & 31) + 32 * nt, 16 * (g % 2) + 8 * (lane >> 5) + e, (g // 2) // 3, (g // 2) % 3])
+        assert abs(val[g, nt, lane, e] - ref) <= max(np.spacing(np.abs(ref)), 2.0 ** (-25 - int(mi[2])))
+    w5, _ = W.fold_bn(sd, 'cnn.model.', 5)
+    fr = blob[W.CNNB_W5:W.CNNB_W6].reshape(4, 18, 2, 64, 8)
+    val = (W.f16_val(fr[:, :, 0]).astype(np.float64) + W.f16_val(fr[:, :, 1])) * 2.0 ** -int(mi[4])
+    for wv, g, lane, e in [(0, 0, 0, 0), (3, 17, 63, 7), (2, 5, 21, 2)]:
+        ref = np.float32(w5[16 * wv + (lane & 15), 32 * (g & 1) + 8 * (lane >> 4) + e, (g >> 1) // 3, (g >> 1) % 3])
+        assert abs(val[wv, g, lane, e] - ref) <= max(np.spacing(np.abs(ref)), 2.0 ** (-25 - int(mi[4])))
 
 
 def test_three_term_linear_fragments_hold_the_weights_exactly():
