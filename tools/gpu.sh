@@ -21,7 +21,7 @@ for step in "$@"; do
   case $kind in
     tests|parity|train)
       files="tests"; [ $kind = parity ] && files=tests/test_gpu_parity.py; [ $kind = train ] && files=tests/test_gpu_train.py
-      if [ -n "$arg" ]; then timeout 1500 python -m pytest $files -m gpu -x -q -k "$arg" > $O/pytest_$n.log 2>&1; else timeout 1500 python -m pytest $files -m gpu -x -q > $O/pytest_$n.log 2>&1; fi
+      if [ -n "$arg" ]; then timeout 1500 python -m pytest $files -m gpu -x -q -rP -k "$arg" > $O/pytest_$n.log 2>&1; else timeout 1500 python -m pytest $files -m gpu -x -q -rP > $O/pytest_$n.log 2>&1; fi
       echo "pytest rc $?"; grep -E "max \||float64|live reference" $O/pytest_$n.log | tail -12; tail -6 $O/pytest_$n.log;;
     bench)
       timeout 600 python bench.py ${arg//,/ } > $O/bench_$n.json 2> $O/bench_$n.err || tail -5 $O/bench_$n.err
