@@ -641,13 +641,8 @@ static int fb_launch(int fmt, bool segx, bool p3, const float* mel_tm, const int
         cnn_front_f16_kernel<false, false>, cnn_front_f16_kernel<false, true>, cnn_front_f16_kernel<true, false>, cnn_front_f16_kernel<true, true>};
     const int which = fmt == 0 ? (segx ? 2 : p3 ? 1 : 0) : 3 + 2 * (fmt - 1) + (segx ? 1 : 0);
     NQ_LAUNCH_BEGIN();
-    static std::atomic<bool> attr[7][64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!attr[which][dev].load(std::memory_order_relaxed)) {
-        if (hipFuncSetAttribute((const void*)kernels[which], hipFuncAttributeMaxDynamicSharedMemorySize, (int)FB_LDS) != hipSuccess) return 2;
-        attr[which][dev].store(true, std::memory_order_relaxed);
-    }
+    static std::atomic<bool> lds_ok[7][64];
+    if (nq_lds_opt_in((const void*)kernels[which], (int)FB_LDS, lds_ok[which])) return 2;
     hipLaunchKernelGGL(kernels[which], dim3(total_tok_padded / 4), dim3(256), FB_LDS, (hipStream_t)stream, mel_tm, frame_off, tok_off, n_wins,
                        clip_floor, n_clips, seg_hop, cnn_w, cnn_wb, p3_opt, feat, seg_x, seg_L, clip_max_enc, top_db);
     return NQ_LAUNCH_STATUS();

@@ -496,14 +496,8 @@ static int x6_launch(const float* mel_tm, const int32_t* frame_off, const int32_
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
     // 117 KB of dynamic LDS is above the 64 KB default: opted in once per device ordinal (a process may drive several GPUs)
-    static std::atomic<bool> attr[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!attr[dev].load(std::memory_order_relaxed)) {
-        if (hipFuncSetAttribute((const void*)cnn_front_bf16x6_kernel<SEGX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X_LDS) != hipSuccess)
-            return 2;
-        attr[dev].store(true, std::memory_order_relaxed);
-    }
+    static std::atomic<bool> lds_ok[64];                  // (one array per SEGX instantiation)
+    if (nq_lds_opt_in((const void*)cnn_front_bf16x6_kernel<SEGX>, (int)X_LDS, lds_ok)) return 2;
     hipLaunchKernelGGL(cnn_front_bf16x6_kernel<SEGX>, dim3(total_tok_padded / 4), dim3(256), X_LDS, (hipStream_t)stream, mel_tm,
                        frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_w, cnn_wx, feat, clip_max_enc, top_db, seg_x, seg_L);
     return NQ_LAUNCH_STATUS();

@@ -465,6 +465,8 @@ extern "C" int nisqa_cnn_standard_bf16(const float* mel_tm, const int32_t* frame
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat20)
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
+    static std::atomic<bool> lds_ok[64];                  // 70.6 KB of dynamic LDS: above the 64 KB default
+    if (nq_lds_opt_in((const void*)cnn_std_bf16_kernel, (int)SS_LDS, lds_ok)) return 2;
     hipLaunchKernelGGL(cnn_std_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), SS_LDS, (hipStream_t)stream, mel_tm,
                        frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_std_w, cnn_wb, feat20);
     return NQ_LAUNCH_STATUS();

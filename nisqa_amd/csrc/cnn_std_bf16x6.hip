@@ -469,14 +469,8 @@ extern "C" int nisqa_cnn_standard_bf16x6(const float* mel_tm, const int32_t* fra
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wx || !feat20)
         return NISQA_ERR_ARG;
     NQ_LAUNCH_BEGIN();
-    static std::atomic<bool> attr[64];                       // 95 KB of dynamic LDS: opted in once per device ordinal
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!attr[dev].load(std::memory_order_relaxed)) {
-        if (hipFuncSetAttribute((const void*)cnn_std_bf16x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SS_LDS) != hipSuccess)
-            return 2;
-        attr[dev].store(true, std::memory_order_relaxed);
-    }
+    static std::atomic<bool> lds_ok[64];                     // 95 KB of dynamic LDS: opted in once per device ordinal
+    if (nq_lds_opt_in((const void*)cnn_std_bf16x6_kernel, (int)SS_LDS, lds_ok)) return 2;
     hipLaunchKernelGGL(cnn_std_bf16x6_kernel, dim3(total_tok_padded / 4), dim3(256), SS_LDS, (hipStream_t)stream, mel_tm,
                        frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_std_w, cnn_wx, feat20);
     return NQ_LAUNCH_STATUS();

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -87,6 +88,17 @@ NQ_DEV void stagger_odd_wave_slot(int first_round_blocks, int sleeps) {
     }
 }
 
+// A launch with more than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize on that kernel, per device: done once
+// per device ordinal (a process may drive several GPUs) behind a flag array the call site owns (one array per kernel).  0 = ok.
+static inline int nq_lds_opt_in(const void* kernel, int bytes, std::atomic<bool> (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!done[dev].load(std::memory_order_relaxed)) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return 2;
+        done[dev].store(true, std::memory_order_relaxed);
+    }
+    return 0;
+}
 // hipGetLastError() is sticky per thread and PyTorch routinely leaves benign errors behind (e.g.
 // hipPointerGetAttributes on pageable host memory).  Clear it before our launches, read it after.
 #define NQ_LAUNCH_BEGIN() (void)hipGetLastError()

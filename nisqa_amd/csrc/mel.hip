@@ -570,7 +570,11 @@ static int mel_db_launch(const T* pcm, const int64_t* clip_off, const int32_t* f
     }
     const int per_wg = waves * frames_per_wave;
     const dim3 grid((total_frames + per_wg - 1) / per_wg), block(64 * waves);
+    // up to 150.5 KB of dynamic LDS (the band table + per-wave planes): every instantiation is opted in for the whole 160 KB once per device
+    static std::atomic<bool> lds_ok[5][64];
+    int which = 0, rc_attr = 0;
     auto go = [&](auto kernel) {
+        if ((rc_attr = nq_lds_opt_in((const void*)kernel, 160 * 1024, lds_ok[which])) != 0) return;
         hipLaunchKernelGGL(kernel, grid, block, lds, (hipStream_t)stream, pcm, clip_off, frame_off, n_clips, total_frames,
                            frames_per_wave, *cfg, mag_stride, w_floats, window, (const float2*)twiddle, band_start,
                            band_len, band_woff, band_w, mel_tm, clip_max_enc);
@@ -578,11 +582,12 @@ static int mel_db_launch(const T* pcm, const int64_t* clip_off, const int32_t* f
     // the two shipped front ends at 48 kHz get the instantiations with compile-time filter-bank trip counts (checked in the kernel)
     const int fb = getenv("NISQA_MEL_FB_GENERIC") ? 0 : (cfg->hop == 480 && cfg->win == 960 && cfg->n_bins == 1707) ? 1
                    : (cfg->hop == 480 && cfg->win == 960 && cfg->n_bins == 683) ? 2 : 0;
-    if (cfg->win <= 1024 && fb == 1) go(mel_frame_kernel<1, T, 1>);
-    else if (cfg->win <= 1024 && fb == 2) go(mel_frame_kernel<1, T, 2>);
-    else if (cfg->win <= 1024) go(mel_frame_kernel<1, T>);
-    else if (cfg->win <= 2048) go(mel_frame_kernel<2, T>);
-    else go(mel_frame_kernel<4, T>);
+    if (cfg->win <= 1024 && fb == 1) { which = 0; go(mel_frame_kernel<1, T, 1>); }
+    else if (cfg->win <= 1024 && fb == 2) { which = 1; go(mel_frame_kernel<1, T, 2>); }
+    else if (cfg->win <= 1024) { which = 2; go(mel_frame_kernel<1, T>); }
+    else if (cfg->win <= 2048) { which = 3; go(mel_frame_kernel<2, T>); }
+    else { which = 4; go(mel_frame_kernel<4, T>); }
+    if (rc_attr) return rc_attr;
     return NQ_LAUNCH_STATUS();
 }
 
