@@ -737,7 +737,7 @@ def main():
         roof = roofline_of(eng.precision, stage_ms['cnn_front'])
         roof['whole_path_tflops'] = round(FLOP_TOTAL * clips / dt / 1e12 / world, 2)
         k = pmc.get(CNN_KERNEL[eng.precision]) or {}
-        if k.get('GRBM_GUI_ACTIVE') and k.get('_ms'):
+        if k.get('GRBM_GUI_ACTIVE') and k.get('_ms', 0) >= 0.05:           # (not a clock for launches under ~50 us: tools/pmc_to_json.py)
             roof['shader_clock_mhz_profiled'] = round(k['GRBM_GUI_ACTIVE'] / 8.0 / (k['_ms'] * 1e-3) / 1e6, 0)
         if world == 1 and not a.no_extras and eng.precision != 'f32':
             sus = sus or mfma_sustained(dev)

@@ -43,7 +43,11 @@ def main():
         tt = t[t.Counter_Name == 'GRBM_GUI_ACTIVE']
         for k, v in ((tt.End_Timestamp - tt.Start_Timestamp) * 1e-6).groupby(tt.k).mean().items():
             kernels[k]['_ms'] = float(v)
-            kernels[k]['_shader_clock_mhz'] = round(kernels[k]['GRBM_GUI_ACTIVE'] / 8.0 / (v * 1e-3) / 1e6, 1)
+            # GRBM_GUI_ACTIVE / 8 (it is summed over the XCDs) over the launch's duration is the shader clock only when the launch
+            # is long against its dispatch / drain time: below ~50 us the counter also ticks before and after the timestamps and the
+            # quotient comes out above the chip's 2.4 GHz (r04: 3.0-3.5 GHz for the td_* / pool_* kernels).  Not a clock there.
+            if v >= 0.05:
+                kernels[k]['_shader_clock_mhz'] = round(kernels[k]['GRBM_GUI_ACTIVE'] / 8.0 / (v * 1e-3) / 1e6, 1)
     with open(out, 'w') as f:
         json.dump({'units': 'mean per launch; FETCH_SIZE / WRITE_SIZE in KiB (FETCH_SIZE counts half the bytes of wide reads on gfx950)',
                    'kernels': kernels}, f, indent=1, sort_keys=True)
