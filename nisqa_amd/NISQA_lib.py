@@ -326,9 +326,13 @@ def _loop_streams(device):
         nk = int(os.environ.get('NISQA_LOOP_KERNEL_STREAMS', '2'))
         ks = [torch.cuda.Stream(device=device) for _ in range(max(1, min(nk, 2)))]
         _STREAMS[key] = (torch.cuda.Stream(device=device, priority=-1), [ks[0], ks[-1]])
+        # a second copy-only stream (its own SDMA engine): the loop sends the two halves of a batch's PCM through the two, so that one
+        # engine's set-up between copies is covered by the other's transfer (round 5: the link idled 0.15-0.2 ms per batch)
+        _COPY2[key] = torch.cuda.Stream(device=device, priority=-1)
     return _STREAMS[key]
 
 
+_COPY2 = {}
 LOOP_STATS = {}                 # host seconds of the last _predict call by phase (tools/probe_loop.py)
 
 
@@ -360,9 +364,11 @@ def batch_policy(eng, ds, indices, bs):
                                byte_cap=int(os.environ.get('NISQA_BATCH_BYTES', BATCH_BYTE_CAP)))
 
 
-def _predict(model, ds, bs, dev, num_workers):
+def _predict(model, ds, bs, dev, num_workers, on_rows=None):
     """Shared body of predict_mos / predict_dim: returns y_hat [N, heads] float32 for ALL items of ds
-    (clip-sharded over ranks when torch.distributed is initialised, then gathered)."""
+    (clip-sharded over ranks when torch.distributed is initialised, then gathered).
+    on_rows(ids, rows): optional callback with every batch's item indices and [B, heads] float32 rows as they come back from
+    the device (nisqaModel.predict formats the table cells there, under the next batches' transfers)."""
     dev = torch.device(dev)
     if model._engine is None and dev.type != 'cuda':
         raise RuntimeError('nisqa_amd has no CPU path: device {} requested but the hot path runs only as HIP kernels '
@@ -417,6 +423,7 @@ def _predict(model, ds, bs, dev, num_workers):
         ing = _ingest.Ingest(ds, batches, pin=on_gpu, num_workers=num_workers, depth=int(os.environ.get('NISQA_LOOP_DEPTH', '3')),
                              device=eng.device if on_gpu else None)
         copy_stream, streams = _loop_streams(eng.device) if on_gpu else (None, [None, None])
+        copy2 = _COPY2.get(str(eng.device)) if on_gpu and os.environ.get('NISQA_LOOP_COPY_STREAMS', '2') != '1' else None
         inflight = []                                                   # (ids, host rows, event behind them)
         keep_inflight = max(1, int(os.environ.get('NISQA_LOOP_INFLIGHT', '2')))
         time_copies = on_gpu and os.environ.get('NISQA_LOOP_TIME_COPIES') == '1'     # tools: HIP events around every batch's H2D copies
@@ -433,6 +440,8 @@ def _predict(model, ds, bs, dev, num_workers):
                 if done is not None:
                     done.synchronize()
                 y_local[np.asarray(ids) - lo] = rows.numpy()
+                if on_rows is not None:
+                    on_rows(ids, rows.numpy())
             T['result_wait'] += clock() - t0
 
         t_it = clock()
@@ -441,7 +450,7 @@ def _predict(model, ds, bs, dev, num_workers):
             T['queue_wait'] += t_got - t_it
             st = streams[bi % 2]
             raw = ing.ring.buf[staged.slot]
-            sent, ev = [], None
+            sent, ev, ev2 = [], None, None
             try:
                 with (torch.cuda.stream(copy_stream) if on_gpu else _nullcontext()):
                     if time_copies:
@@ -451,7 +460,18 @@ def _predict(model, ds, bs, dev, num_workers):
                         plan = eng.plan(g.lengths, g.sr, names=g.names)
                         tables = plan.to(eng.device)
                         host = raw[g.offset:g.offset + g.nbytes].view(torch.int16 if g.is_i16 else torch.float32)
-                        pcm = host.to(eng.device, non_blocking=True)     # PCM16 stays int16: 2 bytes/sample over PCIe
+                        if copy2 is not None and host.numel() >= (1 << 22):
+                            # PCM16 stays int16 (2 bytes/sample over PCIe); the halves go through the two copy-only streams
+                            pcm = torch.empty(host.shape, dtype=host.dtype, device=eng.device)
+                            half = (host.numel() // 2 + 127) & ~127
+                            pcm[:half].copy_(host[:half], non_blocking=True)
+                            with torch.cuda.stream(copy2):
+                                pcm[half:].copy_(host[half:], non_blocking=True)
+                            pcm.record_stream(copy2)
+                            ev2 = torch.cuda.Event()
+                            ev2.record(copy2)
+                        else:
+                            pcm = host.to(eng.device, non_blocking=True)     # PCM16 stays int16: 2 bytes/sample over PCIe
                         sent.append((g, plan, tables, pcm))
                     if on_gpu:
                         ev = torch.cuda.Event(enable_timing=time_copies)
@@ -459,9 +479,17 @@ def _predict(model, ds, bs, dev, num_workers):
                         if time_copies:
                             copy_events.append((e0, ev))
             finally:
-                ing.ring.release_after(staged.slot, ev)
+                if ev2 is not None and ev is not None:
+                    copy_stream.wait_event(ev2)                      # the slot is free when BOTH halves have left it: one event
+                    ev_rel = torch.cuda.Event()                      # behind both streams (ring.release_after takes one)
+                    ev_rel.record(copy_stream)
+                    ing.ring.release_after(staged.slot, ev_rel)
+                else:
+                    ing.ring.release_after(staged.slot, ev)
             if on_gpu:
                 st.wait_event(ev)
+                if ev2 is not None:
+                    st.wait_event(ev2)
             with (torch.cuda.stream(st) if on_gpu else _nullcontext()):
                 for g, plan, tables, pcm in sent:
                     out = eng.forward_pcm(pcm, plan, g.sr)
@@ -499,17 +527,17 @@ def _predict(model, ds, bs, dev, num_workers):
     return _dist.gather_rows(y_local, n, lo, hi, dev, bounds)
 
 
-def predict_mos(model, ds, bs, dev, num_workers=0):
+def predict_mos(model, ds, bs, dev, num_workers=0, on_rows=None):
     """predict_mos (NL:1420-1439): fills ds.df['mos_pred'] (float64 like NL:1438), returns (y_hat, y)."""
-    y_hat = _predict(model, ds, bs, dev, num_workers)[:, :1]
+    y_hat = _predict(model, ds, bs, dev, num_workers, on_rows)[:, :1]
     y = ds.labels(len(ds))[:, :1]
     ds.df['mos_pred'] = y_hat.astype(dtype=float)
     return y_hat, y
 
 
-def predict_dim(model, ds, bs, dev, num_workers=0):
+def predict_dim(model, ds, bs, dev, num_workers=0, on_rows=None):
     """predict_dim (NL:1441-1467): fills mos/noi/dis/col/loud_pred columns, returns (y_hat, y)."""
-    y_hat = _predict(model, ds, bs, dev, num_workers)
+    y_hat = _predict(model, ds, bs, dev, num_workers, on_rows)
     y = ds.labels(len(ds))
     ds.df['mos_pred'] = y_hat[:, 0].reshape(-1, 1)
     ds.df['noi_pred'] = y_hat[:, 1].reshape(-1, 1)

@@ -8,6 +8,7 @@ nisqa_amd/evaluation.py).  ``train()`` runs the reference's epoch loop (nisqa_am
 """
 import datetime
 import os
+import time
 from glob import glob
 
 import numpy as np
@@ -145,11 +146,41 @@ def _load_checkpoint(path):
             'does (torch.load, full unpickler) if you trust its source.'.format(path, why)) from e
 
 
-def _fast_frame_lines(df, widest=None):
+class RowCells(object):
+    """'%.6f' cells of the prediction columns, filled batch by batch while the predict loop runs (NISQA_lib._predict's on_rows):
+    formatting the 100 000-row table the reference prints (NISQA_model.py:79) is 0.1 s of host time that otherwise follows the
+    last batch; here it happens under the next batches' transfers.  frame_to_string still cross-checks the result against pandas."""
+
+    def __init__(self, n_rows, names):
+        self.names = list(names)
+        self.cells = [[None] * n_rows for _ in self.names]
+
+    def __call__(self, ids, rows):
+        ids = [int(i) for i in ids]
+        v = np.asarray(rows, dtype=np.float64)               # float32 results widened like the DataFrame columns (NL:1438, 1455-1459)
+        for h, col in enumerate(self.cells[:v.shape[1]]):
+            for i, x in zip(ids, v[:, h].tolist()):
+                col[i] = '%.6f' % x
+
+    def column(self, name, values):
+        """the cells of column ``name`` if every row was seen and the first / last value agree with the frame's, else None"""
+        if name not in self.names:
+            return None
+        col = self.cells[self.names.index(name)]
+        if len(col) != len(values) or any(c is None for c in col):
+            return None
+        for i in (0, len(col) - 1):
+            if col[i] != '%.6f' % values[i]:
+                return None
+        return col
+
+
+def _fast_frame_lines(df, widest=None, pre=None):
     """The lines of ``df.to_string(index=False)`` for frames of plain float / integer / string columns, or None when
     the frame has anything else (pandas' rules restated: numeric headers carry a leading blank, floats are '%.6f' with
     the zeros common to the whole column trimmed, 'NaN' for missing, every cell right-justified to the column width).
-    ``widest``: optional list that receives, per column, the row of its longest cell."""
+    ``widest``: optional list that receives, per column, the row of its longest cell.  ``pre``: optional RowCells with
+    cells formatted while the loop ran."""
     if df.shape[0] == 0 or df.shape[1] == 0 or not df.columns.is_unique or df.columns.nlevels != 1:
         return None
     cols = []
@@ -161,7 +192,9 @@ def _fast_frame_lines(df, widest=None):
             a = np.abs(v[~np.isnan(v)])
             if a.size and (not np.isfinite(a).all() or (a > 1e6).any() or ((a < 1e-6) & (a > 0)).any()):
                 return None                                  # pandas switches to exponent notation
-            cells = ['%.6f' % x for x in v.tolist()]         # 'nan' for missing values
+            cells = pre.column(name, v) if pre is not None else None
+            if cells is None:
+                cells = ['%.6f' % x for x in v.tolist()]     # 'nan' for missing values
             cut = 0                                          # zeros every number of the column ends with
             while cut < 6 and a.size and all(c.endswith('0', 0, len(c) - cut) for c in cells if c != 'nan'):
                 cut += 1
@@ -191,14 +224,14 @@ def _fast_frame_lines(df, widest=None):
     return [' '.join(r) for r in zip(*cols)]
 
 
-def frame_to_string(df, check_rows=64):
+def frame_to_string(df, check_rows=64, pre=None):
     """``df.to_string(index=False)`` (what the reference prints, NISQA_model.py:79), an order of magnitude faster on the
     frames predict() produces: pandas needs 2.4 s for the 100 000 rows of a predict_csv run, more than the GPU needs to
     score them.  Falls back to pandas for any frame the fast path does not cover, and cross-checks itself against pandas
     on a sample of the rows that contains each column's widest cell."""
     try:
         widest = []
-        lines = _fast_frame_lines(df, widest)
+        lines = _fast_frame_lines(df, widest, pre)
         if lines is not None and len(df) > check_rows:
             pick = sorted(set(range(check_rows // 2)) | set(range(len(df) - check_rows // 2, len(df))) | set(widest))
             ref = df.iloc[pick].to_string(index=False).split('\n')
@@ -283,20 +316,29 @@ class nisqaModel(object):
         print('---> Predicting ...')
         # tr_parallel (nn.DataParallel in the reference, NISQA_model.py:56-57) is superseded: launch one
         # process per GPU with torchrun and the clips are sharded across ranks (nisqa_amd/dist.py).
-        if self.args['dim'] == True:  # noqa: E712  (mirrors the reference's comparison)
+        from . import dist as _dist
+        rank, world = _dist.world()
+        t0 = time.perf_counter()
+        # one process: the table's cells are formatted as the rows come back (under the following batches' transfers); several ranks
+        # receive the other shards' rows only in the closing all_gather, and format at the end
+        dim = self.args['dim'] == True  # noqa: E712  (mirrors the reference's comparison)
+        cells = RowCells(len(self.ds_val), ['mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred'] if dim else ['mos_pred']) \
+            if world == 1 and os.environ.get('NISQA_FORMAT_IN_LOOP', '1') != '0' else None
+        if dim:
             y_val_hat, y_val = NL.predict_dim(self.model, self.ds_val, self.args['tr_bs_val'], self.dev,
-                                              num_workers=self.args['tr_num_workers'])
+                                              num_workers=self.args['tr_num_workers'], on_rows=cells)
         else:
             y_val_hat, y_val = NL.predict_mos(self.model, self.ds_val, self.args['tr_bs_val'], self.dev,
-                                              num_workers=self.args['tr_num_workers'])
-        from . import dist as _dist
-        rank, _ = _dist.world()
+                                              num_workers=self.args['tr_num_workers'], on_rows=cells)
+        t1 = time.perf_counter()
         if self.args['output_dir']:
             self.ds_val.df['model'] = self.args['name']
             if rank == 0:
                 self.ds_val.df.to_csv(os.path.join(self.args['output_dir'], 'NISQA_results.csv'), index=False)
         if rank == 0:
-            print(frame_to_string(self.ds_val.df))
+            print(frame_to_string(self.ds_val.df, pre=cells))
+        # host seconds of this call: scoring (file list -> rows in the frame) and writing / printing the table
+        self.timing = {'predict_s': t1 - t0, 'table_s': time.perf_counter() - t1}
         return self.ds_val.df
 
     # ---- datasets (reference NISQA_model.py:732-847) ---------------------------------------------

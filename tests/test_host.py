@@ -1089,6 +1089,41 @@ def test_frame_to_string_equals_pandas_to_string():
         assert frame_to_string(df) == df.to_string(index=False)
 
 
+def test_table_cells_formatted_inside_the_loop_give_the_reference_table(tmp_path, wav_dir, capsys, monkeypatch):
+    """Round 5: nisqaModel.predict() formats the '%.6f' cells of the prediction columns batch by batch while the loop runs
+    (NISQA_model.RowCells via NISQA_lib._predict(on_rows=...)) instead of behind the last batch; what is printed must be
+    df.to_string(index=False) character for character, with the in-loop path on and off, and a RowCells that missed a row or
+    disagrees with the frame is ignored."""
+    from nisqa_amd import NISQA_model as NM
+    outs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('NISQA_FORMAT_IN_LOOP', flag)
+        m = NM.nisqaModel(_args('predict_dir', _ckpt(tmp_path), data_dir=str(wav_dir)))
+        m.model._engine = FakeEngine(5)
+        seen = []
+        orig = NM.RowCells.__call__
+        monkeypatch.setattr(NM.RowCells, '__call__', lambda self, ids, rows: (seen.append(len(ids)), orig(self, ids, rows))[1])
+        df = m.predict()
+        monkeypatch.setattr(NM.RowCells, '__call__', orig)
+        out = capsys.readouterr().out
+        assert df.to_string(index=False) in out
+        assert (sum(seen) == len(df)) == (flag == '1')
+        assert set(m.timing) == {'predict_s', 'table_s'}
+        outs[flag] = out[out.index('deg  mos_pred'):]             # (a one-time note about the reader threads may precede the table)
+    assert outs['1'] == outs['0']
+    df = pd.DataFrame({'deg': ['a.wav', 'b.wav', 'c.wav'], 'mos_pred': np.array([1.25, 3.5, 4.125], np.float32).astype(np.float64)})
+    full = NM.RowCells(3, ['mos_pred'])
+    full([2, 0, 1], np.array([[4.125], [1.25], [3.5]], np.float32))
+    assert full.column('mos_pred', df['mos_pred'].to_numpy()) == ['1.250000', '3.500000', '4.125000']
+    assert NM.frame_to_string(df, pre=full) == df.to_string(index=False)
+    partial = NM.RowCells(3, ['mos_pred'])
+    partial([0, 1], np.array([[1.25], [3.5]], np.float32))
+    assert partial.column('mos_pred', df['mos_pred'].to_numpy()) is None
+    wrong = NM.RowCells(3, ['mos_pred'])
+    wrong([0, 1, 2], np.array([[9.0], [3.5], [4.125]], np.float32))
+    assert wrong.column('mos_pred', df['mos_pred'].to_numpy()) is None and NM.frame_to_string(df, pre=wrong) == df.to_string(index=False)
+
+
 def test_ingest_cpu_budget_reader_cap_ring_reuse_and_path_cache(tmp_path, monkeypatch):
     """Host details of the predict loop: the reader count respects the cgroup CPU quota, page-locked rings
     are handed from one loop to the next, file names come out of the DataFrame once and travel with the staged groups."""
