@@ -417,7 +417,6 @@ def side_predict_csv(dev, cpu):
                           'are formatted batch by batch inside the loop (under the next batches\' transfers) and table_s is what is left behind '
                           'the last batch in the timed call',
             'predict_s': round(timing.get('predict_s', float('nan')), 3), 'table_s': round(timing.get('table_s', float('nan')), 3),
-            'copy_streams': int(os.environ.get('NISQA_LOOP_COPY_STREAMS', '2')),
             'loop_host_s': {k: round(v, 3) for k, v in loop.items()},
             'cpu_baseline': cpu and {k: cpu[k] for k in ('value', 'unit', 'cores', 'kind')}}
 

@@ -326,13 +326,9 @@ def _loop_streams(device):
         nk = int(os.environ.get('NISQA_LOOP_KERNEL_STREAMS', '2'))
         ks = [torch.cuda.Stream(device=device) for _ in range(max(1, min(nk, 2)))]
         _STREAMS[key] = (torch.cuda.Stream(device=device, priority=-1), [ks[0], ks[-1]])
-        # a second copy-only stream (its own SDMA engine): the loop sends the two halves of a batch's PCM through the two, so that one
-        # engine's set-up between copies is covered by the other's transfer (round 5: the link idled 0.15-0.2 ms per batch)
-        _COPY2[key] = torch.cuda.Stream(device=device, priority=-1)
     return _STREAMS[key]
 
 
-_COPY2 = {}
 LOOP_STATS = {}                 # host seconds of the last _predict call by phase (tools/probe_loop.py)
 
 
@@ -423,7 +419,6 @@ def _predict(model, ds, bs, dev, num_workers, on_rows=None):
         ing = _ingest.Ingest(ds, batches, pin=on_gpu, num_workers=num_workers, depth=int(os.environ.get('NISQA_LOOP_DEPTH', '3')),
                              device=eng.device if on_gpu else None)
         copy_stream, streams = _loop_streams(eng.device) if on_gpu else (None, [None, None])
-        copy2 = _COPY2.get(str(eng.device)) if on_gpu and os.environ.get('NISQA_LOOP_COPY_STREAMS', '2') != '1' else None
         inflight = []                                                   # (ids, host rows, event behind them)
         keep_inflight = max(1, int(os.environ.get('NISQA_LOOP_INFLIGHT', '2')))
         time_copies = on_gpu and os.environ.get('NISQA_LOOP_TIME_COPIES') == '1'     # tools: HIP events around every batch's H2D copies
@@ -450,7 +445,7 @@ def _predict(model, ds, bs, dev, num_workers, on_rows=None):
             T['queue_wait'] += t_got - t_it
             st = streams[bi % 2]
             raw = ing.ring.buf[staged.slot]
-            sent, ev, ev2 = [], None, None
+            sent, ev = [], None
             try:
                 with (torch.cuda.stream(copy_stream) if on_gpu else _nullcontext()):
                     if time_copies:
@@ -460,18 +455,10 @@ def _predict(model, ds, bs, dev, num_workers, on_rows=None):
                         plan = eng.plan(g.lengths, g.sr, names=g.names)
                         tables = plan.to(eng.device)
                         host = raw[g.offset:g.offset + g.nbytes].view(torch.int16 if g.is_i16 else torch.float32)
-                        if copy2 is not None and host.numel() >= (1 << 22):
-                            # PCM16 stays int16 (2 bytes/sample over PCIe); the halves go through the two copy-only streams
-                            pcm = torch.empty(host.shape, dtype=host.dtype, device=eng.device)
-                            half = (host.numel() // 2 + 127) & ~127
-                            pcm[:half].copy_(host[:half], non_blocking=True)
-                            with torch.cuda.stream(copy2):
-                                pcm[half:].copy_(host[half:], non_blocking=True)
-                            pcm.record_stream(copy2)
-                            ev2 = torch.cuda.Event()
-                            ev2.record(copy2)
-                        else:
-                            pcm = host.to(eng.device, non_blocking=True)     # PCM16 stays int16: 2 bytes/sample over PCIe
+                        # PCM16 stays int16: 2 bytes/sample over PCIe.  (Round 5 sent the halves of a batch through TWO copy-only
+                        # streams so that one engine's set-up would be covered by the other's transfer: 48.6 / 47.7 k clips/s against
+                        # 50.4 / 52.3 k with one stream on the same box -- two SDMA queues share the link worse than one fills it.)
+                        pcm = host.to(eng.device, non_blocking=True)
                         sent.append((g, plan, tables, pcm))
                     if on_gpu:
                         ev = torch.cuda.Event(enable_timing=time_copies)
@@ -479,17 +466,9 @@ def _predict(model, ds, bs, dev, num_workers, on_rows=None):
                         if time_copies:
                             copy_events.append((e0, ev))
             finally:
-                if ev2 is not None and ev is not None:
-                    copy_stream.wait_event(ev2)                      # the slot is free when BOTH halves have left it: one event
-                    ev_rel = torch.cuda.Event()                      # behind both streams (ring.release_after takes one)
-                    ev_rel.record(copy_stream)
-                    ing.ring.release_after(staged.slot, ev_rel)
-                else:
-                    ing.ring.release_after(staged.slot, ev)
+                ing.ring.release_after(staged.slot, ev)
             if on_gpu:
                 st.wait_event(ev)
-                if ev2 is not None:
-                    st.wait_event(ev2)
             with (torch.cuda.stream(st) if on_gpu else _nullcontext()):
                 for g, plan, tables, pcm in sent:
                     out = eng.forward_pcm(pcm, plan, g.sr)

@@ -395,7 +395,11 @@ class Ingest(object):
         """Batches of a LengthAware policy: yields (idx, probed) window by window; the headers of window w + 1 are
         probed on a helper thread while the batches of window w are staged."""
         pol = self.batches
-        wins = [pol.indices[s:s + pol.window] for s in range(0, len(pol.indices), pol.window)]
+        # the FIRST window is small: its probe and cut run before anything is staged (25-35 ms for 16 384 headers -- 1.5 % of a
+        # 100 000-row job during which the link carries nothing); every later window is prepared under the one before it
+        first = min(pol.window, 2048)
+        starts = [0] + list(range(first, len(pol.indices), pol.window)) if len(pol.indices) > first else [0]
+        wins = [pol.indices[s:e] for s, e in zip(starts, starts[1:] + [len(pol.indices)])] if len(pol.indices) else []
         box = {}
 
         def probe_into(w):
