@@ -486,9 +486,10 @@ def side_tts(dev, reps, cpu_baseline_on, pmc, two_streams=True):
                    for bi in range(nb)])                     # [batch][mel, cnn, (unused), lstm + pool]
     cnn_ms, lstm_ms = float(ms[:, 1].sum()), float(ms[:, 3].sum())
     ach = float(segs.sum()) * FLOP_STD_SEG / (cnn_ms * 1e-3) / 1e12
-    kname = {'bf16x3': 'cnn_std_bf16_kernel', 'bf16x6': 'cnn_std_bf16x6_kernel'}.get(eng.precision, 'cnn_std_kernel')
+    kname = {'bf16x3': 'cnn_std_bf16_kernel', 'bf16x6': 'cnn_std_bf16x6_kernel', 'f16x4': 'cnn_std_f16_kernel', 'f16x3': 'cnn_std_f16_kernel'}.get(eng.precision, 'cnn_std_kernel')
     kdesc = {'bf16x3': 'split-bf16 MFMA: 3 products per term pair', 'bf16x6': 'three exact bf16 terms per fp32 operand: 6 MFMA products per term pair',
-             'f32': 'fp32 MFMA'}[eng.precision]
+             'f16x4': 'two f16 terms per fp32 operand of the scaled tensors: 4 MFMA products per term pair',
+             'f16x3': 'two f16 terms per fp32 operand of the scaled tensors: 3 MFMA products per term pair', 'f32': 'fp32 MFMA'}[eng.precision]
     kpeak = PEAK_F32 if eng.precision == 'f32' else PEAK_BF16_MFMA
     tr, mu = pmc_derived(pmc.get('tts:' + kname))
     res = {'config': 'configs[3] predict_dir nisqa_tts.tar (Naturalness head), %d clips, durations rng(7).uniform(3, 30) s '
@@ -511,7 +512,7 @@ def side_tts(dev, reps, cpu_baseline_on, pmc, two_streams=True):
         # the same job in the other precision modes: the exact-fp32 kernels (the reference's arithmetic), 'bf16x6' (fp32 operands as
         # three exact bf16 terms, six products: held to the bounds of 'f32' by the parity tests), 'bf16x3' (two terms: the fast mode);
         # the BiLSTM is fp32 VALU in every mode
-        for prec in [q for q in ('f32', 'bf16x6', 'bf16x3') if q != eng.precision]:
+        for prec in [q for q in ALL_PRECISIONS if q != eng.precision]:
             e2 = HipNisqa(targs, tsd, dev, precision=prec)
             for plan, x in batches:
                 o2 = e2.forward_pcm(x, plan, SR)

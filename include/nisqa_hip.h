@@ -233,6 +233,12 @@ int nisqa_cnn_standard_bf16x6(const float* mel_tm, const int32_t* frame_off, con
                               const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                               int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
                               const uint16_t* cnn_wx, float* feat20, void* stream);
+/* nisqa_cnn_standard on two-term f16 operands of the power-of-two-scaled tensors (see nisqa_cnn_adapt_f16; products = 3 or 4;
+ * cnn_wh = nisqa_amd.weights.pack_adapt_cnn_f16 of the StandardCNN's convolutions, fc_out stays fp32 VALU). */
+int nisqa_cnn_standard_f16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                           const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                           int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
+                           const uint16_t* cnn_wh, int32_t products, float* feat20, void* stream);
 int nisqa_lstm_laststep(const float* feat20, const int32_t* tok_off, const int32_t* n_wins,
                         int32_t n_clips, const float* lstm_w, float* hfin_ws, float* seq_opt,
                         float* out, void* stream);
@@ -257,8 +263,9 @@ typedef struct {
                               * nisqa_pool_att_bf16x6; cnn_wb / td_wb / pool_wb = their three-term fragments; td_wb or
                               * pool_wb NULL: self-attention and pooling on the exact fp32 kernels; arch 1: nisqa_cnn_standard_bf16x6, the
                               * BiLSTM is fp32 in every mode),
-                              * 3 / 4 = arch 0 only: AdaptCNN on two-term f16 operands with 3 / 4 products (nisqa_cnn_adapt_f16, cnn_wb =
-                              * its CNNH blob); self-attention and pooling as in mode 2 (td_wb / pool_wb = three-term fragments) */
+                              * 3 / 4 = the CNN on two-term f16 operands with 3 / 4 products (arch 0: nisqa_cnn_adapt_f16, arch 1:
+                              * nisqa_cnn_standard_f16; cnn_wb = the CNNH blob); self-attention and pooling as in mode 2 (td_wb / pool_wb =
+                              * three-term fragments) */
     const uint16_t* td_wb;   /* split-bf16 self-attention fragments, or NULL */
     const uint16_t* pool_wb; /* split-bf16 pooling fragments, or NULL */
     int32_t arch;            /* 0 = CNN-SA-AP (nisqa.tar, nisqa_mos_only.tar); 1 = StandardCNN + BiLSTM + last-step

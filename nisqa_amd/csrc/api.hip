@@ -60,7 +60,7 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
                                   mel, cmax, stream);
     if (rc) return rc;
     // the split-bf16 AdaptCNN kernel derives the top_db floor from cmax itself; the other CNN kernels take clip_floor
-    if (model->cnn_mode < 0 || model->cnn_mode > 4 || (model->arch == 1 && model->cnn_mode > 2)) return NISQA_ERR_ARG;
+    if (model->cnn_mode < 0 || model->cnn_mode > 4) return NISQA_ERR_ARG;
     const bool floor_in_cnn = model->arch == 0 && model->cnn_mode >= 1;
     if (!floor_in_cnn) {
         rc = nisqa_mel_finalize(mel, frame_off, n_clips, total_frames, cmax, cfg->top_db, cfloor, 0, stream);
@@ -76,6 +76,9 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
              : model->cnn_mode == 2
                  ? nisqa_cnn_standard_bf16x6(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded,
                                              model->seg_hop, model->cnn_w, model->cnn_wb, feat, stream)
+             : model->cnn_mode >= 3
+                 ? nisqa_cnn_standard_f16(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded,
+                                          model->seg_hop, model->cnn_w, model->cnn_wb, model->cnn_mode, feat, stream)
                  : nisqa_cnn_standard(mel, frame_off, tok_off, n_wins, cfloor, n_clips, total_tok_padded,
                                       model->seg_hop, model->cnn_w, p3, feat, stream);
         if (rc) return rc;

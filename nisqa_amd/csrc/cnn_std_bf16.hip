@@ -44,13 +44,13 @@ NQ_DEV float row16_sum_dpp(float v) {
 // pixel's chunk for taps in its own image row, the flipped chunk for the rows above and below -- plus a compile-time tap
 // offset; validity is a lane-static 9-bit mask, out-of-image taps read the workgroup's zero block, fragments come through
 // the buffer descriptor.  One K-step per tap (16 channels), A rows one tap ahead, B fragments two.
-template <int MT>
+template <int MT, int FMT = NQ_FMT_BF16X3>
 NQ_DEV void conv_k_bf16_c16(f32x16 (&acc)[MT][1], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
                             const unsigned (&a_same)[MT], const unsigned (&a_flip)[MT], const unsigned (&m9)[MT]) {
-    f32x4 bh[3], bl[3], ah[2][MT], al[2][MT];
+    f32x4 bh[3][1], bl[3][1], ah[2][MT], al[2][MT];
     auto load_b = [&](int g, int slot) {
-        bh[slot] = wfrag_load(rsrc, lane16, wbyte + (g * 2 + 0) * 1024);
-        bl[slot] = wfrag_load(rsrc, lane16, wbyte + (g * 2 + 1) * 1024);
+        bh[slot][0] = wfrag_load(rsrc, lane16, wbyte + (g * 2 + 0) * 1024);
+        bl[slot][0] = wfrag_load(rsrc, lane16, wbyte + (g * 2 + 1) * 1024);
     };
     auto load_a = [&](int g, int slot) {
         const int dy = g / 3, dx = g % 3;
@@ -71,21 +71,33 @@ NQ_DEV void conv_k_bf16_c16(f32x16 (&acc)[MT][1], __amdgpu_buffer_rsrc_t rsrc, i
         if (g + 2 < 9) load_b(g + 2, (g + 2) % 3);
         if (g + 1 < 9) load_a(g + 1, (g + 1) & 1);
         const int sa = g & 1, sb = g % 3;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t][0] = mfma_bf(ah[sa][t], bl[sb], acc[t][0]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t][0] = mfma_bf(al[sa][t], bh[sb], acc[t][0]);
-#pragma unroll
-        for (int t = 0; t < MT; ++t) acc[t][0] = mfma_bf(ah[sa][t], bh[sb], acc[t][0]);
+        mma_pair_fmt<FMT, MT, 1>(acc, ah[sa], al[sa], bh[sb], bl[sb]);
     }
 }
 
-__global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
+// the per-row scale tables of the f16 formats' conv5 / conv6 epilogues (the LDS below the zero block is otherwise unused)
+#define SS_TAB5 0u                         /* [48 rows] {2^(e5 - e4 - kw5), 2^e5} of the row's segment */
+#define SS_TAB6 1024u                      /* [48 rows] 2^-(e5 + kw6) */
+NQ_DEV f32x2_t ss_ld64(unsigned a) { return *(NQ_AS3 const f32x2_t*)(a); }
+template <int FMT>
+NQ_DEV float ss_epi(float v, float c, float t) { return FMT == NQ_FMT_BF16X3 ? fmaxf(v + t, 0.f) : fmaxf(fmaf(v, c, t), 0.f); }
+
+// FMT (conv_bf16.hpp): NQ_FMT_BF16X3 -- bf16 hi + lo, three products (the input keeps a third term) -- or the f16 formats: every
+// tensor as f16 hi + lo of y * 2^e, e from the measured maximum of the layer's input and the layer's weight norm (cnn_bf16.hip's
+// scheme: |y| <= m_in * G + T), three or four products; wb is then the CNNH_ blob (weights.pack_adapt_cnn_f16)
+template <int FMT>
+NQ_DEV void cnn_std_split_body(
     const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off,
     const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
     const float* __restrict__ clip_floor, int n_clips, int seg_hop,
     const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ feat20) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool F16 = FMT != NQ_FMT_BF16X3;
+    const int* __restrict__ meta_i = (const int*)(wb + CNNH_META);         // F16: kw[l], G[l] at +8, T[l] at +16 (l = layer - 1)
+    const float* __restrict__ meta_f = (const float*)(wb + CNNH_META);
+    float dummy_mx = 0.f;
+    int e_in = 0;                                                           // F16: scale exponent / largest magnitude of the tensor
+    float m_in = 0.f;                                                       //      the next layer reads
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p0 = blockIdx.x * 4;                      // tok_off is a multiple of 32: no clip straddling
@@ -120,18 +132,31 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
             const int e = lane + 16 * u, j0 = e >= 48 ? 1 : 0, m = e - 48 * j0;
             ob[u] = pb + ((j0 + 1) * 50 + m + 1) * 2;
         }
+        float s0 = 1.f;
+        if (F16) {                                          // the window's own largest magnitude fixes its scale
+            float mr = 0.f;
+#pragma unroll
+            for (int q = 0; q < 12; ++q) mr = fmaxf(mr, valid ? __builtin_fabsf(fmaxf(vraw[q], fl)) : 0.f);
+            m_in = wave_max_nonneg(mr);
+            e_in = f16_scale_exp(m_in);
+            s0 = pow2_f32(e_in);
+        }
 #pragma unroll
         for (int q = 0; q < 12; ++q) {
             const float v = valid ? fmaxf(vraw[q], fl) : 0.f;
-            const unsigned hi = cvt_pk_bf16(v, 0.f);
-            const float r1 = v - __uint_as_float(hi << 16);
-            const unsigned mid = cvt_pk_bf16(r1, 0.f);
-            const unsigned lo = cvt_pk_bf16(r1 - __uint_as_float(mid << 16), 0.f);
             const unsigned a = ob[q % 3] + (q + q / 3) * 100;
-            if (q < 11 || lane < 16) {
-                lds_st16(a, hi);
-                lds_st16(a + SS_PPLANE, mid);
-                lds_st16(a + 2 * SS_PPLANE, lo);
+            if (F16) {
+                if (q < 11 || lane < 16) lds_store_one_fmt<FMT>(a, SS_PPLANE, v * s0, dummy_mx);
+            } else {
+                const unsigned hi = cvt_pk_bf16(v, 0.f);
+                const float r1 = v - __uint_as_float(hi << 16);
+                const unsigned mid = cvt_pk_bf16(r1, 0.f);
+                const unsigned lo = cvt_pk_bf16(r1 - __uint_as_float(mid << 16), 0.f);
+                if (q < 11 || lane < 16) {
+                    lds_st16(a, hi);
+                    lds_st16(a + SS_PPLANE, mid);
+                    lds_st16(a + 2 * SS_PPLANE, lo);
+                }
             }
         }
     }
@@ -154,7 +179,13 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
         f32x4 w1[3];
 #pragma unroll
         for (int t = 0; t < 3; ++t) w1[t] = wfrag_load(wrs, lane * 16, (CNNB_W1 + t * 512) * 2);
-        const float tn = cw[CNN_T1 + (n & 15)];
+        float tn = cw[CNN_T1 + (n & 15)], c1 = 1.f, ms1 = 0.f;
+        int e1 = 0;
+        if (F16) {
+            e1 = f16_scale_exp(fmaf(m_in, meta_f[8], meta_f[16]));
+            c1 = pow2_f32(e1 - e_in - meta_i[0]);
+            tn *= pow2_f32(e1);
+        }
         const int xq = min(qi, 14);                       // row 15 of a tile is padding (result unused)
         unsigned rd_a = R + SS_PATCH + ((xq + (h ? 2 : 0)) * 50 + 24 * hfi) * 2;
         unsigned rd_b = R + SS_PATCH + ((xq + (h ? 2 : 1)) * 50 + 24 * hfi) * 2;
@@ -171,25 +202,32 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {              // dword reads (ds_read2_b32): the pairs are only 4-byte aligned
+                for (int t = 0; t < (F16 ? 2 : 3); ++t) {  // dword reads (ds_read2_b32): the pairs are only 4-byte aligned
                     const unsigned pa = rd_a + 4 * tt + t * SS_PPLANE, pq = rd_b + 4 * tt + t * SS_PPLANE;
                     xa[tt][t] = f32x4{__uint_as_float(lds_ld32(pa)), __uint_as_float(lds_ld32(pa + 4)),
                                       __uint_as_float(lds_ld32(pq)), __uint_as_float(lds_ld32(pq + 4))};
                 }
             acc[0] = zero16();
             acc[1] = zero16();
+            if (F16) {
+                if (FMT == NQ_FMT_F16X4) { acc[0] = mfma32_fmt<FMT>(xa[0][1], w1[1], acc[0]); acc[1] = mfma32_fmt<FMT>(xa[1][1], w1[1], acc[1]); }
+                acc[0] = mfma32_fmt<FMT>(xa[0][1], w1[0], acc[0]); acc[1] = mfma32_fmt<FMT>(xa[1][1], w1[0], acc[1]);
+                acc[0] = mfma32_fmt<FMT>(xa[0][0], w1[1], acc[0]); acc[1] = mfma32_fmt<FMT>(xa[1][0], w1[1], acc[1]);
+                acc[0] = mfma32_fmt<FMT>(xa[0][0], w1[0], acc[0]); acc[1] = mfma32_fmt<FMT>(xa[1][0], w1[0], acc[1]);
+            } else {
             acc[0] = mfma_bf(xa[0][2], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][2], w1[0], acc[1]);   // smallest products first
             acc[0] = mfma_bf(xa[0][1], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[1], acc[1]);
             acc[0] = mfma_bf(xa[0][0], w1[2], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[2], acc[1]);
             acc[0] = mfma_bf(xa[0][1], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][1], w1[0], acc[1]);
             acc[0] = mfma_bf(xa[0][0], w1[1], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[1], acc[1]);
             acc[0] = mfma_bf(xa[0][0], w1[0], acc[0]); acc[1] = mfma_bf(xa[1][0], w1[0], acc[1]);
+            }
             unsigned r[16];
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int tt = v >> 3, bb = v & 7;
                 const float mx = bb ? fmaxf(acc[tt][2 * bb - 1], acc[tt][2 * bb]) : acc[tt][0];   // frames
-                r[v] = __float_as_uint(fmaxf(mx + tn, 0.f));
+                r[v] = __float_as_uint(ss_epi<FMT>(mx, c1, tn));
             }
             unsigned got[8];
 #pragma unroll
@@ -204,10 +242,11 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
 #pragma unroll
             for (int kk = 0; kk < 8; kk += 2) {             // pixels 16 g2 + 2 kk (+ 1 in the dm = 1 lanes) and two further
                 const unsigned w_ = (kk < 4 ? wrA : wrB) + 512 * g2 + 64 * kk;
-                lds_store_split2(w_, w_ + 64, SS_A1PLANE, fin[kk], fin[kk + 1]);
+                lds_store_pair_fmt<FMT>(w_, w_ + 64, SS_A1PLANE, fin[kk], fin[kk + 1], ms1);
             }
             rd_a += 8; rd_b += 8;                          // mel m0 = 2 gl, gl = 12 hfi + 2 g2 + tt
         }
+        if (F16) { m_in = wave_max_nonneg(ms1) * pow2_f32(-e1); e_in = e1; }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -226,8 +265,14 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
             a_flip[t] = row + (unsigned)((h ^ (~py & 1)) << 4);
         }
         const __amdgpu_buffer_rsrc_t wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
-        conv_k_bf16_c16<6>(acc, wrs2, CNNB_W2 * 2, lane * 16, a_same, a_flip, m2);
-        const float tn = cw[CNN_T2 + n];
+        conv_k_bf16_c16<6, FMT>(acc, wrs2, CNNB_W2 * 2, lane * 16, a_same, a_flip, m2);
+        float tn = cw[CNN_T2 + n], c2 = 1.f, ms2 = 0.f;
+        int e2 = 0;
+        if (F16) {
+            e2 = f16_scale_exp(fmaf(m_in, meta_f[9], meta_f[17]));
+            c2 = pow2_f32(e2 - e_in - meta_i[1]);
+            tn *= pow2_f32(e2);
+        }
         const unsigned wr = R + (6 * hf * 4) * SS_RS2 + n * 2;
 #pragma unroll
         for (int t = 0; t < 6; ++t)
@@ -238,10 +283,11 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
                 for (int e = 0; e < 2; ++e) {
                     const int q = 2 * (bb + e);
                     const float mx = fmaxf(fmaxf(acc[t][0][q], acc[t][0][q + 1]), fmaxf(acc[t][0][8 + q], acc[t][0][8 + q + 1]));
-                    pvv[e] = fmaxf(mx + tn, 0.f);
+                    pvv[e] = ss_epi<FMT>(mx, c2, tn);
                 }
-                lds_store_split2(wr + (4 * t + bb) * SS_RS2, wr + (4 * t + bb + 1) * SS_RS2, SS_P2, pvv[0], pvv[1]);
+                lds_store_pair_fmt<FMT>(wr + (4 * t + bb) * SS_RS2, wr + (4 * t + bb + 1) * SS_RS2, SS_P2, pvv[0], pvv[1], ms2);
             }
+        if (F16) { m_in = wave_max_nonneg(ms2) * pow2_f32(-e2); e_in = e2; }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -266,21 +312,29 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
             base[t] = R + base34[t] * SS_RS2 + (h << 4);
         }
-        conv_k_bf16<32, 2, 2, 4, SS_RS2, SS_P2, SS_ZADDR, true, 3>(acc, wrs, CNNB_W3 * 2, lane16, base, m34);
+        conv_k_bf16<32, 2, 2, 4, SS_RS2, SS_P2, SS_ZADDR, true, 3, FMT>(acc, wrs, CNNB_W3 * 2, lane16, base, m34);
+        float c3 = 1.f, s3 = 1.f, ms3 = 0.f;
+        int e3 = 0;
+        if (F16) {
+            e3 = f16_scale_exp(fmaf(m_in, meta_f[10], meta_f[18]));
+            c3 = pow2_f32(e3 - e_in - meta_i[2]);
+            s3 = pow2_f32(e3);
+        }
         const unsigned wr = R + (24 * hf) * SS_RS3 + n * 2; // pixel (2 (3 hf + (u >> 3)) + ((u >> 2) & 1)) * 4 + (u & 3) = 24 hf + u
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const float tn = cw[CNN_T3 + n + 32 * nt];
+            const float tn = F16 ? cw[CNN_T3 + n + 32 * nt] * s3 : cw[CNN_T3 + n + 32 * nt];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const int u = 16 * t + r;
                     if (u < 24)
-                        lds_store_split2(wr + u * SS_RS3 + 64 * nt, wr + (u + 1) * SS_RS3 + 64 * nt, SS_P3,
-                                         fmaxf(acc[t][nt][r] + tn, 0.f), fmaxf(acc[t][nt][r + 1] + tn, 0.f));
+                        lds_store_pair_fmt<FMT>(wr + u * SS_RS3 + 64 * nt, wr + (u + 1) * SS_RS3 + 64 * nt, SS_P3,
+                                                ss_epi<FMT>(acc[t][nt][r], c3, tn), ss_epi<FMT>(acc[t][nt][r + 1], c3, tn), ms3);
                 }
         }
+        if (F16) { m_in = wave_max_nonneg(ms3) * pow2_f32(-e3); e_in = e3; }
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -298,12 +352,19 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
         unsigned base[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) base[t] = R + base34[t] * SS_RS3 + (h << 4);
-        conv_k_bf16<64, 2, 2, 4, SS_RS3, SS_P3, SS_ZADDR, true, 3>(acc, wrs, CNNB_W4 * 2, lane16, base, m34);
+        conv_k_bf16<64, 2, 2, 4, SS_RS3, SS_P3, SS_ZADDR, true, 3, FMT>(acc, wrs, CNNB_W4 * 2, lane16, base, m34);
+        float c4 = 1.f, s4s = 1.f, ms4 = 0.f;
+        int e4 = 0;
+        if (F16) {
+            e4 = f16_scale_exp(fmaf(m_in, meta_f[11], meta_f[19]));
+            c4 = pow2_f32(e4 - e_in - meta_i[3]);
+            s4s = pow2_f32(e4);
+        }
         __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int c = n + 32 * nt;
-            const float tn = cw[CNN_T4 + c];
+            const float tn = F16 ? cw[CNN_T4 + c] * s4s : cw[CNN_T4 + c];
 #pragma unroll
             for (int gl = 0; gl < 3; ++gl)
 #pragma unroll
@@ -317,9 +378,20 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
                             mx = fmaxf(mx, acc[u >> 4][nt][u & 15]);
                         }
                     const int pp = 12 * wave + (3 * hf + gl) * 2 + bb;
-                    store_split(s4, SS_PLANE, pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2,
-                                fmaxf(mx + tn, 0.f));
+                    const int off4 = pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2;
+                    if (F16) lds_store_one_fmt<FMT>(SS_BASE + off4, SS_PLANE, ss_epi<FMT>(mx, c4, tn), ms4);
+                    else store_split(s4, SS_PLANE, off4, fmaxf(mx + tn, 0.f));
                 }
+        }
+        if (F16) {
+            // conv5 / conv6 run over the four segments' rows at once: every row carries its segment's scales (cnn_bf16.hip)
+            const float m4 = wave_max_nonneg(ms4) * pow2_f32(-e4);
+            const int e5 = f16_scale_exp(fmaf(m4, meta_f[12], meta_f[20]));
+            if (lane < 12) {
+                lds_st32(SS_TAB5 + (12 * wave + lane) * 8, __float_as_uint(pow2_f32(e5 - e4 - meta_i[4])));
+                lds_st32(SS_TAB5 + (12 * wave + lane) * 8 + 4, __float_as_uint(pow2_f32(e5)));
+                lds_st32(SS_TAB6 + (12 * wave + lane) * 4, __float_as_uint(pow2_f32(-(e5 + meta_i[5]))));
+            }
         }
     }
     __syncthreads();
@@ -389,12 +461,7 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
             for (int g = 0; g < 18; ++g) {
                 if (g + 3 < 18) { bq[(g + 3) & 3][0] = wfrag_load(wrs5, lane * 16, wbyte + (g + 3) * 2048); bq[(g + 3) & 3][1] = wfrag_load(wrs5, lane * 16, wbyte + (g + 3) * 2048 + 1024); }
                 if (g + 1 < 18) load_a(g + 1);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(aq[g & 1][t][0], bq[g & 3][1], acc5[t]);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(aq[g & 1][t][1], bq[g & 3][0], acc5[t]);
-#pragma unroll
-                for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(aq[g & 1][t][0], bq[g & 3][0], acc5[t]);
+                mma16_pair_fmt<FMT, 3>(acc5, aq[g & 1], bq[g & 3]);
             }
             const float tn = cw[(layer ? CNN_T6 : CNN_T5) + ch];
             // conv6's fp32 output goes over S4, which every wave finished reading before the barrier that ended conv5
@@ -403,9 +470,19 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rho = 16 * t + 4 * kg + r;
-                    const float v = fmaxf(acc5[t][r] + tn, 0.f);
-                    if (layer) s6[rho * 64 + ch] = v;
-                    else store_split(s5, SS_PLANE, rho * 128 + (((ch >> 3) ^ ((rho >> 1) & 7)) << 4) + (ch & 7) * 2, v);
+                    const int off5 = rho * 128 + (((ch >> 3) ^ ((rho >> 1) & 7)) << 4) + (ch & 7) * 2;
+                    if (F16) {
+                        // conv5: {2^(e5 - e4 - kw5), 2^e5} of the row's segment; conv6 (fp32 output): 2^-(e5 + kw6)
+                        if (layer) s6[rho * 64 + ch] = ss_epi<FMT>(acc5[t][r], __uint_as_float(lds_ld32(SS_TAB6 + (16 * t + r) * 4 + kg * 16)), tn);
+                        else {
+                            const f32x2_t cs = ss_ld64(SS_TAB5 + (16 * t + r) * 8 + kg * 32);
+                            lds_store_one_fmt<FMT>(SS_BASE + SS_WAVE + off5, SS_PLANE, ss_epi<FMT>(acc5[t][r], cs[0], tn * cs[1]), dummy_mx);
+                        }
+                    } else {
+                        const float v = fmaxf(acc5[t][r] + tn, 0.f);
+                        if (layer) s6[rho * 64 + ch] = v;
+                        else store_split(s5, SS_PLANE, off5, v);
+                    }
                 }
             __syncthreads();
         }
@@ -458,16 +535,51 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
     }
 }
 
+__global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
+    const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off, const int32_t* __restrict__ tok_off,
+    const int32_t* __restrict__ n_wins, const float* __restrict__ clip_floor, int n_clips, int seg_hop,
+    const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ feat20) {
+    cnn_std_split_body<NQ_FMT_BF16X3>(mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cw, wb, feat20);
+}
+// fp32 operands as two f16 terms of the power-of-two-scaled tensors; P4: all four term products ('f16x4'), else three ('f16x3')
+template <bool P4>
+__global__ __launch_bounds__(256, 2) void cnn_std_f16_kernel(
+    const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off, const int32_t* __restrict__ tok_off,
+    const int32_t* __restrict__ n_wins, const float* __restrict__ clip_floor, int n_clips, int seg_hop,
+    const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ feat20) {
+    cnn_std_split_body<P4 ? NQ_FMT_F16X4 : NQ_FMT_F16X3>(mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cw, wb, feat20);
+}
+
+typedef void (*ss_kernel_t)(const float*, const int32_t*, const int32_t*, const int32_t*, const float*, int, int, const float*,
+                            const unsigned short*, float*);
+// fmt: 0 bf16x3, 1 f16x3, 2 f16x4; 70.6 KB of dynamic LDS: above the 64 KB default, opted in once per kernel and device
+static int ss_launch(int fmt, const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off, const int32_t* n_wins,
+                     const float* clip_floor, int32_t n_clips, int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
+                     const uint16_t* cnn_wb, float* feat20, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat20 || fmt < 0 || fmt > 2)
+        return NISQA_ERR_ARG;
+    static const ss_kernel_t kernels[3] = {cnn_std_bf16_kernel, cnn_std_f16_kernel<false>, cnn_std_f16_kernel<true>};
+    NQ_LAUNCH_BEGIN();
+    static std::atomic<bool> lds_ok[3][64];
+    if (nq_lds_opt_in((const void*)kernels[fmt], (int)SS_LDS, lds_ok[fmt])) return 2;
+    hipLaunchKernelGGL(kernels[fmt], dim3(total_tok_padded / 4), dim3(256), SS_LDS, (hipStream_t)stream, mel_tm, frame_off, tok_off, n_wins,
+                       clip_floor, n_clips, seg_hop, cnn_std_w, cnn_wb, feat20);
+    return NQ_LAUNCH_STATUS();
+}
+
 extern "C" int nisqa_cnn_standard_bf16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
                                        const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
                                        int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
                                        const uint16_t* cnn_wb, float* feat20, void* stream) {
-    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat20)
-        return NISQA_ERR_ARG;
-    NQ_LAUNCH_BEGIN();
-    static std::atomic<bool> lds_ok[64];                  // 70.6 KB of dynamic LDS: above the 64 KB default
-    if (nq_lds_opt_in((const void*)cnn_std_bf16_kernel, (int)SS_LDS, lds_ok)) return 2;
-    hipLaunchKernelGGL(cnn_std_bf16_kernel, dim3(total_tok_padded / 4), dim3(256), SS_LDS, (hipStream_t)stream, mel_tm,
-                       frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cnn_std_w, cnn_wb, feat20);
-    return NQ_LAUNCH_STATUS();
+    return ss_launch(0, mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, total_tok_padded, seg_hop, cnn_std_w, cnn_wb, feat20, stream);
+}
+
+// the f16 formats (cnn_wh: nisqa_amd.weights.pack_adapt_cnn_f16 of the StandardCNN's convolutions; products = 3 or 4)
+extern "C" int nisqa_cnn_standard_f16(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                                      const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                                      int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
+                                      const uint16_t* cnn_wh, int32_t products, float* feat20, void* stream) {
+    if (products != 3 && products != 4) return NISQA_ERR_ARG;
+    return ss_launch(products - 2, mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, total_tok_padded, seg_hop, cnn_std_w, cnn_wh, feat20,
+                     stream);
 }

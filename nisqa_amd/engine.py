@@ -151,8 +151,6 @@ class HipNisqa(object):
         self.precision = precision or os.environ.get('NISQA_HIP_PRECISION') or DEFAULT_PRECISION
         if self.precision not in PRECISIONS:
             raise ValueError('precision must be one of {}, got {}'.format(', '.join(PRECISIONS), self.precision))
-        if self.arch == 1 and self.precision in ('f16x3', 'f16x4'):
-            self.precision = 'bf16x6'           # the f16 formats are built for the AdaptCNN; nisqa_tts.tar runs its StandardCNN as 'bf16x6'
         # the operand format of self-attention / pooling: the f16 CNN modes pair with the three-term kernels
         self.td_precision = 'bf16x6' if self.precision in ('f16x3', 'f16x4') else self.precision
         if self.arch == 1:
@@ -164,6 +162,8 @@ class HipNisqa(object):
             self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict, conv1_pairs=True).view(np.int16)) if self.precision == 'bf16x3' else None
             if self.precision == 'bf16x6':               # three-term fragments (the BiLSTM and the pooling are fp32 in every mode)
                 self.cnn_wb = up(_w.pack_adapt_cnn_bf16(state_dict, conv1_pairs=True, terms=3).view(np.int16))
+            if self.precision in ('f16x3', 'f16x4'):     # two-term f16 fragments of the scaled weights + per-layer constants
+                self.cnn_wb = up(_w.pack_adapt_cnn_f16(state_dict).view(np.int16))
             self.td_wb = self.pool_wb = None
             self._mel = {}
             self._ws = {}
@@ -327,6 +327,12 @@ class HipNisqa(object):
         """StandardCNN + fc_out -> feat20 [NP, 20]"""
         d = plan.to(self.device)
         feat = torch.zeros((plan.total_tok, 20), dtype=torch.float32, device=self.device)
+        if self.precision in ('f16x3', 'f16x4'):
+            _lib.check(self.lib.nisqa_cnn_standard_f16(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']),
+                                                       _ptr(clip_floor), plan.n_clips, plan.total_tok, self.seg_hop, _ptr(self.cnn_w),
+                                                       _ptr(self.cnn_wb), int(self.precision[-1]), _ptr(feat), self._stream()),
+                       'nisqa_cnn_standard_f16')
+            return feat
         if self.precision in ('bf16x3', 'bf16x6'):
             fn = self.lib.nisqa_cnn_standard_bf16 if self.precision == 'bf16x3' else self.lib.nisqa_cnn_standard_bf16x6
             _lib.check(fn(_ptr(mel_tm), _ptr(d['frame_off']), _ptr(d['tok_off']), _ptr(d['n_wins']), _ptr(clip_floor), plan.n_clips,

@@ -35,7 +35,7 @@ PRECISIONS = ['f32', 'bf16x3']
 # 'f16x4' / 'f16x3' (AdaptCNN on two f16 terms of the power-of-two-scaled tensors, four / three products; self-attention and pooling as
 # in 'bf16x6'): the SAME bounds as 'f32' too
 PRECISIONS_SA = PRECISIONS + ['bf16x6', 'f16x4', 'f16x3']
-PRECISIONS_TTS = PRECISIONS + ['bf16x6']          # nisqa_tts.tar: the f16 formats are built for the AdaptCNN (the engine maps them to 'bf16x6')
+PRECISIONS_TTS = PRECISIONS_SA                     # nisqa_tts.tar: the StandardCNN runs the same five operand formats (BiLSTM fp32 VALU in all)
 MEL_TOL = 1e-3          # dB
 # stage tolerances per precision path: (CNN features / td output, final outputs)
 TOL = {'f32': (2e-4, 1e-4), 'bf16x3': (1e-3, 2e-4), 'bf16x6': (2e-4, 1e-4), 'f16x4': (2e-4, 1e-4), 'f16x3': (2e-4, 1e-4)}
@@ -423,7 +423,7 @@ def test_predict_dir_drop_in_surface(tmp_path):
 
 @pytest.mark.parametrize('ckpt,precision', [('nisqa.tar', 'bf16x3'), ('nisqa.tar', 'f32'), ('nisqa.tar', 'bf16x6'), ('nisqa.tar', 'f16x4'),
                                             ('nisqa_mos_only.tar', 'bf16x3'), ('nisqa_mos_only.tar', 'bf16x6'),
-                                            ('nisqa_tts.tar', 'bf16x3'), ('nisqa_tts.tar', 'f32'), ('nisqa_tts.tar', 'bf16x6')])
+                                            ('nisqa_tts.tar', 'bf16x3'), ('nisqa_tts.tar', 'f32'), ('nisqa_tts.tar', 'bf16x6'), ('nisqa_tts.tar', 'f16x4')])
 def test_against_the_live_reference_loop_on_fresh_random_clips(tmp_path, ckpt, precision, monkeypatch):
     """Not a committed fixture: FRESH clips every run (seed from os.urandom, printed), scored by the reference's OWN loop on
     the CPU -- NISQA_lib.py as shipped (staged by build() under oracle/_ref/nisqa, git-ignored): SpeechQualityDataset ->

@@ -32,13 +32,13 @@ try:
     cfg = d.get('config') if isinstance(d.get('config'), dict) else {}
     print('value', d.get('value'), cfg.get('precision'), 'ms/step', d.get('ms_per_step'), d.get('stage_ms'), 'frac', d.get('roofline', {}).get('frac'))
     if d.get('leg'):
-        print(' leg', d['leg'], {k: d.get(k) for k in ('seconds', 'predict_s', 'table_s', 'print_s', 'value_f32', 'value_bf16x6', 'value_bf16x3', 'ms_per_job') if k in d},
+        print(' leg', d['leg'], {k: d.get(k) for k in ('seconds', 'predict_s', 'table_s', 'print_s', 'value_f32', 'value_bf16x6', 'value_f16x4', 'value_f16x3', 'value_bf16x3', 'ms_per_job', 'stage_ms') if k in d},
               {k: v for k, v in d.get('roofline', {}).items() if k in ('achieved', 'link_only_GBps', 'frac_of_link_only', 'frac')}, d.get('loop_host_s'), d.get('lstm'))
     for k in d:
-        if k.startswith('value_'):
+        if k.startswith('value_') and isinstance(d.get(k[6:]), dict):
             print(' ', k, d[k], d[k[6:]].get('stage_ms'), 'vs primary', d[k[6:]].get('max_abs_diff_vs_primary'), 'vs f32', d[k[6:]].get('max_abs_diff_vs_f32'))
     for k, v in d.get('side', {}).items():
-        print(' side', k, {q: v.get(q) for q in ('value', 'value_f32', 'value_bf16x6', 'value_bf16x3', 'stage_ms', 'error') if q in v})
+        print(' side', k, {q: v.get(q) for q in ('value', 'value_f32', 'value_bf16x6', 'value_f16x4', 'value_f16x3', 'value_bf16x3', 'stage_ms', 'error') if q in v})
 except Exception as e:
     print('bench line unreadable:', e)
 PY
