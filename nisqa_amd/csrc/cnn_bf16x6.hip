@@ -465,6 +465,60 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
                 if (rho < 24) lds_st32(fo + (slot * 96 + i16 * 6 + y) * 4, __float_as_uint(fmaxf(acc6[t][r] + acc6b[t][r] + tn6, 0.f)));
             }
         __builtin_amdgcn_wave_barrier();
+#ifdef NQ_TAIL_PROBE
+        // COST stand-in of a fused Linear 384 -> 64 + LayerNorm tail (VERDICT r4 task 3; results of this build are wrong: the fragments
+        // are conv5's, the normalised rows overwrite features).  Every wave takes its K quarter (its own 96 features of the four
+        // tokens = 3 steps of 32) against all 64 outputs on 16x16x32 MFMAs: M = 16 rows (4 valid tokens), 4 N tiles, three-term
+        // operands -> 3 x 4 x 6 = 72 MFMAs and 36 KB of fragments per wave; the A rows come from the staged fp32 features (two
+        // 16-byte reads + a three-term split in registers per step); partial sums meet in LDS, one barrier, then wave w
+        // normalises token w (64 outputs = 64 lanes) and stores its row.
+        {
+            f32x4 accp[4][1];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) accp[nt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const unsigned ar = fo + (i16 & 3) * 384 + (32 * s3 + 8 * kg) * 4;
+                const f32x4 v0 = lds_ld128(ar), v1 = lds_ld128(ar + 16);
+                f32x4 at[1][XT];
+                float r8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                for (int t = 0; t < XT; ++t) {
+                    unsigned pk[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pk[e] = cvt_pk_bf16(r8[2 * e], r8[2 * e + 1]);
+                        r8[2 * e] -= __uint_as_float(pk[e] << 16);
+                        r8[2 * e + 1] -= __uint_as_float(pk[e] & 0xffff0000u);
+                    }
+                    at[0][t] = f32x4{__uint_as_float(pk[0]), __uint_as_float(pk[1]), __uint_as_float(pk[2]), __uint_as_float(pk[3])};
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x4 bt[XT];
+#pragma unroll
+                    for (int t = 0; t < XT; ++t) bt[t] = wfrag_load(wrs, lane16, w5b + (((s3 * 4 + nt) % 18) * XT + t) * 1024);
+                    mma16_terms<1>(accp[nt], at, bt);
+                }
+            }
+            const unsigned red = S5 + wave * 1024;          // [4 tokens][64 outputs] floats of this wave (S5 is dead since conv6's loop)
+            if (kg == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lds_st32(red + (r * 64 + 16 * nt + i16) * 4, __float_as_uint(accp[nt][0][r]));
+            }
+            __syncthreads();
+            float xs = cw[CNN_T1 + (lane & 15)];            // (stand-in for the bias)
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) xs += __uint_as_float(lds_ld32(S5 + w4 * 1024 + (wave * 64 + lane) * 4));
+            const float mu = wave_sum(xs) * (1.f / 64.f);
+            const float dv = xs - mu;
+            const float var = wave_sum(dv * dv) * (1.f / 64.f);
+            const float yn = dv * __builtin_amdgcn_rsqf(var + 1e-5f) * tn1 + tn2;
+            if (wave < nvalid) feat[(size_t)(p0 + wave) * 384 + 320 + lane] = yn;
+        }
+#endif
 #pragma unroll
         for (int q0 = 0; q0 < 96; q0 += 64) {
             const int q = q0 + lane;                                         // float4 index: slot = q / 24
