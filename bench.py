@@ -606,7 +606,32 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
            'other_precision_modes': {k: v for k, v in modes.items() if k != 'f32'},
            'peak_mem_GB': round(peak_mem, 2)}
     if cpu_baseline_on:
-        from oracle import mel as omel, net as onet, train as otrain
+        from oracle import mel as omel, net as onet, train as otrain, ref_shim
+        ref_base = None
+        if ref_shim.reference_available():
+            # the reference's OWN step (NISQA_model.py:96-152: its dataset + DataLoader + modules in train mode + biasLoss + Adam) at
+            # configs[4]'s own batch size, one step; librosa's three entry points served by oracle/mel.py
+            import shutil
+            import tempfile
+            d = tempfile.mkdtemp(prefix='nisqa_bench_train_')
+            try:
+                names = []
+                for i in range(bs):
+                    synth.write_wav(os.path.join(d, 't%02d.wav' % i), synth.synth_pcm16(i % 8, SECONDS), SR)
+                    names.append('t%02d.wav' % i)
+                targs = dict(args)
+                targs.update({'ms_sr': None, 'ms_fmax': synth.MOS_ARGS.get('ms_fmax', 20000), 'model': 'NISQA'})
+                r = ref_shim.reference_train_step(targs, sd, d, names, y[:, 0], bs, lr=1e-3, steps=1)
+                ref_base = {'value': round(bs / r['seconds'][-1], 3), 'unit': 'clips/s', 'cores': int(torch.get_num_threads()),
+                            'kind': 'reference-torch + oracle-mel',
+                            'sample': 'ONE step of the reference\'s own loop at bs = %d x 10 s (%d segments; SpeechQualityDataset -> DataLoader -> '
+                                      'NISQA.forward in train mode -> biasLoss.get_loss -> backward -> Adam.step, NISQA_model.py:96-152), device '
+                                      'cpu, %d torch threads, %.1f s, loss %.4f; librosa served by oracle/mel.py (mel stage parity unpinned)'
+                                      % (bs, r['segments'], int(torch.get_num_threads()), r['seconds'][-1], r['loss'])}
+            except Exception as e:                            # noqa: BLE001  (the port below still gives a baseline)
+                ref_base = {'error': '%s: %s' % (type(e).__name__, e)}
+            finally:
+                shutil.rmtree(d, ignore_errors=True)
         nb = 8
         clips = [synth.synth_pcm16(i, SECONDS).astype(np.float32) / np.float32(32768.0) for i in range(nb)]
         t0 = time.perf_counter()
@@ -616,9 +641,13 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
         torch.manual_seed(0)
         out = otrain.train_step(sd, args, xs, np.array([n for _, n in segs]), y[:nb], lr=1e-3)
         t = time.perf_counter() - t0
-        res['cpu_baseline'] = {'value': round(nb / t, 3), 'unit': 'clips/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
-                               'sample': 'ONE step at bs = %d x 10 s (%d segments): oracle.mel + oracle.train.train_step '
-                                         '(torch CPU autograd fp32 + Adam) %.2f s, loss %.4f' % (nb, sum(n for _, n in segs), t, out['loss'])}
+        port = {'value': round(nb / t, 3), 'unit': 'clips/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+                'sample': 'ONE step at bs = %d x 10 s (%d segments): oracle.mel + oracle.train.train_step '
+                          '(torch CPU autograd fp32 + Adam) %.2f s, loss %.4f' % (nb, sum(n for _, n in segs), t, out['loss'])}
+        if ref_base is not None and 'value' in ref_base:
+            res['cpu_baseline'] = dict(ref_base, port=port)
+        else:
+            res['cpu_baseline'] = dict(port, reference_error=(ref_base or {}).get('error', 'reference NISQA_lib.py not staged (oracle/_ref)'))
     return res
 
 

@@ -142,3 +142,45 @@ def reference_predict(checkpoint, data_dir, files, bs, num_workers=0, ms_channel
     if timings is not None:
         timings['predict_s'] = time.perf_counter() - t0
     return y_hat.astype('float32')
+
+
+def reference_train_step(args, state_dict, data_dir, files, labels, bs, lr=1e-3, steps=1):
+    """The reference's own training step on the CPU (NISQA_model.py:96-152): its SpeechQualityDataset (get_librosa_melspec ->
+    segment_specs padded to [ms_max_segments, 1, 48, 15]) behind a torch DataLoader of batch size ``bs`` (shuffle off so that the
+    timed batch is the first ``bs`` files), model(x, n_wins) of its NISQA / NISQA_DIM in train mode, biasLoss.get_loss
+    (NL:1879-1894; first_order mapping, before any bias update: the plain NaN-aware MSE), loss.backward(), torch.optim.Adam.step().
+    librosa's three entry points are served by oracle/mel.py (PARITY UNPINNED there).  labels: [N] MOS values.
+    -> dict(seconds per step incl. the DataLoader fetch, loss of the last step, segments of the last batch)."""
+    import time
+    import pandas as pd
+    import torch
+    from torch.utils.data import DataLoader
+    NL = import_reference_lib(functional_librosa=True)
+    args = dict(args)
+    args.setdefault('double_ended', False)
+    model = {'NISQA': NL.NISQA, 'NISQA_DIM': NL.NISQA_DIM}[args['model']](**{k: args[k] for k in MODEL_ARG_KEYS})
+    model.load_state_dict({k: torch.as_tensor(v) for k, v in state_dict.items()}, strict=True)
+    df = pd.DataFrame({'deg': list(files), 'mos': [float(v) for v in labels], 'db': ['bench'] * len(files)})
+    ds = NL.SpeechQualityDataset(
+        df, df_con=None, data_dir=data_dir, filename_column='deg', mos_column='mos', seg_length=args['ms_seg_length'],
+        max_length=args['ms_max_segments'], to_memory=None, to_memory_workers=None, seg_hop_length=args['ms_seg_hop_length'],
+        transform=None, ms_n_fft=args['ms_n_fft'], ms_hop_length=args['ms_hop_length'], ms_win_length=args['ms_win_length'],
+        ms_n_mels=args['ms_n_mels'], ms_sr=args['ms_sr'], ms_fmax=args['ms_fmax'], ms_channel=None, double_ended=False,
+        dim=False, filename_column_ref=None)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    bias = NL.biasLoss(df.db, anchor_db=None, mapping='first_order', min_r=0.7, do_print=False)
+    dl = DataLoader(ds, batch_size=bs, shuffle=False, drop_last=False, pin_memory=False, num_workers=0)
+    model.train()
+    out = {'seconds': [], 'loss': None, 'segments': None}
+    it = iter(dl)
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        xb, yb, (idx, n_wins) = next(it)
+        y_hat = model(xb, n_wins)
+        loss = bias.get_loss(yb, y_hat, idx)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        out['seconds'].append(time.perf_counter() - t0)
+        out['loss'], out['segments'] = float(loss.item()), int(n_wins.sum())
+    return out
