@@ -675,6 +675,8 @@ def main():
     ap.add_argument('--no-side', action='store_true', help='skip the side legs (configs[2], [3], [4])')
     a = ap.parse_args()
     BATCH = a.batch
+    if a.precision:                                           # every leg of this run (tts, predict_csv) follows it
+        os.environ['NISQA_HIP_PRECISION'] = a.precision
     if a.workload == 'predict_csv':
         return bench_predict_csv(a)
 
@@ -760,7 +762,7 @@ def main():
                 flop, peak, kname, kern = (FLOP_CONV1_4 + FLOP_CONV5_6) * BATCH, PEAK_BF16_MFMA, 'cnn_front_bf16x6_kernel', \
                     'cnn_front_bf16x6_kernel (AdaptCNN conv1-6 + pools, three exact bf16 terms per fp32 operand: 6 MFMA products per term pair)'
             elif prec in ('f16x4', 'f16x3'):
-                flop, peak, kname, kern = (FLOP_CONV1_4 + FLOP_CONV5_6) * BATCH, PEAK_BF16_MFMA, 'cnn_front_f16_kernel<%s>' % prec, \
+                flop, peak, kname, kern = (FLOP_CONV1_4 + FLOP_CONV5_6) * BATCH, PEAK_BF16_MFMA, 'cnn_front_f16_kernel' if prec == 'f16x4' else 'n/a (the PMC passes profile the four-product instantiation)', \
                     'cnn_front_f16_kernel (AdaptCNN conv1-6 + pools, two f16 terms per fp32 operand of the scaled tensors: %s MFMA products per term pair; ' \
                     'the f16 matrix peak is the bf16 one)' % prec[-1]
             else:
