@@ -495,6 +495,45 @@ def test_inner_operator_forward_on_segment_tensors(eng_rand, batch, monkeypatch)
     assert (x - xr).abs().max() < 2e-3
 
 
+@pytest.mark.parametrize('precision', ['f16x4', 'f16x3'])
+@pytest.mark.parametrize('gain', [1e-6, 1e-3, 1.0, 1e3, 1e6])
+def test_f16_formats_keep_every_finite_input_in_range(precision, gain):
+    """The f16 formats store every tensor as y * 2^e with e from the MEASURED maximum of the layer's input for the segment and the layer's
+    weight norm (|y| <= m_in * G + T): no calibration, nothing to overflow.  The CNN on segment tensors scaled by 1e-6 ... 1e6 (dB values
+    are bounded by +-385; this is the inner operator with arbitrary input) and on weights scaled by 1e-3 / 1e3 must stay finite and agree
+    with the exact-fp32 kernels to the relative precision fp32 arithmetic itself has -- features up to ~1e8 included."""
+    args = dict(helpers.DIM_ARGS)
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy((rng.standard_normal((3, 40, 1, 48, 15)) * 25 - 40).astype(np.float32) * np.float32(gain))
+    n_wins = np.array([40, 17, 1])
+    for wscale in (1.0, 1e-3, 1e3):
+        sd = {k: (v * wscale if k.endswith(('conv3.weight', 'conv5.weight')) else v) for k, v in helpers.random_state_dict(7, 'NISQA_DIM').items()}
+        ref_eng, eng = _engine(args, sd, 'f32'), _engine(args, sd, precision)
+        from nisqa_amd.engine import BatchPlan
+        plan = BatchPlan.from_n_wins(n_wins)
+        d = plan.to(eng.device)
+        feats = {}
+        for e, tag in ((ref_eng, 'f32'), (eng, precision)):
+            feat = torch.zeros((plan.total_tok, 384), dtype=torch.float32, device=e.device)
+            xd = x.to(e.device).contiguous()
+            if tag == 'f32':
+                p3 = torch.empty((plan.total_tok, 18, 64), dtype=torch.float32, device=e.device)
+                rc = e.lib.nisqa_cnn_adapt_segments(xd.data_ptr(), 40, d['tok_off'].data_ptr(), d['n_wins'].data_ptr(), 3, plan.total_tok,
+                                                    e.cnn_w.data_ptr(), p3.data_ptr(), feat.data_ptr(), e._stream())
+            else:
+                rc = e.lib.nisqa_cnn_adapt_segments_f16(xd.data_ptr(), 40, d['tok_off'].data_ptr(), d['n_wins'].data_ptr(), 3, plan.total_tok,
+                                                        e.cnn_w.data_ptr(), e.cnn_wb.data_ptr(), int(precision[-1]), feat.data_ptr(), e._stream())
+            assert rc == 0
+            torch.cuda.synchronize()
+            feats[tag] = feat.cpu().numpy()[plan.token_index()]
+        a, b = feats['f32'], feats[precision]
+        assert np.isfinite(b).all()
+        scale = max(float(np.abs(a).max()), 1e-30)
+        err = float(np.abs(a - b).max()) / scale
+        print(precision, 'input x %g, conv3/conv5 weights x %g: max |feature| %.3g, max |d| / max %.2e' % (gain, wscale, scale, err))
+        assert err < 2e-5, (gain, wscale, scale, err)
+
+
 # ---- nisqa_tts.tar architecture: StandardCNN + fc_out + BiLSTM + last-step pooling (SURVEY.md section 8f-1) -------
 TTS_CLIPS = [0, 3, 4, 5, 6, 1]            # indices into CLIPS, same set as tests/golden/net_tts_*.npz
 
