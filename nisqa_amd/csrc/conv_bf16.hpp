@@ -414,6 +414,19 @@ NQ_DEV void conv_k_bf16(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int 
 template <int T>
 NQ_DEV void lds_store_terms2(unsigned a0, unsigned a1, int plane, float v0, float v1, bool st0 = true, bool st1 = true) {
     f32x2_t r = {v0, v1};
+    if (NQ_KO & 256) {                     // timing experiment (results wrong): ONE dword store per term and value pair at a 4-byte lane pitch
+        const unsigned dl = (threadIdx.x & 31) * 2 + ((threadIdx.x & 32) ? 32 : 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const unsigned pk = cvt_pk_bf16(r[0], r[1]);
+            if (st0 || st1) lds_st32(a0 + dl + t * plane, pk);
+            if (t + 1 < T) {
+                const f32x2_t part = {__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
+                r = r - part;
+            }
+        }
+        return;
+    }
 #ifdef NQ_X6_TRUNC
 #pragma unroll
     for (int t = 0; t < T; ++t) {
