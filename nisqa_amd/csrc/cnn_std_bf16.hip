@@ -1,3 +1,8 @@
+// ONE source for the four 16-bit operand formats of this kernel (conv_bf16.hpp): 'bf16x3' (two bf16 terms, three products), 'f16x3' /
+// 'f16x4' (two f16 terms of the scaled tensors, three / four products) and 'bf16x6' (three bf16 terms -- an exact split -- and six
+// products: three planes per tensor, 23.7 KB of LDS per wave, ONE workgroup per CU, the K loops of conv_k_terms with their scheduling
+// fence; until round 5 a separate file, cnn_std_bf16x6.hip).  The text below was written for the first form.
+//
 // StandardCNN (fixed 2x2 max-pools) + fc_out on split-bf16 MFMA ("bf16x3") for the nisqa_tts.tar
 // architecture -- same role, inputs and outputs as cnn_std_front_kernel + cnn_std_back_kernel in cnn_std.hip
 // (reference nisqa/NISQA_lib.py:2239-2282, 487-502, 811-836), built from the blocks of conv_bf16.hpp exactly
@@ -14,20 +19,23 @@
 #include "../../include/nisqa_hip.h"
 
 #define SS_A1PLANE 6144                    /* 192 px x 16 ch bf16 */
-#define SS_PATCH 12288                     /* conv1 input: three zero-bordered bf16 planes [17][50] behind the A1 planes */
 #define SS_PPLANE 1700
-#define SS_ZERO 17408                      /* 128 B of zeros per wave (the generic-pointer K loops of conv2 / conv5 / conv6) */
-#define SS_WAVE 17536
+/* the per-wave region depends on the planes per tensor (T = 2, or 3 for 'bf16x6'): A1 / A2 / A3 planes, then the conv1 input patch (up to
+   three zero-bordered planes [17][50], 5 120 B), then 128 B of zeros (the zero block of wave 3 serves conv5 / conv6) */
+#define SS_PATCH_T(T) ((T) * SS_A1PLANE)
+#define SS_ZERO_T(T) (SS_PATCH_T(T) + 5120)
+#define SS_WAVE_T(T) (SS_ZERO_T(T) + 128)  /* 17 536 (T = 2) / 23 680 (T = 3) */
+#define SS_LDS_T(T) (SS_BASE + 4 * SS_WAVE_T(T))   /* 72 320 B -> two workgroups per CU / 96 896 B -> one */
 #define SS_ZADDR 2048u                     /* a zero block shared by the workgroup, above the largest tap offset (conv_k_bf16) */
 #define SS_BASE 2176u                      /* first wave region */
-#define SS_LDS (SS_BASE + 4 * SS_WAVE)     /* 72320 B -> two workgroups (8 waves) per CU */
 #define SS_PLANE 6144                      /* S4 / S5: 48 rows x 64 ch bf16, chunk-swizzled */
 /* conv2 -> conv3 -> conv4 activations: pixel rows padded by 16 bytes, NOT swizzled (every address = lane base + immediate) */
 #define SS_RS2 80                          /* A2: 48 px x 32 ch */
 #define SS_P2 (48 * SS_RS2)
 #define SS_RS3 144                         /* A3: 48 px x 64 ch */
 #define SS_P3 (48 * SS_RS3)
-static_assert(2 * SS_P3 <= SS_ZERO && 2 * SS_LDS <= 160 * 1024, "LDS plan");
+static_assert(2 * SS_P3 <= SS_ZERO_T(2) && 2 * SS_LDS_T(2) <= 160 * 1024, "LDS plan, two planes per tensor");
+static_assert(3 * SS_P3 <= SS_ZERO_T(3) && 3 * SS_PLANE <= SS_WAVE_T(3) && SS_LDS_T(3) <= 160 * 1024 && 3 * SS_PPLANE <= 5120, "LDS plan, three planes");
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
 NQ_DEV float row16_sum_dpp(float v) {
@@ -75,12 +83,45 @@ NQ_DEV void conv_k_bf16_c16(f32x16 (&acc)[MT][1], __amdgpu_buffer_rsrc_t rsrc, i
     }
 }
 
+// conv2's K loop with T terms per operand and the products of mma_terms (T = 3: six), one wave per SIMD: A rows one tap ahead, fragments
+// two, a scheduling fence behind each step's requests (conv_k_terms)
+template <int MT, int T>
+NQ_DEV void conv_k_terms_c16(f32x16 (&acc)[MT][1], __amdgpu_buffer_rsrc_t rsrc, int wbyte, unsigned lane16,
+                             const unsigned (&a_same)[MT], const unsigned (&a_flip)[MT], const unsigned (&m9)[MT]) {
+    f32x4 b[3][1][T], a[2][MT][T];
+    auto load_b = [&](int g, int slot) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) b[slot][0][t] = wfrag_load(rsrc, lane16, wbyte + (g * T + t) * 1024);
+    };
+    auto load_a = [&](int g, int slot) {
+        const int dy = g / 3, dx = g % 3;
+        const int tapoff = ((dy - 1) * 8 + (dx - 1)) * 32;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const bool ok = (m9[m] >> g) & 1u;
+            const unsigned ad = (unsigned)((int)(dy == 1 ? a_same[m] : a_flip[m]) + tapoff);
+#pragma unroll
+            for (int t = 0; t < T; ++t) a[slot][m][t] = lds_ld128_a(ok ? ad + t * SS_A1PLANE : SS_ZADDR);
+        }
+    };
+    load_b(0, 0);
+    load_b(1, 1);
+    load_a(0, 0);
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+        if (g + 2 < 9) load_b(g + 2, (g + 2) % 3);
+        if (g + 1 < 9) load_a(g + 1, (g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_terms<T, MT, 1>(acc, a[g & 1], b[g % 3]);
+    }
+}
+
 // the per-row scale tables of the f16 formats' conv5 / conv6 epilogues (the LDS below the zero block is otherwise unused)
 #define SS_TAB5 0u                         /* [48 rows] {2^(e5 - e4 - kw5), 2^e5} of the row's segment */
 #define SS_TAB6 1024u                      /* [48 rows] 2^-(e5 + kw6) */
 NQ_DEV f32x2_t ss_ld64(unsigned a) { return *(NQ_AS3 const f32x2_t*)(a); }
 template <int FMT>
-NQ_DEV float ss_epi(float v, float c, float t) { return FMT == NQ_FMT_BF16X3 ? fmaxf(v + t, 0.f) : fmaxf(fmaf(v, c, t), 0.f); }
+NQ_DEV float ss_epi(float v, float c, float t) { return (FMT == NQ_FMT_BF16X3 || FMT == NQ_FMT_BF16X6) ? fmaxf(v + t, 0.f) : fmaxf(fmaf(v, c, t), 0.f); }
 
 // FMT (conv_bf16.hpp): NQ_FMT_BF16X3 -- bf16 hi + lo, three products (the input keeps a third term) -- or the f16 formats: every
 // tensor as f16 hi + lo of y * 2^e, e from the measured maximum of the layer's input and the layer's weight norm (cnn_bf16.hip's
@@ -92,7 +133,13 @@ NQ_DEV void cnn_std_split_body(
     const float* __restrict__ clip_floor, int n_clips, int seg_hop,
     const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ feat20) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool F16 = FMT != NQ_FMT_BF16X3;
+    constexpr bool X6 = FMT == NQ_FMT_BF16X6;
+    constexpr bool F16 = FMT == NQ_FMT_F16X3 || FMT == NQ_FMT_F16X4;
+    constexpr int NT_ = X6 ? 3 : 2;                                         // planes per activation tensor / terms per weight fragment
+    constexpr unsigned SS_PATCH = SS_PATCH_T(NT_), SS_ZERO = SS_ZERO_T(NT_), SS_WAVE = SS_WAVE_T(NT_);
+    // fragment blob of the term count: CNNB_ (two terms, also the CNNH_ blob of the f16 formats) or CNNX_ (three)
+    constexpr int W1_ = X6 ? CNNX_W1 : CNNB_W1, W2_ = X6 ? CNNX_W2 : CNNB_W2, W3_ = X6 ? CNNX_W3 : CNNB_W3, W4_ = X6 ? CNNX_W4 : CNNB_W4,
+                  W5_ = X6 ? CNNX_W5 : CNNB_W5, W6_ = X6 ? CNNX_W6 : CNNB_W6, WU16_ = X6 ? CNNX_U16S : CNNB_U16S;
     const int* __restrict__ meta_i = (const int*)(wb + CNNH_META);         // F16: kw[l], G[l] at +8, T[l] at +16 (l = layer - 1)
     const float* __restrict__ meta_f = (const float*)(wb + CNNH_META);
     float dummy_mx = 0.f;
@@ -175,10 +222,10 @@ NQ_DEV void cnn_std_split_body(
     //      pair's maximum needs the partner 16 lanes away: lane group dm = 0 finalises the even pooled pixels of an
     //      iteration, dm = 1 the odd ones (one ds_swizzle per pixel pair); ReLU first, maxima on non-negative floats as uints.
     {
-        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, WU16_ * 2, 0x00020000);
         f32x4 w1[3];
 #pragma unroll
-        for (int t = 0; t < 3; ++t) w1[t] = wfrag_load(wrs, lane * 16, (CNNB_W1 + t * 512) * 2);
+        for (int t = 0; t < 3; ++t) w1[t] = wfrag_load(wrs, lane * 16, (W1_ + t * 512) * 2);
         float tn = cw[CNN_T1 + (n & 15)], c1 = 1.f, ms1 = 0.f;
         int e1 = 0;
         if (F16) {
@@ -264,8 +311,9 @@ NQ_DEV void cnn_std_split_body(
             a_same[t] = row + (unsigned)((h ^ (py & 1)) << 4);
             a_flip[t] = row + (unsigned)((h ^ (~py & 1)) << 4);
         }
-        const __amdgpu_buffer_rsrc_t wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
-        conv_k_bf16_c16<6, FMT>(acc, wrs2, CNNB_W2 * 2, lane * 16, a_same, a_flip, m2);
+        const __amdgpu_buffer_rsrc_t wrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, WU16_ * 2, 0x00020000);
+        if constexpr (X6) conv_k_terms_c16<6, 3>(acc, wrs2, W2_ * 2, lane * 16, a_same, a_flip, m2);
+        else conv_k_bf16_c16<6, FMT>(acc, wrs2, W2_ * 2, lane * 16, a_same, a_flip, m2);
         float tn = cw[CNN_T2 + n], c2 = 1.f, ms2 = 0.f;
         int e2 = 0;
         if (F16) {
@@ -293,7 +341,7 @@ NQ_DEV void cnn_std_split_body(
 
     // conv3 / conv4 on 12x4: a lane half owns 3 pooled rows = 3 groups of 8 pixels; u = 8*gl + 4*yy + x.  Second-generation
     // K loop (conv_bf16.hpp: lane-static tap masks, one select per tap and tile, fragments through a buffer descriptor)
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, WU16_ * 2, 0x00020000);
     const unsigned lane16 = lane * 16;
     unsigned base34[2], m34[2];
 #pragma unroll
@@ -312,7 +360,8 @@ NQ_DEV void cnn_std_split_body(
             for (int nt = 0; nt < 2; ++nt) acc[t][nt] = zero16();
             base[t] = R + base34[t] * SS_RS2 + (h << 4);
         }
-        conv_k_bf16<32, 2, 2, 4, SS_RS2, SS_P2, SS_ZADDR, true, 3, FMT>(acc, wrs, CNNB_W3 * 2, lane16, base, m34);
+        if constexpr (X6) conv_k_terms<3, 32, 2, 2, 4, SS_RS2, SS_P2, SS_ZADDR, 3>(acc, wrs, W3_ * 2, lane16, base, m34);
+        else conv_k_bf16<32, 2, 2, 4, SS_RS2, SS_P2, SS_ZADDR, true, 3, FMT>(acc, wrs, W3_ * 2, lane16, base, m34);
         float c3 = 1.f, s3 = 1.f, ms3 = 0.f;
         int e3 = 0;
         if (F16) {
@@ -352,7 +401,8 @@ NQ_DEV void cnn_std_split_body(
         unsigned base[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) base[t] = R + base34[t] * SS_RS3 + (h << 4);
-        conv_k_bf16<64, 2, 2, 4, SS_RS3, SS_P3, SS_ZADDR, true, 3, FMT>(acc, wrs, CNNB_W4 * 2, lane16, base, m34);
+        if constexpr (X6) conv_k_terms<3, 64, 2, 2, 4, SS_RS3, SS_P3, SS_ZADDR, 3>(acc, wrs, W4_ * 2, lane16, base, m34);
+        else conv_k_bf16<64, 2, 2, 4, SS_RS3, SS_P3, SS_ZADDR, true, 3, FMT>(acc, wrs, W4_ * 2, lane16, base, m34);
         float c4 = 1.f, s4s = 1.f, ms4 = 0.f;
         int e4 = 0;
         if (F16) {
@@ -379,7 +429,7 @@ NQ_DEV void cnn_std_split_body(
                         }
                     const int pp = 12 * wave + (3 * hf + gl) * 2 + bb;
                     const int off4 = pp * 128 + (((c >> 3) ^ ((pp >> 1) & 7)) << 4) + (c & 7) * 2;
-                    if (F16) lds_store_one_fmt<FMT>(SS_BASE + off4, SS_PLANE, ss_epi<FMT>(mx, c4, tn), ms4);
+                    if (F16 || X6) lds_store_one_fmt<FMT>(SS_BASE + off4, SS_PLANE, ss_epi<FMT>(mx, c4, tn), ms4);
                     else store_split(s4, SS_PLANE, off4, fmaxf(mx + tn, 0.f));
                 }
         }
@@ -435,33 +485,47 @@ NQ_DEV void cnn_std_split_body(
                 pok |= ok ? (1u << (3 * tap + t)) : 0u;
             }
         const unsigned Z3 = SS_BASE + 3 * SS_WAVE + SS_ZERO;
-        const __amdgpu_buffer_rsrc_t wrs5 = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrs5 = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, WU16_ * 2, 0x00020000);
 #pragma unroll 1
         for (int layer = 0; layer < 2; ++layer) {
             const unsigned srcA = layer ? SS_BASE + SS_WAVE : SS_BASE;
             f32x4 acc5[3];
 #pragma unroll
             for (int t = 0; t < 3; ++t) acc5[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int wbyte = ((layer ? CNNB_W6 : CNNB_W5) + wave * (18 * 2 * 512)) * 2;
-            f32x4 bq[4][2], aq[2][3][2];                   // fragments three K-steps ahead, A rows one step ahead
+            const int wbyte = ((layer ? W6_ : W5_) + wave * (18 * NT_ * 512)) * 2;
+            f32x4 bq[4][NT_], aq[2][3][NT_];               // fragments three K-steps ahead, A rows one step ahead
             auto load_a = [&](int g) {
                 const int tap = g >> 1, sx = (g & 1) << 6;
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     const bool ok = (pok >> (3 * tap + t)) & 1u;
                     const unsigned ah_ = ok ? (srcA + poff[tap][t]) ^ sx : Z3;
-                    aq[g & 1][t][0] = lds_ld128(ah_);
-                    aq[g & 1][t][1] = lds_ld128(ok ? ah_ + SS_PLANE : Z3);
+#pragma unroll
+                    for (int q = 0; q < NT_; ++q) aq[g & 1][t][q] = lds_ld128(ok ? ah_ + q * SS_PLANE : Z3);
                 }
             };
+            auto load_bq = [&](int g) {
 #pragma unroll
-            for (int g = 0; g < 3; ++g) { bq[g][0] = wfrag_load(wrs5, lane * 16, wbyte + g * 2048); bq[g][1] = wfrag_load(wrs5, lane * 16, wbyte + g * 2048 + 1024); }
+                for (int q = 0; q < NT_; ++q) bq[g & 3][q] = wfrag_load(wrs5, lane * 16, wbyte + (g * NT_ + q) * 1024);
+            };
+#pragma unroll
+            for (int g = 0; g < 3; ++g) load_bq(g);
             load_a(0);
 #pragma unroll
             for (int g = 0; g < 18; ++g) {
-                if (g + 3 < 18) { bq[(g + 3) & 3][0] = wfrag_load(wrs5, lane * 16, wbyte + (g + 3) * 2048); bq[(g + 3) & 3][1] = wfrag_load(wrs5, lane * 16, wbyte + (g + 3) * 2048 + 1024); }
+                if (g + 3 < 18) load_bq(g + 3);
                 if (g + 1 < 18) load_a(g + 1);
-                mma16_pair_fmt<FMT, 3>(acc5, aq[g & 1], bq[g & 3]);
+                if constexpr (X6) {
+                    __builtin_amdgcn_sched_barrier(0);             // requests stay ahead of the step's MFMAs (one wave per SIMD)
+#pragma unroll
+                    for (int order = 2; order >= 0; --order)      // the six products, smallest first
+#pragma unroll
+                        for (int i_ = order; i_ >= 0; --i_)
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) acc5[t] = mfma_bf16x16(aq[g & 1][t][i_], bq[g & 3][order - i_], acc5[t]);
+                } else {
+                    mma16_pair_fmt<FMT, 3>(acc5, aq[g & 1], bq[g & 3]);
+                }
             }
             const float tn = cw[(layer ? CNN_T6 : CNN_T5) + ch];
             // conv6's fp32 output goes over S4, which every wave finished reading before the barrier that ended conv5
@@ -481,6 +545,7 @@ NQ_DEV void cnn_std_split_body(
                     } else {
                         const float v = fmaxf(acc5[t][r] + tn, 0.f);
                         if (layer) s6[rho * 64 + ch] = v;
+                        else if (X6) lds_store_terms<3>(SS_BASE + SS_WAVE + off5, SS_PLANE, v);
                         else store_split(s5, SS_PLANE, off5, v);
                     }
                 }
@@ -541,6 +606,13 @@ __global__ __launch_bounds__(256, 2) void cnn_std_bf16_kernel(
     const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ feat20) {
     cnn_std_split_body<NQ_FMT_BF16X3>(mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cw, wb, feat20);
 }
+// three exact bf16 terms per operand, six products: three planes per tensor, one workgroup per CU
+__global__ __launch_bounds__(256, 1) void cnn_std_bf16x6_kernel(
+    const float* __restrict__ mel_tm, const int32_t* __restrict__ frame_off, const int32_t* __restrict__ tok_off,
+    const int32_t* __restrict__ n_wins, const float* __restrict__ clip_floor, int n_clips, int seg_hop,
+    const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ feat20) {
+    cnn_std_split_body<NQ_FMT_BF16X6>(mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, seg_hop, cw, wb, feat20);
+}
 // fp32 operands as two f16 terms of the power-of-two-scaled tensors; P4: all four term products ('f16x4'), else three ('f16x3')
 template <bool P4>
 __global__ __launch_bounds__(256, 2) void cnn_std_f16_kernel(
@@ -552,17 +624,18 @@ __global__ __launch_bounds__(256, 2) void cnn_std_f16_kernel(
 
 typedef void (*ss_kernel_t)(const float*, const int32_t*, const int32_t*, const int32_t*, const float*, int, int, const float*,
                             const unsigned short*, float*);
-// fmt: 0 bf16x3, 1 f16x3, 2 f16x4; 70.6 KB of dynamic LDS: above the 64 KB default, opted in once per kernel and device
+// fmt: 0 bf16x3, 1 f16x3, 2 f16x4, 3 bf16x6; 70.6 / 94.6 KB of dynamic LDS: above the 64 KB default, opted in once per kernel and device
 static int ss_launch(int fmt, const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off, const int32_t* n_wins,
                      const float* clip_floor, int32_t n_clips, int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
                      const uint16_t* cnn_wb, float* feat20, void* stream) {
-    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat20 || fmt < 0 || fmt > 2)
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 31) || seg_hop <= 0 || !cnn_wb || !feat20 || fmt < 0 || fmt > 3)
         return NISQA_ERR_ARG;
-    static const ss_kernel_t kernels[3] = {cnn_std_bf16_kernel, cnn_std_f16_kernel<false>, cnn_std_f16_kernel<true>};
+    static const ss_kernel_t kernels[4] = {cnn_std_bf16_kernel, cnn_std_f16_kernel<false>, cnn_std_f16_kernel<true>, cnn_std_bf16x6_kernel};
+    const int lds = fmt == 3 ? SS_LDS_T(3) : SS_LDS_T(2);
     NQ_LAUNCH_BEGIN();
-    static std::atomic<bool> lds_ok[3][64];
-    if (nq_lds_opt_in((const void*)kernels[fmt], (int)SS_LDS, lds_ok[fmt])) return 2;
-    hipLaunchKernelGGL(kernels[fmt], dim3(total_tok_padded / 4), dim3(256), SS_LDS, (hipStream_t)stream, mel_tm, frame_off, tok_off, n_wins,
+    static std::atomic<bool> lds_ok[4][64];
+    if (nq_lds_opt_in((const void*)kernels[fmt], lds, lds_ok[fmt])) return 2;
+    hipLaunchKernelGGL(kernels[fmt], dim3(total_tok_padded / 4), dim3(256), lds, (hipStream_t)stream, mel_tm, frame_off, tok_off, n_wins,
                        clip_floor, n_clips, seg_hop, cnn_std_w, cnn_wb, feat20);
     return NQ_LAUNCH_STATUS();
 }
@@ -582,4 +655,12 @@ extern "C" int nisqa_cnn_standard_f16(const float* mel_tm, const int32_t* frame_
     if (products != 3 && products != 4) return NISQA_ERR_ARG;
     return ss_launch(products - 2, mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, total_tok_padded, seg_hop, cnn_std_w, cnn_wh, feat20,
                      stream);
+}
+
+// the three-term form (cnn_wx: nisqa_amd.weights.pack_adapt_cnn_bf16(terms=3) of the StandardCNN's convolutions)
+extern "C" int nisqa_cnn_standard_bf16x6(const float* mel_tm, const int32_t* frame_off, const int32_t* tok_off,
+                                         const int32_t* n_wins, const float* clip_floor, int32_t n_clips,
+                                         int32_t total_tok_padded, int32_t seg_hop, const float* cnn_std_w,
+                                         const uint16_t* cnn_wx, float* feat20, void* stream) {
+    return ss_launch(3, mel_tm, frame_off, tok_off, n_wins, clip_floor, n_clips, total_tok_padded, seg_hop, cnn_std_w, cnn_wx, feat20, stream);
 }

@@ -38,6 +38,7 @@ NQ_DEV f32x4 mfma_bf16x16(f32x4 a, f32x4 b, f32x4 c) {     // 16x16x32: A[i = l&
 #define NQ_FMT_BF16X3 0
 #define NQ_FMT_F16X3 1
 #define NQ_FMT_F16X4 2
+#define NQ_FMT_BF16X6 3                    /* three bf16 terms, six products (exact operands): the kernels that template over it keep conv_k_terms' loops */
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 template <int FMT>
@@ -301,9 +302,12 @@ NQ_DEV unsigned cvt_pk_f16(float a, float b) {
 }
 // lds_store_split2 for either format; `mx` (F16 formats) gathers the maximum of the stored values (they are >= 0 behind a ReLU; the
 // conv1 input passes |v|): the next layer's scale comes from it
+template <int T> NQ_DEV void lds_store_terms2(unsigned a0, unsigned a1, int plane, float v0, float v1, bool st0 = true, bool st1 = true);
+template <int T> NQ_DEV void lds_store_terms(unsigned a, int plane, float v);
 template <int FMT, bool KO_DW = true>
 NQ_DEV void lds_store_pair_fmt(unsigned a0, unsigned a1, int plane, float v0, float v1, float& mx, bool st0 = true, bool st1 = true) {
     if (FMT == NQ_FMT_BF16X3) { lds_store_split2<KO_DW>(a0, a1, plane, v0, v1, st0, st1); return; }
+    if (FMT == NQ_FMT_BF16X6) { lds_store_terms2<3>(a0, a1, plane, v0, v1, st0, st1); return; }
     const unsigned hi2 = cvt_pk_f16(v0, v1);
     const f32x2_t vv = {v0, v1};
     const f32x2_t hf = __builtin_convertvector(__builtin_bit_cast(f16x2_t, hi2), f32x2_t);
@@ -316,6 +320,7 @@ NQ_DEV void lds_store_pair_fmt(unsigned a0, unsigned a1, int plane, float v0, fl
 template <int FMT>
 NQ_DEV void lds_store_one_fmt(unsigned a, int plane, float v, float& mx) {
     if (FMT == NQ_FMT_BF16X3) { lds_store_split(a, plane, v); return; }
+    if (FMT == NQ_FMT_BF16X6) { lds_store_terms<3>(a, plane, v); return; }
     const unsigned hi = cvt_pk_f16(v, 0.f);
     const float hf = (float)__builtin_bit_cast(f16x2_t, hi)[0];
     const unsigned lo = cvt_pk_f16(v - hf, 0.f);
@@ -412,7 +417,7 @@ NQ_DEV void conv_k_bf16(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int 
 // instead of 9).  Also an exact split, 2 % faster, but |term t+1| < 2^-7 |term t| makes the dropped products up to eight times
 // larger: the kernel's distance from float64 grows from 1.0 x to 1.4 x the fp32 kernels'.  Not used.
 template <int T>
-NQ_DEV void lds_store_terms2(unsigned a0, unsigned a1, int plane, float v0, float v1, bool st0 = true, bool st1 = true) {
+NQ_DEV void lds_store_terms2(unsigned a0, unsigned a1, int plane, float v0, float v1, bool st0, bool st1) {
     f32x2_t r = {v0, v1};
     if (NQ_KO & 256) {                     // timing experiment (results wrong): ONE dword store per term and value pair at a 4-byte lane pitch
         const unsigned dl = (threadIdx.x & 31) * 2 + ((threadIdx.x & 32) ? 32 : 0);
