@@ -149,30 +149,64 @@ def _load_checkpoint(path):
 class RowCells(object):
     """'%.6f' cells of the prediction columns, filled batch by batch while the predict loop runs (NISQA_lib._predict's on_rows):
     formatting the 100 000-row table the reference prints (NISQA_model.py:79) is 0.1 s of host time that otherwise follows the
-    last batch; here it happens under the next batches' transfers.  frame_to_string still cross-checks the result against pandas."""
+    last batch; here it happens under the next batches' transfers.  frame_to_string still cross-checks the result against pandas.
+
+    The cells are written right-justified to the width the column will have if every value is a non-negative number below 10
+    (8 characters, or the header if that is wider) and at least one cell does not end in '0' (pandas trims zeros common to the
+    whole column): ``final()`` hands them out as they are when that held for the whole column -- checked per batch on the
+    VALUES, vectorised, and confirmed on one formatted cell -- so that nothing per cell is left to do behind the last batch;
+    otherwise ``column()`` hands out nothing and the cells are formatted from the frame as before."""
 
     def __init__(self, n_rows, names):
         self.names = list(names)
-        self.cells = [[None] * n_rows for _ in self.names]
+        self.n = int(n_rows)
+        self.width = [max(len(' ' + nm), 8) for nm in self.names]
+        self.cells = [[None] * self.n for _ in self.names]
+        self.filled = [0] * len(self.names)
+        self.regular = [True] * len(self.names)              # every value finite, >= 0 (no sign), formats to 8 characters
+        self.tail = [False] * len(self.names)                # some cell confirmed not to end in '0': no common zeros to trim
 
     def __call__(self, ids, rows):
         ids = [int(i) for i in ids]
         v = np.asarray(rows, dtype=np.float64)               # float32 results widened like the DataFrame columns (NL:1438, 1455-1459)
         for h, col in enumerate(self.cells[:v.shape[1]]):
-            for i, x in zip(ids, v[:, h].tolist()):
-                col[i] = '%.6f' % x
+            x = v[:, h]
+            w = self.width[h]
+            if self.regular[h] and not (np.isfinite(x).all() and not np.signbit(x).any() and (x < 9.9999994).all()):
+                self.regular[h] = False
+            fmt = '%' + str(w) + '.6f'
+            for i, c in zip(ids, x.tolist()):
+                col[i] = fmt % c
+            self.filled[h] += len(ids)
+            if not self.tail[h] and len(ids):
+                k = int(np.argmax(np.rint(x * 1e6) % 10 != 0))
+                self.tail[h] = not col[ids[k]].endswith('0')
 
-    def column(self, name, values):
-        """the cells of column ``name`` if every row was seen and the first / last value agree with the frame's, else None"""
+    def _complete(self, h, values):
+        col = self.cells[h]
+        if len(values) != self.n or self.filled[h] != self.n:   # (every row exactly once: the loop scatters each item once)
+            return False
+        fmt = '%' + str(self.width[h]) + '.6f'
+        return all(col[i] is not None and col[i] == fmt % values[i] for i in (0, self.n // 2, self.n - 1))
+
+    def final(self, name, values):
+        """(cells already right-justified, their width) when the whole column was seen, is regular and has no common trailing
+        zeros; else None"""
         if name not in self.names:
             return None
-        col = self.cells[self.names.index(name)]
-        if len(col) != len(values) or any(c is None for c in col):
+        h = self.names.index(name)
+        if not (self.regular[h] and self.tail[h] and self._complete(h, values)):
             return None
-        for i in (0, len(col) - 1):
-            if col[i] != '%.6f' % values[i]:
-                return None
-        return col
+        return self.cells[h], self.width[h]
+
+    def column(self, name, values):
+        """the unpadded cells of column ``name`` if every row was seen and sampled values agree with the frame's, else None"""
+        if name not in self.names:
+            return None
+        h = self.names.index(name)
+        if not self._complete(h, values) or any(c is None for c in self.cells[h]):
+            return None
+        return [c.lstrip(' ') for c in self.cells[h]]
 
 
 def _fast_frame_lines(df, widest=None, pre=None):
@@ -192,6 +226,13 @@ def _fast_frame_lines(df, widest=None, pre=None):
             a = np.abs(v[~np.isnan(v)])
             if a.size and (not np.isfinite(a).all() or (a > 1e6).any() or ((a < 1e-6) & (a > 0)).any()):
                 return None                                  # pandas switches to exponent notation
+            done = pre.final(name, v) if pre is not None else None
+            if done is not None:                             # formatted and justified inside the loop: nothing per cell left
+                cells, w = done
+                if widest is not None:
+                    widest.append(0)
+                cols.append([(' ' + str(name)).rjust(w)] + cells)
+                continue
             cells = pre.column(name, v) if pre is not None else None
             if cells is None:
                 cells = ['%.6f' % x for x in v.tolist()]     # 'nan' for missing values

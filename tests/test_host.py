@@ -1122,6 +1122,28 @@ def test_table_cells_formatted_inside_the_loop_give_the_reference_table(tmp_path
     wrong = NM.RowCells(3, ['mos_pred'])
     wrong([0, 1, 2], np.array([[9.0], [3.5], [4.125]], np.float32))
     assert wrong.column('mos_pred', df['mos_pred'].to_numpy()) is None and NM.frame_to_string(df, pre=wrong) == df.to_string(index=False)
+    # cells justified inside the loop (final()): only for columns of non-negative values below 10 with no common trailing zeros;
+    # anything else -- a value >= 10, a negative one, -0.0, NaN, 9.9999996 (formats as 10.000000), all-zero tails -- takes the general path
+    rng = np.random.default_rng(2)
+    base = rng.uniform(1, 5, (200, 2)).astype(np.float32)
+    for label, edit, expect_final in (('regular', None, True), ('ten', 12.5, False), ('negative', -1.25, False), ('minus zero', -0.0, False),
+                                      ('nan', np.nan, False), ('rounds to ten', 9.9999996, False), ('just below', 9.999999, True)):
+        v = base.copy()
+        if edit is not None:
+            v[17, 1] = edit
+        fr = pd.DataFrame({'deg': ['f%03d.wav' % i for i in range(200)], 'mos_pred': v[:, 0].astype(np.float64), 'loud_pred': v[:, 1].astype(np.float64)})
+        rc = NM.RowCells(200, ['mos_pred', 'loud_pred'])
+        order = rng.permutation(200)
+        for s0 in range(0, 200, 64):
+            ids = order[s0:s0 + 64]
+            rc(ids.tolist(), v[ids])
+        assert (rc.final('loud_pred', fr['loud_pred'].to_numpy()) is not None) == expect_final, label
+        assert rc.final('mos_pred', fr['mos_pred'].to_numpy()) is not None
+        assert NM.frame_to_string(fr, pre=rc) == fr.to_string(index=False), label
+    zeros = pd.DataFrame({'deg': ['a', 'b'], 'mos_pred': [1.5, 2.25]})
+    rz = NM.RowCells(2, ['mos_pred'])
+    rz([0, 1], np.array([[1.5], [2.25]], np.float32))
+    assert rz.final('mos_pred', zeros['mos_pred'].to_numpy()) is None and NM.frame_to_string(zeros, pre=rz) == zeros.to_string(index=False)
 
 
 def test_ingest_cpu_budget_reader_cap_ring_reuse_and_path_cache(tmp_path, monkeypatch):
