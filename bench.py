@@ -566,7 +566,7 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
     cnn = (FLOP_CONV1_4 + FLOP_CONV5_6) * bs
     rest = FLOP_NET_CLIP * bs - cnn
     modes, segments, peak_mem = {}, 0, 0.0
-    for mode in ('f32', 'bf16x6', 'mixed', 'bf16x3'):
+    for mode in ('f32', 'bf16x6', 'f16x4', 'mixed', 'bf16x3'):
         tr = HipTrainer(args, sd, dev, lr=1e-3, precision=mode)
         plan = tr.eng.plan([int(SECONDS * SR)] * bs, SR)
         x = tr.eng.pcm16_to_f32(torch.from_numpy(pcm).to(dev))
@@ -583,7 +583,8 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
         # the two gradient passes on split-bf16 ('mixed', 'bf16x3') or fp32 ('f32'); attention / pooling / projection fp32
         # ('bf16x6': all three on the bf16 pipe with six products per term pair instead of three)
         pk_f, pk_b = (PEAK_F32 if mode in ('f32', 'mixed') else PEAK_BF16_MFMA), (PEAK_F32 if mode == 'f32' else PEAK_BF16_MFMA)
-        ideal = ((2 if mode == 'bf16x6' else 1) * (cnn / pk_f + 2 * cnn / pk_b) + 3 * rest / PEAK_F32) / 1e12
+        # ('f16x4': forward and input gradient with four products per term pair instead of three, the weight gradient with six)
+        ideal = (((2 if mode == 'bf16x6' else 1) * (cnn / pk_f + 2 * cnn / pk_b) if mode != 'f16x4' else (4.0 / 3 * 2 + 2) * cnn / PEAK_BF16_MFMA) + 3 * rest / PEAK_F32) / 1e12
         ach = flop / dt / 1e12
         modes[mode] = {'ms_per_step': round(dt * 1e3, 3), 'value': round(bs / dt, 1), 'achieved_TFLOPs': round(ach, 2),
                        'frac_of_fp32_peak': round(ach / PEAK_F32, 4), 'frac_of_mode_ideal': round(ideal / dt, 4),

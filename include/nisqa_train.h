@@ -128,6 +128,17 @@ int nisqa_segconv_f32(int32_t mode, const float* src, const float* frags, float*
  * nisqa_segconv_bf16x6 mirror nisqa_segconv_frag_bytes / nisqa_segconv_pack_many / nisqa_segconv_bf16 argument for argument
  * (three-term fragments: 1.5 x the bytes). */
 int64_t nisqa_segconv_frag_bytes_x6(int32_t mode, int32_t ci, int32_t co);
+/* The same two products on TWO f16 terms per operand, all four term products (precision mode 'f16x4'): the staged tensor of a
+ * workgroup's group of segments as f16 hi + lo of x * 2^e, e from the group's own largest magnitude (measured while the values are
+ * in registers); the weights as f16 hi + lo of W * 2^kw, kw from the layer's largest |W| of this optimiser step (computed on the
+ * device by the packer, stored behind the fragments: the buffer is 16 bytes longer).  11 + 11 significand bits and the low term's
+ * sign: the fp32 value itself for ~75 % of the operands, one fp32 ulp off otherwise; held to the bounds of nisqa_segconv_f32 by the
+ * same test.  Mirrors nisqa_segconv_frag_bytes / nisqa_segconv_pack_many / nisqa_segconv_bf16 argument for argument. */
+int64_t nisqa_segconv_frag_bytes_f16(int32_t mode, int32_t ci, int32_t co);
+int nisqa_segconv_pack_f16_many(int32_t n_jobs, const int32_t* modes, const float* const* w, const int32_t* ci, const int32_t* co,
+                                uint16_t* const* frags, void* stream);
+int nisqa_segconv_f16(int32_t mode, const float* src, const uint16_t* frags, float* out, int32_t n_segments, int32_t h, int32_t w,
+                      int32_t ci, int32_t co, int32_t pad_w, const float* bias, double* stats2c, void* stream);
 int nisqa_segconv_pack_x6_many(int32_t n_jobs, const int32_t* modes, const float* const* w, const int32_t* ci, const int32_t* co,
                                uint16_t* const* frags, void* stream);
 int nisqa_segconv_bf16x6(int32_t mode, const float* src, const uint16_t* frags, float* out, int32_t n_segments, int32_t h, int32_t w,

@@ -119,6 +119,49 @@ __global__ __launch_bounds__(256) void segconv_pack_many_kernel(segconv_pack_job
     }
 }
 
+// ---- f16 formats (precision mode 'f16x4'): fragments of W * 2^kw as f16 hi + lo in the two-term layout, kw from the layer's largest
+//      |W| of THIS optimiser step (the largest lands in [2^14, 2^15)), stored as one int32 behind the fragments (the buffer is 16 bytes
+//      longer): segconv_wmax_kernel writes it, the packer and the convolution read it
+__global__ __launch_bounds__(256) void segconv_wmax_kernel(segconv_pack_jobs jobs, int frag_u16_unused) {
+    const int j = blockIdx.x;
+    const float* __restrict__ w = jobs.w[j];
+    const int n = jobs.ci[j] * jobs.co[j] * 9;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    m = wave_max(m);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const int kc = jobs.mode[j] ? jobs.co[j] : jobs.ci[j], n_real = jobs.mode[j] ? jobs.ci[j] : jobs.co[j];
+        const size_t u16s = (size_t)9 * (kc / 16) * ((n_real + 31) / 32) * 2 * 512;
+        *(int*)(jobs.out[j] + u16s) = (m > 0.f && m < 3.0e38f) ? f16_scale_exp(m) : 0;
+    }
+}
+__global__ __launch_bounds__(256) void segconv_pack_f16_many_kernel(segconv_pack_jobs jobs) {
+    const int j = blockIdx.y;
+    const float* __restrict__ w = jobs.w[j];
+    unsigned short* __restrict__ out = jobs.out[j];
+    const int ci = jobs.ci[j], co = jobs.co[j], mode = jobs.mode[j];
+    const int kc = mode ? co : ci, n_real = mode ? ci : co;
+    const int s16 = kc / 16, nt_n = (n_real + 31) / 32;
+    const int total = 9 * s16 * nt_n * 64 * 8;
+    const float sc = pow2_f32(*(const int*)(out + (size_t)total * 2));
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int e = i & 7, lane = (i >> 3) & 63, nt = (i >> 9) % nt_n, g = (i >> 9) / nt_n;
+        const int tap = g / s16, c = 16 * (g % s16) + 8 * (lane >> 5) + e, n = 32 * nt + (lane & 31);
+        float v = 0.f;
+        if (n < n_real) v = mode ? w[(size_t)c * (9 * ci) + (8 - tap) * ci + n] : w[(size_t)n * (9 * ci) + tap * ci + c];
+        v *= sc;
+        const size_t o = (((size_t)(g * nt_n + nt) * 2) * 64 + lane) * 8 + e;
+        const unsigned hi = cvt_pk_f16(v, 0.f) & 0xffffu;
+        const float hf = (float)__builtin_bit_cast(f16x2_t, hi)[0];
+        out[o] = (unsigned short)hi;
+        out[o + 512] = (unsigned short)(cvt_pk_f16(v - hf, 0.f) & 0xffffu);
+    }
+}
+
 extern "C" int64_t nisqa_segconv_frag_bytes(int32_t mode, int32_t ci, int32_t co) {
     if (mode < 0 || mode > 1 || ci < 16 || co < 16 || (ci & 15) || (co & 15)) return -1;
     const int kc = mode ? co : ci, n_real = mode ? ci : co;
@@ -130,6 +173,25 @@ extern "C" int nisqa_segconv_pack(int32_t mode, const float* w, int32_t ci, int3
     NQ_LAUNCH_BEGIN();
     const int total = (int)(nisqa_segconv_frag_bytes(mode, ci, co) / 4);          // elements of one plane pair / 2
     hipLaunchKernelGGL(segconv_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, ci, co, mode, frags);
+    return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int64_t nisqa_segconv_frag_bytes_f16(int32_t mode, int32_t ci, int32_t co) {
+    const int64_t b = nisqa_segconv_frag_bytes(mode, ci, co);
+    return b < 0 ? b : b + 16;                                  // + the layer's scale exponent (int32) behind the fragments
+}
+extern "C" int nisqa_segconv_pack_f16_many(int32_t n_jobs, const int32_t* modes, const float* const* w, const int32_t* ci,
+                                           const int32_t* co, uint16_t* const* frags, void* stream) {
+    if (n_jobs < 1 || n_jobs > 10 || !modes || !w || !ci || !co || !frags) return NISQA_ERR_ARG;
+    segconv_pack_jobs jobs = {};
+    jobs.terms = 2;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!w[j] || !frags[j] || nisqa_segconv_frag_bytes(modes[j], ci[j], co[j]) < 0) return NISQA_ERR_ARG;
+        jobs.w[j] = w[j]; jobs.out[j] = frags[j]; jobs.ci[j] = ci[j]; jobs.co[j] = co[j]; jobs.mode[j] = modes[j];
+    }
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(segconv_wmax_kernel, dim3(n_jobs), dim3(256), 0, (hipStream_t)stream, jobs, 0);
+    hipLaunchKernelGGL(segconv_pack_f16_many_kernel, dim3(36, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
     return NQ_LAUNCH_STATUS();
 }
 
@@ -271,7 +333,12 @@ NQ_DEV void sc_store_terms4(unsigned a, int plane, f32x4 v) {
 // tap (ty, tx) is (y + ty - 1, x + tx - PADX)
 // TERMS (split-bf16 only): 2 = hi / lo planes and three products per term pair; 3 = hi / mid / lo planes, an exact split of the
 // fp32 activations, and six products (conv_k_terms: the accuracy of the fp32 variant at 2.7 x its matrix-pipe rate)
-template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false, int TERMS = 2>
+// FMT (TERMS = 2 only): NQ_FMT_BF16X3 (default) or NQ_FMT_F16X4 -- the staged tensor of a workgroup's GROUP of segments as f16 hi + lo of
+// x * 2^e, e from the group's own largest magnitude (measured while the values are in registers, exchanged between the four waves
+// through the barrier the staging has anyway), all four term products; the output leaves as fp32 (acc * 2^-(e + kw) + bias), so no
+// bound on the next tensor is needed here
+#define SC_MAXSLOT 1024u                   /* four floats below the zero block: the waves' maxima of the group being staged */
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false, int TERMS = 2, int FMT = NQ_FMT_BF16X3>
 struct segconv_cfg {
     static constexpr int RS = F32 ? 4 * CIN + 16 : 2 * CIN + 16;
     static constexpr int PXS = HS * WS, PXR = HR * WR;
@@ -286,11 +353,15 @@ struct segconv_cfg {
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
 };
 
-template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false, int TERMS = 2>
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false, int TERMS = 2, int FMT = NQ_FMT_BF16X3>
 __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
     const float* __restrict__ src, const unsigned short* __restrict__ frags, float* __restrict__ out, int n_segments,
     const float* __restrict__ bias, double* __restrict__ stats) {
-    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS> C;
+    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS, FMT> C;
+    constexpr bool F16 = FMT == NQ_FMT_F16X4;
+    static_assert(!F16 || (!F32 && TERMS == 2), "the f16 format is a two-term form");
+    // F16: the layer's weight-scale exponent sits behind the fragments (nisqa_segconv_pack_f16_many)
+    const int kw = F16 ? *(const int*)(frags + (size_t)9 * (CIN / 16) * NT * 2 * 512) : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid0 = threadIdx.x, lane0 = tid0 & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -354,9 +425,25 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
         // of the epilogue is computed once before the loop and kept in registers across it -- 100+ of them)
         int tid = tid0, lane = lane0;
         asm volatile("" : "+v"(tid), "+v"(lane));
+        float gscale = 1.f, cinv = 1.f;                       // F16: 2^e of this group's staged tensor, 2^-(e + kw) for its outputs
         {
             SC_CLK(0);
+            if constexpr (F16) {
+                float mr = 0.f;
+#pragma unroll
+                for (int j = 0; j < C::NV; ++j)                  // (values beyond the group's end were loaded as zeros)
+                    mr = fmaxf(fmaxf(mr, fmaxf(__builtin_fabsf(v[j][0]), __builtin_fabsf(v[j][1]))), fmaxf(__builtin_fabsf(v[j][2]), __builtin_fabsf(v[j][3])));
+                mr = wave_max_nonneg(mr);
+                if (lane == 0) lds_st32(SC_MAXSLOT + 4 * wave, __float_as_uint(mr));
+            }
             __syncthreads();                                    // every wave has left the K loop over the previous planes
+            if constexpr (F16) {
+                // (the slot is rewritten only behind the NEXT group's first barrier's predecessor: the barrier below separates)
+                const f32x4 m4 = lds_ld128(SC_MAXSLOT);
+                const int ge = f16_scale_exp(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])));
+                gscale = pow2_f32(ge);
+                cinv = pow2_f32(-(ge + kw));
+            }
             SC_CLK(1);
 #pragma unroll
             for (int j = 0; j < C::NV; ++j) {
@@ -370,6 +457,16 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
                     const unsigned a = SC_BASE + pix * C::RS + 2 * c;
                     if constexpr (TERMS == 3) {
                         sc_store_terms4<3>(a, C::PLANE, v[j]);
+                        continue;
+                    }
+                    if constexpr (F16) {
+                        const f32x4 sv = v[j] * gscale;
+                        const unsigned h0 = cvt_pk_f16(sv[0], sv[1]), h1 = cvt_pk_f16(sv[2], sv[3]);
+                        const f32x2_t f0 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, h0), f32x2_t);
+                        const f32x2_t f1 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, h1), f32x2_t);
+                        lds_st32(a, h0); lds_st32(a + 4, h1);
+                        lds_st32(a + C::PLANE, cvt_pk_f16(sv[0] - f0[0], sv[1] - f0[1]));
+                        lds_st32(a + C::PLANE + 4, cvt_pk_f16(sv[2] - f1[0], sv[3] - f1[1]));
                         continue;
                     }
                     const unsigned h0 = cvt_pk_bf16(v[j][0], v[j][1]), h1 = cvt_pk_bf16(v[j][2], v[j][3]);
@@ -408,7 +505,7 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
         if (active) {
             if constexpr (F32) conv_k_f32<CIN, MT, NT, WS, C::RS, C::ZADDR, SC_RING>(acc, rsrc, lane0 * 16, base, m9);
             else if constexpr (TERMS == 3) conv_k_terms<3, CIN, MT, NT, WS, C::RS, C::PLANE, SC_ZADDR, SC_RING, SC_X6_FENCE>(acc, rsrc, 0, lane0 * 16, base, m9);
-            else conv_k_bf16<CIN, MT, NT, WS, C::RS, C::PLANE, SC_ZADDR, (MT * NT <= 4), SC_RING>(acc, rsrc, 0, lane0 * 16, base, m9);
+            else conv_k_bf16<CIN, MT, NT, WS, C::RS, C::PLANE, SC_ZADDR, (MT * NT <= 4), SC_RING, FMT>(acc, rsrc, 0, lane0 * 16, base, m9);
         }
 
         SC_CLK(4);                                              // K loop
@@ -429,7 +526,7 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
                 for (int r = 0; r < 16; ++r) {
                     const int row = (wave * MT + t) * 32 + NQ_DROW(r, lane >> 5);
                     if (row < rows && col < NOUT) {
-                        const float zv = acc[t][nt][r] + bv[nt];
+                        const float zv = F16 ? fmaf(acc[t][nt][r], cinv, bv[nt]) : acc[t][nt][r] + bv[nt];
                         o[(size_t)row * NOUT + col] = zv;
                         if (FWD) { s1[nt] += (double)zv; s2[nt] += (double)zv * (double)zv; }
                     }
@@ -496,19 +593,19 @@ static int sc_cu_count() {
     return v;
 }
 
-template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false, int TERMS = 2>
+template <int CIN, int NT, int NOUT, int HR, int WR, int HS, int WS, int PADX, int SEGS, int MT, bool FWD, bool F32 = false, int TERMS = 2, int FMT = NQ_FMT_BF16X3>
 static void segconv_launch(hipStream_t st, const float* src, const uint16_t* frags, float* out, int n_segments,
                            const float* bias, double* stats) {
-    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS> C;
+    typedef segconv_cfg<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS, FMT> C;
     static std::atomic<int> per_cu_dev[SC_MAX_DEV];             // resident workgroups per CU (registers and LDS), asked once per device
     const int dev = sc_device();
     int per_cu = per_cu_dev[dev].load(std::memory_order_relaxed);
     if (!per_cu) {
         // 50-80 KB of dynamic LDS: opt in explicitly (a runtime that enforces the 64 KB default would refuse the launch)
-        (void)hipFuncSetAttribute((const void*)segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS>,
+        (void)hipFuncSetAttribute((const void*)segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS, FMT>,
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS>, 256,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS, FMT>, 256,
                                                          C::LDS) != hipSuccess || nb < 1)
             nb = 2;
         per_cu = nb;
@@ -516,7 +613,7 @@ static void segconv_launch(hipStream_t st, const float* src, const uint16_t* fra
     }
     const int n_groups = (n_segments + SEGS - 1) / SEGS;
     const int grid = n_groups < per_cu * sc_cu_count() ? n_groups : per_cu * sc_cu_count();
-    hipLaunchKernelGGL((segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS>), dim3(grid), dim3(256), C::LDS, st, src,
+    hipLaunchKernelGGL((segconv_bf16_kernel<CIN, NT, NOUT, HR, WR, HS, WS, PADX, SEGS, MT, FWD, F32, TERMS, FMT>), dim3(grid), dim3(256), C::LDS, st, src,
                        frags, out, n_segments, bias, stats);
 }
 
@@ -553,6 +650,36 @@ extern "C" int nisqa_segconv_bf16(int32_t mode, const float* src, const uint16_t
         else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, false>(st, src, frags, out, n, nullptr, nullptr);
         else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 14, 2, false>(st, src, frags, out, n, nullptr, nullptr);
         else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 3, 6, 1, 2, 14, 2, false>(st, src, frags, out, n, nullptr, nullptr);
+        else return NISQA_ERR_ARG;
+    }
+    return NQ_LAUNCH_STATUS();
+}
+
+// the same two products on f16 hi + lo of the per-group scaled tensors, four term products (precision mode 'f16x4'; frags =
+// nisqa_segconv_pack_f16_many of the same mode, nisqa_segconv_frag_bytes_f16 bytes)
+extern "C" int nisqa_segconv_f16(int32_t mode, const float* src, const uint16_t* frags, float* out, int32_t n_segments,
+                                  int32_t h, int32_t w, int32_t ci, int32_t co, int32_t pad_w, const float* bias,
+                                  double* stats2c, void* stream) {
+    if (mode < 0 || mode > 1 || !src || !frags || !out || n_segments <= 0 || (mode == 1 && (bias || stats2c)) ||
+        !nisqa_segconv_supported(h, w, ci, co, pad_w))
+        return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    NQ_LAUNCH_BEGIN();
+    const int key = ((h * 100 + w) * 100 + ci) * 100 + co;
+    const int n = n_segments;
+    if (mode == 0) {
+        if (key == SC_KEY(24, 7, 16, 32) && pad_w == 1) segconv_launch<16, 1, 32, 24, 7, 24, 7, 1, 3, 4, true, false, 2, NQ_FMT_F16X4>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<32, 2, 64, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, true, false, 2, NQ_FMT_F16X4>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, true, false, 2, NQ_FMT_F16X4>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 14, 2, true, false, 2, NQ_FMT_F16X4>(st, src, frags, out, n, bias, stats2c);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 1, 6, 3, 0, 15, 1, true, false, 2, NQ_FMT_F16X4>(st, src, frags, out, n, bias, stats2c);
+        else return NISQA_ERR_ARG;
+    } else {                                                  // staged tensor = dz [S][h * wo][co], rows = the h * w input pixels
+        if (key == SC_KEY(24, 7, 16, 32) && pad_w == 1) segconv_launch<32, 1, 16, 24, 7, 24, 7, 1, 2, 3, false, false, 2, NQ_FMT_F16X4>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(12, 5, 32, 64) && pad_w == 1) segconv_launch<64, 1, 32, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, false, false, 2, NQ_FMT_F16X4>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(12, 5, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 12, 5, 12, 5, 1, SC_SEGS60, SC_SEGS60 / 2, false, false, 2, NQ_FMT_F16X4>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 1) segconv_launch<64, 2, 64, 6, 3, 6, 3, 1, 14, 2, false, false, 2, NQ_FMT_F16X4>(st, src, frags, out, n, nullptr, nullptr);
+        else if (key == SC_KEY(6, 3, 64, 64) && pad_w == 0) segconv_launch<64, 2, 64, 6, 3, 6, 1, 2, 14, 2, false, false, 2, NQ_FMT_F16X4>(st, src, frags, out, n, nullptr, nullptr);
         else return NISQA_ERR_ARG;
     }
     return NQ_LAUNCH_STATUS();

@@ -111,6 +111,9 @@ TRAIN_SYMBOLS = {
     'nisqa_segconv_pack_f32_many': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nisqa_segconv_f32': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_segconv_frag_bytes_x6': (ctypes.c_int64, [c_i32, c_i32, c_i32]),
+    'nisqa_segconv_frag_bytes_f16': (ctypes.c_int64, [c_i32, c_i32, c_i32]),
+    'nisqa_segconv_pack_f16_many': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
+    'nisqa_segconv_f16': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_segconv_pack_x6_many': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nisqa_segconv_bf16x6': (ctypes.c_int, [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p]),
     'nisqa_segconv_wgrad_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),

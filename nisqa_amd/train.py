@@ -87,14 +87,18 @@ class HipTrainer(object):
           'bf16x6' (default) forward, dgrad and wgrad at fp32 OPERAND precision on the bf16 matrix pipe: activations, gradients and weights as
                    three exact bf16 terms, six MFMA products per term pair (csrc/train_conv.hip, TERMS = 3): held to the bounds
                    of 'f32' by the same tests, at 2.7 x its matrix-pipe rate;
+          'f16x4'  (round 5) the control flow of 'bf16x6' with the forward and input-gradient convolutions on TWO f16 terms per operand and all
+                   four products (csrc/train_conv.hip, FMT = F16X4: the staged tensor of a group of segments scaled by a power of two from
+                   its own largest magnitude, the weights from the layer's largest |W| of the step); weight gradients as 'bf16x6'.  Held
+                   to the bounds of 'f32' by the same tests; an operand may be one fp32 ulp off (DESIGN.md 4.5.1), hence opt-in;
           'bf16x3' the forward convolutions on split-bf16 MFMA as well (the arithmetic of the inference path's default):
                    y_hat moves by <= 1e-4.  On the random-weight fixtures that is enough to move individual gradient
                    tensors by per cent (the network's Jacobian at a random initialisation is that sensitive to its
                    activations; the backward kernels themselves agree with fp32 to 1e-5, tests/test_gpu_train.py)."""
         a = args
         self.precision = precision or os.environ.get('NISQA_HIP_TRAIN_PRECISION', 'bf16x6')
-        if self.precision not in ('f32', 'mixed', 'bf16x3', 'bf16x6'):
-            raise ValueError('precision must be f32, mixed, bf16x3 or bf16x6, got {}'.format(self.precision))
+        if self.precision not in ('f32', 'mixed', 'bf16x3', 'bf16x6', 'f16x4'):
+            raise ValueError('precision must be f32, mixed, bf16x3, bf16x6 or f16x4, got {}'.format(self.precision))
         if not (a.get('cnn_model') == 'adapt' and a.get('td') == 'self_att' and a.get('pool') == 'att') \
                 or a.get('td_2') not in (None, 'skip') or a['model'] not in ('NISQA', 'NISQA_DIM'):
             raise NotImplementedError('HIP training step covers NISQA / NISQA_DIM with cnn_model=adapt, td=self_att, '
@@ -115,13 +119,15 @@ class HipTrainer(object):
         self.segconv_f32_fwd = os.environ.get('NISQA_HIP_TRAIN_SEGCONV_F32_FWD', '1') != '0' and self.precision in ('f32', 'mixed')
         self._sc32_frags, self._sc32_bufs = {}, {}
         self._conv_fwd = fast if self.precision == 'bf16x3' else exact
-        self._conv_bwd = exact if self.precision in ('f32', 'bf16x6') else fast     # (layer shapes train_conv.hip does not instantiate)
+        self._conv_bwd = exact if self.precision in ('f32', 'bf16x6', 'f16x4') else fast     # (layer shapes train_conv.hip does not instantiate)
         # 'bf16x6' walks the control flow of 'bf16x3' -- segment-resident kernels on uint16 fragments for forward, dgrad and wgrad --
         # through the three-term entry points
-        x6 = self.precision == 'bf16x6'
-        self._sc_frag_bytes = self.lib.nisqa_segconv_frag_bytes_x6 if x6 else self.lib.nisqa_segconv_frag_bytes
-        self._sc_pack_many = self.lib.nisqa_segconv_pack_x6_many if x6 else self.lib.nisqa_segconv_pack_many
-        self._sc_conv = self.lib.nisqa_segconv_bf16x6 if x6 else self.lib.nisqa_segconv_bf16
+        # 'f16x4' (round 5): the control flow of 'bf16x6' with the forward and input-gradient convolutions on two f16 terms of the
+        # per-group scaled tensors and all four products (nisqa_segconv_f16); the weight gradients stay on the three-term kernels
+        x6, h4 = self.precision == 'bf16x6', self.precision == 'f16x4'
+        self._sc_frag_bytes = self.lib.nisqa_segconv_frag_bytes_x6 if x6 else self.lib.nisqa_segconv_frag_bytes_f16 if h4 else self.lib.nisqa_segconv_frag_bytes
+        self._sc_pack_many = self.lib.nisqa_segconv_pack_x6_many if x6 else self.lib.nisqa_segconv_pack_f16_many if h4 else self.lib.nisqa_segconv_pack_many
+        self._sc_conv = self.lib.nisqa_segconv_bf16x6 if x6 else self.lib.nisqa_segconv_f16 if h4 else self.lib.nisqa_segconv_bf16
         # split-bf16 forward / input-gradient convolutions segment-resident (csrc/train_conv.hip) where the layer shape is
         # one of the reference configuration's; weight fragments are packed once per step (_segconv_pack)
         self.segconv = os.environ.get('NISQA_HIP_TRAIN_SEGCONV', '1') != '0' and self.precision != 'f32'
@@ -272,7 +278,7 @@ class HipTrainer(object):
             hi, wi = geo[i - 2][2]
             if not self.lib.nisqa_segconv_supported(hi, wi, ci, co, 0 if i == 6 else 1):
                 continue
-            for mode in ((0, 1) if self.precision in ('bf16x3', 'bf16x6') else (1,)):
+            for mode in ((0, 1) if self.precision in ('bf16x3', 'bf16x6', 'f16x4') else (1,)):
                 buf = self._sc_bufs.get((mode, i))
                 if buf is None:
                     buf = self._sc_bufs[(mode, i)] = torch.empty(self._sc_frag_bytes(mode, ci, co) // 2,
@@ -812,7 +818,7 @@ class HipTrainer(object):
                 dp = _ptr(c['drop']) if c['drop'] is not None else None
                 self._ck(L_.nisqa_bn_pool_bwd_sums(_ptr(da), c['arg'].data_ptr(), dp, _ptr(c['z']), _ptr(c['mr']), _ptr(g), _ptr(b_), S,
                                                    c['h'], c['w'], co, c['ho'], c['wo'], s2.data_ptr(), st), 'nisqa_bn_pool_bwd_sums')
-                self._ck((L_.nisqa_segconv_wgrad_bf16x6 if self.precision == 'bf16x6' else L_.nisqa_segconv_wgrad_bn_bf16)(
+                self._ck((L_.nisqa_segconv_wgrad_bf16x6 if self.precision in ('bf16x6', 'f16x4') else L_.nisqa_segconv_wgrad_bn_bf16)(
                     _ptr(c['x']), _ptr(c['z']), _ptr(da), c['arg'].data_ptr(), dp, _ptr(c['mr']),
                                                         _ptr(g), _ptr(b_), s2.data_ptr(), _ptr(dz),
                                                         _ptr(self.G['cnn.model.bn%d.weight' % i]), _ptr(self.G['cnn.model.bn%d.bias' % i]),
@@ -856,7 +862,7 @@ class HipTrainer(object):
                     self._ck(L_.nisqa_segconv_wgrad_f32(_ptr(c['x']), None, None, None, None, None, None, None, None, _ptr(dz), None, None,
                                                         _ptr(self.G[wk]), S, hi, wi, ci, co, pad, c['ho'], c['wo'], st),
                              'nisqa_segconv_wgrad_f32')
-                elif (1, i) in self._sc_frags and self.precision == 'bf16x6':
+                elif (1, i) in self._sc_frags and self.precision in ('bf16x6', 'f16x4'):
                     self._ck(L_.nisqa_segconv_wgrad_bf16x6(_ptr(c['x']), None, None, None, None, None, None, None, None, _ptr(dz), None, None,
                                                            _ptr(self.G[wk]), S, hi, wi, ci, co, pad, c['ho'], c['wo'], st),
                              'nisqa_segconv_wgrad_bf16x6')

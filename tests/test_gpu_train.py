@@ -316,7 +316,8 @@ def test_segment_resident_fp32_convolutions_forward_and_input_gradient(h, w, ci,
     want_dx = xd.grad.permute(0, 2, 3, 1).reshape(S, h * w, ci)
     n = 2
     for fam, nbytes, pack, conv, dt, esz in (('f32', L.nisqa_segconv_frag_bytes_f32, L.nisqa_segconv_pack_f32_many, L.nisqa_segconv_f32, torch.float32, 4),
-                                             ('bf16x6', L.nisqa_segconv_frag_bytes_x6, L.nisqa_segconv_pack_x6_many, L.nisqa_segconv_bf16x6, torch.int16, 2)):
+                                             ('bf16x6', L.nisqa_segconv_frag_bytes_x6, L.nisqa_segconv_pack_x6_many, L.nisqa_segconv_bf16x6, torch.int16, 2),
+                                             ('f16x4', L.nisqa_segconv_frag_bytes_f16, L.nisqa_segconv_pack_f16_many, L.nisqa_segconv_f16, torch.int16, 2)):
         fr = []
         for mode in (0, 1):
             nb = nbytes(mode, ci, co)
@@ -610,7 +611,7 @@ def _case(name):
     return g, args, sd, specs, y
 
 
-@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x6'])
+@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x6', 'f16x4'])
 @pytest.mark.parametrize('name', ['mos', 'dim'])
 def test_training_step_matches_reference_fixture(name, precision):
     from nisqa_amd.train import HipTrainer
@@ -658,7 +659,7 @@ def test_training_step_matches_reference_fixture(name, precision):
     HipNisqa(args, tr.state_dict(), DEV)
 
 
-@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x3', 'bf16x6', 'f16x4'])
 def test_training_step_from_the_published_weights(precision):
     """Fine-tuning step from nisqa.tar (fixture: the reference's NISQA_DIM in train mode on the same seeded batch,
     tests/golden/make_golden_train.py run('dim_real')): a trained network, not a random initialisation -- the case the
@@ -710,7 +711,7 @@ def _cfg5_case(name):
     return g, args, sd, specs, y
 
 
-@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('precision', ['f32', 'mixed', 'bf16x3', 'bf16x6', 'f16x4'])
 @pytest.mark.parametrize('name', ['cfg5_mos', 'cfg5_dim_real'])
 def test_training_step_at_configs4_size_matches_reference_fixture(name, precision):
     """BASELINE configs[4] at ITS OWN size -- bs 32 x 10 s = 7 904 segments, the size bench.py's train_step leg times --
@@ -871,7 +872,7 @@ def test_fused_self_attention_block_matches_the_operator_by_operator_path(name, 
             assert (d[solid].max(initial=0) if solid is not None else d.max(initial=0) * (0 if _conv_bias(k) else 1)) < 1e-4, k
 
 
-@pytest.mark.parametrize('precision', ['mixed', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('precision', ['mixed', 'bf16x3', 'bf16x6', 'f16x4'])
 @pytest.mark.parametrize('use_masks', [False, True])
 def test_batchnorm_backward_folded_into_the_weight_gradient_kernel_agrees_with_the_dense_pass(precision, use_masks, monkeypatch):
     """nisqa_segconv_wgrad_bn_bf16 (the dense z -> dz pass of layers 2..6 computed inside the weight-gradient kernel's staging,
@@ -1105,7 +1106,7 @@ def test_training_step_edge_shapes_match_oracle():
     assert worst < 1e-3, (worst, wk)
 
 
-@pytest.mark.parametrize('precision', ['mixed', 'bf16x3', 'bf16x6'])
+@pytest.mark.parametrize('precision', ['mixed', 'bf16x3', 'bf16x6', 'f16x4'])
 def test_segment_resident_and_implicit_convolution_paths_agree_in_the_step(precision, monkeypatch):
     """HipTrainer with the segment-resident convolutions (default) and with NISQA_HIP_TRAIN_SEGCONV=0 (implicit GEMMs): the
     same split-bf16 arithmetic in a different summation order -- loss, y_hat and every gradient agree to 2e-4 of a tensor's
@@ -1131,13 +1132,13 @@ def test_segment_resident_and_implicit_convolution_paths_agree_in_the_step(preci
     assert len(fr1) == (5 if precision == 'mixed' else 10) and not fr0
     # 'mixed': identical fp32 forward; 'bf16x3': two summation orders of the split-bf16 forward, each ~7e-5 from fp32
     assert l1 == pytest.approx(l0, rel=1e-4 if precision == 'bf16x3' else 1e-5)
-    assert np.abs(y1 - y0).max() < {'mixed': 2e-6, 'bf16x6': 2e-5, 'bf16x3': 2e-4}[precision]   # (mixed: the same fp32 forward twice)
+    assert np.abs(y1 - y0).max() < {'mixed': 2e-6, 'bf16x6': 2e-5, 'f16x4': 2e-5, 'bf16x3': 2e-4}[precision]   # (mixed: the same fp32 forward twice)
     worst = max(float(np.abs(g1[k].numpy() - g0[k].numpy()).max()) / max(1e-3, float(np.abs(g0[k].numpy()).max())) for k in g0
                 if not _conv_bias(k))
     print('segment-resident vs implicit convolutions,', precision, ': worst relative gradient difference %.2e' % worst)
     # 'bf16x3': forward rounding differs too (sensitivity: DESIGN.md 4.7); 'bf16x6': two fp32-grade but DIFFERENT forward evaluations
     # (y_hat 8e-6 apart): the ReLU gates behind train-mode BatchNorm that flip between them move gradient entries by ~1e-3
-    assert worst < {'mixed': 2e-4, 'bf16x6': 2e-3, 'bf16x3': 5e-2}[precision]
+    assert worst < {'mixed': 2e-4, 'bf16x6': 2e-3, 'f16x4': 2e-3, 'bf16x3': 5e-2}[precision]
 
 
 @pytest.mark.parametrize('model', ['NISQA', 'NISQA_DIM'])
