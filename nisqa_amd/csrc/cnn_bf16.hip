@@ -111,7 +111,7 @@ NQ_DEV float epi_fmt(float v, float c, float t) { return FMT == NQ_FMT_BF16X3 ? 
 //      all four products.  For the f16 formats wb is the CNNH_ blob (fragments of W * 2^kw + per-layer constants) and every activation
 //      tensor is stored as y * 2^e with e = 15 - ceil(log2(m_in * G + T)): m_in the MEASURED maximum of the layer's input for this
 //      segment, G = max_c sum |W_c| and T = max |shift| of the layer -- |y| <= m_in * G + T, so the scaled tensor stays below 2^15 for
-//      any finite input and any weights (no calibration, no clamping), 5-6 bits below it for the shipped weights.
+//      any finite input and any weights (no calibration, no clamping), 3-5 bits below it for the shipped weights.
 // SEGX: the input is the reference's segment tensor x[B][L][1][48][15] (inner-operator mode) instead of the spectrogram
 // P3: also write the pooled conv4 output as fp32 (debug / parity callers of nisqa_cnn_adapt_bf16 that pass p3_opt)
 template <int FMT, bool SEGX, bool P3>
