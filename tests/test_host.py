@@ -873,6 +873,42 @@ def test_raise_together_is_a_plain_raise_without_a_process_group():
         dist.raise_together(ValueError('x'))
 
 
+_WORKER_RT = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import torch
+from nisqa_amd import dist
+rank = int(sys.argv[1]); world = int(sys.argv[2])
+torch.distributed.init_process_group('gloo', init_method='tcp://127.0.0.1:%(port)d', rank=rank, world_size=world)
+class Odd(Exception):
+    pass
+out = []
+for case, err in (('none', None), ('value', ValueError('Could not load file x.wav') if rank == 1 else None),
+                  ('two', (NotImplementedError('first') if rank == 1 else RuntimeError('second') if rank == 2 else None)),
+                  ('custom', Odd('strange') if rank == 2 else None)):
+    try:
+        dist.raise_together(err)
+        out.append([case, None, None])
+    except Exception as e:
+        out.append([case, type(e).__name__, str(e)])
+json.dump(out, open(os.path.join(%(out)r, 'r%%d.json' %% rank), 'w'))
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_raise_together_carries_the_first_failing_ranks_exception_to_every_rank(tmp_path):
+    """dist.raise_together at world 3 (gloo): nobody failed -> nobody raises; one rank failed -> everyone raises its type and message;
+    two ranks failed -> the lower rank's exception wins everywhere (the failing higher rank included); an exception type outside the
+    allow-list arrives as RuntimeError('<TypeName>: <message>') on the other ranks and as itself on its own."""
+    res = _run_ranks(tmp_path, _WORKER_RT % {'root': ROOT, 'port': _free_port(), 'out': str(tmp_path)}, 3, timeout=120)
+    for r, rows in enumerate(res):
+        got = {c: (t, m) for c, t, m in rows}
+        assert got['none'] == (None, None)
+        assert got['value'] == ('ValueError', 'Could not load file x.wav')
+        assert got['two'] == ('NotImplementedError', 'first')
+        assert got['custom'] == (('Odd', 'strange') if r == 2 else ('RuntimeError', 'Odd: strange'))
+
+
 def test_predict_loop_at_world_eight_matches_one_process(tmp_path):
     """The real loop (header probe, work-balanced contiguous shards, length-aware batches, fail-together exchange, closing
     all_gather) on eight gloo ranks with a counting engine: a length-sorted list of 0.2 ... 2.4 s clips, every rank ends with
