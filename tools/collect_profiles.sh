@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profiles (run on the GPU box from the repo root): bench lines, rocprofv3 kernel stats and PMC passes for the
-# predict path (both precisions), the nisqa_tts.tar leg and the training step.  Output: gpurun_out/prof_rNN/ -> copy into profiles/.
+# predict path (every precision form), the nisqa_tts.tar leg and the training step.  Output: gpurun_out/prof_rNN/ -> copy into profiles/.
 #   tools/collect_profiles.sh r03
 R=${1:-r05}
 O=gpurun_out/prof_$R
