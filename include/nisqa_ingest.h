@@ -2,7 +2,7 @@
  * (SURVEY.md section 8f-2).  Plain C, no HIP: it fills caller-owned (page-locked) staging memory; the H2D copy
  * and everything after it belong to libnisqa_hip.so.
  *
- * Replaces, for RIFF/WAVE input, what the reference does per file inside
+ * Replaces, for RIFF/WAVE and FLAC input, what the reference does per file inside
  * SpeechQualityDataset._load_spec -> get_librosa_melspec -> lb.load(path, sr=None)
  * (nisqa/NISQA_lib.py:2129-2160, 2299-2306) from the DataLoader workers of predict_mos / predict_dim
  * (NISQA_lib.py:1425-1431, 1446-1452), each decoding one file into a fresh float32 array: here a pool of native
@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define NISQA_INGEST_ABI_VERSION 1
+#define NISQA_INGEST_ABI_VERSION 2
 
 /* per-file status */
 #define NISQA_WAV_OK 0
@@ -37,6 +37,11 @@ extern "C" {
 #define NISQA_WAV_TAG_MULAW 7        /* G.711 mu-law, 8 bits per sample */
 #define NISQA_WAV_TAG_BIG_ENDIAN 0x10000   /* flag OR-ed into tag: a RIFX file -- header fields were read big-endian and the
                                               samples of the data chunk ARE big-endian (nisqa_ingest_read copies them verbatim) */
+
+#define NISQA_WAV_TAG_FLAC 0xF1AC          /* not a WAVE file: a native FLAC stream ("fLaC", possibly behind an ID3v2 tag), 4-24 bits per
+                                              sample; data_offset = offset of the "fLaC" marker, n_frames from STREAMINFO (or counted by
+                                              decoding when STREAMINFO leaves it open), block_align = channels * (bits + 7) / 8 of the
+                                              DECODED samples.  lb.load reads these through the same soundfile call as a WAVE file. */
 
 typedef struct nisqa_wav_info {
     int32_t status;        /* NISQA_WAV_* */
@@ -57,9 +62,17 @@ int nisqa_ingest_probe(const char* const* paths, int32_t n, nisqa_wav_info* info
 
 /* Copy the data chunk of every file i with dst_off[i] >= 0 (info[i].n_frames * info[i].block_align bytes, verbatim)
  * to (char*)dst + dst_off[i].  info must come from nisqa_ingest_probe on the same paths; failures are recorded in
- * info[i].status (NISQA_WAV_ERR_OPEN / NISQA_WAV_ERR_READ).  Returns the number of failed files. */
+ * info[i].status (NISQA_WAV_ERR_OPEN / NISQA_WAV_ERR_READ).  Returns the number of failed files.
+ * A FLAC file (tag NISQA_WAV_TAG_FLAC) is DECODED into its slot as int16 -- mono 16-bit streams only (n_frames * 2 bytes, the
+ * form a mono PCM16 data chunk has); any other FLAC stream fails with NISQA_WAV_ERR_FORMAT here and goes through
+ * nisqa_ingest_decode_flac.  Every frame CRC, the stream length and STREAMINFO's MD5 of the samples are verified. */
 int nisqa_ingest_read(const char* const* paths, int32_t n, nisqa_wav_info* info, void* dst,
                       const int64_t* dst_off, int32_t n_threads);
+
+/* Decode one FLAC file (info from nisqa_ingest_probe, tag NISQA_WAV_TAG_FLAC) to interleaved int32 samples:
+ * dst[frame * channels + channel], info->n_frames * info->channels values, each the stream's integer sample (soundfile's
+ * float32 is that value / 2^(bits - 1)).  Returns NISQA_WAV_OK or an NISQA_WAV_ERR_* code. */
+int nisqa_ingest_decode_flac(const char* path, const nisqa_wav_info* info, int32_t* dst);
 
 #ifdef __cplusplus
 }

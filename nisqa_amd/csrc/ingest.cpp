@@ -3,9 +3,11 @@
 // Replaces the per-file lb.load of the reference's DataLoader workers (nisqa/NISQA_lib.py:2299-2306) for RIFF/WAVE
 // input.  A persistent pool of threads walks the RIFF chunks of a whole batch (probe) and then pread()s every data
 // chunk straight into the caller's staging buffer (read): one host copy per sample -- page cache -> page-locked
-// memory -- with no interpreter in the loop.  Decoding of the sample format is NOT done here: mono PCM16 goes to
+// memory -- with no interpreter in the loop.  Decoding of the WAVE sample format is NOT done here: mono PCM16 goes to
 // the GPU verbatim (nisqa_pcm16_to_f32 scales it there); everything else is decoded by the host mirror
-// (nisqa_amd/wavio.py) with lb.load's semantics.
+// (nisqa_amd/wavio.py) with lb.load's semantics.  FLAC files (flac.hpp) ARE decoded here, by the same threads: a mono
+// 16-bit stream straight into its int16 slot of the staging buffer (the same fast path as PCM16 from then on), any other
+// stream to interleaved int32 for the host mirror (nisqa_ingest_decode_flac).
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
@@ -18,6 +20,7 @@
 #include <vector>
 
 #include "../../include/nisqa_ingest.h"
+#include "flac.hpp"
 
 namespace {
 
@@ -125,6 +128,82 @@ bool pread_full(int fd, void* dst, size_t want, off_t at) {
     return true;
 }
 
+// A file image in memory (FLAC frames are decoded from the whole compressed file: a tenth of the size of its samples).
+bool slurp(int fd, std::vector<uint8_t>& buf) {
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || sb.st_size <= 0 || sb.st_size > (int64_t)1 << 31) return false;
+    buf.resize((size_t)sb.st_size);
+    return pread_full(fd, buf.data(), buf.size(), 0);
+}
+
+// FLAC: STREAMINFO -> the same record a WAVE header gives.  A stream whose STREAMINFO does not say how long it is (total = 0:
+// a piped encoder) is decoded once here to count it.
+void probe_flac(int fd, int64_t fsize, const unsigned char* head, size_t got, nisqa_wav_info* out) {
+    nqflac::Stream s;
+    int rc = nqflac::stream_info(head, got, s);
+    unsigned char far[64];
+    if (rc == 1 && (int64_t)s.marker + 42 <= fsize && s.marker > 0 && pread_full(fd, far, 42, (off_t)s.marker)) {
+        const size_t at = s.marker;                        // behind a long ID3v2 tag
+        rc = nqflac::stream_info(far, 42, s);
+        s.marker = at;
+    }
+    if (rc != 0) return;
+    int64_t total = s.total;
+    if (total == 0) {
+        std::vector<uint8_t> buf;
+        if (!slurp(fd, buf)) { out->status = NISQA_WAV_ERR_READ; return; }
+        if (nqflac::decode(buf.data(), buf.size(), s, nullptr, &total) != 0) return;
+    }
+    out->tag = NISQA_WAV_TAG_FLAC;
+    out->channels = s.channels;
+    out->bits = s.bits;
+    out->block_align = s.channels * ((s.bits + 7) / 8);
+    out->sample_rate = s.sample_rate;
+    out->data_offset = (int64_t)s.marker;
+    out->n_frames = total;
+    out->status = NISQA_WAV_OK;
+}
+
+// FLAC -> samples.  as_i16: mono 16-bit stream -> int16 at dst; otherwise interleaved int32 (channel-minor) at dst.
+struct PcmSink : nqflac::Sink {
+    char* dst;
+    bool as_i16;
+    int64_t at = 0, cap;
+    PcmSink(char* d, bool i16, int64_t frames) : dst(d), as_i16(i16), cap(frames) {}
+    void block(const int32_t* const* chan, int ch, int count) override {
+        if (at + count > cap) count = (int)(cap - at);      // never beyond the slot the header promised
+        if (as_i16) {
+            int16_t* w = (int16_t*)dst + at;
+            for (int i = 0; i < count; ++i) w[i] = (int16_t)chan[0][i];
+        } else {
+            int32_t* w = (int32_t*)dst + at * ch;
+            for (int i = 0; i < count; ++i)
+                for (int c = 0; c < ch; ++c) *w++ = chan[c][i];
+        }
+        at += count;
+    }
+};
+
+int decode_flac_file(const char* path, const nisqa_wav_info* info, char* dst, bool as_i16) {
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return NISQA_WAV_ERR_OPEN;
+    std::vector<uint8_t> buf;
+    const bool ok = slurp(fd, buf);
+    close(fd);
+    if (!ok) return NISQA_WAV_ERR_READ;
+    nqflac::Stream s;
+    if ((size_t)info->data_offset + 42 > buf.size() || nqflac::stream_info(buf.data() + info->data_offset, buf.size() - (size_t)info->data_offset, s) != 0)
+        return NISQA_WAV_ERR_FORMAT;
+    s.marker = (size_t)info->data_offset;
+    if (s.channels != info->channels || s.bits != info->bits || (s.total && s.total != info->n_frames)) return NISQA_WAV_ERR_FORMAT;
+    if (as_i16 && (s.channels != 1 || s.bits != 16)) return NISQA_WAV_ERR_FORMAT;
+    PcmSink sink(dst, as_i16, info->n_frames);
+    int64_t done = 0;
+    const int rc = nqflac::decode(buf.data(), buf.size(), s, &sink, &done);
+    if (rc != 0) return rc == 3 ? NISQA_WAV_ERR_READ : NISQA_WAV_ERR_FORMAT;
+    return done == info->n_frames ? NISQA_WAV_OK : NISQA_WAV_ERR_READ;
+}
+
 // Walk the RIFF (or RF64, or big-endian RIFX) chunks like soundfile/libsndfile does for the cases lb.load meets: 'fmt ' (PCM, IEEE float,
 // WAVE_FORMAT_EXTENSIBLE with the sub-format in the GUID's first two bytes) then 'data'; other chunks are skipped
 // (word-aligned); a data size of 0xFFFFFFFF or one that overruns the file means "to end of file".
@@ -138,6 +217,11 @@ void probe_one(const char* path, nisqa_wav_info* out) {
     unsigned char head[4096];
     const ssize_t got = pread(fd, head, sizeof(head), 0);
     out->status = NISQA_WAV_ERR_FORMAT;
+    if (got >= 4 && (!std::memcmp(head, "fLaC", 4) || !std::memcmp(head, "ID3", 3))) {
+        probe_flac(fd, fsize, head, (size_t)got, out);
+        close(fd);
+        return;
+    }
     const bool be = got >= 4 && !std::memcmp(head, "RIFX", 4);       // big-endian variant: header fields AND samples
     if (got >= 12 && (!std::memcmp(head, "RIFF", 4) || !std::memcmp(head, "RF64", 4) || be) && !std::memcmp(head + 8, "WAVE", 4)) {
         int64_t pos = 12;
@@ -188,6 +272,10 @@ void probe_one(const char* path, nisqa_wav_info* out) {
 
 void read_one(const char* path, nisqa_wav_info* info, char* dst) {
     if (info->status != NISQA_WAV_OK) return;
+    if (info->tag == NISQA_WAV_TAG_FLAC) {                   // (only a mono 16-bit stream has a verbatim int16 form)
+        info->status = decode_flac_file(path, info, dst, true);
+        return;
+    }
     const int fd = open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) { info->status = NISQA_WAV_ERR_OPEN; return; }
     const size_t want = (size_t)info->n_frames * (size_t)info->block_align;
@@ -216,4 +304,9 @@ extern "C" int nisqa_ingest_read(const char* const* paths, int32_t n, nisqa_wav_
     int bad = 0;
     for (int i = 0; i < n; ++i) bad += dst_off[i] >= 0 && info[i].status != NISQA_WAV_OK;
     return bad;
+}
+
+extern "C" int nisqa_ingest_decode_flac(const char* path, const nisqa_wav_info* info, int32_t* dst) {
+    if (!path || !info || !dst || info->status != NISQA_WAV_OK || info->tag != NISQA_WAV_TAG_FLAC) return NISQA_WAV_ERR_FORMAT;
+    return decode_flac_file(path, info, (char*)dst, false);
 }

@@ -10,7 +10,8 @@ buffer (page cache -> pinned memory).  Three such buffers rotate: one being fill
 a slot is recycled only after the HIP event recorded behind its H2D copy has completed.
 
 Files that are not mono PCM16 (stereo, 8/24/32-bit, float) are decoded by ``wavio.read_wav`` with the reference's
-``lb.load`` semantics and staged as float32 through the same buffers.
+``lb.load`` semantics and staged as float32 through the same buffers.  FLAC files (lb.load reads them through the same
+soundfile call) are decoded by the native reader threads: mono 16-bit streams straight into their int16 slot, others via ``wavio``.
 """
 import ctypes
 import os
@@ -99,6 +100,12 @@ def probe_headers(ds, indices, num_workers=0):
     workers = max(1, min(asked if asked > 0 else budget, budget))
     _lib.load_ingest().nisqa_ingest_probe(paths, n, infos, workers)
     return np.ctypeslib.as_array(infos).copy()
+
+
+def _verbatim_i16(info):
+    """Which files of a header array reach the staging buffer as int16: mono PCM16 data chunks (copied verbatim) and mono 16-bit
+    FLAC streams (decoded into the slot by the reader threads, csrc/flac.hpp)."""
+    return ((info['tag'] == _lib.WAV_TAG_PCM) | (info['tag'] == _lib.WAV_TAG_FLAC)) & (info['bits'] == 16) & (info['channels'] == 1)
 
 
 class StagingRing(object):
@@ -349,7 +356,7 @@ class Ingest(object):
         info = np.ascontiguousarray(info)
         infos = ctypes.cast(info.ctypes.data, ctypes.POINTER(_lib.WavInfo))
         frames, srs = info['n_frames'], info['sample_rate']
-        fast = (info['tag'] == 1) & (info['bits'] == 16) & (info['channels'] == 1)
+        fast = _verbatim_i16(info)
         # batch layout from the headers alone: clips of one rate are contiguous, int16 if ALL of them are mono PCM16
         layout, total = [], 0
         dst_off = np.full(n, -1, dtype=np.int64)
@@ -413,7 +420,7 @@ class Ingest(object):
                 names, enc, info = self._probe(wins[w], loc)
                 # the window's batches are cut HERE, on the helper thread: sorting and walking 16 384 items in Python is
                 # 10-20 ms during which the producer staged nothing and the link ran dry once per window
-                fast = (info['tag'] == 1) & (info['bits'] == 16) & (info['channels'] == 1)
+                fast = _verbatim_i16(info)
                 cuts = pol.cut(info['n_frames'].astype(np.int64), info['sample_rate'].astype(np.int64), np.where(fast, 2, 4))
                 box[w] = ('ok', (names, enc, info, cuts), loc)
             except BaseException as e:

@@ -169,8 +169,9 @@ def load():
 
 # ---- libnisqa_ingest.so (include/nisqa_ingest.h): native WAV ingest, plain C++ -- loadable without a GPU ----------
 INGEST_PATH = os.path.join(_HERE, 'libnisqa_ingest.so')
-INGEST_ABI_VERSION = 1
+INGEST_ABI_VERSION = 2
 WAV_OK, WAV_ERR_OPEN, WAV_ERR_FORMAT, WAV_ERR_READ = 0, 1, 2, 3
+WAV_TAG_PCM, WAV_TAG_FLAC = 1, 0xF1AC
 
 
 class WavInfo(ctypes.Structure):
@@ -184,6 +185,7 @@ INGEST_SYMBOLS = {
     'nisqa_ingest_probe': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), c_i32, ctypes.POINTER(WavInfo), c_i32]),
     'nisqa_ingest_read': (ctypes.c_int, [ctypes.POINTER(ctypes.c_char_p), c_i32, ctypes.POINTER(WavInfo), c_p,
                                          ctypes.POINTER(c_i64), c_i32]),
+    'nisqa_ingest_decode_flac': (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(WavInfo), c_p]),
 }
 
 _ingest = None

@@ -1,5 +1,7 @@
 """WAV ingest for the predict path: what ``lb.load(path, sr=None[, mono=False])`` does at
-reference nisqa/NISQA_lib.py:2299-2304, for RIFF / RF64 / RIFX (big-endian) WAVE files, without librosa/soundfile.
+reference nisqa/NISQA_lib.py:2299-2304, for RIFF / RF64 / RIFX (big-endian) WAVE files and for FLAC files, without
+librosa/soundfile.  (FLAC streams are decoded by libnisqa_ingest.so -- csrc/flac.hpp, every frame CRC and the stream's MD5
+verified -- and scaled here like soundfile does: integer sample / 2**(bits - 1).)
 
 soundfile semantics: integer PCM -> float32 scaled by 1/2**(8*bytes-1) of its CONTAINER (1-4 bytes per sample = bits
 rounded up; 12- or 20-bit samples sit left-justified in 2 / 3 bytes; a 1-byte container is unsigned, offset
@@ -14,6 +16,7 @@ import struct
 import numpy as np
 
 _PCM, _FLOAT, _ALAW, _MULAW, _EXT = 1, 3, 6, 7, 0xFFFE
+_FLAC = 0xF1AC                                     # lib.WAV_TAG_FLAC: not a WAVE tag, a FLAC stream
 
 
 def _g711_tables():
@@ -37,7 +40,7 @@ _ALAW_TAB, _MULAW_TAB = _g711_tables()
 class Header(object):
     """An opened WAV file whose RIFF chunks have been walked: format fields, position and frame count of the data
     chunk.  ``fast`` marks mono PCM16, whose data chunk can be copied verbatim (2 bytes/sample cross PCIe)."""
-    __slots__ = ('path', 'fd', 'tag', 'ch', 'sr', 'blk', 'bits', 'data_off', 'n', 'fast', 'ms_channel', 'be')
+    __slots__ = ('path', 'fd', 'tag', 'ch', 'sr', 'blk', 'bits', 'data_off', 'n', 'fast', 'ms_channel', 'be', 'info')
 
     def close(self):
         if self.fd is not None:
@@ -75,11 +78,51 @@ def _walk(fd):
     raise ValueError('missing fmt/data chunk')
 
 
+def _probe_flac(path, fd, ms_channel):
+    """STREAMINFO of a FLAC file through the native ingest library -> Header (tag _FLAC; ``info`` keeps the native record)."""
+    import ctypes
+    from . import lib as _lib
+    L = _lib.load_ingest()
+    info = (_lib.WavInfo * 1)()
+    paths = (ctypes.c_char_p * 1)(os.fsencode(path))
+    if L.nisqa_ingest_probe(paths, 1, info, 1) != 0 or info[0].tag != _FLAC:
+        raise ValueError('not a FLAC stream this decoder reads')
+    h = Header()
+    h.path, h.fd, h.tag, h.ch, h.sr, h.blk, h.bits, h.be = path, fd, _FLAC, info[0].channels, int(info[0].sample_rate), \
+        info[0].block_align, info[0].bits, False
+    h.data_off, h.n, h.ms_channel, h.fast, h.info = info[0].data_offset, int(info[0].n_frames), ms_channel, False, info
+    return h
+
+
+def _decode_flac(h):
+    """FLAC -> int16 [n] (mono 16-bit, like mono PCM16) or float32 [n]: integer sample / 2**(bits - 1), as libsndfile hands a
+    FLAC stream to soundfile's float32 read; channels then like any other file."""
+    import ctypes
+    from . import lib as _lib
+    v = np.empty((h.n, h.ch), dtype=np.int32)
+    rc = _lib.load_ingest().nisqa_ingest_decode_flac(os.fsencode(h.path), h.info, ctypes.c_void_p(v.ctypes.data))
+    if rc != 0:
+        raise ValueError('FLAC stream does not decode (status {})'.format(rc))
+    if h.ch == 1 and h.bits == 16:
+        return v[:, 0].astype(np.int16)
+    y = (v.astype(np.float64) / float(1 << (h.bits - 1))).astype(np.float32)
+    if h.ch == 1:
+        y = y[:, 0]
+    elif h.ms_channel is not None:
+        y = y[:, h.ms_channel]                     # NISQA_lib.py:2300-2302
+    else:
+        y = np.mean(y.T, axis=0, dtype=np.float32)  # librosa.to_mono
+    return np.ascontiguousarray(y, dtype=np.float32)
+
+
 def probe(path, ms_channel=None):
     """Open ``path`` and parse its header -> Header (caller closes).  Raises the reference's load error."""
     fd = None
     try:
         fd = os.open(path, os.O_RDONLY)
+        magic = os.pread(fd, 4, 0)
+        if magic == b'fLaC' or magic[:3] == b'ID3':
+            return _probe_flac(path, fd, ms_channel)
         (tag, ch, sr, blk, bits, be), off, size = _walk(fd)
         if ch < 1 or blk != ch * ((bits + 7) // 8):
             raise ValueError('bad block align')
@@ -90,6 +133,7 @@ def probe(path, ms_channel=None):
         h.path, h.fd, h.tag, h.ch, h.sr, h.blk, h.bits, h.be = path, fd, tag, ch, int(sr), blk, bits, be
         h.data_off, h.n, h.ms_channel = off, size // blk, ms_channel
         h.fast = tag == _PCM and bits == 16 and ch == 1 and not be
+        h.info = None
         return h
     except Exception:
         if fd is not None:
@@ -152,6 +196,8 @@ def _decode(h, data):
 
 
 def _read_decoded(h):
+    if h.tag == _FLAC:
+        return _decode_flac(h)
     data = bytearray(h.n * h.blk)
     read_data_into(h, data)
     return _decode(h, data)

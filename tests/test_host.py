@@ -291,7 +291,7 @@ def test_ingest_library_exports_every_declared_symbol():
     assert declared == set(lib.INGEST_SYMBOLS), declared ^ set(lib.INGEST_SYMBOLS)
     out = subprocess.check_output(['nm', '-D', '--defined-only', lib.INGEST_PATH]).decode()
     assert declared <= set(re.findall(r' T (nisqa_\w+)', out))
-    assert L.nisqa_ingest_abi_version() == 1 and ctypes.sizeof(lib.WavInfo) == 40
+    assert L.nisqa_ingest_abi_version() == 2 and ctypes.sizeof(lib.WavInfo) == 40
 
 
 def _riff(fmt_body, data, extra_before=b'', data_size=None, riff=b'RIFF'):
