@@ -295,6 +295,17 @@ int nisqa_predict_batch_pcm16(const int16_t* pcm, const int64_t* clip_off, const
 /* int16 PCM -> float32 (x / 32768), the soundfile scaling lb.load applies (NISQA_lib.py:2304). */
 int nisqa_pcm16_to_f32(const int16_t* pcm16, float* pcm, int64_t n, void* stream);
 
+/* lb.load(path, sr=ms_sr) for clips already on the device (NISQA_lib.py:2300, 2304 -> librosa.resample(y, sr_file, ms_sr,
+ * res_type='kaiser_best') -> resampy): clip b = pcm[in_off[b] .. in_off[b + 1]) (float32 samples, or int16 PCM scaled by 1 / 32768
+ * when is_pcm16) at the file's rate -> out[out_off[b] .. out_off[b + 1]) at ratio = ms_sr / sr_file.  out_off[b + 1] - out_off[b] =
+ * ceil(len_b * ratio) (librosa's fix_length), of which the first out_valid[b] = (int64)(len_b * ratio) samples are interpolated and the
+ * rest is zero; max_out = the longest output clip.  table [nwin][2]: the 'kaiser_best' half window (64 zero crossings, num_table = 512
+ * entries per crossing, nwin = 32 769; multiplied by ratio when ratio < 1) and its forward differences
+ * (nisqa_amd.melbank.kaiser_best_table).  All device pointers; offsets in samples.  No shipped checkpoint sets ms_sr. */
+int nisqa_resample(const void* pcm, int32_t is_pcm16, const int64_t* in_off, const int64_t* out_off, const int64_t* out_valid,
+                   int32_t n_clips, int64_t max_out, double ratio, const float* table, int32_t nwin, int32_t num_table,
+                   float* out, void* stream);
+
 /* Self-test of the MFMA fragment maps the kernels rely on: D = A(32xK) * B(Kx32) with
  * v_mfma_f32_32x32x2_f32, a/b/d [dev] row-major.  Used by tests only. */
 int nisqa_selftest_mfma(const float* a, const float* b, float* d, int32_t k, void* stream);

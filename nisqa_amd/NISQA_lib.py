@@ -283,8 +283,9 @@ class SpeechQualityDataset(object):
             raise RuntimeError('SpeechQualityDataset item access needs bind_engine(...) (spectrograms are computed on the GPU)')
         eng = self._engine_factory()
         y, sr = self.load_audio(index)
-        plan = eng.plan([len(y)], sr, names=[self.file_path(index)])
-        mel, _ = eng.mel(torch.from_numpy(y).to(eng.device), plan, sr, clamp=True)   # int16 PCM or float32 samples
+        plan = eng.audio_plan([len(y)], sr, names=[self.file_path(index)])
+        pcm = eng.resample(torch.from_numpy(y).to(eng.device), [len(y)], sr)          # (ms_sr: lb.load resamples first, NL:2300-2304)
+        mel, _ = eng.mel(pcm, plan, eng.rate(sr), clamp=True)                         # int16 PCM or float32 samples
         spec = mel.cpu().numpy()                                   # [T, n_mels]
         n_wins = int(plan.n_wins[0])
         idx = self.seg_hop_length * np.arange(n_wins)[:, None] + np.arange(self.seg_length)[None, :]
@@ -345,8 +346,12 @@ def tokens_of(ds, n_frames, sample_rate):
     """Segments per clip from WAV header fields alone: frames T = 1 + samples // hop (librosa centre framing, NL:2311),
     n_wins = ceil((T - (seg_length - 1)) / seg_hop) (NL:2256-2273).  hop as melbank.MelTables derives it."""
     sr = np.asarray(sample_rate, dtype=np.float64)
+    n_frames = np.asarray(n_frames, dtype=np.int64)
+    if getattr(ds, 'ms_sr', None) is not None:                     # lb.load(..., sr=ms_sr): ceil(n * ms_sr / sr) samples at ms_sr
+        n_frames = np.ceil(n_frames.astype(np.float64) * (float(ds.ms_sr) / np.maximum(sr, 1.0))).astype(np.int64)
+        sr = np.full_like(sr, float(ds.ms_sr))
     hop = np.maximum(1, (sr * float(ds.ms_hop_length)).astype(np.int64))
-    T = 1 + np.asarray(n_frames, dtype=np.int64) // hop
+    T = 1 + n_frames // hop
     return np.maximum(1, -(-(T - (int(ds.seg_length) - 1)) // max(1, int(ds.seg_hop_length))))
 
 
@@ -452,7 +457,7 @@ def _predict(model, ds, bs, dev, num_workers, on_rows=None):
                         e0 = torch.cuda.Event(enable_timing=True)
                         e0.record(copy_stream)
                     for g in staged.groups:                          # files of one rate share the mel tables
-                        plan = eng.plan(g.lengths, g.sr, names=g.names)
+                        plan = eng.audio_plan(g.lengths, g.sr, names=g.names)
                         tables = plan.to(eng.device)
                         host = raw[g.offset:g.offset + g.nbytes].view(torch.int16 if g.is_i16 else torch.float32)
                         # PCM16 stays int16: 2 bytes/sample over PCIe.  (Round 5 sent the halves of a batch through TWO copy-only
@@ -471,7 +476,7 @@ def _predict(model, ds, bs, dev, num_workers, on_rows=None):
                 st.wait_event(ev)
             with (torch.cuda.stream(st) if on_gpu else _nullcontext()):
                 for g, plan, tables, pcm in sent:
-                    out = eng.forward_pcm(pcm, plan, g.sr)
+                    out = eng.forward_audio(pcm, g.lengths, g.sr, plan)      # (resampled to ms_sr first when the checkpoint sets it)
                     if on_gpu:
                         pcm.record_stream(st)                        # allocated on the copy stream, consumed on this one
                         tables['_buf'].record_stream(st)

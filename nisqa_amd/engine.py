@@ -13,7 +13,7 @@ import torch
 
 from . import lib as _lib
 from . import weights as _w
-from .melbank import MelTables
+from .melbank import KAISER_BEST_PRECISION, MelTables, kaiser_best_table, resampled_lengths
 
 SEG_LEN = 15
 TOK_PAD = 32
@@ -142,8 +142,9 @@ class HipNisqa(object):
                     or not a.get('td_lstm_bidirectional') or a['model'] != 'NISQA'):
             raise NotImplementedError('HIP engine is built for the nisqa_tts.tar geometry (fc 20, BiLSTM 128 x 1 layer)')
         self.arch = 1 if tts else 0
-        if a.get('ms_sr') is not None:
-            raise NotImplementedError('ms_sr resampling is not implemented (all shipped checkpoints use ms_sr=None)')
+        # ms_sr: lb.load(path, sr=ms_sr) resamples every file to that rate first (NISQA_lib.py:2300, 2304); None in every shipped checkpoint
+        self.ms_sr = int(a['ms_sr']) if a.get('ms_sr') is not None else None
+        self._resample_tables = {}
         self.seg_hop = int(a['ms_seg_hop_length'])
         self.max_segments = a['ms_max_segments']
         self.dim = a['model'] == 'NISQA_DIM'
@@ -210,6 +211,45 @@ class HipNisqa(object):
 
     def plan(self, lengths, sr, names=None):
         return BatchPlan(lengths, self.mel_tables(sr)['host'].hop, self.seg_hop, self.max_segments, names)
+
+    # -- ms_sr: what the batch looks like after lb.load(path, sr=ms_sr) -------------------------------------
+    def rate(self, sr):
+        """The rate the spectrogram is computed at for a file of rate ``sr``: ms_sr when the checkpoint sets it."""
+        return int(sr) if self.ms_sr is None else self.ms_sr
+
+    def audio_plan(self, lengths, sr, names=None):
+        """plan() of a batch of files of rate ``sr`` as the network sees them (resampled to ms_sr when that is set)."""
+        if self.ms_sr is None or int(sr) == self.ms_sr:
+            return self.plan(lengths, sr, names)
+        return self.plan(resampled_lengths(lengths, sr, self.ms_sr)[0], self.ms_sr, names)
+
+    def resample(self, pcm, lengths, sr):
+        """pcm: device tensor, the clips of ``lengths`` samples back to back at rate ``sr`` (float32 or int16 PCM) -> float32 device
+        tensor, the clips at ms_sr back to back (librosa.resample(..., res_type='kaiser_best') + fix_length: nisqa_resample)."""
+        sr = int(sr)
+        if self.ms_sr is None or sr == self.ms_sr:
+            return pcm
+        ratio = float(self.ms_sr) / float(sr)
+        if sr not in self._resample_tables:
+            self._resample_tables[sr] = torch.from_numpy(kaiser_best_table(ratio)).to(self.device)
+        table = self._resample_tables[sr]
+        lengths = np.asarray(lengths, dtype=np.int64).reshape(-1)
+        n_out, valid = resampled_lengths(lengths, sr, self.ms_sr)
+        offs = np.concatenate([np.concatenate([[0], np.cumsum(lengths)]), np.concatenate([[0], np.cumsum(n_out)]), valid]).astype(np.int64)
+        assert pcm.numel() == int(lengths.sum()) and pcm.dtype in (torch.float32, torch.int16)
+        dev = torch.from_numpy(offs).to(self.device)
+        b = len(lengths)
+        out = torch.empty(int(n_out.sum()), dtype=torch.float32, device=self.device)
+        rc = self.lib.nisqa_resample(_ptr(pcm), 1 if pcm.dtype == torch.int16 else 0, _ptr(dev[:b + 1]), _ptr(dev[b + 1:2 * b + 2]),
+                                     _ptr(dev[2 * b + 2:]), b, int(n_out.max()), ratio, _ptr(table), table.shape[0],
+                                     1 << KAISER_BEST_PRECISION, _ptr(out), self._stream())
+        _lib.check(rc, 'nisqa_resample')
+        return out
+
+    def forward_audio(self, pcm, lengths, sr, plan, stage_events=None):
+        """forward_pcm for a batch as the files hold it: resampled to ms_sr first when the checkpoint asks for that (``plan`` from
+        audio_plan(lengths, sr))."""
+        return self.forward_pcm(self.resample(pcm, lengths, sr), plan, self.rate(sr), stage_events)
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

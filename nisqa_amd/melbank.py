@@ -102,3 +102,32 @@ class MelTables(object):
         self.true_len = true_len
         self.n_bins = int((start + true_len).max()) if true_len.any() else 1
         self.dense = fb
+
+
+# ---- lb.load(path, sr=ms_sr): the table of librosa's default resampler (res_type='kaiser_best' -> resampy) ----------------------
+KAISER_BEST_ZEROS, KAISER_BEST_PRECISION = 64, 9
+KAISER_BEST_ROLLOFF, KAISER_BEST_BETA = 0.9475937167399596, 14.769656459379492
+
+
+def kaiser_best_table(ratio):
+    """float32 [64 * 512 + 1, 2] for csrc/resample.hip (nisqa_resample): column 0 the 'kaiser_best' half window of resampy --
+    rolloff * sinc(rolloff * t) under the right half of a Kaiser window (beta 14.77), 64 zero crossings at 512 entries each,
+    multiplied by ``ratio`` when downsampling -- column 1 its forward differences (the linear interpolation between
+    entries).  Parameters by recollection of resampy 0.2.2 (a floating dependency of librosa 0.8.1, reference env.yml:16)."""
+    n = (1 << KAISER_BEST_PRECISION) * KAISER_BEST_ZEROS
+    win = KAISER_BEST_ROLLOFF * np.sinc(KAISER_BEST_ROLLOFF * np.linspace(0, KAISER_BEST_ZEROS, num=n + 1, endpoint=True))
+    win = win * np.kaiser(2 * n + 1, KAISER_BEST_BETA)[n:]
+    if ratio < 1:
+        win = win * ratio
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    return np.ascontiguousarray(np.stack([win, delta], axis=1), dtype=np.float32)
+
+
+def resampled_lengths(lengths, sr, target_sr):
+    """(out, valid): samples per clip after lb.load(..., sr=target_sr) -- librosa fixes the length to ceil(n * ratio), resampy
+    computes int(n * ratio) of them (both in float64 like the originals)."""
+    n = np.asarray(lengths, dtype=np.int64)
+    ratio = float(target_sr) / float(sr)
+    prod = n.astype(np.float64) * ratio
+    return np.ceil(prod).astype(np.int64), prod.astype(np.int64)

@@ -182,14 +182,15 @@ def train(nm):
                     raise NotImplementedError('a training batch mixes sample rates {}: BatchNorm statistics span the batch, '
                                               'so it cannot be split'.format([g.sr for g in staged.groups]))
                 g = staged.groups[0]
-                plan = tr.eng.plan(g.lengths, g.sr, names=g.names)
+                plan = tr.eng.audio_plan(g.lengths, g.sr, names=g.names)     # (at ms_sr when the run sets it: lb.load resamples)
                 raw = ing.ring.buf[staged.slot]
                 host = raw[g.offset:g.offset + g.nbytes].view(torch.int16 if g.is_i16 else torch.float32)
                 pcm = host.to(tr.device, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 ing.ring.release_after(staged.slot, ev)
-                if g.is_i16:
+                pcm = tr.eng.resample(pcm, g.lengths, g.sr)              # a no-op unless ms_sr is set and differs from the files' rate
+                if pcm.dtype == torch.int16:
                     pcm = tr.eng.pcm16_to_f32(pcm)
                 ids = np.asarray(g.ids)
                 bias = None
@@ -200,7 +201,7 @@ def train(nm):
                 if pending is not None:                                  # fetch the previous step's numbers while this one runs
                     y_hat_train[pending[0]] = pending[1].cpu().numpy()
                     loss_sum += float(pending[2])
-                loss = tr.step_pcm(pcm, plan, g.sr, y_train[ids].astype(np.float32), bias=bias)
+                loss = tr.step_pcm(pcm, plan, tr.eng.rate(g.sr), y_train[ids].astype(np.float32), bias=bias)
                 pending = (ids, tr.last['y_hat'], loss)
             if pending is not None:
                 y_hat_train[pending[0]] = pending[1].cpu().numpy()

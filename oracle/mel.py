@@ -172,10 +172,76 @@ def melspec_db_from_audio(y, sr, n_fft=4096, hop_length=0.01, win_length=0.02,
     return amplitude_to_db(M)
 
 
+# --------------------------------------------------------------------------------------------------------------
+# librosa.load(path, sr=ms_sr) -> librosa.resample(y, sr_native, ms_sr, res_type='kaiser_best') -> resampy.resample
+# (NISQA_lib.py:2300, 2304 pass sr=ms_sr; None in every shipped checkpoint).  resampy is a dependency of librosa 0.8.1
+# (>= 0.2.2, not pinned in env.yml, not in /root/reference): its published algorithm -- Smith's band-limited
+# interpolation with a precomputed half window and linear interpolation between table entries -- is restated here BY
+# RECOLLECTION of resampy 0.2.2 (resampy/filters.py sinc_window + the 'kaiser_best' parameters; resampy/interpn.py
+# resample_f).  PARITY UNPINNED; tests/test_oracle.py checks it as a resampler (band-limited signals against their
+# analytic values at the new rate), which holds whatever the exact table constants.
+# --------------------------------------------------------------------------------------------------------------
+KAISER_BEST = {'num_zeros': 64, 'precision': 9, 'rolloff': 0.9475937167399596, 'beta': 14.769656459379492}
+
+
+def kaiser_best_half_window():
+    """resampy.filters.sinc_window(num_zeros=64, precision=9, window=kaiser(beta), rolloff): float64 [64 * 512 + 1]."""
+    from scipy.signal.windows import kaiser
+    p = KAISER_BEST
+    n = (2 ** p['precision']) * p['num_zeros']
+    sinc_win = p['rolloff'] * np.sinc(p['rolloff'] * np.linspace(0, p['num_zeros'], num=n + 1, endpoint=True))
+    taper = kaiser(2 * n + 1, p['beta'])[n:]
+    return taper * sinc_win
+
+
+def resample_kaiser_best(y, sr_orig, sr_new):
+    """librosa.resample(y, sr_orig, sr_new) with its defaults (res_type='kaiser_best', fix=True, scale=False) for a mono
+    float32 signal: resampy's loop (one output sample = left wing + right wing of the interpolated window, accumulated in
+    the float32 output element one tap at a time), then util.fix_length to ceil(len * ratio)."""
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    if sr_orig == sr_new:
+        return y
+    ratio = float(sr_new) / sr_orig
+    n_orig = len(y)
+    n_out = int(n_orig * ratio)
+    win = kaiser_best_half_window()
+    num_table = 2 ** KAISER_BEST['precision']
+    if ratio < 1:
+        win = win * ratio
+    delta = np.zeros_like(win)
+    delta[:-1] = np.diff(win)
+    scale = min(1.0, ratio)
+    index_step = int(scale * num_table)
+    nwin = len(win)
+    # time_register += time_increment, one addition per output sample (cumsum adds sequentially)
+    time = np.concatenate(([0.0], np.cumsum(np.full(max(0, n_out - 1), 1.0 / ratio))))[:n_out]
+    n = time.astype(np.int64)
+    out = np.zeros(n_out, dtype=np.float32)
+    xp = np.concatenate((y.astype(np.float64), [0.0]))               # (index n_orig: masked taps read a zero)
+    for wing in (0, 1):
+        frac = scale * (time - n) if wing == 0 else scale - scale * (time - n)
+        index_frac = frac * num_table
+        offset = index_frac.astype(np.int64)
+        eta = index_frac - offset
+        limit = (n + 1) if wing == 0 else (n_orig - n - 1)
+        taps = np.minimum(limit, (nwin - offset) // index_step)
+        for i in range(int(taps.max()) if n_out else 0):
+            live = i < taps
+            idx = np.where(live, offset + i * index_step, 0)
+            weight = win[idx] + eta * delta[idx]
+            src = np.where(live, (n - i) if wing == 0 else (n + i + 1), n_orig)
+            out = np.where(live, (out.astype(np.float64) + weight * xp[src]).astype(np.float32), out)
+    want = int(np.ceil(n_orig * ratio))                              # librosa.util.fix_length
+    if want > n_out:
+        out = np.concatenate((out, np.zeros(want - n_out, dtype=np.float32)))
+    return np.ascontiguousarray(out[:want])
+
+
 def get_melspec(path, sr=None, n_fft=4096, hop_length=0.01, win_length=0.02,
                 n_mels=48, fmax=20000.0, ms_channel=None):
-    """Whole of get_librosa_melspec (NISQA_lib.py:2284-2331) for ms_sr=None."""
-    if sr is not None:
-        raise NotImplementedError('oracle covers ms_sr=None (all shipped checkpoints)')
-    y, sr = load_wav(path, ms_channel)
-    return melspec_db_from_audio(y, sr, n_fft, hop_length, win_length, n_mels, fmax)
+    """Whole of get_librosa_melspec (NISQA_lib.py:2284-2331); sr = ms_sr (None: the file's rate, as in every shipped
+    checkpoint; a number: lb.load resamples to it first)."""
+    y, sr_file = load_wav(path, ms_channel)
+    if sr is not None and int(sr) != sr_file:
+        y, sr_file = resample_kaiser_best(y, sr_file, int(sr)), int(sr)
+    return melspec_db_from_audio(y, sr_file, n_fft, hop_length, win_length, n_mels, fmax)

@@ -421,6 +421,58 @@ def test_predict_dir_drop_in_surface(tmp_path):
     assert np.abs(np.array([df2[c].iloc[0] for c in cols], np.float32) - ref).max() < 1e-3
 
 
+def test_ms_sr_resampling_kernel_and_drop_in_surface(tmp_path):
+    """A checkpoint that sets ms_sr (none of the shipped ones does): lb.load(path, sr=ms_sr) resamples every file first
+    (NL:2300-2304 -> librosa.resample 'kaiser_best' -> resampy).  (i) nisqa_resample against the CPU restatement
+    (oracle.mel.resample_kaiser_best; PARITY UNPINNED against resampy itself) for up- and downsampling, int16 and float32 input,
+    several clips per launch, bar 5e-6 of full scale; (ii) nisqaModel.predict() with ms_sr = 48 000 on 16 / 44.1 / 48 kHz files
+    against the oracle path, bar 1e-3; the reference item format (dataset[i]) goes through the same resampler."""
+    from nisqa_amd.engine import HipNisqa
+    from nisqa_amd.NISQA_model import nisqaModel
+    args = dict(helpers.DIM_ARGS)
+    args.update({'pretrained_model': False, 'tr_bs_val': 2, 'tr_num_workers': 0, 'ms_sr': 48000})
+    sd = helpers.random_state_dict(7)
+    worst = 0.0
+    for sr_in, target in ((16000, 48000), (44100, 48000), (8000, 48000), (96000, 48000), (48000, 16000), (48000, 44100)):
+        eng = HipNisqa(dict(args, ms_sr=target), sd, precision='f32')
+        clips = [synth.synth_pcm16(700 + k, du, sr=sr_in) for k, du in enumerate((0.31, 0.5, 0.2003))]
+        lengths = [len(c) for c in clips]
+        want = np.concatenate([omel.resample_kaiser_best(c.astype(np.float32) / np.float32(32768.0), sr_in, target) for c in clips])
+        for dtype in (np.int16, np.float32):
+            host = np.concatenate(clips)
+            host = host if dtype == np.int16 else host.astype(np.float32) / np.float32(32768.0)
+            got = eng.resample(torch.from_numpy(host).to(eng.device), lengths, sr_in).cpu().numpy()
+            assert got.shape == want.shape
+            worst = max(worst, float(np.abs(got - want).max()))
+            assert np.abs(got - want).max() < 5e-6, (sr_in, target, dtype)
+        assert eng.resample(torch.zeros(4, device=eng.device), [4], target).numel() == 4          # the files' rate = ms_sr: untouched
+    print('nisqa_resample vs the restatement: max |d| %.3g' % worst)
+    path = str(tmp_path / 'rand.tar')
+    torch.save({'args': args, 'model_state_dict': sd}, path)
+    d = tmp_path / 'wavs'
+    d.mkdir()
+    synth.write_wav(str(d / 'a_16k.wav'), synth.synth_pcm16(60, 2.0, sr=16000), 16000)
+    synth.write_wav(str(d / 'b_44k.wav'), synth.synth_pcm16(61, 1.5, sr=44100), 44100)
+    synth.write_wav(str(d / 'c_48k.wav'), synth.synth_pcm16(62, 1.2), 48000)
+    synth.write_wav(str(d / 'd_16k_f32.wav'), (synth.synth_pcm16(63, 0.9, sr=16000) / 40000.0).astype(np.float32), 16000)
+    a = {'mode': 'predict_dir', 'pretrained_model': path, 'deg': None, 'data_dir': str(d), 'output_dir': None, 'csv_file': None,
+         'csv_deg': None, 'num_workers': 0, 'bs': 2, 'ms_channel': None, 'tr_bs_val': 2, 'tr_num_workers': 0}
+    m = nisqaModel(a)
+    assert m.args['ms_sr'] == 48000
+    df = m.predict()
+    cols = ['mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred']
+    for _, row in df.iterrows():
+        spec = omel.get_melspec(str(d / row['deg']), 48000, 4096, 0.01, 0.02, 48, 20000)
+        ref = onet.predict_from_melspec(sd, m.args, spec)
+        err = np.abs(row[cols].to_numpy(dtype=np.float32) - ref).max()
+        print(row['deg'], 'ms_sr = 48 000: max|d|', err)
+        assert err < 1e-3
+    x, _, (idx, n_wins) = m.ds_val[0]                                  # the reference's item format: segments of the RESAMPLED clip
+    spec = omel.get_melspec(str(d / df['deg'].iloc[0]), 48000, 4096, 0.01, 0.02, 48, 20000)
+    assert int(n_wins) == -(-(spec.shape[1] - 14) // 4)
+    assert np.abs(x[0, 0].numpy() - spec[:, :15]).max() < 1e-3
+
+
 @pytest.mark.parametrize('ckpt,precision', [('nisqa.tar', 'bf16x3'), ('nisqa.tar', 'f32'), ('nisqa.tar', 'bf16x6'), ('nisqa.tar', 'f16x4'),
                                             ('nisqa_mos_only.tar', 'bf16x3'), ('nisqa_mos_only.tar', 'bf16x6'),
                                             ('nisqa_tts.tar', 'bf16x3'), ('nisqa_tts.tar', 'f32'), ('nisqa_tts.tar', 'bf16x6'), ('nisqa_tts.tar', 'f16x4')])

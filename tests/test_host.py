@@ -526,6 +526,18 @@ class FakeEngine(object):
     def plan(self, lengths, sr, names=None):
         return BatchPlan(lengths, int(sr * 0.01), 4, 1300, names)
 
+    def audio_plan(self, lengths, sr, names=None):                  # (ms_sr = None: the files' own rate)
+        return self.plan(lengths, sr, names)
+
+    def forward_audio(self, pcm, lengths, sr, plan):
+        return self.forward_pcm(pcm, plan, sr)
+
+    def resample(self, pcm, lengths, sr):
+        return pcm
+
+    def rate(self, sr):
+        return int(sr)
+
     def forward_pcm(self, pcm, plan, sr):
         if pcm.dtype == torch.int16:
             pcm = pcm.to(torch.float32) / 32768.0

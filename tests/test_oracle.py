@@ -323,3 +323,51 @@ def test_reference_loop_through_the_functional_librosa_stand_in_matches_the_orac
     mono = st[:, 1].astype(np.float32) / np.float32(32768.0)
     want = onet.predict_from_melspec(sd, args, omel.melspec_db_from_audio(mono, 48000))
     assert np.abs(y1[0] - want).max() < 5e-6 and np.abs(y1[0] - y[1]).max() > 1e-4
+
+
+# ---- lb.load(path, sr=ms_sr): the resampler restatement (PARITY UNPINNED: resampy is not in the image) ---------------------------
+@pytest.mark.parametrize('sr_in,sr_out,bar', [(16000, 48000, 5e-6), (8000, 48000, 5e-6), (44100, 48000, 5e-6), (32000, 48000, 5e-6),
+                                              (48000, 16000, 5e-3), (48000, 44100, 1e-3), (96000, 48000, 5e-6)])
+def test_resampler_restatement_reconstructs_band_limited_signals(sr_in, sr_out, bar):
+    """oracle.mel.resample_kaiser_best is restated from resampy's publication by recollection; whatever its exact constants, it must
+    BE a band-limited interpolator: two sines well inside both Nyquist bands come out as the same sines sampled at the new rate
+    (away from the clip edges, where the one-sided window sums differ).  Upsampling and integer-step downsampling: 5e-6 of full scale.
+    A non-integer table step (48 -> 16 kHz: int(512 / 3) = 170 for 170.67) walks the window a little too slowly -- resampy 0.2.2's
+    known error of that case, 0.3 % / 0.05 % of full scale here: the restatement keeps it, the bar says so."""
+    n = sr_in // 2
+    t = np.arange(n) / sr_in
+    f = 0.2 * min(sr_in, sr_out)
+    y = (0.5 * np.sin(2 * np.pi * f * t) + 0.2 * np.sin(2 * np.pi * 0.37 * f * t + 1)).astype(np.float32)
+    z = omel.resample_kaiser_best(y, sr_in, sr_out)
+    assert z.dtype == np.float32 and len(z) == int(np.ceil(n * (float(sr_out) / sr_in)))     # librosa's expression, rounding and all (22 050 -> 24 001)
+    tt = np.arange(len(z)) / sr_out
+    want = 0.5 * np.sin(2 * np.pi * f * tt) + 0.2 * np.sin(2 * np.pi * 0.37 * f * tt + 1)
+    mid = slice(len(z) // 8, -len(z) // 8)
+    assert np.abs(z[mid] - want[mid]).max() < bar
+    assert omel.resample_kaiser_best(y, sr_in, sr_in) is not None and np.array_equal(omel.resample_kaiser_best(y, sr_in, sr_in), y)
+
+
+def test_resampler_lengths_and_the_product_table(tmp_path):
+    """fix_length: ceil(n * ratio) samples, the last one a zero when resampy's int(n * ratio) is one short; the table the GPU
+    kernel reads (nisqa_amd.melbank.kaiser_best_table: numpy's kaiser) equals the restatement's (scipy's) to float32 rounding; the
+    oracle's get_melspec resamples like lb.load(sr=ms_sr)."""
+    from nisqa_amd import melbank
+    y = np.linspace(-0.5, 0.5, 1001).astype(np.float32)
+    z = omel.resample_kaiser_best(y, 44100, 48000)
+    assert len(z) == int(np.ceil(1001 * 48000 / 44100)) == 1090 and int(1001 * (48000 / 44100)) == 1089 and z[-1] == 0.0
+    out, valid = melbank.resampled_lengths([1001, 44100, 7], 44100, 48000)
+    # (44 100 * (48 000 / 44 100) = 48 000.00000000001 in float64: librosa's ceil makes that 48 001 samples, the last one a zero)
+    assert out.tolist() == [1090, 48001, 8] and valid.tolist() == [1089, 48000, 7]
+    for ratio in (3.0, 48000 / 44100, 1 / 3.0):
+        tab = melbank.kaiser_best_table(ratio)
+        win = omel.kaiser_best_half_window() * (ratio if ratio < 1 else 1.0)
+        assert tab.shape == (64 * 512 + 1, 2) and tab.dtype == np.float32
+        np.testing.assert_allclose(tab[:, 0], win, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(tab[:-1, 1], np.diff(win), rtol=0, atol=1e-7)
+    p = str(tmp_path / 'a.wav')
+    synth.write_wav(p, synth.synth_pcm16(3, 0.5, sr=16000), 16000)
+    spec = omel.get_melspec(p, 48000, 4096, 0.01, 0.02, 48, 20000)
+    y16, _ = omel.load_wav(p)
+    want = omel.melspec_db_from_audio(omel.resample_kaiser_best(y16, 16000, 48000), 48000, 4096, 0.01, 0.02, 48, 20000)
+    np.testing.assert_array_equal(spec, want)
+    assert spec.shape[1] == 1 + (len(y16) * 3) // 480
