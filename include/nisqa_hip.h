@@ -301,10 +301,13 @@ int nisqa_pcm16_to_f32(const int16_t* pcm16, float* pcm, int64_t n, void* stream
  * ceil(len_b * ratio) (librosa's fix_length), of which the first out_valid[b] = (int64)(len_b * ratio) samples are interpolated and the
  * rest is zero; max_out = the longest output clip.  table [nwin][2]: the 'kaiser_best' half window (64 zero crossings, num_table = 512
  * entries per crossing, nwin = 32 769; multiplied by ratio when ratio < 1) and its forward differences
- * (nisqa_amd.melbank.kaiser_best_table).  All device pointers; offsets in samples.  No shipped checkpoint sets ms_sr. */
+ * (nisqa_amd.melbank.kaiser_best_table).  ws: nisqa_resample_workspace_bytes(n_clips, max_out) bytes of device scratch (resampy's
+ * read position is ONE float64 addition per output sample; it is accumulated the same way, checkpointed every 256 samples).
+ * All device pointers; offsets in samples.  No shipped checkpoint sets ms_sr. */
+size_t nisqa_resample_workspace_bytes(int32_t n_clips, int64_t max_out);
 int nisqa_resample(const void* pcm, int32_t is_pcm16, const int64_t* in_off, const int64_t* out_off, const int64_t* out_valid,
                    int32_t n_clips, int64_t max_out, double ratio, const float* table, int32_t nwin, int32_t num_table,
-                   float* out, void* stream);
+                   void* ws, size_t ws_bytes, float* out, void* stream);
 
 /* Self-test of the MFMA fragment maps the kernels rely on: D = A(32xK) * B(Kx32) with
  * v_mfma_f32_32x32x2_f32, a/b/d [dev] row-major.  Used by tests only. */

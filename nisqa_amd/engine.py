@@ -240,9 +240,10 @@ class HipNisqa(object):
         dev = torch.from_numpy(offs).to(self.device)
         b = len(lengths)
         out = torch.empty(int(n_out.sum()), dtype=torch.float32, device=self.device)
+        ws = torch.empty(max(8, self.lib.nisqa_resample_workspace_bytes(b, int(n_out.max()))), dtype=torch.uint8, device=self.device)
         rc = self.lib.nisqa_resample(_ptr(pcm), 1 if pcm.dtype == torch.int16 else 0, _ptr(dev[:b + 1]), _ptr(dev[b + 1:2 * b + 2]),
                                      _ptr(dev[2 * b + 2:]), b, int(n_out.max()), ratio, _ptr(table), table.shape[0],
-                                     1 << KAISER_BEST_PRECISION, _ptr(out), self._stream())
+                                     1 << KAISER_BEST_PRECISION, _ptr(ws), ws.numel(), _ptr(out), self._stream())
         _lib.check(rc, 'nisqa_resample')
         return out
 

@@ -70,7 +70,8 @@ SYMBOLS = {
     'nisqa_predict_batch_pcm16': (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, ctypes.POINTER(MelCfg),
                                                  ctypes.POINTER(ModelDev), c_p, ctypes.c_size_t, c_p, c_p]),
     'nisqa_pcm16_to_f32': (ctypes.c_int, [c_p, c_p, c_i64, c_p]),
-    'nisqa_resample': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_p, c_i32, c_i64, ctypes.c_double, c_p, c_i32, c_i32, c_p, c_p]),
+    'nisqa_resample_workspace_bytes': (ctypes.c_size_t, [c_i32, c_i64]),
+    'nisqa_resample': (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_p, c_i32, c_i64, ctypes.c_double, c_p, c_i32, c_i32, c_p, ctypes.c_size_t, c_p, c_p]),
     'nisqa_selftest_mfma': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_p]),
     'nisqa_probe_mfma_sustained': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p]),
 }
