@@ -49,6 +49,30 @@ def main():
                                               pad_mode='reflect', power=1.0, n_mels=48, fmin=0.0, fmax=fmax,
                                               htk=False, norm='slaney')               # NL:2311-2328
                 fix['%s_%d' % (tag, i)] = lb.core.amplitude_to_db(S, ref=1.0, amin=1e-4, top_db=80.0).astype(np.float32)
+        # round 5 -- lb.load(path, sr=ms_sr): librosa's default resampler (kaiser_best -> resampy) on a 16 kHz and a 44.1 kHz clip
+        # (nisqa_resample / oracle.mel.resample_kaiser_best restate it by recollection), and a FLAC file written by soundfile
+        # itself with its bytes (the decoder of libnisqa_ingest.so has only seen streams of tests/flac_enc.py so far)
+        import resampy
+        fix['resampy_version'] = np.array(resampy.__version__)
+        for tag, sr_in, seed in (('rs16', 16000, 40), ('rs44', 44100, 41)):
+            pcm = synth.synth_pcm16(seed, 1.0, sr=sr_in)
+            path = os.path.join(d, tag + '.wav')
+            synth.write_wav(path, pcm, sr_in)
+            y, sr = lb.load(path, sr=48000)                                          # NL:2304 with ms_sr = 48000
+            assert sr == 48000
+            fix[tag + '_pcm_crc32'] = np.array(zlib.crc32(pcm.tobytes()), dtype=np.uint64)
+            fix[tag + '_48k'] = y.astype(np.float32)
+        try:
+            import soundfile as sf
+            for tag, data in (('flac_mono16', synth.synth_pcm16(42, 1.0)),
+                              ('flac_stereo16', np.stack([synth.synth_pcm16(43, 0.7), synth.synth_pcm16(44, 0.7)], 1))):
+                path = os.path.join(d, tag + '.flac')
+                sf.write(path, data, 48000, subtype='PCM_16')
+                y, sr = lb.load(path, sr=None)
+                fix[tag + '_bytes'] = np.frombuffer(open(path, 'rb').read(), dtype=np.uint8)
+                fix[tag + '_y'] = y.astype(np.float32)
+        except Exception as e:                                                       # noqa: BLE001
+            print('no FLAC pin written:', e)
     fix['pcm_crc32'] = np.array(crc, dtype=np.uint64)
     np.savez_compressed(os.path.join(HERE, 'mel_librosa.npz'), **fix)
     print('wrote', os.path.join(HERE, 'mel_librosa.npz'))

@@ -298,6 +298,26 @@ def test_mel_oracle_against_librosa_fixture_or_report_unpinned():
                 continue
             got = omel.melspec_db_from_audio(pcm.astype(np.float32) / np.float32(32768.0), 48000, fmax=fmax)
             np.testing.assert_allclose(got, g['%s_%d' % (tag, i)], rtol=0, atol=1e-3)
+    # round 5: the resampler restatement against resampy through lb.load(path, sr=48000), and a FLAC file written by soundfile
+    for tag, sr_in, seed in (('rs16', 16000, 40), ('rs44', 44100, 41)):
+        if tag + '_48k' in g.files:
+            pcm = synth.synth_pcm16(seed, 1.0, sr=sr_in)
+            assert zlib.crc32(pcm.tobytes()) == int(g[tag + '_pcm_crc32'])
+            got = omel.resample_kaiser_best(pcm.astype(np.float32) / np.float32(32768.0), sr_in, 48000)
+            assert got.shape == g[tag + '_48k'].shape
+            np.testing.assert_allclose(got, g[tag + '_48k'], rtol=0, atol=2e-6)
+    for tag in ('flac_mono16', 'flac_stereo16'):
+        if tag + '_bytes' in g.files:
+            import tempfile
+            from nisqa_amd import wavio
+            with tempfile.TemporaryDirectory() as d:
+                p = os.path.join(d, tag + '.flac')
+                with open(p, 'wb') as f:
+                    f.write(g[tag + '_bytes'].tobytes())
+                y, sr = wavio.read_wav(p)
+            y = y.astype(np.float32) / np.float32(32768.0) if y.dtype == np.int16 else y
+            assert sr == 48000
+            np.testing.assert_array_equal(y, g[tag + '_y'])
 
 
 def test_reference_loop_through_the_functional_librosa_stand_in_matches_the_oracle(tmp_path):
