@@ -242,13 +242,31 @@ def cpu_baseline(args, sd, bs=BATCH):
         return port
 
 
+def self_launch(gpus):
+    """`python bench.py --gpus N` started WITHOUT torch.distributed.run (WORLD_SIZE unset): start the N ranks ourselves --
+    the command the contract names, one rank per GPU, rendezvous on 127.0.0.1 at a free port -- pass our argv through, and
+    hand rank 0's single JSON line to our own stdout.  Returns the exit code of the launch (0 = all ranks finished).
+    Replaces what nn.DataParallel did inside one process (reference nisqa/NISQA_model.py:56-57)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // gpus)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def init_dist(a):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world != a.gpus and world == 1 and a.gpus > 1:
-        raise SystemExit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
-                         % (a.gpus, a.gpus))
+    if world != a.gpus and a.gpus > 1:
+        raise SystemExit('bench.py --gpus %d inside a WORLD_SIZE=%d launch: start it as `python bench.py --gpus %d` (it launches its '
+                         'own ranks) or under torch.distributed.run --nproc-per-node %d' % (a.gpus, world, a.gpus, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU path)')
     # NISQA_BENCH_SHARED_GPU=1 is a test knob: all ranks share cuda:0 over gloo, to exercise the N > 1 code path on a
@@ -675,6 +693,8 @@ def main():
                     help='profiling runs: only this part (main = the contract workload without side legs)')
     ap.add_argument('--no-side', action='store_true', help='skip the side legs (configs[2], [3], [4])')
     a = ap.parse_args()
+    if a.gpus > 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1:   # plain `python bench.py --gpus N`: launch the ranks ourselves
+        sys.exit(self_launch(a.gpus))
     BATCH = a.batch
     if a.precision:                                           # every leg of this run (tts, predict_csv) follows it
         os.environ['NISQA_HIP_PRECISION'] = a.precision
@@ -737,13 +757,15 @@ def main():
         torch.cuda.current_stream(dev).wait_stream(st)
     if world > 1:                           # the path's one exchange step: gather the MOS rows
         rows = torch.cat(outs, 0)
+        if backend == 'gloo':               # (the shared-GPU test knob: gloo gathers host tensors)
+            rows = rows.cpu()
         parts = [torch.empty_like(rows) for _ in range(world)]
         torch.distributed.all_gather(parts, rows)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
         torch.distributed.barrier()
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == 'nccl' else 'cpu')
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
 

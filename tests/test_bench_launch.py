@@ -1,0 +1,58 @@
+"""`python bench.py --gpus N` launches its own ranks (VERDICT r5 "next" item 2): the multi-GPU scaling run must not depend on
+the caller wrapping it in torch.distributed.run.  What it replaces: nn.DataParallel inside one process (reference
+nisqa/NISQA_model.py:56-57) -> one process per GPU, clips sharded, one all_gather of the result rows."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None, timeout=600):
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, cwd=ROOT, env=env, timeout=timeout,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def test_bench_gpus2_launches_its_own_ranks_cpu_box():
+    """No GPU here: the two ranks must each be STARTED (torch.distributed.run env) and each refuse with the no-CPU-path message --
+    not the old 'must be launched with torch.distributed.run' exit of the parent."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU box: the -m gpu test below runs the real thing')
+    r = _run(['--gpus', '2', '--steps', '2', '--warmup', '1', '--no-side', '--no-cpu-baseline'])
+    assert r.returncode != 0
+    assert 'must be launched with' not in r.stderr
+    assert r.stderr.count('bench.py needs an MI355X (no CPU path)') >= 2, r.stderr[-2000:]
+    assert r.stdout.strip() == ''                                       # no JSON line from a failed launch
+
+
+@pytest.mark.gpu
+def test_bench_gpus2_plain_python_one_json_line():
+    """The form the driver may use for the scaling curve: plain `python bench.py --gpus 2 ...`.  Both ranks share cuda:0 (test knob,
+    gloo instead of RCCL: RCCL refuses two ranks on one device); rc 0, exactly ONE JSON line, world_size_seen == 2."""
+    r = _run(['--gpus', '2', '--steps', '5', '--warmup', '2', '--no-side', '--no-cpu-baseline'], {'NISQA_BENCH_SHARED_GPU': '1'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['world_size_seen'] == 2 and d['steps'] == 5 and d['warmup'] == 2
+    assert d['config']['collective_backend'] == 'gloo'                  # 'nccl' (= RCCL) when every rank has its own GPU
+    assert d['scaling'] == 'weak' and d['value'] > 0 and d['unit'] == 'clips/s'
+
+
+@pytest.mark.gpu
+def test_bench_predict_csv_gpus2_plain_python_one_json_line():
+    r = _run(['--workload', 'predict_csv', '--gpus', '2', '--clips', '1024', '--bs', '64', '--distinct', '16', '--workers', '4',
+              '--warmup', '1'], {'NISQA_BENCH_SHARED_GPU': '1'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['world_size_seen'] == 2 and d['scaling'] == 'strong'
