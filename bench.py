@@ -257,7 +257,14 @@ def self_launch(gpus):
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // gpus)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # the ranks' stdout is read here: JSON lines go to our stdout (rank 0 prints exactly one), anything else a library wrote there
+    # (gloo's connection banner) to stderr -- a caller that parses stdout sees the bench line and nothing else
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for ln in p.stdout:
+        out = sys.stdout if ln.lstrip().startswith('{') else sys.stderr
+        out.write(ln)
+        out.flush()
+    return p.wait()
 
 
 def init_dist(a):

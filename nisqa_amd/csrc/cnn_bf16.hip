@@ -31,12 +31,8 @@
 #include "internal.hpp"
 #include "../../include/nisqa_hip.h"
 // weight-fragment ring depths of the conv2 / conv3-4 K loops (slots; RING - 1 K-steps are in flight)
-#ifndef NQ_RING2
 #define NQ_RING2 3
-#endif
-#ifndef NQ_RING34
 #define NQ_RING34 3
-#endif
 
 // LDS plan (byte addresses; the kernel has no static LDS, so the dynamic segment starts at 0 and addresses are used as
 // plain 32-bit numbers): one 128-byte zero block shared by the four waves ABOVE the largest tap offset (so "zero block
@@ -54,17 +50,10 @@
 #define FB_PPLANE 1700                     /* bytes per patch plane (850 bf16) */
 #define FB_ZADDR 2048u                     /* the shared zero block */
 #define FB_BASE 2176u                      /* first wave region */
-#ifdef NQ_OCC        /* occupancy probe (results wrong: the wave regions overlap): NQ_OCC workgroups per CU */
-#define FB_WAVE ((((160u * 1024u / NQ_OCC) - 4096u - FB_BASE) / 4u) & ~63u)   /* 4 KB slack: the allocation granule */
-#define FB_WGS NQ_OCC
-#else
 #define FB_WAVE 19584u
 #define FB_WGS 2
-#endif
 #define FB_LDS (FB_BASE + 4 * FB_WAVE)     /* 80512 B -> two workgroups (8 waves) per CU */
-#ifndef NQ_OCC
 static_assert(FB_PATCH + 2 * FB_PPLANE <= FB_WAVE && 2 * FB_P3 <= FB_WAVE && 2 * FB_PS <= 2 * FB_WAVE, "LDS plan");
-#endif
 static_assert(FB_WGS * FB_LDS <= 160 * 1024, "workgroups per CU");
 
 __device__ constexpr int bwin75_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : b == 2 ? 2 : b == 3 ? 4 : 5; }
@@ -72,31 +61,8 @@ __device__ constexpr int bwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b =
 __device__ constexpr int bwin53_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : 3; }
 __device__ constexpr int bwin53_hi(int b) { return b == 0 ? 2 : b == 1 ? 4 : 5; }
 
-// -DNQ_PHASE_CLOCK (tools/phase_clock.sh): shader-clock stamps at the layer boundaries.  Every wave of a launch writes
-// its 16 numbers to its OWN slot with plain stores (a first version added them to 16 shared counters: 250 k atomics on
-// one cache line per launch made the kernel 4x slower and its phase profile meaningless); the host adds the slots up.
-#ifdef NQ_PHASE_CLOCK
-#define NQ_CLK_SLOTS 32768
-__device__ unsigned long long g_phase_clk[NQ_CLK_SLOTS * 16];
-#define NQ_CLK(i) clk[i] = clock64()
-extern "C" int nisqa_debug_phase_clock(unsigned long long* out16, int reset) {
-    if (out16) {
-        unsigned long long* h = (unsigned long long*)malloc(sizeof(g_phase_clk));
-        if (!h || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk), sizeof(g_phase_clk)) != hipSuccess) { free(h); return -1; }
-        for (int q = 0; q < 16; ++q) out16[q] = 0;
-        for (int w = 0; w < NQ_CLK_SLOTS; ++w)
-            for (int q = 0; q < 16; ++q) out16[q] += h[(size_t)w * 16 + q];
-        free(h);
-    }
-    if (reset) {
-        void* d = nullptr;
-        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_phase_clk)) != hipSuccess || hipMemset(d, 0, sizeof(g_phase_clk)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#else
-#define NQ_CLK(i)
-#endif
+// layer-boundary stamps of the phase clock (tools/phase_clock.py; empty macros unless the unit is built with -DNQ_EXPERIMENTAL)
+NQ_CLK_EXPORT(g_phase_clk, nisqa_debug_phase_clock)
 
 // the per-row scale tables of the f16 formats' conv5 / conv6 epilogues (the LDS below the zero block is otherwise unused)
 #define FB_TAB5 0u                         /* [72 rows] {2^(e5 - e4 - kw5), 2^e5} of the row's segment */
@@ -129,10 +95,7 @@ NQ_DEV void cnn_front_split_body(
     const int* __restrict__ meta_i = (const int*)(wb + CNNH_META);
     const float* __restrict__ meta_f = (const float*)(wb + CNNH_META);
     float dummy_mx = 0.f;
-#ifdef NQ_PHASE_CLOCK
-    const long long clk_top = clock64(), wall_top = wall_clock64();
-    long long clk[13];
-#endif
+    NQ_STAMP_BEGIN();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p0 = blockIdx.x * 4;                      // tok_off is a multiple of 32: no clip straddling (an XCD-grouped order measured 1.7 % slower)
@@ -140,20 +103,12 @@ NQ_DEV void cnn_front_split_body(
     const int k0 = p0 - tok_off[b];
     const int nvalid = min(4, n_wins[b] - k0);
     if (nvalid <= 0) return;                             // whole workgroup is padding
-#ifdef NQ_STAGGER
-    // experiment: the two workgroups of a CU start in step and stay in step (same work, same duration): both waves of a SIMD
-    // are in their MFMA-free phases at the same time.  Delay the first-round workgroups that sit in the odd wave slot.
-    if (blockIdx.x < NQ_STAGGER_WGS && (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 1)) {
-        const long long t0 = clock64();
-        while (clock64() - t0 < NQ_STAGGER) __builtin_amdgcn_s_sleep(64);
-    }
-#endif
     const bool valid = wave < nvalid;                    // padding waves still walk the barriers (on zeros)
     const int p = p0 + wave, k = k0 + wave;
     const unsigned R = FB_BASE + wave * FB_WAVE;         // this wave's LDS region
     const unsigned lane16 = lane * 16;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNB_U16S * 2, 0x00020000);
-    NQ_CLK(0);
+    NQ_STAMP(0);
 
     // ---- stage the 15-frame window as two zero-bordered bf16 planes (hi, lo) [frame j + 1][mel m + 1]:
     //      the 3x3 taps of any output pixel are then at constant offsets from it, no bounds checks.
@@ -212,7 +167,7 @@ NQ_DEV void cnn_front_split_body(
 #pragma unroll
             for (int q = 0; q < 12; q += 2) {
                 const float v0 = vin[q] * s0, v1 = vin[q + 1] * s0;
-                lds_store_pair_fmt<FMT, false>(ob[q % 3] + (q + q / 3) * 100, ob[(q + 1) % 3] + (q + 1 + (q + 1) / 3) * 100, FB_PPLANE, v0, v1,
+                lds_store_pair_fmt<FMT>(ob[q % 3] + (q + q / 3) * 100, ob[(q + 1) % 3] + (q + 1 + (q + 1) / 3) * 100, FB_PPLANE, v0, v1,
                                                dummy_mx, true, q + 1 < 11 || lane < 16);
             }
         } else {
@@ -225,7 +180,7 @@ NQ_DEV void cnn_front_split_body(
         }
     }
     __builtin_amdgcn_wave_barrier();
-    NQ_CLK(1);
+    NQ_STAMP(1);
 
     const int i = lane & 31, hfi = (i >> 2) & 1, qi = (i & 3) + 4 * (i >> 3);
     const int n = lane & 31, hf = lane >> 5, h = lane >> 5;
@@ -305,7 +260,7 @@ NQ_DEV void cnn_front_split_body(
         if (F16) { m_in = wave_max_nonneg(ms1) * pow2_f32(-e1); e_in = e1; }
     }
 
-    NQ_CLK(2);
+    NQ_STAMP(2);
     // ---- conv2 16->32 on 24x7, pool -> 12x5 (row maps as in cnn.hip)
     {
         f32x16 acc[6][1];
@@ -320,7 +275,7 @@ NQ_DEV void cnn_front_split_body(
             base[t] = R + ((py - 1) * 7 + (px - 1)) * FB_RS1 + (h << 4);
         }
         conv_k_bf16<16, 6, 1, 7, FB_RS1, FB_P1, FB_ZADDR, false, NQ_RING2, FMT>(acc, wrs, CNNB_W2 * 2, lane16, base, m9);
-        NQ_CLK(3);
+        NQ_STAMP(3);
         float tn = tn2, c2 = 1.f, ms2 = 0.f;
         int e2 = 0;
         if (F16) {
@@ -350,7 +305,7 @@ NQ_DEV void cnn_front_split_body(
         if (F16) { m_in = wave_max_nonneg(ms2) * pow2_f32(-e2); e_in = e2; }
     }
 
-    NQ_CLK(4);
+    NQ_STAMP(4);
     unsigned base34[2], m34[2];                           // conv3 and conv4 share the 12 x 5 geometry
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -372,7 +327,7 @@ NQ_DEV void cnn_front_split_body(
             base[t] = R + base34[t] * FB_RS2 + (h << 4);
         }
         conv_k_bf16<32, 2, 2, 5, FB_RS2, FB_P2, FB_ZADDR, true, NQ_RING34, FMT>(acc, wrs, CNNB_W3 * 2, lane16, base, m34);
-        NQ_CLK(5);
+        NQ_STAMP(5);
         float tn[2] = {tn3[0], tn3[1]}, c3 = 1.f, ms3 = 0.f;
         int e3 = 0;
         if (F16) {
@@ -398,7 +353,7 @@ NQ_DEV void cnn_front_split_body(
 
     // ---- conv4 64->64 on 12x5, pool -> 6x3.  The pooled outputs of the workgroup's four segments go to a
     //      SHARED pair of bf16 planes S4[72 px][64 ch] (row = 18 * wave + pixel) for the N-split conv5/conv6.
-    NQ_CLK(6);
+    NQ_STAMP(6);
     const unsigned S4 = FB_BASE;                          // 2 planes x FB_PS (wave 0/1 regions; their A3 is dead by then)
     const unsigned S5 = FB_BASE + 2 * FB_WAVE;            // conv5 output, same shape (wave 2/3 regions)
     // conv5 / conv6 weight fragments of this wave (its 16 output channels), [step][hi,lo][lane][8]: rings of 4 / 8
@@ -417,7 +372,7 @@ NQ_DEV void cnn_front_split_body(
             base[t] = R + base34[t] * FB_RS3 + (h << 4);
         }
         conv_k_bf16<64, 2, 2, 5, FB_RS3, FB_P3, FB_ZADDR, true, NQ_RING34, FMT>(acc, wrs, CNNB_W4 * 2, lane16, base, m34);
-        NQ_CLK(7);
+        NQ_STAMP(7);
         float tn[2] = {tn4[0], tn4[1]}, c4 = 1.f, ms4 = 0.f;
         int e4 = 0;
         if (F16) {
@@ -428,7 +383,7 @@ NQ_DEV void cnn_front_split_body(
         }
 #pragma unroll
         for (int g = 0; g < 3; ++g) { b5[g][0] = wfrag_load(wrs, lane16, w5b + g * 2048); b5[g][1] = wfrag_load(wrs, lane16, w5b + g * 2048 + 1024); }
-        NQ_SYNC();                   // every wave has consumed its A3: the regions may be re-used
+        __syncthreads();                   // every wave has consumed its A3: the regions may be re-used
         const unsigned wr = S4 + (18 * wave + 9 * hf) * FB_RS3 + n * 2;
         float* dst = P3 ? p3 + (size_t)p * (18 * 64) : nullptr;
 #pragma unroll
@@ -463,8 +418,8 @@ NQ_DEV void cnn_front_split_body(
             if (lane < 6) lds_st32(FB_TAB6 + (6 * wave + lane) * 4, __float_as_uint(pow2_f32(-(e5 + meta_i[5]))));
         }
     }
-    NQ_SYNC();
-    NQ_CLK(8);
+    __syncthreads();
+    NQ_STAMP(8);
 
     // ---- conv5 / conv6 with N split over the waves: wave w owns output channels 16w..16w+15 of ALL four
     //      segments (72 / 24 output rows in 16-row tiles of v_mfma_f32_16x16x32_bf16) and streams its private
@@ -498,8 +453,8 @@ NQ_DEV void cnn_front_split_body(
             }
 #pragma unroll
             for (int t = 0; t < 5; ++t) {
-                a5[g & 1][t][0] = lds_ld128_a(a5h[t] + tapoff + 64 * s);
-                a5[g & 1][t][1] = lds_ld128_a(a5l[t] + tapoff + 64 * s);
+                a5[g & 1][t][0] = lds_ld128(a5h[t] + tapoff + 64 * s);
+                a5[g & 1][t][1] = lds_ld128(a5l[t] + tapoff + 64 * s);
             }
         };
         load_a5(0);
@@ -509,7 +464,7 @@ NQ_DEV void cnn_front_split_body(
             if (g + 1 < 18) load_a5(g + 1);
             mma16_pair_fmt<FMT, 5>(acc5, a5[g & 1], b5[g & 3]);
         }
-        NQ_CLK(9);
+        NQ_STAMP(9);
 #pragma unroll
         for (int g = 0; g < 7; ++g) { b6[g][0] = wfrag_load(wrs, lane16, w6b + g * 2048); b6[g][1] = wfrag_load(wrs, lane16, w6b + g * 2048 + 1024); }
         {
@@ -525,8 +480,8 @@ NQ_DEV void cnn_front_split_body(
                                                 epi_fmt<FMT>(acc5[t][r], cs0[0], tn5 * cs0[1]), epi_fmt<FMT>(acc5[t][r + 1], cs1[0], tn5 * cs1[1]), dummy_mx);
                     }
         }
-        NQ_SYNC();
-        NQ_CLK(10);
+        __syncthreads();
+        NQ_STAMP(10);
 
         // conv6 (3 x 3 kernel, padding (1,0)) = padding-1 conv at the centre column: rows (slot, y), 24 of 32
         f32x4 acc6[2], acc6b[2];            // even / odd K-steps accumulate separately: four independent chains
@@ -555,8 +510,8 @@ NQ_DEV void cnn_front_split_body(
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                a6[g & 1][t][0] = lds_ld128_a(a6h[t] + tapoff + 64 * s);
-                a6[g & 1][t][1] = lds_ld128_a(a6l[t] + tapoff + 64 * s);
+                a6[g & 1][t][0] = lds_ld128(a6h[t] + tapoff + 64 * s);
+                a6[g & 1][t][1] = lds_ld128(a6l[t] + tapoff + 64 * s);
             }
         };
         load_a6(0);
@@ -567,7 +522,7 @@ NQ_DEV void cnn_front_split_body(
             if (g & 1) mma16_pair_fmt<FMT, 2>(acc6b, a6[1], b6[g & 7]);
             else mma16_pair_fmt<FMT, 2>(acc6, a6[0], b6[g & 7]);
         }
-        NQ_CLK(11);
+        NQ_STAMP(11);
         // this wave's 4 x 96 outputs (slot, channel * 6 + y) go through S4 (dead since the barrier above) so that the
         // feature rows leave as 16-byte stores: 384 contiguous bytes per slot
         const unsigned fo = S4 + wave * 2048;
@@ -591,17 +546,7 @@ NQ_DEV void cnn_front_split_body(
                 *(f32x4*)(feat + (size_t)(p0 + slot) * 384 + 96 * wave + 4 * (q - 24 * slot)) = lds_ld128(fo + 16 * q);
         }
     }
-#ifdef NQ_PHASE_CLOCK
-    clk[12] = clock64();
-    if (lane == 0) {                                      // the LAST launch's numbers stay (slots are overwritten)
-        unsigned long long* slot = g_phase_clk + (size_t)((((blockIdx.y * gridDim.x + blockIdx.x) << 2) + wave) & (NQ_CLK_SLOTS - 1)) * 16;
-#pragma unroll
-        for (int q = 0; q < 12; ++q) slot[q] = (unsigned long long)(clk[q + 1] - clk[q]);
-        slot[12] = 1ull;
-        slot[13] = (unsigned long long)(wall_clock64() - wall_top);
-        slot[14] = (unsigned long long)(clk[0] - clk_top);
-    }
-#endif
+    NQ_STAMP_END(g_phase_clk, ((blockIdx.y * gridDim.x + blockIdx.x) << 2) + wave);
 }
 
 // ---- kernels: one body, three operand formats -------------------------------------------------------------------------------------

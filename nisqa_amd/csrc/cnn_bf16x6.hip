@@ -45,30 +45,8 @@ __device__ constexpr int xwin75_hi(int b) { return b == 0 ? 2 : b == 1 ? 3 : b =
 __device__ constexpr int xwin53_lo(int b) { return b == 0 ? 0 : b == 1 ? 1 : 3; }
 __device__ constexpr int xwin53_hi(int b) { return b == 0 ? 2 : b == 1 ? 4 : 5; }
 
-// -DNQ_PHASE_CLOCK (tools/ab_build_multi.sh clock6 "-DNQ_PHASE_CLOCK" cnn_bf16x6; tools/phase_clock.py with NQ_PRECISION=bf16x6):
-// shader-clock stamps at the layer boundaries, every wave writes its numbers to its own slot (cnn_bf16.hip)
-#ifdef NQ_PHASE_CLOCK
-#define X_CLK_SLOTS 32768
-__device__ unsigned long long g_phase_clk6[X_CLK_SLOTS * 16];
-#define X_CLK(i) clk[i] = clock64()
-extern "C" int nisqa_debug_phase_clock6(unsigned long long* out16, int reset) {
-    if (out16) {
-        unsigned long long* h = (unsigned long long*)malloc(sizeof(g_phase_clk6));
-        if (!h || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_clk6), sizeof(g_phase_clk6)) != hipSuccess) { free(h); return -1; }
-        for (int q = 0; q < 16; ++q) out16[q] = 0;
-        for (int w = 0; w < X_CLK_SLOTS; ++w)
-            for (int q = 0; q < 16; ++q) out16[q] += h[(size_t)w * 16 + q];
-        free(h);
-    }
-    if (reset) {
-        void* d = nullptr;
-        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_phase_clk6)) != hipSuccess || hipMemset(d, 0, sizeof(g_phase_clk6)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#else
-#define X_CLK(i)
-#endif
+// layer-boundary stamps of the phase clock (tools/phase_clock.py with NQ_PRECISION=bf16x6; empty macros unless built with -DNQ_EXPERIMENTAL)
+NQ_CLK_EXPORT(g_phase_clk6, nisqa_debug_phase_clock6)
 
 // 16x16x32 products of T-term operands for conv5 / conv6 (smallest first)
 template <int MT>
@@ -93,10 +71,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
     const float* __restrict__ cw, const unsigned short* __restrict__ wb, float* __restrict__ feat,
     const uint32_t* __restrict__ clip_max_enc, float top_db, const float* __restrict__ seg_x, int seg_L) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef NQ_PHASE_CLOCK
-    const long long clk_top = clock64(), wall_top = wall_clock64();
-    long long clk[13];
-#endif
+    NQ_STAMP_BEGIN();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p0 = blockIdx.x * 4;                      // tok_off is a multiple of 32: no clip straddling
@@ -106,7 +81,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
     if (nvalid <= 0) return;                             // whole workgroup is padding
     const bool valid = wave < nvalid;                    // padding waves still walk the barriers (on zeros)
     const int k = k0 + wave;
-    X_CLK(0);
+    NQ_STAMP(0);
     const unsigned R = X_BASE + wave * X_WAVE;           // this wave's LDS region
     const unsigned lane16 = lane * 16;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, CNNX_U16S * 2, 0x00020000);
@@ -160,7 +135,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
         }
     }
     __builtin_amdgcn_wave_barrier();
-    X_CLK(1);
+    NQ_STAMP(1);
 
     const int i = lane & 31, hfi = (i >> 2) & 1, qi = (i & 3) + 4 * (i >> 3);
     const int n = lane & 31, hf = lane >> 5, h = lane >> 5;
@@ -221,7 +196,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
         }
     }
 
-    X_CLK(2);
+    NQ_STAMP(2);
     // ---- conv2 16->32 on 24x7, pool -> 12x5
     conv_k_ring<XT, 2, 3> ring34;                         // conv3's, then conv4's first fragments
     {
@@ -237,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             base[t] = R + ((py - 1) * 7 + (px - 1)) * X_RS1 + (h << 4);
         }
         conv_k_terms_ring<XT, 16, 6, 1, 7, X_RS1, X_P1, X_ZADDR, 3, true, true>(acc, wrs, CNNX_W2 * 2, lane16, base, m9, ring2);
-        X_CLK(3);
+        NQ_STAMP(3);
         conv_k_preload(ring34, wrs, CNNX_W3 * 2, lane16);
         __builtin_amdgcn_sched_barrier(0);                // (hipcc would sink the requests below the epilogue, to their use)
         const unsigned wr = R + (6 * hf * 5) * X_RS2 + n * 2;
@@ -261,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
         }
     }
 
-    X_CLK(4);
+    NQ_STAMP(4);
     unsigned base34[2], m34[2];                           // conv3 and conv4 share the 12 x 5 geometry
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -283,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             base[t] = R + base34[t] * X_RS2 + (h << 4);
         }
         conv_k_terms_ring<XT, 32, 2, 2, 5, X_RS2, X_P2, X_ZADDR, 3, true, true>(acc, wrs, CNNX_W3 * 2, lane16, base, m34, ring34);
-        X_CLK(5);
+        NQ_STAMP(5);
         conv_k_preload(ring34, wrs, CNNX_W4 * 2, lane16);
         __builtin_amdgcn_sched_barrier(0);
         const unsigned wr = R + (6 * hf * 5) * X_RS3 + n * 2;
@@ -302,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
 
     // ---- conv4 64->64 on 12x5, pool -> 6x3.  The pooled outputs of the workgroup's four segments go to SHARED planes
     //      S4[72 px][64 ch] (row = 18 * wave + pixel) for the N-split conv5 / conv6.
-    X_CLK(6);
+    NQ_STAMP(6);
     const unsigned S4 = X_BASE;                           // XT planes x X_PS (wave 0/1 regions; their A3 is dead by then)
     const unsigned S5 = X_BASE + 2 * X_WAVE;              // conv5 output, same shape (wave 2/3 regions)
     const int w5b = __builtin_amdgcn_readfirstlane((CNNX_W5 + wave * (18 * XT * 512)) * 2);
@@ -318,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             base[t] = R + base34[t] * X_RS3 + (h << 4);
         }
         conv_k_terms_ring<XT, 64, 2, 2, 5, X_RS3, X_P3, X_ZADDR, 3, true, true>(acc, wrs, CNNX_W4 * 2, lane16, base, m34, ring34);
-        X_CLK(7);
+        NQ_STAMP(7);
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -346,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             }
     }
     __syncthreads();
-    X_CLK(8);
+    NQ_STAMP(8);
 
     // ---- conv5 / conv6 with N split over the waves: wave w owns output channels 16w..16w+15 of ALL four segments (72 / 24
     //      output rows in 16-row tiles of v_mfma_f32_16x16x32_bf16); fragments [wave][step][term][lane][8]
@@ -379,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
 #pragma unroll
             for (int t = 0; t < 5; ++t)
 #pragma unroll
-                for (int q = 0; q < XT; ++q) a5[g & 1][t][q] = lds_ld128_a(a5ad[t][q] + tapoff + 64 * s);
+                for (int q = 0; q < XT; ++q) a5[g & 1][t][q] = lds_ld128(a5ad[t][q] + tapoff + 64 * s);
         };
         load_a5(0);
 #pragma unroll
@@ -392,7 +367,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             __builtin_amdgcn_sched_barrier(0);             // requests stay ahead of the step's MFMAs (conv_k_terms: FENCE)
             mma16_terms<5>(acc5, a5[g & 1], b5[g & 3]);
         }
-        X_CLK(9);
+        NQ_STAMP(9);
 #pragma unroll
         for (int g = 0; g < 7; ++g)
 #pragma unroll
@@ -408,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
                                              fmaxf(acc5[t][r] + tn5, 0.f), fmaxf(acc5[t][r + 1] + tn5, 0.f));
         }
         __syncthreads();
-        X_CLK(10);
+        NQ_STAMP(10);
 
         // conv6 (3 x 3 kernel, padding (1,0)) = padding-1 conv at the centre column: rows (slot, y), 24 of 32
         f32x4 acc6[2], acc6b[2];            // even / odd K-steps accumulate separately
@@ -438,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int q = 0; q < XT; ++q) a6[g & 1][t][q] = lds_ld128_a(a6ad[t][q] + tapoff + 64 * s);
+                for (int q = 0; q < XT; ++q) a6[g & 1][t][q] = lds_ld128(a6ad[t][q] + tapoff + 64 * s);
         };
         load_a6(0);
 #pragma unroll
@@ -452,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
             if (g & 1) mma16_terms<2>(acc6b, a6[1], b6[g & 7]);
             else mma16_terms<2>(acc6, a6[0], b6[g & 7]);
         }
-        X_CLK(11);
+        NQ_STAMP(11);
         // this wave's 4 x 96 outputs (slot, channel * 6 + y) go through S4 (dead since the barrier above) so that the
         // feature rows leave as 16-byte stores: 384 contiguous bytes per slot
         const unsigned fo = S4 + wave * 2048;
@@ -465,60 +440,6 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
                 if (rho < 24) lds_st32(fo + (slot * 96 + i16 * 6 + y) * 4, __float_as_uint(fmaxf(acc6[t][r] + acc6b[t][r] + tn6, 0.f)));
             }
         __builtin_amdgcn_wave_barrier();
-#ifdef NQ_TAIL_PROBE
-        // COST stand-in of a fused Linear 384 -> 64 + LayerNorm tail (VERDICT r4 task 3; results of this build are wrong: the fragments
-        // are conv5's, the normalised rows overwrite features).  Every wave takes its K quarter (its own 96 features of the four
-        // tokens = 3 steps of 32) against all 64 outputs on 16x16x32 MFMAs: M = 16 rows (4 valid tokens), 4 N tiles, three-term
-        // operands -> 3 x 4 x 6 = 72 MFMAs and 36 KB of fragments per wave; the A rows come from the staged fp32 features (two
-        // 16-byte reads + a three-term split in registers per step); partial sums meet in LDS, one barrier, then wave w
-        // normalises token w (64 outputs = 64 lanes) and stores its row.
-        {
-            f32x4 accp[4][1];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) accp[nt][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
-                const unsigned ar = fo + (i16 & 3) * 384 + (32 * s3 + 8 * kg) * 4;
-                const f32x4 v0 = lds_ld128(ar), v1 = lds_ld128(ar + 16);
-                f32x4 at[1][XT];
-                float r8[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-                for (int t = 0; t < XT; ++t) {
-                    unsigned pk[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        pk[e] = cvt_pk_bf16(r8[2 * e], r8[2 * e + 1]);
-                        r8[2 * e] -= __uint_as_float(pk[e] << 16);
-                        r8[2 * e + 1] -= __uint_as_float(pk[e] & 0xffff0000u);
-                    }
-                    at[0][t] = f32x4{__uint_as_float(pk[0]), __uint_as_float(pk[1]), __uint_as_float(pk[2]), __uint_as_float(pk[3])};
-                }
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    f32x4 bt[XT];
-#pragma unroll
-                    for (int t = 0; t < XT; ++t) bt[t] = wfrag_load(wrs, lane16, w5b + (((s3 * 4 + nt) % 18) * XT + t) * 1024);
-                    mma16_terms<1>(accp[nt], at, bt);
-                }
-            }
-            const unsigned red = S5 + wave * 1024;          // [4 tokens][64 outputs] floats of this wave (S5 is dead since conv6's loop)
-            if (kg == 0) {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) lds_st32(red + (r * 64 + 16 * nt + i16) * 4, __float_as_uint(accp[nt][0][r]));
-            }
-            __syncthreads();
-            float xs = cw[CNN_T1 + (lane & 15)];            // (stand-in for the bias)
-#pragma unroll
-            for (int w4 = 0; w4 < 4; ++w4) xs += __uint_as_float(lds_ld32(S5 + w4 * 1024 + (wave * 64 + lane) * 4));
-            const float mu = wave_sum(xs) * (1.f / 64.f);
-            const float dv = xs - mu;
-            const float var = wave_sum(dv * dv) * (1.f / 64.f);
-            const float yn = dv * __builtin_amdgcn_rsqf(var + 1e-5f) * tn1 + tn2;
-            if (wave < nvalid) feat[(size_t)(p0 + wave) * 384 + 320 + lane] = yn;
-        }
-#endif
 #pragma unroll
         for (int q0 = 0; q0 < 96; q0 += 64) {
             const int q = q0 + lane;                                         // float4 index: slot = q / 24
@@ -527,17 +448,7 @@ __global__ __launch_bounds__(256, 1) void cnn_front_bf16x6_kernel(
                 *(f32x4*)(feat + (size_t)(p0 + slot) * 384 + 96 * wave + 4 * (q - 24 * slot)) = lds_ld128(fo + 16 * q);
         }
     }
-#ifdef NQ_PHASE_CLOCK
-    clk[12] = clock64();
-    if (lane == 0) {                                      // the LAST launch's numbers stay (slots are overwritten)
-        unsigned long long* slot = g_phase_clk6 + (size_t)((((blockIdx.y * gridDim.x + blockIdx.x) << 2) + wave) & (X_CLK_SLOTS - 1)) * 16;
-#pragma unroll
-        for (int q = 0; q < 12; ++q) slot[q] = (unsigned long long)(clk[q + 1] - clk[q]);
-        slot[12] = 1ull;
-        slot[13] = (unsigned long long)(wall_clock64() - wall_top);
-        slot[14] = (unsigned long long)(clk[0] - clk_top);
-    }
-#endif
+    NQ_STAMP_END(g_phase_clk6, ((blockIdx.y * gridDim.x + blockIdx.x) << 2) + wave);
 }
 
 template <bool SEGX>

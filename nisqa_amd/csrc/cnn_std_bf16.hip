@@ -67,8 +67,8 @@ NQ_DEV void conv_k_bf16_c16(f32x16 (&acc)[MT][1], __amdgpu_buffer_rsrc_t rsrc, i
         for (int t = 0; t < MT; ++t) {
             const bool ok = (m9[t] >> g) & 1u;
             const unsigned a = (unsigned)((int)(dy == 1 ? a_same[t] : a_flip[t]) + tapoff);
-            ah[slot][t] = lds_ld128_a(ok ? a : SS_ZADDR);
-            al[slot][t] = lds_ld128_a(ok ? a + SS_A1PLANE : SS_ZADDR);
+            ah[slot][t] = lds_ld128(ok ? a : SS_ZADDR);
+            al[slot][t] = lds_ld128(ok ? a + SS_A1PLANE : SS_ZADDR);
         }
     };
     load_b(0, 0);
@@ -101,7 +101,7 @@ NQ_DEV void conv_k_terms_c16(f32x16 (&acc)[MT][1], __amdgpu_buffer_rsrc_t rsrc, 
             const bool ok = (m9[m] >> g) & 1u;
             const unsigned ad = (unsigned)((int)(dy == 1 ? a_same[m] : a_flip[m]) + tapoff);
 #pragma unroll
-            for (int t = 0; t < T; ++t) a[slot][m][t] = lds_ld128_a(ok ? ad + t * SS_A1PLANE : SS_ZADDR);
+            for (int t = 0; t < T; ++t) a[slot][m][t] = lds_ld128(ok ? ad + t * SS_A1PLANE : SS_ZADDR);
         }
     };
     load_b(0, 0);

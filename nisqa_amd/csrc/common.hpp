@@ -19,6 +19,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define NQ_DEV static __device__ __forceinline__
 
+// In-kernel phase clocks are measurement scaffolding (csrc/experimental.hpp), compiled in ONLY by -DNQ_EXPERIMENTAL builds of one
+// unit (tools/ab_build.sh); the default build sees these empty macros, and no product source carries an experiment #ifdef.
+#ifdef NQ_EXPERIMENTAL
+#include "experimental.hpp"
+#else
+#define NQ_CLK_EXPORT(ARR, FN)
+#define NQ_STAMP_BEGIN()
+#define NQ_STAMP(i)
+#define NQ_STAMP_END(ARR, WAVE_INDEX)
+#define NQ_SUM_BEGIN()
+#define NQ_SUM_RESTART()
+#define NQ_SUM(i)
+#define NQ_SUM_COUNT(i, n)
+#define NQ_SUM_END(ARR, WAVE_INDEX, COND)
+#endif
+
 NQ_DEV f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }

@@ -5,24 +5,10 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// experiment hook (tools/ab_build.sh): wave priority around the MFMA K loops.  1: K loops at priority 1, epilogues 0;
-// 2: the reverse; 3: static, by the parity of the hardware wave slot (the two waves of a SIMD differ in it)
-#ifndef NQ_EXP_PRIO
-#define NQ_EXP_PRIO 0
-#endif
-#define NQ_PRIO_KLOOP_BEGIN() do { if (NQ_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(1); if (NQ_EXP_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
-#define NQ_PRIO_KLOOP_END() do { if (NQ_EXP_PRIO == 1) __builtin_amdgcn_s_setprio(0); if (NQ_EXP_PRIO == 2) __builtin_amdgcn_s_setprio(1); } while (0)
-
 NQ_DEV f32x16 mfma_bf(f32x4 a, f32x4 b, f32x16 c) {
-#ifdef NQ_KO
-    if (NQ_KO & 8) { c[0] += a[0] * b[0]; return c; }
-#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 NQ_DEV f32x4 mfma_bf16x16(f32x4 a, f32x4 b, f32x4 c) {     // 16x16x32: A[i = l&15][k = 8*(l>>4)+e], D row 4*(l>>4)+r
-#ifdef NQ_KO
-    if (NQ_KO & 8) { c[0] += a[0] * b[0]; return c; }
-#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 // ---- operand formats of the two-term kernels (cnn_bf16.hip) ---------------------------------------------------------------------
@@ -44,17 +30,11 @@ typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 template <int FMT>
 NQ_DEV f32x16 mfma32_fmt(f32x4 a, f32x4 b, f32x16 c) {
     if (FMT == NQ_FMT_BF16X3) return mfma_bf(a, b, c);
-#ifdef NQ_KO
-    if (NQ_KO & 8) { c[0] += a[0] * b[0]; return c; }
-#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 template <int FMT>
 NQ_DEV f32x4 mfma16_fmt(f32x4 a, f32x4 b, f32x4 c) {
     if (FMT == NQ_FMT_BF16X3) return mfma_bf16x16(a, b, c);
-#ifdef NQ_KO
-    if (NQ_KO & 8) { c[0] += a[0] * b[0]; return c; }
-#endif
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 // the term products of one (A, B) fragment pair, smallest first: ll (F16X4 only), hl, lh, hh
@@ -197,7 +177,6 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
     load_b(0, 0);
     load_b(1, 1);
     if (APF) load_a(0, 0);
-    NQ_PRIO_KLOOP_BEGIN();
 #pragma unroll
     for (int g = 0; g < TOTAL; ++g) {
         if (g + 2 < TOTAL) load_b(g + 2, (g + 2) % 3);
@@ -218,7 +197,6 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
             for (int nt = 0; nt < NT; ++nt) acc[t][nt] = mfma_bf(ah[sa][t], bh[sb][nt], acc[t][nt]);
 
     }
-    NQ_PRIO_KLOOP_END();
 }
 
 
@@ -241,32 +219,15 @@ NQ_DEV void conv3x3_bf16(f32x16 (&acc)[MT][NT], const char* act_in, const char* 
 #endif
 #define NQ_STEP_FENCE() do { if (NQ_SB & 1) __builtin_amdgcn_sched_barrier(0); } while (0)
 #define NQ_ISSUE_FENCE() do { if (NQ_SB & 2) __builtin_amdgcn_sched_barrier(0); } while (0)
-#ifndef NQ_KO
-#define NQ_KO 0
-#endif
-#define NQ_SYNC() do { if (!(NQ_KO & 16)) __syncthreads(); } while (0)
 NQ_DEV f32x4 lds_ld128(unsigned a) { return *(NQ_AS3 const f32x4*)(a); }
-NQ_DEV f32x4 lds_ld128_a(unsigned a) {       // A-operand read (knock-out 2 replaces it by register values)
-#ifdef NQ_KO
-    if (NQ_KO & 2) return f32x4{__uint_as_float(a), 1.f, 2.f, 3.f};
-#endif
-    return lds_ld128(a);
-}
 NQ_DEV unsigned lds_ld32(unsigned a) { return *(NQ_AS3 const unsigned*)(a); }
 NQ_DEV void lds_st16(unsigned a, unsigned v) { *(NQ_AS3 unsigned short*)(a) = (unsigned short)v; }
 NQ_DEV void lds_st32(unsigned a, unsigned v) { *(NQ_AS3 unsigned*)(a) = v; }
 NQ_DEV void lds_st128(unsigned a, f32x4 v) { *(NQ_AS3 f32x4*)(a) = v; }
 // v = hi + lo into the two bf16 planes (lo plane `plane` bytes behind the hi plane)
 NQ_DEV void lds_store_split(unsigned a, int plane, float v) {
-#ifdef NQ_KO
-    if (NQ_KO & 64) { if (__float_as_uint(v) == 0x7fc12345u) lds_st16(a, 0); return; }      // no split arithmetic, no stores
-    if (NQ_KO & 128) { lds_st16(a, cvt_pk_bf16(v, 0.f)); return; }                          // hi plane only: half the stores
-#endif
     const unsigned hi = cvt_pk_bf16(v, 0.f);
     const unsigned lo = cvt_pk_bf16(v - __uint_as_float(hi << 16), 0.f);
-#ifdef NQ_KO
-    if (NQ_KO & 4) { if (hi + lo == 0x12345u) lds_st16(a, hi); return; }
-#endif
     lds_st16(a, hi);
     lds_st16(a + plane, lo);
 }
@@ -274,19 +235,7 @@ NQ_DEV void lds_store_split(unsigned a, int plane, float v) {
 // packed results stored with ds_write_b16 / ds_write_b16_d16_hi (2.5 VALU instructions per value instead of 4; the bits are
 // those of lds_store_split)
 NQ_DEV void lds_st16_hi(unsigned a, unsigned v) { *(NQ_AS3 unsigned short*)(a) = (unsigned short)(v >> 16); }
-template <bool KO_DW = true>
 NQ_DEV void lds_store_split2(unsigned a0, unsigned a1, int plane, float v0, float v1, bool st0 = true, bool st1 = true) {
-#ifdef NQ_KO
-    if (NQ_KO & (4 | 64 | 128)) { if (st0) lds_store_split(a0, plane, v0); if (st1) lds_store_split(a1, plane, v1); return; }
-#endif
-    if (KO_DW && (NQ_KO & 256)) {          // timing experiment: ONE dword store per value (hi | lo << 16) at 4-byte lane pitch: no sub-dword
-        const unsigned h0 = cvt_pk_bf16(v0, 0.f), h1 = cvt_pk_bf16(v1, 0.f);       // bank conflicts, half the stores; results wrong
-        const unsigned l0 = cvt_pk_bf16(v0 - __uint_as_float(h0 << 16), 0.f), l1 = cvt_pk_bf16(v1 - __uint_as_float(h1 << 16), 0.f);
-        const unsigned dl = (threadIdx.x & 31) * 2 + ((threadIdx.x & 32) ? 32 : 0);
-        if (st0) lds_st32(a0 + dl, h0 | (l0 << 16));
-        if (st1) lds_st32(a1 + dl, h1 | (l1 << 16));
-        return;
-    }
     const unsigned hi2 = cvt_pk_bf16(v0, v1);
     const f32x2_t vv = {v0, v1};
     const f32x2_t hf = {__uint_as_float(hi2 << 16), __uint_as_float(hi2 & 0xffff0000u)};
@@ -304,9 +253,9 @@ NQ_DEV unsigned cvt_pk_f16(float a, float b) {
 // conv1 input passes |v|): the next layer's scale comes from it
 template <int T> NQ_DEV void lds_store_terms2(unsigned a0, unsigned a1, int plane, float v0, float v1, bool st0 = true, bool st1 = true);
 template <int T> NQ_DEV void lds_store_terms(unsigned a, int plane, float v);
-template <int FMT, bool KO_DW = true>
+template <int FMT>
 NQ_DEV void lds_store_pair_fmt(unsigned a0, unsigned a1, int plane, float v0, float v1, float& mx, bool st0 = true, bool st1 = true) {
-    if (FMT == NQ_FMT_BF16X3) { lds_store_split2<KO_DW>(a0, a1, plane, v0, v1, st0, st1); return; }
+    if (FMT == NQ_FMT_BF16X3) { lds_store_split2(a0, a1, plane, v0, v1, st0, st1); return; }
     if (FMT == NQ_FMT_BF16X6) { lds_store_terms2<3>(a0, a1, plane, v0, v1, st0, st1); return; }
     const unsigned hi2 = cvt_pk_f16(v0, v1);
     const f32x2_t vv = {v0, v1};
@@ -330,15 +279,7 @@ NQ_DEV void lds_store_one_fmt(unsigned a, int plane, float v, float& mx) {
 }
 NQ_DEV f32x16 splat16(float v) { f32x16 r; for (int q = 0; q < 16; ++q) r[q] = v; return r; }
 typedef int nq_i32x4 __attribute__((ext_vector_type(4)));
-// NQ_KO: knock-out bits for timing experiments (results are WRONG): 32 weight fragments read from LDS instead, 1 no weight loads, 2 no A-operand LDS reads,
-// 4 no epilogue LDS stores, 8 no MFMAs, 16 no workgroup barriers, 64 no hi/lo split and no plane stores, 128 hi plane only.
-// Builds that replace operands by constants run at a HIGHER shader clock: compare cycles (tools/phase_clock.py), not ms
-#ifndef NQ_KO
-#define NQ_KO 0
-#endif
 NQ_DEV f32x4 wfrag_load(__amdgpu_buffer_rsrc_t rsrc, unsigned lane16, int byte_off) {
-    if (NQ_KO & 1) return f32x4{__uint_as_float(lane16 + byte_off), 1.f, 2.f, 3.f};
-    if (NQ_KO & 32) return *(NQ_AS3 const f32x4*)(2176u + 16128u + lane16 + (byte_off & 2048));   // weights "from LDS": 1 KiB conflict-free reads
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane16, byte_off, 0));
 }
 // 9-bit tap mask of output pixel (y, x) of an H x W image: bit dy * 3 + dx set iff (y + dy - 1, x + dx - 1) is inside
@@ -385,8 +326,8 @@ NQ_DEV void conv_k_bf16(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int 
         }
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            ah[slot][t] = lds_ld128_a(a_hi[t] + tapoff + 32 * s);
-            al[slot][t] = lds_ld128_a(a_lo[t] + tapoff + 32 * s);
+            ah[slot][t] = lds_ld128(a_hi[t] + tapoff + 32 * s);
+            al[slot][t] = lds_ld128(a_lo[t] + tapoff + 32 * s);
         }
     };
 #pragma unroll
@@ -412,37 +353,9 @@ NQ_DEV void conv_k_bf16(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc, int 
 // ======================================================================================================================
 // v0, v1 -> T bf16 terms each (round to nearest: |term t+1| <= 2^-8 |term t|), plane t `t * plane` bytes behind the first; the halves of the packed conversions are stored with
 // ds_write_b16 / ds_write_b16_d16_hi as in lds_store_split2.
-// -DNQ_X6_TRUNC (A/B, tools/gpu_r04_q.sh): terms by truncation -- the upper half of an fp32 register IS its truncated bf16, so
-// a term is stored straight from the running remainder and costs one v_and + one subtraction (6 VALU instructions per pair
-// instead of 9).  Also an exact split, 2 % faster, but |term t+1| < 2^-7 |term t| makes the dropped products up to eight times
-// larger: the kernel's distance from float64 grows from 1.0 x to 1.4 x the fp32 kernels'.  Not used.
 template <int T>
 NQ_DEV void lds_store_terms2(unsigned a0, unsigned a1, int plane, float v0, float v1, bool st0, bool st1) {
     f32x2_t r = {v0, v1};
-    if (NQ_KO & 256) {                     // timing experiment (results wrong): ONE dword store per term and value pair at a 4-byte lane pitch
-        const unsigned dl = (threadIdx.x & 31) * 2 + ((threadIdx.x & 32) ? 32 : 0);
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const unsigned pk = cvt_pk_bf16(r[0], r[1]);
-            if (st0 || st1) lds_st32(a0 + dl + t * plane, pk);
-            if (t + 1 < T) {
-                const f32x2_t part = {__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
-                r = r - part;
-            }
-        }
-        return;
-    }
-#ifdef NQ_X6_TRUNC
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        if (st0) lds_st16_hi(a0 + t * plane, __float_as_uint(r[0]));
-        if (st1) lds_st16_hi(a1 + t * plane, __float_as_uint(r[1]));
-        if (t + 1 < T) {
-            const f32x2_t part = {__uint_as_float(__float_as_uint(r[0]) & 0xffff0000u), __uint_as_float(__float_as_uint(r[1]) & 0xffff0000u)};
-            r = r - part;
-        }
-    }
-#else
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const unsigned pk = cvt_pk_bf16(r[0], r[1]);
@@ -453,21 +366,15 @@ NQ_DEV void lds_store_terms2(unsigned a0, unsigned a1, int plane, float v0, floa
             r = r - part;
         }
     }
-#endif
 }
 template <int T>
 NQ_DEV void lds_store_terms(unsigned a, int plane, float v) {
     float r = v;
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-#ifdef NQ_X6_TRUNC
-        lds_st16_hi(a + t * plane, __float_as_uint(r));
-        if (t + 1 < T) r -= __uint_as_float(__float_as_uint(r) & 0xffff0000u);
-#else
         const unsigned pk = cvt_pk_bf16(r, 0.f);
         lds_st16(a + t * plane, pk);
         if (t + 1 < T) r -= __uint_as_float(pk << 16);
-#endif
     }
 }
 // acc[m][nt] += sum over the kept term products of a[m][i] x b[nt][j]; smallest products first, consecutive MFMAs on
@@ -531,7 +438,7 @@ NQ_DEV void conv_k_terms_ring(f32x16 (&acc)[MT][NT], __amdgpu_buffer_rsrc_t rsrc
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int t = 0; t < T; ++t) a[slot][m][t] = lds_ld128_a(a_ad[m][t] + tapoff + 32 * s);
+            for (int t = 0; t < T; ++t) a[slot][m][t] = lds_ld128(a_ad[m][t] + tapoff + 32 * s);
     };
     if (!PRE) {
 #pragma unroll

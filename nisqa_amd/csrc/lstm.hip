@@ -42,18 +42,8 @@ NQ_DEV float quad_bcast(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), N * 0x55, 0xF, 0xF, true));   // quad_perm [N,N,N,N]
 }
 
-// -DNQ_LSTM_CLOCK: shader-clock stamps inside a step, summed per workgroup (wave 0, lane 0) -> g_lstm_clk[phase]
-#ifdef NQ_LSTM_CLOCK
-__device__ unsigned long long g_lstm_clk[8];
-extern "C" int nisqa_debug_lstm_clock(unsigned long long* out8, int reset) {
-    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_lstm_clk), sizeof(g_lstm_clk)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_lstm_clk), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#define LSTM_CLK(i) do { const long long t_ = clock64(); lclk[i] += t_ - tprev; tprev = t_; } while (0)
-#else
-#define LSTM_CLK(i)
-#endif
+// per-step phase clock (tools/lstm_clock.py; empty macros unless the unit is built with -DNQ_EXPERIMENTAL): phases 0..4, [7] = steps
+NQ_CLK_EXPORT(g_lstm_clk, nisqa_debug_lstm_clock)
 
 __global__ __launch_bounds__(512, 1) void lstm_dir_kernel(
     const float* __restrict__ feat20, const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
@@ -96,9 +86,7 @@ __global__ __launch_bounds__(512, 1) void lstm_dir_kernel(
     };
     float xv[5];
     if (n > 0) xload(0, xv);
-#ifdef NQ_LSTM_CLOCK
-    long long lclk[6] = {0, 0, 0, 0, 0, 0}, tprev = clock64();
-#endif
+    NQ_SUM_BEGIN();
     for (int t = 0; t < n; ++t) {
         // h_{t-1}: the 32 values of this lane's quarter
         const f32x4* hp = (const f32x4*)(hbuf[t & 1] + 32 * q);
@@ -113,7 +101,7 @@ __global__ __launch_bounds__(512, 1) void lstm_dir_kernel(
             a[g] = __builtin_elementwise_fma(wih[g][1], f32x2{xv[2], xv[3]}, a[g]);
             a[g] = __builtin_elementwise_fma(wih[g][2], f32x2{xv[4], 0.f}, a[g]);
         }
-        LSTM_CLK(0);                                                   // h reads issued + input projection
+        NQ_SUM(0);                                                   // h reads issued + input projection
         if (t + 1 < n) xload(t + 1, xv);                               // in flight across the product and the barrier
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
@@ -125,29 +113,25 @@ __global__ __launch_bounds__(512, 1) void lstm_dir_kernel(
         // lane q of the quad finishes gate q: the pre-activation sum over the quad, then the non-linearity -- sigmoid for
         // i, f, o and tanh(x) = 2 sigmoid(2 x) - 1 for g share one formula with per-lane constants (ONE v_exp / v_rcp per
         // lane instead of four); the four results come back through quad broadcasts
-        LSTM_CLK(1);                                                   // recurrent product
+        NQ_SUM(1);                                                   // recurrent product
         const float p0 = quad_sum(a[0][0] + a[0][1]), p1 = quad_sum(a[1][0] + a[1][1]);
         const float p2 = quad_sum(a[2][0] + a[2][1]), p3 = quad_sum(a[3][0] + a[3][1]);
         const float pre = q == 0 ? p0 : q == 1 ? p1 : q == 2 ? p2 : p3;
         const float act = fmaf(gk, __builtin_amdgcn_rcpf(1.0f + __expf(-gk * pre)), gb);      // gk = 1 or 2, gb = 0 or -1
         const float ig = quad_bcast<0>(act), fg = quad_bcast<1>(act), gg = quad_bcast<2>(act), og = quad_bcast<3>(act);
-        LSTM_CLK(2);                                                   // quad sums, gate non-linearity, broadcasts
+        NQ_SUM(2);                                                   // quad sums, gate non-linearity, broadcasts
         c = fmaf(fg, c, ig * gg);
         h = og * tanh_fast(c);
         if (q == 0) {
             hbuf[(t + 1) & 1][u] = h;
             if (seq) seq[(size_t)(c0 + (dir == 0 ? t : n - 1 - t)) * 256 + dir * 128 + u] = h;
         }
-        LSTM_CLK(3);                                                   // state update + publish
+        NQ_SUM(3);                                                   // state update + publish
         __syncthreads();
-        LSTM_CLK(4);                                                   // barrier
+        NQ_SUM(4);                                                   // barrier
     }
-#ifdef NQ_LSTM_CLOCK
-    if (i == 0) {
-        for (int k = 0; k < 5; ++k) atomicAdd(&g_lstm_clk[k], (unsigned long long)lclk[k]);
-        atomicAdd(&g_lstm_clk[7], (unsigned long long)n);
-    }
-#endif
+    NQ_SUM_COUNT(7, n);
+    NQ_SUM_END(g_lstm_clk, blockIdx.y * gridDim.x + blockIdx.x, i == 0);
     if (q == 0) hfin[((size_t)b * 2 + dir) * 128 + u] = h;
 }
 

@@ -91,28 +91,13 @@ __device__ constexpr float W32S[32] = {-0.000000000e+00f, -1.950903220e-01f, -3.
 __device__ constexpr float W16C[16] = {1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f, 6.123233996e-17f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f, -1.000000000e+00f, -9.238795325e-01f, -7.071067812e-01f, -3.826834324e-01f, -1.836970199e-16f, 3.826834324e-01f, 7.071067812e-01f, 9.238795325e-01f};
 __device__ constexpr float W16S[16] = {-0.000000000e+00f, -3.826834324e-01f, -7.071067812e-01f, -9.238795325e-01f, -1.000000000e+00f, -9.238795325e-01f, -7.071067812e-01f, -3.826834324e-01f, -1.224646799e-16f, 3.826834324e-01f, 7.071067812e-01f, 9.238795325e-01f, 1.000000000e+00f, 9.238795325e-01f, 7.071067812e-01f, 3.826834324e-01f};
 
-// wave-private LDS round trips: a compiler barrier, plus (NQ_MEL_LDS_WAIT) a wait for the wave's outstanding LDS operations
-#ifdef NQ_MEL_LDS_WAIT
-#define MEL_WBAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
-#else
+// wave-private LDS round trips: a compiler barrier (the hardware keeps one wave's LDS operations in order)
 #define MEL_WBAR() __builtin_amdgcn_wave_barrier()
-#endif
 // waves per workgroup: the 48 kHz-class instantiation (NQ = 1) fits 168 registers and 9.3 KB of LDS per wave -> ONE workgroup of
 // twelve waves per CU = three per SIMD (the kernel is short of resident waves); longer windows keep four
 #define MEL_WAVES_OF(NQ) ((NQ) == 1 ? 12 : 4)
-// -DNQ_MEL_CLOCK (tools/ab_build.sh melclk mel -DNQ_MEL_CLOCK; tools/mel_clock.py): shader-clock stamps at the phase
-// boundaries of a frame, summed over all frames
-#ifdef NQ_MEL_CLOCK
-__device__ unsigned long long g_mel_clk[16];
-#define MEL_CLK(i) do { const long long t_ = clock64(); mclk[i] += t_ - tprev; tprev = t_; } while (0)
-extern "C" int nisqa_debug_mel_clock(unsigned long long* out16, int reset) {
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mel_clk), sizeof(g_mel_clk)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_mel_clk), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#else
-#define MEL_CLK(i)
-#endif
+// per-frame phase clock (tools/mel_clock.py; empty macros unless the unit is built with -DNQ_EXPERIMENTAL): phases 0..6, [8] = frames
+NQ_CLK_EXPORT(g_mel_clk, nisqa_debug_mel_clock)
 #define MEL_TAB_BYTES (4096 + 2048 + 1536 + 6144)   /* window taps, W4096 / W2048 twiddles, per-(pass, lane) filter-bank offsets */
 #define MEL_EXCH_BYTES 5120            /* exchange 1 [8][72] complex (4608 B) and exchange 2 64 x 80 B alias */
 
@@ -319,9 +304,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
 
     float raw[8][2];
     if (NQ == 1) load_frame(f_begin, b, 0, raw);
-#ifdef NQ_MEL_CLOCK
-    long long mclk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
-#endif
+    NQ_SUM_BEGIN();
     for (int f = f_begin; f < f_end; ++f) {
         c32 zq[NQ][8];
         const int fn = f + 1;
@@ -362,7 +345,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
 
         c32 u[8], u1[8];
         const int mir = 63 - lane;
-        MEL_CLK(0);                                   // window + prefetch
+        NQ_SUM(0);                                   // window + prefetch
         // r = 0: partner Z_0[512 - k] = lane (64 - l) & 63, register 7 - q2 (lane 0: register (8 - q2) & 7)
         fold(0, z);
         fft512<0>(u, z, tw, exch, lane, tab_a);
@@ -397,7 +380,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
             if (lane == 0 && 512 < mag_stride) mag[512] = 2.0f * fabsf(u[0].x - u[0].y);   // Nyquist bin: 2 X[2048] = 2 (Re Z0 - Im Z0)
 
         }
-        MEL_CLK(1);                                   // FFT r = 0 + magnitudes
+        NQ_SUM(1);                                   // FFT r = 0 + magnitudes
         // r = 2: partner Z_2[511 - k] = lane 63 - l, register 7 - q2
         fold(2, z);
         fft512<2>(u, z, tw, exch, lane, tab_a);
@@ -421,13 +404,13 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
                     mag[1 * mag_stride + lane + 64 * q2] = xmag(u[q2], zb[e], wl, cmk(W16C[q2], W16S[q2]));
             }
         }
-        MEL_CLK(2);                                   // FFT r = 2 + magnitudes
+        NQ_SUM(2);                                   // FFT r = 2 + magnitudes
         // r = 1 and r = 3 are each other's partners
         fold(1, z);
         fft512<1>(u1, z, tw, exch, lane, tab_a);
         fold(3, z);
         fft512<3>(u, z, tw, exch, lane, tab_a);
-        MEL_CLK(3);                                   // FFTs r = 1, 3
+        NQ_SUM(3);                                   // FFTs r = 1, 3
 #pragma unroll
         for (int q0 = 0; q0 < 8; q0 += MG) {               // MG groups at a time: 2 MG partners, then 2 MG chains
             c32 z3m[MG], z1m[MG];
@@ -448,7 +431,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
             }
         }
         MEL_WBAR();
-        MEL_CLK(4);                                   // magnitudes r = 1, 3
+        NQ_SUM(4);                                   // magnitudes r = 1, 3
 
         // ---- sparse slaney filterbank: 4 bands per pass (one per 16-lane row)
         float mine = 0.f;
@@ -484,7 +467,7 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
             if (l16 == ps) mine = part;                 // lane 16*row + ps holds band 4*ps + row
         }
         MEL_WBAR();
-        MEL_CLK(5);                                   // filterbank
+        NQ_SUM(5);                                   // filterbank
         // ---- amplitude_to_db(ref=1, amin=1e-4): 10*log10(max(amin^2, S^2)); running per-clip max
         if (l16 < 12) {
             const float db = 10.0f * log10f(fmaxf(cfg.amin_sq, mine * mine));
@@ -497,15 +480,10 @@ __global__ __launch_bounds__(64 * MEL_WAVES_OF(NQ), NQ == 2 ? 2 : 1) void mel_fr
             runmax = -3.0e38f;
             b = bn;
         }
-        MEL_CLK(6);                                   // dB, store, clip maximum
+        NQ_SUM(6);                                   // dB, store, clip maximum
     }
-#ifdef NQ_MEL_CLOCK
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < 7; ++q) atomicAdd(&g_mel_clk[q], (unsigned long long)mclk[q]);
-        atomicAdd(&g_mel_clk[8], (unsigned long long)(f_end - f_begin));
-    }
-#endif
+    NQ_SUM_COUNT(8, f_end - f_begin);
+    NQ_SUM_END(g_mel_clk, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane == 0);
 }
 
 __global__ void mel_floor_kernel(const uint32_t* __restrict__ clip_max_enc, float top_db, int n_clips,

@@ -22,54 +22,20 @@
 // one scheduling fence per K-step of conv_k_bf16 in THIS unit: the two workgroups of a CU run in step here, nobody fills the
 // stalls of a sunk prefetch (measured -9 % forward, -15 % input gradient; the inference kernel, whose waves are out of step,
 // is faster without: conv_bf16.hpp)
-#ifndef NQ_SB
 #define NQ_SB 1
-#endif
 #include "conv_bf16.hpp"
 #include "../../include/nisqa_hip.h"
 #include "../../include/nisqa_train.h"
 
 #define SC_ZADDR 2048u                     /* 128-byte zero block above the largest tap offset */
 #define SC_BASE 2176u                      /* hi plane; the lo plane follows */
-// -DSC_CLOCK: shader-clock stamps per phase, summed per wave into g_sc_clk[wave slot][8] (tools/bench_segconv.py prints them)
-#ifdef SC_CLOCK
-__device__ unsigned long long g_sc_clk[8192 * 8];
-#define SC_CLK(i) do { const long long t_ = clock64(); clk[i] += t_ - tprev; tprev = t_; } while (0)
-extern "C" int nisqa_debug_segconv_clock(unsigned long long* out8, int reset) {
-    if (out8) {
-        unsigned long long* h = (unsigned long long*)malloc(sizeof(g_sc_clk));
-        if (!h || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sc_clk), sizeof(g_sc_clk)) != hipSuccess) { free(h); return -1; }
-        for (int q = 0; q < 8; ++q) out8[q] = 0;
-        for (int w = 0; w < 8192; ++w)
-            for (int q = 0; q < 8; ++q) out8[q] += h[(size_t)w * 8 + q];
-        free(h);
-    }
-    if (reset) {
-        void* d = nullptr;
-        if (hipGetSymbolAddress(&d, HIP_SYMBOL(g_sc_clk)) != hipSuccess || hipMemset(d, 0, sizeof(g_sc_clk)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#else
-#define SC_CLK(i)
-#endif
-#ifndef SC_W_MSPLIT
+// per-phase clock of the segment-conv kernels (tools/bench_segconv.py; empty macros unless built with -DNQ_EXPERIMENTAL): phases 0..5, [6] = groups, [7] = waves
+NQ_CLK_EXPORT(g_sc_clk, nisqa_debug_segconv_clock)
 #define SC_W_MSPLIT 1         /* weight gradient of the 64 -> 64 layers: 1 = a wave takes both M tiles and every 8th N tile, 2 = one M tile, every 4th */
-#endif
-#ifndef SC_SEGS60
 #define SC_SEGS60 4            /* segments per workgroup of the 12 x 5 layers (two 32-row tiles per wave at 4, one at 2) */
-#endif
-#ifndef SC_WGS
 #define SC_WGS 2
-#endif
-#ifndef SC_RING
 #define SC_RING 3            /* weight-fragment ring of the K loop (slots) */
-#endif
-#ifndef SC_NOFENCE
 #define SC_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define SC_FENCE()
-#endif
 
 // ---- fragment packing: [step g][NT][hi, lo][64 lanes][8 bf16];  step g = (tap, 16-channel group), lane l holds column
 //      n = 32 nt + (l & 31) and reduction channels 16 (g % S16) + 8 (l >> 5) .. + 7 of that tap
@@ -324,9 +290,7 @@ NQ_DEV void sc_store_terms4(unsigned a, int plane, f32x4 v) {
         }
     }
 }
-#ifndef SC_X6_FENCE
 #define SC_X6_FENCE true     /* sched_barrier behind a K step's requests in the three-term loops (conv_k_terms) */
-#endif
 
 // CIN: channels of the staged tensor (the reduction runs over 9 x CIN); NT: 32-column tiles of the output channels
 // HR x WR: output pixels of a segment (the rows); HS x WS: pixels of the staged tensor; source pixel of row (y, x) and
@@ -405,9 +369,7 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
     // Output stores are never waited for.
     constexpr int LINES = SEGS * C::PXS * CIN / 32;             // 128-byte lines of a group
     constexpr int NTOUCH = (LINES + 255) / 256;
-#ifdef SC_CLOCK
-    long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
-#endif
+    NQ_SUM_BEGIN();
     f32x4 v[C::NV];
     auto request = [&](int grp, int tid) {                      // the 128-bit loads of a group, all in flight together
         const int seg0 = grp * SEGS;
@@ -427,7 +389,7 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
         asm volatile("" : "+v"(tid), "+v"(lane));
         float gscale = 1.f, cinv = 1.f;                       // F16: 2^e of this group's staged tensor, 2^-(e + kw) for its outputs
         {
-            SC_CLK(0);
+            NQ_SUM(0);
             if constexpr (F16) {
                 float mr = 0.f;
 #pragma unroll
@@ -444,7 +406,7 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
                 gscale = pow2_f32(ge);
                 cinv = pow2_f32(-(ge + kw));
             }
-            SC_CLK(1);
+            NQ_SUM(1);
 #pragma unroll
             for (int j = 0; j < C::NV; ++j) {
                 const int i = tid + 256 * j;
@@ -477,9 +439,9 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
                 }
             }
         }
-        SC_CLK(2);                                              // split + stored (includes the wait for the loads)
+        NQ_SUM(2);                                              // split + stored (includes the wait for the loads)
         __syncthreads();
-        SC_CLK(3);
+        NQ_SUM(3);
         float touch[NTOUCH];
         {
             const int nxt = grp + (int)gridDim.x;
@@ -508,7 +470,7 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
             else conv_k_bf16<CIN, MT, NT, WS, C::RS, C::PLANE, SC_ZADDR, (MT * NT <= 4), SC_RING, FMT>(acc, rsrc, 0, lane0 * 16, base, m9);
         }
 
-        SC_CLK(4);                                              // K loop
+        NQ_SUM(4);                                              // K loop
         // the next group's real loads go out BEFORE this group's output stores (they would queue behind 64 stores per lane
         // otherwise: 13 % of a group's time); its lines were touched into L2 before the K loop, the accumulators are the only
         // other large live set here
@@ -534,18 +496,11 @@ __global__ __launch_bounds__(256, SC_WGS) void segconv_bf16_kernel(
         }
 #pragma unroll
         for (int j = 0; j < NTOUCH; ++j) asm volatile("" ::"v"(touch[j]));      // the touches end here, not before
-        SC_CLK(5);                                              // epilogue
-#ifdef SC_CLOCK
-        clk[6] += 1;
-#endif
+        NQ_SUM(5);                                              // epilogue
+        NQ_SUM_COUNT(6, 1);
     }
-#ifdef SC_CLOCK
-    if (lane0 == 0) {
-        const int slot = (blockIdx.x * 4 + wave) & 8191;
-        for (int q = 0; q < 7; ++q) g_sc_clk[slot * 8 + q] += clk[q];
-        g_sc_clk[slot * 8 + 7] += 1;
-    }
-#endif
+    NQ_SUM_COUNT(7, 1);
+    NQ_SUM_END(g_sc_clk, blockIdx.x * 4 + wave, lane0 == 0);
 
     // ---- BatchNorm statistics of the workgroup's rows: lane pairs, the four waves through LDS, one atomic per channel
     if (with_stats) {
@@ -995,15 +950,13 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
     deposit(0u, tid0, grp);
     __syncthreads();
     unsigned cur = 0u;
-#ifdef SC_CLOCK
-    long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = clock64();
-#endif
+    NQ_SUM_BEGIN();
     for (; grp < n_groups; grp += gridDim.x) {
         int tid = tid0;
         asm volatile("" : "+v"(tid));                          // keep the staging addresses inside the loop
         request(grp + gridDim.x, tid);                          // the next group travels while this one is multiplied
         __builtin_amdgcn_sched_barrier(0);                      // (hipcc would sink these loads to their use behind the K loop)
-        SC_CLK(0);                                              // requests issued
+        NQ_SUM(0);                                              // requests issued
         unsigned za[C::KSTEPS][2], xa[C::KSTEPS][2];
 #pragma unroll
         for (int st = 0; st < C::KSTEPS; ++st)
@@ -1014,19 +967,15 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
             }
         segwgrad_kloop<C>(acc, za, xa, noff, n_own);
         __builtin_amdgcn_sched_barrier(0);
-        SC_CLK(4);                                              // K loop
+        NQ_SUM(4);                                              // K loop
         deposit(C::BUF - cur, tid, grp + (int)gridDim.x);       // the other buffer: last read before the previous barrier
-        SC_CLK(2);                                              // wait for the loads + split + store
+        NQ_SUM(2);                                              // wait for the loads + split + store
         __syncthreads();
-        SC_CLK(3);
+        NQ_SUM(3);
         cur = C::BUF - cur;
-#ifdef SC_CLOCK
-        clk[6] += 1;
-#endif
+        NQ_SUM_COUNT(6, 1);
     }
-#ifdef SC_CLOCK
-    tprev = clock64();
-#endif
+    NQ_SUM_RESTART();
     // ---- this workgroup's share of dw
 #pragma unroll
     for (int j = 0; j < C::NTW; ++j) {
@@ -1042,14 +991,9 @@ __global__ __launch_bounds__(512, 1) void segwgrad_bf16_kernel(const float* __re
                 }
         }
     }
-#ifdef SC_CLOCK
-    SC_CLK(5);                                                  // the atomics (issue only)
-    if (lane0 == 0) {
-        const int slot = (blockIdx.x * 8 + wave) & 8191;
-        for (int q = 0; q < 7; ++q) g_sc_clk[slot * 8 + q] += clk[q];
-        g_sc_clk[slot * 8 + 7] += 1;
-    }
-#endif
+    NQ_SUM(5);                                                  // the atomics (issue only)
+    NQ_SUM_COUNT(7, 1);
+    NQ_SUM_END(g_sc_clk, blockIdx.x * 8 + wave, lane0 == 0);
 }
 
 template <int CI, int CO, int H, int W, int WO, int PADW, int SEGS, int MSPLIT, int PH = 0, int PW = 0, int TERMS = 2>

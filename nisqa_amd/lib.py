@@ -145,6 +145,43 @@ TRAIN_SYMBOLS = {
 _lib = None
 
 
+def exported_symbols(path, prefix=''):
+    """Names in the dynamic symbol table (.dynsym) of an ELF64 shared object that are DEFINED there and start with `prefix`."""
+    import struct
+    with open(path, 'rb') as f:
+        d = f.read()
+    if d[:4] != b'\x7fELF' or d[4] != 2 or d[5] != 1:
+        raise RuntimeError('nisqa_amd: %s is not a little-endian ELF64 file' % path)
+    shoff, = struct.unpack_from('<Q', d, 0x28)
+    shentsize, shnum = struct.unpack_from('<HH', d, 0x3A)
+    sec = [struct.unpack_from('<IIQQQQIIQQ', d, shoff + i * shentsize) for i in range(shnum)]
+    out = []
+    for (_, typ, _, _, off, size, link, _, _, entsize) in sec:
+        if typ != 11 or not entsize:                 # SHT_DYNSYM
+            continue
+        stroff = sec[link][4]
+        for k in range(size // entsize):
+            st_name, _, _, st_shndx = struct.unpack_from('<IBBH', d, off + k * entsize)
+            if st_shndx == 0:                        # undefined: an import
+                continue
+            end = d.index(b'\0', stroff + st_name)
+            name = d[stroff + st_name:end].decode('ascii', 'replace')
+            if name.startswith(prefix):
+                out.append(name)
+    return sorted(out)
+
+
+def refuse_debug_library(path):
+    """A library that exports nisqa_debug_* readers was built with -DNQ_EXPERIMENTAL (csrc/experimental.hpp: in-kernel phase clocks and
+    whatever else an experiment compiled in): it times differently from the product and is never what a caller should score audio
+    with.  Refused unless NISQA_ALLOW_DEBUG_LIB=1 (the tools/ that read the clocks set it)."""
+    dbg = exported_symbols(path, 'nisqa_debug_')
+    if dbg and os.environ.get('NISQA_ALLOW_DEBUG_LIB') != '1':
+        raise RuntimeError('nisqa_amd: %s exports %s -- an instrumented (-DNQ_EXPERIMENTAL) build, not the product library; '
+                           'set NISQA_ALLOW_DEBUG_LIB=1 to load it for a measurement' % (path, ', '.join(dbg)))
+    return dbg
+
+
 def load():
     """Load (once) and return the ctypes library with typed entry points."""
     global _lib
@@ -158,6 +195,7 @@ def load():
         raise RuntimeError(
             'nisqa_amd: HIP library not built: %s is missing (run __graft_entry__.build() or '
             '`make -C nisqa_amd/csrc`); there is no CPU fallback.' % LIB_PATH)
+    refuse_debug_library(LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in list(SYMBOLS.items()) + list(TRAIN_SYMBOLS.items()):
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

@@ -486,6 +486,39 @@ def test_library_exports_every_declared_symbol():
     assert declared <= exported
 
 
+def test_product_library_exports_no_debug_symbol_and_an_instrumented_one_is_refused(tmp_path):
+    """experiment scaffolding lives in csrc/experimental.hpp, which only -DNQ_EXPERIMENTAL builds include; such a
+    build exports nisqa_debug_* readers and lib.load() refuses it unless NISQA_ALLOW_DEBUG_LIB=1."""
+    from nisqa_amd import lib
+    assert lib.exported_symbols(lib.LIB_PATH, 'nisqa_debug_') == []
+    mine = set(lib.exported_symbols(lib.LIB_PATH, 'nisqa_'))
+    nm = subprocess.check_output(['nm', '-D', '--defined-only', lib.LIB_PATH]).decode()
+    assert mine == set(re.findall(r' T (nisqa_\w+)', nm))                       # the ELF reader agrees with binutils
+    csrc = os.path.join(ROOT, 'nisqa_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):                                          # no experiment #ifdef in any product kernel source
+        if f.endswith('.hip'):
+            src = open(os.path.join(csrc, f)).read()
+            assert not re.search(r'#\s*if(def|ndef)?\s+\(?\s*(defined\s*\(\s*)?(NQ_|SC_)', src), f
+            assert 'experimental.hpp' not in src, f
+    hpp = open(os.path.join(csrc, 'common.hpp')).read()
+    assert re.search(r'#ifdef NQ_EXPERIMENTAL\n#include "experimental.hpp"', hpp)
+    # an instrumented stand-in: a shared object that defines one nisqa_debug_* symbol (what -DNQ_EXPERIMENTAL adds to the real one)
+    stub = tmp_path / 'libdbg.so'
+    (tmp_path / 'dbg.c').write_text('int nisqa_debug_phase_clock6(unsigned long long* o, int r) { (void)o; (void)r; return 0; }\n'
+                                    'int nisqa_abi_version(void) { return 2; }\n')
+    subprocess.check_call(['gcc', '-shared', '-fPIC', '-o', str(stub), str(tmp_path / 'dbg.c')])
+    assert lib.exported_symbols(str(stub), 'nisqa_debug_') == ['nisqa_debug_phase_clock6']
+    code = ('import os, sys; sys.path.insert(0, %r); from nisqa_amd import lib\n'
+            'try:\n    lib.load(); print("LOADED")\n'
+            'except RuntimeError as e:\n    print("REFUSED" if "instrumented" in str(e) else "OTHER " + str(e))\n'
+            'except AttributeError as e:\n    print("PAST-THE-GATE")\n' % ROOT)
+    env = dict(os.environ, NISQA_HIP_LIB=str(stub))
+    env.pop('NISQA_ALLOW_DEBUG_LIB', None)
+    assert subprocess.check_output([sys.executable, '-c', code], env=env).decode().strip().endswith('REFUSED')
+    env['NISQA_ALLOW_DEBUG_LIB'] = '1'      # the gate opens (the stub then fails on its missing product symbols, which is fine)
+    assert subprocess.check_output([sys.executable, '-c', code], env=env).decode().strip().endswith('PAST-THE-GATE')
+
+
 def test_training_operators_are_declared_and_exported():
     from nisqa_amd import lib
     hdr = open(os.path.join(ROOT, 'include', 'nisqa_train.h')).read()

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B builds of libnisqa_hip.so with experiment flags on ONE translation unit:  tools/ab_build.sh NAME UNIT "-DFLAG=1 ..."
-# -> ab_libs/NAME.so (all other objects are the regular ones; run `make -C nisqa_amd/csrc` first).  Use with
+# -> ab_libs/NAME.so (all other objects are the regular ones; run `make -C nisqa_amd/csrc` first).  FLAGS "-DNQ_EXPERIMENTAL" compiles
+# the unit's phase clock in (csrc/experimental.hpp); such a library loads only with NISQA_ALLOW_DEBUG_LIB=1.  Use with
 # NISQA_HIP_LIB=$PWD/ab_libs/NAME.so python bench.py ...
 set -e
 NAME=$1; UNIT=$2; FLAGS=$3

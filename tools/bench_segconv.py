@@ -54,7 +54,7 @@ for (h, w, ci, co, pad) in [(24, 7, 16, 32, 1), (12, 5, 32, 64, 1), (12, 5, 64, 
     t.append(timeit(lambda: wg(p(x), p(dz), p(dw), S, h, w, ci, co, pad, st)) if wg is not None else float('nan'))
     fl = 2.0 * rows * co * 9 * ci
     dbg = getattr(L, 'nisqa_debug_segconv_clock', None)
-    if dbg is not None:                      # -DSC_CLOCK build: mean shader-clock cycles per group and wave, by phase
+    if dbg is not None:                      # -DNQ_EXPERIMENTAL build of train_conv.hip (NISQA_ALLOW_DEBUG_LIB=1): mean shader-clock cycles per group and wave, by phase
         import ctypes
         dbg.restype, dbg.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]
         names = ['issue loads', 'barrier (prev K loops)', 'wait + split + store', 'barrier', 'K loop', 'epilogue']
@@ -67,7 +67,7 @@ for (h, w, ci, co, pad) in [(24, 7, 16, 32, 1), (12, 5, 32, 64, 1), (12, 5, 64, 
             else:                                # wgrad: 'epilogue' = the final atomics (per wave, not per group)
                 L.nisqa_segconv_wgrad_bf16(p(x), p(dz), p(dw), S, h, w, ci, co, pad, st)
             torch.cuda.synchronize()
-            o8 = (ctypes.c_ulonglong * 8)()
+            o8 = (ctypes.c_ulonglong * 16)()
             dbg(o8, 0)
             g = max(1, o8[6])
             print('    %s: %d waves, %.2f groups per wave; cycles per group: ' % (nm, o8[7], g / max(1, o8[7])) +

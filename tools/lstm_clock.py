@@ -1,5 +1,5 @@
-"""Where a step of lstm_dir_kernel spends its cycles (build: tools/ab_build.sh lstmclk lstm "-DNQ_LSTM_CLOCK").
-Run on the GPU box:  NISQA_HIP_LIB=$PWD/ab_libs/lstmclk.so python tools/lstm_clock.py"""
+"""Where a step of lstm_dir_kernel spends its cycles (build: tools/ab_build.sh lstmclk lstm "-DNQ_EXPERIMENTAL").
+Run on the GPU box:  NISQA_ALLOW_DEBUG_LIB=1 NISQA_HIP_LIB=$PWD/ab_libs/lstmclk.so python tools/lstm_clock.py"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -22,7 +22,7 @@ L.nisqa_debug_lstm_clock(None, 1)
 for _ in range(5):
     eng.forward_pcm(dev_pcm, plan, 48000)
 torch.cuda.synchronize()
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 16)()
 assert L.nisqa_debug_lstm_clock(out, 0) == 0
 n = out[7]
 names = ['h reads issued + input projection', 'recurrent product (64 v_pk_fma_f32)', 'quad sums + gate non-linearity + broadcasts',

@@ -1,5 +1,5 @@
-"""Per-phase shader-clock profile of mel_frame_kernel (build: tools/ab_build.sh melclk mel "-DNQ_MEL_CLOCK").
-Run on the GPU box:  NISQA_HIP_LIB=$PWD/ab_libs/melclk.so python tools/mel_clock.py"""
+"""Per-phase shader-clock profile of mel_frame_kernel (build: tools/ab_build.sh melclk mel "-DNQ_EXPERIMENTAL").
+Run on the GPU box:  NISQA_ALLOW_DEBUG_LIB=1 NISQA_HIP_LIB=$PWD/ab_libs/melclk.so python tools/mel_clock.py"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,6 @@
 """Per-phase shader-clock profile of cnn_front_bf16_kernel (build: tools/phase_clock.sh -> ab_libs/clock.so).
 
-Run on the GPU box:  NISQA_HIP_LIB=$PWD/ab_libs/clock.so python tools/phase_clock.py
+Run on the GPU box:  NISQA_ALLOW_DEBUG_LIB=1 NISQA_HIP_LIB=$PWD/ab_libs/clock.so python tools/phase_clock.py
 Prints the mean cycles one wave spends between the layer boundaries (under the real 2-waves-per-SIMD contention)."""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
