@@ -149,6 +149,11 @@ void probe_flac(int fd, int64_t fsize, const unsigned char* head, size_t got, ni
     }
     if (rc != 0) return;
     int64_t total = s.total;
+    // STREAMINFO's 36-bit total is a CLAIM until frames are decoded; staging buffers are sized from it.  A frame is at least 10 bytes
+    // (header 5 + CRC-8 + one subframe byte + CRC-16 + padding) and carries at most max_block samples per channel, so a file of fsize
+    // bytes cannot hold more than (fsize / 10 + 1) * max_block: a larger claim is a malformed header ("Could not load file"), not a
+    // 100 GB allocation.
+    if (total > (fsize / 10 + 1) * (int64_t)s.max_block) return;
     if (total == 0) {
         std::vector<uint8_t> buf;
         if (!slurp(fd, buf)) { out->status = NISQA_WAV_ERR_READ; return; }
