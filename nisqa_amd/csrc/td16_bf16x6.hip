@@ -1,0 +1,543 @@
+// Self-attention (Linear 384 -> 64 + LayerNorm, then the TransformerEncoder layers; reference nisqa/NISQA_lib.py:988-996,
+// 1025-1040) at fp32 OPERAND precision on the bf16 matrix pipe, round-6 form: 16-token tiles on v_mfma_f32_16x16x32_bf16, FOUR
+// waves = 64 tokens of ONE clip per workgroup, one workgroup per CU, every shared operand staged ONCE per workgroup in LDS.
+//
+// Why: the round 1-5 kernels ran one wave per 32-token tile -- 512 waves for 64 x 10 s on 1 024 SIMDs, a
+// dependent chain of ~700 32x32x16 MFMAs per layer and wave, every wave streaming the layer's 144 KB of weight fragments and its
+// clip's 196 KB of K / V through the vector-memory path.  Here a tile is half as wide (all 1 024 SIMDs work, every per-wave
+// chain -- MFMA and the VALU around it -- is half as long), and what the four waves of a workgroup share (weight fragments, the
+// clip's K / V blocks) is fetched from L2 once per workgroup and read from LDS as 1 KB conflict-free ds_read_b128 fragments.
+//
+// Operands: every fp32 operand as THREE bf16 terms (hi + mid + lo, an exact split) and the six products hh hm mh hl lh mm, fp32
+// accumulate, smallest products first -- the arithmetic of td_bf16x6.hip's round-5 kernels (softmax, LayerNorm, biases, residuals
+// fp32 in registers).
+//
+// Fragment maps (wave64, lane l: c = l & 15, g = l >> 4):
+//   A (16 x 32): A[row c][k-slot 8 g + e]    B (32 x 16): B[k-slot 8 g + e][col c]    D (16 x 16): D[row 4 g + r][col c], r = 0..3
+// A token tile's activations live FEATURE-major in D layout: x[mt][r] = X[token c][feature 16 mt + 4 g + r] (four D tiles).  The
+// contraction order of a chain GEMM is free as long as both operands agree, so k-slot (s, g, e) of K-step s means
+//   feature(s, g, e) = 16 (2 s + (e >> 2)) + 4 g + (e & 3)
+// -- the B fragment of step s is exactly {x[2 s][0..3], x[2 s + 1][0..3]}, no lane exchange between GEMMs; the weight fragments are
+// packed in that order on the host (nisqa_amd/weights.py: linear_a_fragments_bf16_t16).  The same registers serve as the A operand
+// when the roles are swapped (V is computed token-major so that its D tile IS the V^T A-fragment of the P V product).
+//
+// Q / K / V of a layer never exist as matrices: the producing wave stores them as the MFMA fragments the consumer needs (per layer
+// buffer, bf16 units):  Q  [tile][s 2][term 3][64 lanes][8]          (B fragments of S^T = K Q^T, pre-scaled by 1/8)
+//                       KV [32-key block][ K: [jt 2][s 2][term 3][64][8] | V: [ft 4][term 3][64][8] ]   (24 KB per block)
+// K fragments are the producer's own D registers; a V fragment interleaves the two 16-token tiles of its block (8 bytes per lane
+// each).  The consumer copies a block linearly into LDS (double buffered, one barrier per block) and reads fragments at lane * 16.
+#include "common.hpp"
+#include "layout.hpp"
+#include "../../include/nisqa_hip.h"
+
+#define XT 3
+#define LN_EPS 1e-5f
+#define NQ_AS3 __attribute__((address_space(3)))
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short u16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define T16_FRAG 1024                                 /* bytes of one fragment: 64 lanes x 8 bf16 */
+#define T16_GEMM (2 * 4 * XT * T16_FRAG)              /* 64 x 64 GEMM: [s 2][mt 4][term][1 KB] = 24 KB */
+#define T16_KVBLK (24 * T16_FRAG)                     /* one 32-key block: K 12 fragments, V 12 fragments */
+#define T16_QTILE_U16 (2 * XT * 512)                  /* Q fragments of a 16-token tile, bf16 units */
+#define T16_KVBLK_U16 (24 * 512)
+
+namespace {
+
+NQ_DEV f32x4 mfma16(f32x4 a, f32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// LDS fragment reads are plain loads (the compiler tracks them with lgkmcnt).  What it must NOT see is the LDS-DMA staging of the layer
+// kernel's K / V ring: hipcc orders every LDS read behind ALL outstanding LDS-DMA of the wave (s_waitcnt vmcnt(0): it cannot tell the
+// ring slots apart), i.e. the block being prefetched would have to land before the block in hand is read.  dma16_asm below issues the
+// request from inline asm, invisible to that bookkeeping; the protocol that makes a read safe is explicit (the issuing wave's vmcnt +
+// a workgroup barrier).  The compiler's own vmcnt waits for its global loads then count too few younger requests: they wait for more
+// than they need, never for less.
+template <int OFF>
+NQ_DEV f32x4 lds_rd(unsigned a) { return *(NQ_AS3 const f32x4*)(a + OFF); }
+NQ_DEV void lds_wait(f32x4 (&)[12]) {}
+NQ_DEV unsigned cvt_pk_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// (v0, v1) -> XT packed bf16 pairs, each term rounded to nearest: v = t[0] + t[1] + t[2] exactly
+NQ_DEV void split2t(float v0, float v1, unsigned (&t)[XT]) {
+    f32x2_t r = {v0, v1};
+#pragma unroll
+    for (int q = 0; q < XT; ++q) {
+        t[q] = cvt_pk_bf16(r[0], r[1]);
+        if (q + 1 < XT) r = r - f32x2_t{__uint_as_float(t[q] << 16), __uint_as_float(t[q] & 0xffff0000u)};
+    }
+}
+// the 8 k-slots of one K-step (two D tiles of 4 registers) -> XT operand fragments
+NQ_DEV void split8(const f32x4& lo, const f32x4& hi, f32x4 (&b)[XT], float scale = 1.0f) {
+    unsigned t0[XT], t1[XT], t2[XT], t3[XT];
+    split2t(lo[0] * scale, lo[1] * scale, t0);
+    split2t(lo[2] * scale, lo[3] * scale, t1);
+    split2t(hi[0] * scale, hi[1] * scale, t2);
+    split2t(hi[2] * scale, hi[3] * scale, t3);
+#pragma unroll
+    for (int k = 0; k < XT; ++k) b[k] = f32x4{__uint_as_float(t0[k]), __uint_as_float(t1[k]), __uint_as_float(t2[k]), __uint_as_float(t3[k])};
+}
+
+struct tile16 { f32x4 v[4]; };                         // [mt][r]: feature 16 mt + 4 g + r of token c (or the swapped role, see V)
+
+// a 64-vector (bias, LayerNorm weight) in D layout: v[mt][r] = p[16 mt + 4 g + r]
+NQ_DEV void load_dvec(const float* __restrict__ p, tile16& o, int g) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) o.v[mt] = *(const f32x4*)(p + 16 * mt + 4 * g);
+}
+// reductions over the four lanes (g = 0..3: the four 16-lane rows) that share a token: v_permlane16_swap / v_permlane32_swap
+// exchange rows inside the VALU (a __shfl_xor is a ds_bpermute: an LDS round trip in the middle of every softmax step)
+NQ_DEV float swap16(float v) {                             // rows (0,1) and (2,3) exchanged against a copy: [v0 v0 v2 v2] / [v1 v1 v3 v3]
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0] ^ r[1] ^ __float_as_uint(v));   // the OTHER row's value (one of r[0], r[1] is this lane's own)
+}
+NQ_DEV float swap32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0] ^ r[1] ^ __float_as_uint(v));
+}
+NQ_DEV float sum_g(float v) { v += swap16(v); v += swap32(v); return v; }
+NQ_DEV float max_g(float v) { v = fmaxf(v, swap16(v)); v = fmaxf(v, swap32(v)); return v; }
+
+NQ_DEV void layernorm64(tile16& x, const tile16& gm, const tile16& bt) {
+    float s = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += x.v[mt][r];
+    const float mean = sum_g(s) * (1.0f / 64.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = x.v[mt][r] - mean;
+            q = fmaf(d, d, q);
+        }
+    const float rstd = 1.0f / sqrtf(sum_g(q) * (1.0f / 64.0f) + LN_EPS);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x.v[mt][r] = (x.v[mt][r] - mean) * rstd * gm.v[mt][r] + bt.v[mt][r];
+}
+
+// the six term products (weight term i, activation term j), i + j <= 2, smallest first; consecutive MFMAs go to the four
+// different output tiles.  SWAP: the activation fragment is the A operand (token-major result: rows = tokens, cols = features).
+template <bool SWAP>
+NQ_DEV void mma_terms(const f32x4 (&w)[4][XT], const f32x4 (&x)[XT], tile16& out) {
+#pragma unroll
+    for (int order = XT - 1; order >= 0; --order)
+#pragma unroll
+        for (int i = order; i >= 0; --i)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                out.v[mt] = SWAP ? mfma16(x[order - i], w[mt][i], out.v[mt]) : mfma16(w[mt][i], x[order - i], out.v[mt]);
+}
+
+// the fragments of one 64 x 64 GEMM ([s 2][mt 4][term][1 KB] in LDS) in registers: requested a phase ahead of their MFMAs
+struct gemm_frags { f32x4 w[2][4 * XT]; };            // [s][mt * XT + term]
+template <int I>
+NQ_DEV void frags_rd12(f32x4 (&w)[12], unsigned a) {
+    if constexpr (I < 12) {
+        w[I] = lds_rd<I * T16_FRAG>(a);
+        frags_rd12<I + 1>(w, a);
+    }
+}
+NQ_DEV void frags_load(gemm_frags& f, unsigned wbase, unsigned lane16) {
+    frags_rd12<0>(f.w[0], wbase + lane16);
+    frags_rd12<0>(f.w[1], wbase + 12 * T16_FRAG + lane16);
+}
+// six products of one K-step from 12 fragments [mt * XT + term] (see mma_terms)
+template <bool SWAP>
+NQ_DEV void mma_terms12(const f32x4 (&w)[12], const f32x4 (&x)[XT], tile16& out) {
+#pragma unroll
+    for (int order = XT - 1; order >= 0; --order)
+#pragma unroll
+        for (int i = order; i >= 0; --i)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                out.v[mt] = SWAP ? mfma16(x[order - i], w[mt * XT + i], out.v[mt]) : mfma16(w[mt * XT + i], x[order - i], out.v[mt]);
+}
+// out += W in  (waits for the fragment reads of frags_load)
+template <bool SWAP = false>
+NQ_DEV void chain_mma(gemm_frags& f, const tile16& in, tile16& out) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f32x4 b[XT];
+        split8(in.v[2 * s], in.v[2 * s + 1], b);
+        lds_wait(f.w[s]);
+        mma_terms12<SWAP>(f.w[s], b, out);
+    }
+}
+
+// ---- global -> LDS without registers: global_load_lds_dwordx4 writes the wave's 64 x 16 bytes to LDS base (M0) + lane * 16, i.e.
+// one 1 KB fragment per instruction.  Fragment f of a block is taken by wave f & 3; `rot` rotates the order per workgroup so that
+// the 256 workgroups, which all want the SAME weight fragments at the same moment, do not walk the L2 channels in step.
+// Completion is the issuing wave's vmcnt (in order) plus a workgroup barrier for the other waves' reads.
+#define NQ_AS1 __attribute__((address_space(1)))
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"           /* "m0 is a reserved register": named so that the compiler reloads it after us */
+template <bool ASM>
+NQ_DEV void dma16(const u16* src_lane, unsigned lds_uniform) {
+    if constexpr (ASM)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds_uniform) : "memory", "m0");
+    else
+        __builtin_amdgcn_global_load_lds((const NQ_AS1 void*)src_lane, (NQ_AS3 void*)lds_uniform, 16, 0, 0);
+}
+#pragma clang diagnostic pop
+template <int N, bool ASM = false>                          // N fragments per wave, 4 N per block
+NQ_DEV void dma_frags(const u16* __restrict__ src, unsigned dst, int wave, int lane, int rot) {
+    int ii = rot % N;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int f = 4 * ii + wave;
+        dma16<ASM>(src + (size_t)f * 512 + lane * 8, __builtin_amdgcn_readfirstlane(dst + f * T16_FRAG));
+        ii = ii + 1 == N ? 0 : ii + 1;
+    }
+}
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define FENCE() asm volatile("" ::: "memory")
+
+// ---- Q / K / V of the NEXT layer from this tile's activations, stored as the consumer's fragments --------------------------------
+// lds_q / lds_k / lds_v: the three GEMMs' weight fragments in LDS; lw: the layer's fp32 parameter block (biases)
+NQ_DEV void qkv_store(unsigned lds_q, unsigned lds_k, unsigned lds_v, const float* __restrict__ lw, const tile16& x,
+                      u16* __restrict__ qbuf, u16* __restrict__ kvbuf, int tile, int lane, int c, int g, unsigned lane16) {
+    gemm_frags fa, fb;
+    frags_load(fa, lds_q, lane16);
+    frags_load(fb, lds_k, lane16);
+    tile16 q, k, v;
+    load_dvec(lw + TDL_QKV_B, q, g);
+    load_dvec(lw + TDL_QKV_B + 64, k, g);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {                       // V token-major: the bias is per column = per lane
+        const float bv = lw[TDL_QKV_B + 128 + 16 * nt + c];
+        v.v[nt] = f32x4{bv, bv, bv, bv};
+    }
+    chain_mma(fa, x, q);
+    frags_load(fa, lds_v, lane16);
+    chain_mma(fb, x, k);
+    u16* qd = qbuf + (size_t)tile * T16_QTILE_U16 + lane * 8;
+    u16* kd = kvbuf + (size_t)(tile >> 1) * T16_KVBLK_U16 + (tile & 1) * (2 * XT * 512) + lane * 8;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f32x4 fq[XT];
+        split8(q.v[2 * s], q.v[2 * s + 1], fq, 0.125f);           // (a power of two: the split of q / 8 is the split of q)
+#pragma unroll
+        for (int t = 0; t < XT; ++t) *(f32x4*)(qd + (s * XT + t) * 512) = fq[t];
+    }
+    // V token-major: D[row = token 4 g + r][col = feature 16 nt + c]
+    chain_mma<true>(fa, x, v);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f32x4 fk[XT];
+        split8(k.v[2 * s], k.v[2 * s + 1], fk);
+#pragma unroll
+        for (int t = 0; t < XT; ++t) *(f32x4*)(kd + (s * XT + t) * 512) = fk[t];
+    }
+    u16* vd = kvbuf + (size_t)(tile >> 1) * T16_KVBLK_U16 + 12 * 512 + lane * 8 + 4 * (tile & 1);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        unsigned a[XT], b[XT];
+        split2t(v.v[nt][0], v.v[nt][1], a);
+        split2t(v.v[nt][2], v.v[nt][3], b);
+#pragma unroll
+        for (int t = 0; t < XT; ++t) *(u32x2*)(vd + (nt * XT + t) * 512) = u32x2{a[t], b[t]};
+    }
+}
+
+// LDS plan of the projection kernel: the 384 -> 64 fragments in three 48 KB chunks (4 K-steps each); the layer-0 Q / K / V
+// fragments overwrite chunks 0 and 1 once those are consumed
+#define PJ_CHUNK (4 * 4 * XT * T16_FRAG)               /* 48 KB */
+#define PJ_LDS (3 * PJ_CHUNK)                          /* 144 KB */
+
+}  // namespace
+
+// phase stamps of the two kernels (tools/td16_clock.py; empty macros unless the unit is built with -DNQ_EXPERIMENTAL)
+NQ_CLK_EXPORT(g_td16_proj_clk, nisqa_debug_td16_proj_clock)
+NQ_CLK_EXPORT(g_td16_layer_clk, nisqa_debug_td16_layer_clock)
+NQ_CLK_EXPORT(g_td16_loop_clk, nisqa_debug_td16_loop_clock)       // sum clock inside the attention loop
+
+// Linear 384 -> 64 + LayerNorm + layer-0 Q / K / V
+__global__ __launch_bounds__(256, 1) void td16_proj_kernel(const float* __restrict__ feat, const int32_t* __restrict__ tok_off,
+                                                           const int32_t* __restrict__ n_wins, int n_clips, int np,
+                                                           const float* __restrict__ tw, const u16* __restrict__ twx,
+                                                           float* __restrict__ x_out, u16* __restrict__ qbuf, u16* __restrict__ kvbuf) {
+    NQ_STAMP_BEGIN();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane16 = lane * 16;
+    const int wg = xcd_tile(blockIdx.x, gridDim.x), rot = blockIdx.x;
+    const int tok0 = wg * 64;
+    const int tile = wg * 4 + wave, tok = tile * 16 + c;
+    // Everything the workgroup needs is requested up front, in the order of its use: this token's feature row (K-step s needs floats
+    // 32 s + 8 g .. + 7; rows of padding tokens exist, they are zeroed behind the load) and the three weight chunks (LDS-DMA).  The
+    // order is pinned (vmcnt counts in order): a chunk's wait below names exactly the requests issued behind it.
+    const f32x4* frow = (const f32x4*)(feat + (size_t)tok * 384) + 2 * g;
+    tile16 acc, g0, b0;
+    load_dvec(tw + TD_PROJ_B, acc, g);
+    load_dvec(tw + TD_LN0_G, g0, g);
+    load_dvec(tw + TD_LN0_B, b0, g);
+    FENCE();
+    f32x4 fr[12][2];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+#pragma unroll
+        for (int s = 4 * ch; s < 4 * ch + 4; ++s) { fr[s][0] = frow[8 * s]; fr[s][1] = frow[8 * s + 1]; }
+        FENCE();
+        dma_frags<12>(twx + TDX_PROJ + (size_t)ch * (PJ_CHUNK / 2), ch * PJ_CHUNK, wave, lane, rot);
+        FENCE();
+    }
+    // the clip of this workgroup by scalar loads (their counter is not the vector memory's: nothing above is waited for)
+    const int b = find_segment(tok_off, n_clips, tok0);
+    const int n = n_wins[b], c0 = tok_off[b];
+    const bool active = ((tok0 - c0) >> 4) + wave < 2 * ((n + 31) >> 5);   // this tile lies in a 32-key block some query reads
+    const bool valid = tok - c0 < n;                      // padding tokens enter as zero rows: everything behind stays finite
+    NQ_STAMP(0);                                          // requests issued, clip lookup
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        if (ch == 0) VMCNT(40); else if (ch == 1) VMCNT(20); else VMCNT(0);    // chunk ch landed (behind it: the 20 requests of every later chunk)
+        __syncthreads();                                 // ... in every wave; ch = 2: chunks 0 / 1 are consumed
+        NQ_STAMP(1 + 2 * ch);
+        if (ch == 2) dma_frags<18>(twx + TDX_LAYER0 + TDXL_QKV, 0, wave, lane, rot);      // layer-0 Q, K, V fragments over chunks 0 / 1
+        if (active) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int s = 4 * ch + s4;
+                f32x4 w[12];
+                frags_rd12<0>(w, ch * PJ_CHUNK + s4 * 12 * T16_FRAG + lane16);
+                f32x4 bt[XT];
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                split8(valid ? fr[s][0] : z4, valid ? fr[s][1] : z4, bt);
+                lds_wait(w);
+                mma_terms12<false>(w, bt, acc);
+            }
+        }
+        NQ_STAMP(2 + 2 * ch);
+    }
+    if (active) {
+        layernorm64(acc, g0, b0);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *(f32x4*)(x_out + (size_t)tok * 64 + 16 * mt + 4 * g) = acc.v[mt];
+    }
+    VMCNT(0);
+    __syncthreads();
+    NQ_STAMP(7);                                          // LayerNorm, x stored, Q / K / V fragments landed
+    if (active) qkv_store(0, T16_GEMM, 2 * T16_GEMM, tw + TD_LAYER0, acc, qbuf, kvbuf, tile, lane, c, g, lane16);
+    NQ_STAMP(8); NQ_STAMP(9); NQ_STAMP(10); NQ_STAMP(11);
+    NQ_STAMP_END(g_td16_proj_clk, blockIdx.x * 4 + wave);
+}
+
+// LDS plan of the layer kernel: a ring of three K / V blocks (two in flight under the one being multiplied), then the layer's own
+// GEMMs; the next layer's Q / K / V fragments overwrite the ring behind the loop
+#define LY_RING 0u
+#define LY_WOUT (LY_RING + 3 * T16_KVBLK)               /* out-projection, feed-forward 1, feed-forward 2 */
+#define LY_WFF1 (LY_WOUT + T16_GEMM)
+#define LY_WFF2 (LY_WFF1 + T16_GEMM)
+#define LY_LDS (LY_WFF2 + T16_GEMM)                     /* 144 KB */
+
+// one encoder layer for 64 tokens: attention over the clip's K / V blocks (LDS ring filled by LDS-DMA), out-projection, residual +
+// LayerNorm, feed-forward, residual + LayerNorm, and the next layer's Q / K / V
+__global__ __launch_bounds__(256, 1) void td16_layer_kernel(const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
+                                                            int n_clips, int np, const float* __restrict__ lw,
+                                                            const u16* __restrict__ lwx, const float* __restrict__ lw_next,
+                                                            const u16* __restrict__ lwx_next, const float* x_in,
+                                                            const u16* __restrict__ qbuf, const u16* __restrict__ kvbuf,
+                                                            float* x_out, u16* __restrict__ qbuf_next, u16* __restrict__ kvbuf_next) {
+    NQ_STAMP_BEGIN();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lane16 = lane * 16;
+    const int wg = xcd_tile(blockIdx.x, gridDim.x), rot = blockIdx.x;
+    const int tok0 = wg * 64;
+    const int tile = wg * 4 + wave, tok = tile * 16 + c;
+    // this tile's Q fragments and residual rows do not depend on the clip: requested before the lookup
+    f32x4 q[2][XT];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < XT; ++t) q[s][t] = *(const f32x4*)(qbuf + (size_t)tile * T16_QTILE_U16 + (s * XT + t) * 512 + lane * 8);
+    tile16 xr;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) xr.v[mt] = *(const f32x4*)(x_in + (size_t)tok * 64 + 16 * mt + 4 * g);
+    FENCE();
+    const int b = find_segment(tok_off, n_clips, tok0);   // scalar loads
+    const int n = n_wins[b], c0 = tok_off[b];
+    const int nkb = (n + 31) >> 5;                        // 32-key blocks of this clip
+    const bool active = ((tok0 - c0) >> 4) + wave < 2 * nkb;
+    const u16* kvg = kvbuf + (size_t)(c0 >> 5) * T16_KVBLK_U16;
+    dma_frags<6, true>(kvg, LY_RING, wave, lane, 0);
+    if (nkb > 1) { dma_frags<6, true>(kvg + T16_KVBLK_U16, LY_RING + T16_KVBLK, wave, lane, 0); VMCNT(6); } else { VMCNT(0); }
+    __syncthreads();
+    // q and xr are older than block 0: they have landed.  The compiler does not know (it cannot see the asm requests) and would wait
+    // for them at their first use -- with a count that ignores the requests of iteration 0; here its wait costs block 1 at most.
+    asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(xr.v[0]), "+v"(xr.v[1]),
+                 "+v"(xr.v[2]), "+v"(xr.v[3]));
+    NQ_STAMP(0);                                          // clip lookup, first K / V block landed
+
+    tile16 o;
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) o.v[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+    const float L2E = 1.44269504088896341f;
+    int wb = 0;                                            // weight batches (out, ff1, ff2) travel under the first key blocks
+    unsigned slot = LY_RING, slot2 = LY_RING + 2 * T16_KVBLK;      // block kb, block kb + 2
+    NQ_SUM_BEGIN();
+    for (int kb = 0; kb < nkb; ++kb) {
+        int issued = 0;
+        if (kb + 2 < nkb) { dma_frags<6, true>(kvg + (size_t)(kb + 2) * T16_KVBLK_U16, slot2, wave, lane, 0); issued += 6; }
+        if (wb < 3) { dma_frags<6, true>(lwx + TDXL_OUT + (size_t)wb * (T16_GEMM / 2), LY_WOUT + wb * T16_GEMM, wave, lane, rot); issued += 6; ++wb; }
+        NQ_SUM(0);                                       // requests of block kb + 2 and a weight batch
+        if (active) {
+            // S^T = K Q^T for the two 16-key sub-tiles: one accumulator per product ORDER (independent chains), added smallest first
+            f32x4 kf[12], vf[12];                          // K: [(jt * 2 + s) * XT + term], V: [ft * XT + term]
+            frags_rd12<0>(kf, slot + lane16);
+            frags_rd12<0>(vf, slot + 12 * T16_FRAG + lane16);
+            lds_wait(kf);
+            f32x4 sa[2][XT];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int k = 0; k < XT; ++k) sa[jt][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int order = XT - 1; order >= 0; --order)
+#pragma unroll
+                    for (int i = order; i >= 0; --i)
+#pragma unroll
+                        for (int jt = 0; jt < 2; ++jt) sa[jt][order] = mfma16(kf[(jt * 2 + s) * XT + i], q[s][order - i], sa[jt][order]);
+            NQ_SUM(1);                                   // K / V fragment reads, S MFMAs issued
+            f32x4 st[2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[jt][r] = (sa[jt][2][r] + sa[jt][1][r]) + sa[jt][0][r];
+            NQ_SUM(2);                                   // S available
+            // online softmax over the keys (rows: key 32 kb + 16 jt + 4 g + r; a query's keys sit in the four lanes g = 0..3)
+            float mx = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (32 * kb + 16 * jt + 4 * g + r >= n) st[jt][r] = -INFINITY;
+                    mx = fmaxf(mx, st[jt][r]);
+                }
+            mx = max_g(mx);
+            const float m_new = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m - m_new) * L2E);
+            float rs = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[jt][r] = __builtin_amdgcn_exp2f((st[jt][r] - m_new) * L2E);
+                    rs += st[jt][r];
+                }
+            l = l * alpha + rs;                          // (per-lane partial sums: alpha is the same in the four lanes of a query)
+            m = m_new;
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) o.v[ft] *= alpha;
+            f32x4 p[XT];
+            split8(st[0], st[1], p);
+            NQ_SUM(3);                                   // softmax, rescale, split
+            lds_wait(vf);
+            mma_terms12<false>(vf, p, o);
+            NQ_SUM(4);                                   // P V MFMAs issued
+        }
+        // block kb + 1 (requested one iteration ago) has landed once only this iteration's requests are outstanding
+        if (kb + 1 < nkb) { if (issued == 12) VMCNT(12); else if (issued == 6) VMCNT(6); else VMCNT(0); }
+        NQ_SUM(5);                                       // block kb + 1 landed
+        __syncthreads();                                 // ... in every wave; and every wave is done with block kb's slot
+        NQ_SUM(6);
+        NQ_SUM_COUNT(8, 1);
+        slot2 = slot;
+        slot = slot + T16_KVBLK == LY_RING + 3 * T16_KVBLK ? LY_RING : slot + T16_KVBLK;
+    }
+    NQ_SUM_END(g_td16_loop_clk, blockIdx.x * 4 + wave, lane == 0);
+    NQ_STAMP(1);                                          // attention over the clip's key blocks
+    for (; wb < 3; ++wb) dma_frags<6, true>(lwx + TDXL_OUT + (size_t)wb * (T16_GEMM / 2), LY_WOUT + wb * T16_GEMM, wave, lane, rot);
+    FENCE();
+    // the next layer's Q / K / V fragments go where the K / V blocks were (every wave is behind the loop's last barrier)
+    if (lw_next) { dma_frags<18, true>(lwx_next + TDXL_QKV, LY_RING, wave, lane, rot); VMCNT(18); } else { VMCNT(0); }
+    __syncthreads();                                     // out / ff1 / ff2 fragments landed in every wave
+    NQ_STAMP(2);
+    if (active) {
+        gemm_frags fa, fb;
+        frags_load(fa, LY_WOUT, lane16);
+        tile16 y, gm, bt, h1, h2;
+        load_dvec(lw + TDL_OUT_B, y, g);
+        load_dvec(lw + TDL_LN1_G, gm, g);
+        load_dvec(lw + TDL_LN1_B, bt, g);
+        load_dvec(lw + TDL_FF1_B, h1, g);
+        const float inv_l = 1.0f / sum_g(l);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) o.v[ft] *= inv_l;
+        frags_load(fb, LY_WFF1, lane16);
+        chain_mma(fa, o, y);
+        frags_load(fa, LY_WFF2, lane16);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) y.v[mt] += xr.v[mt];
+        layernorm64(y, gm, bt);
+        NQ_STAMP(3);                                      // out-projection, residual, LayerNorm
+        load_dvec(lw + TDL_FF2_B, h2, g);
+        load_dvec(lw + TDL_LN2_G, gm, g);
+        load_dvec(lw + TDL_LN2_B, bt, g);
+        chain_mma(fb, y, h1);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1.v[mt][r] = fmaxf(h1.v[mt][r], 0.f);
+        chain_mma(fa, h1, h2);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) y.v[mt] += h2.v[mt];
+        layernorm64(y, gm, bt);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *(f32x4*)(x_out + (size_t)tok * 64 + 16 * mt + 4 * g) = y.v[mt];
+        o = y;
+    } else {
+        NQ_STAMP(3);
+    }
+    NQ_STAMP(4);                                          // feed-forward, residual, LayerNorm, x stored
+    if (lw_next) {
+        VMCNT(0);
+        __syncthreads();
+        NQ_STAMP(5);                                      // next layer's Q / K / V fragments landed
+        if (active) qkv_store(LY_RING, LY_RING + T16_GEMM, LY_RING + 2 * T16_GEMM, lw_next, o, qbuf_next, kvbuf_next, tile, lane, c, g, lane16);
+    } else {
+        NQ_STAMP(5);
+    }
+    NQ_STAMP(6); NQ_STAMP(7); NQ_STAMP(8); NQ_STAMP(9); NQ_STAMP(10); NQ_STAMP(11);
+    NQ_STAMP_END(g_td16_layer_clk, (lw_next ? 0 : 16384) + blockIdx.x * 4 + wave);
+}
+
+// ws: 9 * np * 64 floats = two layer buffers of np * 576 bf16 each (Q: np * 192, K / V blocks: np * 384)
+extern "C" int nisqa_td_selfatt_bf16x6(const float* feat, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                                       int32_t total_tok_padded, int32_t n_layers, const float* td_w, const uint16_t* td_wx,
+                                       float* ws, float* x_out, void* stream) {
+    if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 63) || n_layers < 1 || !td_wx) return NISQA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int np = total_tok_padded;
+    u16* lbuf[2] = {(u16*)ws, (u16*)ws + (size_t)np * 576};
+    const int wgs = np / 64;
+    static std::atomic<bool> ok_p[64], ok_l[64];
+    if (nq_lds_opt_in((const void*)td16_proj_kernel, PJ_LDS, ok_p) || nq_lds_opt_in((const void*)td16_layer_kernel, LY_LDS, ok_l))
+        return NISQA_ERR_LAUNCH;
+    NQ_LAUNCH_BEGIN();
+    hipLaunchKernelGGL(td16_proj_kernel, dim3(wgs), dim3(256), PJ_LDS, st, feat, tok_off, n_wins, n_clips, np, td_w, td_wx, x_out,
+                       lbuf[0], lbuf[0] + (size_t)np * 192);
+    for (int l = 0; l < n_layers; ++l) {
+        const float* lw = td_w + TD_LAYER0 + (size_t)l * TDL_FLOATS;
+        const uint16_t* lwx = td_wx + TDX_LAYER0 + (size_t)l * TDXL_U16S;
+        const bool more = l + 1 < n_layers;
+        u16 *cur = lbuf[l & 1], *nxt = lbuf[(l & 1) ^ 1];
+        hipLaunchKernelGGL(td16_layer_kernel, dim3(wgs), dim3(256), LY_LDS, st, tok_off, n_wins, n_clips, np, lw, lwx,
+                           more ? lw + TDL_FLOATS : (const float*)nullptr, more ? lwx + TDXL_U16S : (const uint16_t*)nullptr,
+                           (const float*)x_out, (const u16*)cur, (const u16*)(cur + (size_t)np * 192), x_out, nxt,
+                           nxt + (size_t)np * 192);
+    }
+    return NQ_LAUNCH_STATUS();
+}

@@ -16,7 +16,7 @@ from . import weights as _w
 from .melbank import KAISER_BEST_PRECISION, MelTables, kaiser_best_table, resampled_lengths
 
 SEG_LEN = 15
-TOK_PAD = 32
+TOK_PAD = 64          # tokens of a clip are padded to whole 64-token workgroups (csrc/td16_bf16x6.hip); the other kernels need 32
 # The precision every GEMM of the path runs in unless the caller (or NISQA_HIP_PRECISION) says otherwise.  'bf16x6' carries the
 # reference's fp32 operands EXACTLY (three bf16 terms, six MFMA products per term pair, fp32 accumulation): reference-grade
 # arithmetic, as far from a float64 evaluation as the exact-fp32 kernels and the reference's own CPU float32

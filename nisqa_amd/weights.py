@@ -414,25 +414,47 @@ def linear_a_fragments_bf16(w, chain, terms=2):
     return np.stack(bf16_split(vals, terms), 2).reshape(-1)
 
 
+def linear_a_fragments_bf16_t16(w, chain, terms=3):
+    """w [rows][K] -> uint16 [rows/64][K/32][4][terms][64][8]: 16 x 32 fragments of v_mfma_f32_16x16x32_bf16 for the 16-token tiles
+    of csrc/td16_bf16x6.hip, one 64-row GEMM block after the other.  Lane l = (i = l & 15, g = l >> 4) of fragment (s, mt) holds row
+    64 blk + 16 mt + i and, in k-slot e, column 32 s + 8 g + e (natural: the other operand is read from memory) or
+    16 (2 s + (e >> 2)) + 4 g + (e & 3) (chain: the other operand is the previous GEMM's D tiles, feature 16 mt + 4 g + r in
+    register r of tile mt)."""
+    w = np.asarray(w, np.float32)
+    rows, K = w.shape
+    blk = np.arange(rows // 64)[:, None, None, None, None]
+    s = np.arange(K // 32)[None, :, None, None, None]
+    mt = np.arange(4)[None, None, :, None, None]
+    lane = _LANE[None, None, None, :, None]
+    e = np.arange(8)[None, None, None, None, :]
+    g = lane >> 4
+    col = 16 * (2 * s + (e >> 2)) + 4 * g + (e & 3) if chain else 32 * s + 8 * g + e
+    vals = w[64 * blk + 16 * mt + (lane & 15), col]
+    return np.stack(bf16_split(vals, terms), 3).reshape(-1)
+
+
 def pack_self_att_bf16(sd, n_layers, pfx='time_dependency.model.', terms=2):
-    """terms = 2: hi / lo fragments of td_bf16.hip (TDB_* offsets); terms = 3: hi / mid / lo of td_bf16x6.hip (TDX_*)"""
+    """terms = 2: hi / lo fragments of td_bf16.hip (32 x 16 fragments, TDB_* offsets); terms = 3: hi / mid / lo fragments of
+    td16_bf16x6.hip (16 x 32 fragments for its 16-token tiles; the TDX_* offsets: the blocks hold the same number of elements)"""
     if terms == 2:
         PROJ, LAYER0, QKV, OUT, FF1, FF2, LSZ = TDB_PROJ, TDB_LAYER0, TDBL_QKV, TDBL_OUT, TDBL_FF1, TDBL_FF2, TDBL_U16S
+        frag = lambda w, chain: linear_a_fragments_bf16(w, chain=chain, terms=2)
     else:
         PROJ, LAYER0, QKV, OUT, FF1, FF2, LSZ = TDX_PROJ, TDX_LAYER0, TDXL_QKV, TDXL_OUT, TDXL_FF1, TDXL_FF2, TDXL_U16S
+        frag = lambda w, chain: linear_a_fragments_bf16_t16(w, chain=chain, terms=3)
     blob = np.zeros(LAYER0 + n_layers * LSZ, np.uint16)
 
     def put(off, fr):
         blob[off:off + fr.size] = fr
 
-    put(PROJ, linear_a_fragments_bf16(_np(sd, pfx + 'linear.weight'), chain=False, terms=terms))
+    put(PROJ, frag(_np(sd, pfx + 'linear.weight'), False))
     for l in range(n_layers):
         p = pfx + 'layers.%d.' % l
         base = LAYER0 + l * LSZ
-        put(base + QKV, linear_a_fragments_bf16(_np(sd, p + 'self_attn.in_proj_weight'), chain=True, terms=terms))
-        put(base + OUT, linear_a_fragments_bf16(_np(sd, p + 'self_attn.out_proj.weight'), chain=True, terms=terms))
-        put(base + FF1, linear_a_fragments_bf16(_np(sd, p + 'linear1.weight'), chain=True, terms=terms))
-        put(base + FF2, linear_a_fragments_bf16(_np(sd, p + 'linear2.weight'), chain=True, terms=terms))
+        put(base + QKV, frag(_np(sd, p + 'self_attn.in_proj_weight'), True))
+        put(base + OUT, frag(_np(sd, p + 'self_attn.out_proj.weight'), True))
+        put(base + FF1, frag(_np(sd, p + 'linear1.weight'), True))
+        put(base + FF2, frag(_np(sd, p + 'linear2.weight'), True))
     return blob
 
 

@@ -140,6 +140,17 @@ def test_three_term_linear_fragments_hold_the_weights_exactly():
         for s_, mt, lane, e in [(0, 0, 0, 0), (3, 5, 63, 7), (2, 1, 37, 5)]:
             col = 16 * s_ + ((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) if chain else 8 * (lane >> 5) + e)
             assert total[s_, mt, lane, e] == np.float64(w[(lane & 31) + 32 * mt, col])
+    # td16_bf16x6.hip: 16 x 32 fragments [rows/64][K/32][4][3][64][8] for 16-token tiles (lane = (i = l & 15, g = l >> 4))
+    for chain in (False, True):
+        fr = W.linear_a_fragments_bf16_t16(w, chain=chain).reshape(3, 2, 4, 3, 64, 8)
+        total = val(fr[:, :, :, 0]) + val(fr[:, :, :, 1]) + val(fr[:, :, :, 2])
+        for blk, s_, mt, lane, e in [(0, 0, 0, 0, 0), (2, 1, 3, 63, 7), (1, 0, 2, 37, 5), (1, 1, 1, 16, 4)]:
+            g = lane >> 4
+            col = 16 * (2 * s_ + (e >> 2)) + 4 * g + (e & 3) if chain else 32 * s_ + 8 * g + e
+            assert total[blk, s_, mt, lane, e] == np.float64(w[64 * blk + 16 * mt + (lane & 15), col])
+        cols = {(int(s_), int(16 * (2 * s_ + (e >> 2)) + 4 * g + (e & 3)) if chain else int(32 * s_ + 8 * g + e))
+                for s_ in range(2) for g in range(4) for e in range(8)}
+        assert len(cols) == 64 and {c_ for _, c_ in cols} == set(range(64))                # every column exactly once per row
     sd = synth.random_state_dict(7, 'NISQA_DIM')
     heads = ['pool_layers.%d.model.' % h for h in range(5)]
     assert W.pack_self_att_bf16(sd, 2, terms=3).size == W.TDX_LAYER0 + 2 * W.TDXL_U16S
@@ -214,7 +225,7 @@ def test_batch_plan_counts_and_errors():
     p = BatchPlan([480000, 14 * 480, 144000], 480, 4, 1300)
     assert list(p.T) == [1001, 15, 301]
     assert list(p.n_wins) == [247, 1, 72] == [onet.n_wins_of(int(t)) for t in p.T]
-    assert list(p.tok_off) == [0, 256, 288, 384] and p.total_tok == 384
+    assert list(p.tok_off) == [0, 256, 320, 448] and p.total_tok == 448              # whole 64-token workgroups per clip
     assert list(p.frame_off) == [0, 1001, 1016, 1317]
     assert len(p.token_index()) == 247 + 1 + 72
     with pytest.raises(ValueError, match='Sample too short'):

@@ -9,7 +9,7 @@ UNITS=" $* "
 cd "$(dirname "$0")/../nisqa_amd/csrc"
 mkdir -p ../../ab_libs /tmp/nq_ab_$NAME
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-strict-aliasing -I../../include"
-for s in api mel cnn cnn_bf16 cnn_bf16x6 cnn_std cnn_std_bf16 lstm td td_bf16 td_bf16x6 train train_conv train_td probe resample; do
+for f in *.hip; do s=${f%.hip}
   X=""; [ $s = train_td ] && X="-fno-slp-vectorize"
   if [[ "$UNITS" == *" $s "* ]]; then /opt/rocm/bin/hipcc $F $X $FLAGS -c $s.hip -o /tmp/nq_ab_$NAME/$s.o; else cp $s.o /tmp/nq_ab_$NAME/$s.o; fi
 done

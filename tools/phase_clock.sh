@@ -7,7 +7,7 @@ NAME=${1:-clock}; FLAGS=$2
 cd "$(dirname "$0")/../nisqa_amd/csrc"
 mkdir -p ../../ab_libs /tmp/nq_$NAME
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-strict-aliasing -I../../include"
-for s in api mel cnn cnn_bf16 cnn_bf16x6 cnn_std cnn_std_bf16 lstm td td_bf16 td_bf16x6 train train_conv train_td probe resample; do
+for f in *.hip; do s=${f%.hip}
   if [ $s = cnn_bf16 ]; then /opt/rocm/bin/hipcc $F -DNQ_EXPERIMENTAL $FLAGS -c $s.hip -o /tmp/nq_$NAME/$s.o; else cp $s.o /tmp/nq_$NAME/$s.o; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab_libs/$NAME.so /tmp/nq_$NAME/*.o
