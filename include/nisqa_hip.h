@@ -205,6 +205,15 @@ int nisqa_pool_att_bf16x6(const float* x, const int32_t* tok_off, const int32_t*
 int nisqa_pool_score_bf16x6(const float* x, const int32_t* tok_off, const int32_t* n_wins,
                             int32_t n_clips, int32_t total_tok_padded, int32_t n_heads, const float* pool_w,
                             const uint16_t* pool_wx, float* ws, void* stream);
+/* Self-attention AND attention pooling (SelfAttention.forward + 5 x PoolAttFF.forward, NISQA_lib.py:988-996, 1025-1040, 1171-1183)
+ * in n_layers + 1 launches: the last encoder layer's launch scores its own tokens for every pooling head and the clip's last
+ * workgroup to arrive does the softmax over the clip's tokens.  pool_wx: pack_pool_att_bf16(terms=3) followed by
+ * pack_pool_att_t16 (nisqa_amd/weights.py); ws as for nisqa_td_selfatt_bf16x6; ws_pool: 16 * total_tok_padded floats +
+ * n_clips int32; total_tok_padded a multiple of 64 with every tok_off[b] a multiple of 64. */
+int nisqa_td_pool_bf16x6(const float* feat, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                         int32_t total_tok_padded, int32_t n_layers, const float* td_w, const uint16_t* td_wx,
+                         int32_t n_heads, const uint16_t* pool_wx, float* ws, float* x_out, float* ws_pool, float* out,
+                         void* stream);
 /* second pass of the pooling (masked softmax over tokens + weighted sum) on scores left in ws */
 int nisqa_pool_final(const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
                      int32_t total_tok_padded, int32_t n_heads, const float* ws, float* out, void* stream);

@@ -22,7 +22,7 @@ static ws_plan plan_ws(int32_t n_clips, int32_t total_frames, int32_t np) {
     p.feat = o;   o += align256((size_t)np * NISQA_FEAT * 4);
     p.td = o;     o += align256((size_t)np * 64 * 9 * 4);          // (nine bf16 planes x two layer buffers in the three-term mode)
     p.x = o;      o += align256((size_t)np * 64 * 4);
-    p.pool = o;   o += align256((size_t)np * 8 * 2 * 4);
+    p.pool = o;   o += align256((size_t)np * 8 * 2 * 4 + (size_t)n_clips * 4);     // scores, values, per-clip arrival counters
     p.total = o;
     return p;
 }
@@ -118,6 +118,14 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
     NQ_STAGE(3);
     const bool bf = model->cnn_mode == 1 && model->td_wb && model->pool_wb;
     const bool x6 = model->cnn_mode >= 2 && model->td_wb && model->pool_wb;      // three-term fragments in td_wb / pool_wb
+    if (x6) {                                            // self-attention and pooling in n_layers + 1 launches
+        rc = nisqa_td_pool_bf16x6(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w, model->td_wb,
+                                  model->n_heads, model->pool_wb, td, x, pool, out, stream);
+        if (rc) return rc;
+        NQ_STAGE(4);
+        NQ_STAGE(5);
+        return NISQA_OK;
+    }
     rc = bf ? nisqa_td_selfatt_bf16(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w,
                                     model->td_wb, td, x, stream)
          : x6 ? nisqa_td_selfatt_bf16x6(feat, tok_off, n_wins, n_clips, total_tok_padded, model->n_layers, model->td_w,

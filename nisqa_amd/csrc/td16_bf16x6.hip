@@ -199,6 +199,13 @@ NQ_DEV void dma_frags(const u16* __restrict__ src, unsigned dst, int wave, int l
         ii = ii + 1 == N ? 0 : ii + 1;
     }
 }
+// n = 1..3 fragment blocks of 24 KB (the layer kernel's asm requests); returns the requests per wave
+NQ_DEV int dma_blocks(const u16* __restrict__ src, unsigned dst, int n, int wave, int lane, int rot) {
+    if (n >= 3) dma_frags<18, true>(src, dst, wave, lane, rot);
+    else if (n == 2) dma_frags<12, true>(src, dst, wave, lane, rot);
+    else if (n == 1) dma_frags<6, true>(src, dst, wave, lane, rot);
+    return n >= 3 ? 18 : 6 * n;
+}
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define FENCE() asm volatile("" ::: "memory")
 
@@ -265,7 +272,8 @@ NQ_CLK_EXPORT(g_td16_loop_clk, nisqa_debug_td16_loop_clock)       // sum clock i
 __global__ __launch_bounds__(256, 1) void td16_proj_kernel(const float* __restrict__ feat, const int32_t* __restrict__ tok_off,
                                                            const int32_t* __restrict__ n_wins, int n_clips, int np,
                                                            const float* __restrict__ tw, const u16* __restrict__ twx,
-                                                           float* __restrict__ x_out, u16* __restrict__ qbuf, u16* __restrict__ kvbuf) {
+                                                           float* __restrict__ x_out, u16* __restrict__ qbuf, u16* __restrict__ kvbuf,
+                                                           int32_t* __restrict__ arrivals) {
     NQ_STAMP_BEGIN();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -296,6 +304,7 @@ __global__ __launch_bounds__(256, 1) void td16_proj_kernel(const float* __restri
     const int n = n_wins[b], c0 = tok_off[b];
     const bool active = ((tok0 - c0) >> 4) + wave < 2 * ((n + 31) >> 5);   // this tile lies in a 32-key block some query reads
     const bool valid = tok - c0 < n;                      // padding tokens enter as zero rows: everything behind stays finite
+    if (arrivals && tok0 == c0 && threadIdx.x == 0) arrivals[b] = 0;      // the pooling tail of the last layer counts the clip's workgroups
     NQ_STAMP(0);                                          // requests issued, clip lookup
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
@@ -338,15 +347,29 @@ __global__ __launch_bounds__(256, 1) void td16_proj_kernel(const float* __restri
 #define LY_WFF1 (LY_WOUT + T16_GEMM)
 #define LY_WFF2 (LY_WFF1 + T16_GEMM)
 #define LY_LDS (LY_WFF2 + T16_GEMM)                     /* 144 KB */
+// Pooling tail of the LAST layer (5 x PoolAttFF, NISQA_lib.py:1171-1183): a head's 64 -> 128 linear is two 64-row blocks of the same
+// fragment form; blocks travel three at a time, alternately into the ring and into the layer's own weight area (both free by
+// then); the fp32 vectors of every block (b1 | w2 | w3 | b2, b3: 1 KB) sit behind them
+#define PL16_PAR LY_LDS
+#define PL16_BLK_U16 (24 * 512)
+struct pool_args {
+    int n_heads;
+    const u16* wx;                                      // [2 n_heads][24 fragments] then [2 n_heads][256 floats]
+    float* sc;                                          // [np][8] scores, then [np][8] values
+    int32_t* arrivals;                                  // per clip: workgroups done (zeroed by td16_proj_kernel)
+    float* out;                                         // [n_clips][n_heads]
+};
 
 // one encoder layer for 64 tokens: attention over the clip's K / V blocks (LDS ring filled by LDS-DMA), out-projection, residual +
 // LayerNorm, feed-forward, residual + LayerNorm, and the next layer's Q / K / V
+template <bool POOL>
 __global__ __launch_bounds__(256, 1) void td16_layer_kernel(const int32_t* __restrict__ tok_off, const int32_t* __restrict__ n_wins,
                                                             int n_clips, int np, const float* __restrict__ lw,
                                                             const u16* __restrict__ lwx, const float* __restrict__ lw_next,
                                                             const u16* __restrict__ lwx_next, const float* x_in,
                                                             const u16* __restrict__ qbuf, const u16* __restrict__ kvbuf,
-                                                            float* x_out, u16* __restrict__ qbuf_next, u16* __restrict__ kvbuf_next) {
+                                                            float* x_out, u16* __restrict__ qbuf_next, u16* __restrict__ kvbuf_next,
+                                                            pool_args pl) {
     NQ_STAMP_BEGIN();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -459,10 +482,18 @@ __global__ __launch_bounds__(256, 1) void td16_layer_kernel(const int32_t* __res
     }
     NQ_SUM_END(g_td16_loop_clk, blockIdx.x * 4 + wave, lane == 0);
     NQ_STAMP(1);                                          // attention over the clip's key blocks
+    const int nblk = POOL ? 2 * pl.n_heads : 0;
+    if constexpr (POOL) {                                 // the blocks' fp32 vectors: requested first, so that the wait below covers them
+        for (int f = wave; f < nblk; f += 4) dma16<true>(pl.wx + (size_t)nblk * PL16_BLK_U16 + (size_t)f * 512 + lane * 8, PL16_PAR + f * T16_FRAG);
+    }
     for (; wb < 3; ++wb) dma_frags<6, true>(lwx + TDXL_OUT + (size_t)wb * (T16_GEMM / 2), LY_WOUT + wb * T16_GEMM, wave, lane, rot);
     FENCE();
-    // the next layer's Q / K / V fragments go where the K / V blocks were (every wave is behind the loop's last barrier)
-    if (lw_next) { dma_frags<18, true>(lwx_next + TDXL_QKV, LY_RING, wave, lane, rot); VMCNT(18); } else { VMCNT(0); }
+    // the next layer's Q / K / V fragments (last layer: the first three pooling blocks) go where the K / V blocks were (every wave is
+    // behind the loop's last barrier)
+    if (POOL) {
+        const int rq = dma_blocks(pl.wx, LY_RING, nblk, wave, lane, rot);
+        if (rq == 18) VMCNT(18); else if (rq == 12) VMCNT(12); else VMCNT(6);
+    } else if (lw_next) { dma_frags<18, true>(lwx_next + TDXL_QKV, LY_RING, wave, lane, rot); VMCNT(18); } else { VMCNT(0); }
     __syncthreads();                                     // out / ff1 / ff2 fragments landed in every wave
     NQ_STAMP(2);
     if (active) {
@@ -502,7 +533,118 @@ __global__ __launch_bounds__(256, 1) void td16_layer_kernel(const int32_t* __res
         NQ_STAMP(3);
     }
     NQ_STAMP(4);                                          // feed-forward, residual, LayerNorm, x stored
-    if (lw_next) {
+    if constexpr (POOL) {
+        f32x4 xb[2][XT];
+        float vpart = 0.f;                                // linear3 of the head in hand over this lane's 16 features
+        if (active) { split8(o.v[0], o.v[1], xb[0]); split8(o.v[2], o.v[3], xb[1]); }
+        float spart = 0.f;
+        for (int b0 = 0, grp = 0; b0 < nblk; b0 += 3, ++grp) {
+            VMCNT(0);
+            __syncthreads();                             // blocks b0 .. b0 + 2 landed in every wave; every wave is done with the other area
+            const unsigned here = (grp & 1) ? LY_WOUT : LY_RING, there = (grp & 1) ? LY_RING : LY_WOUT;
+            dma_blocks(pl.wx + (size_t)(b0 + 3) * PL16_BLK_U16, there, nblk - b0 - 3, wave, lane, rot);
+            if (active) {
+                gemm_frags f[2];                          // block j + 1's fragments are requested under block j's products
+                frags_load(f[0], here, lane16);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int blk = b0 + j;
+                    if (blk >= nblk) break;
+                    const unsigned par = PL16_PAR + blk * T16_FRAG + 16 * g;
+                    tile16 h, w2;                        // (requested ahead of the prefetch: LDS reads return in order)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) { h.v[mt] = *(NQ_AS3 const f32x4*)(par + 64 * mt); w2.v[mt] = *(NQ_AS3 const f32x4*)(par + 256 + 64 * mt); }
+                    if (j + 1 < 3 && blk + 1 < nblk) frags_load(f[(j + 1) & 1], here + (j + 1) * T16_GEMM, lane16);
+                    mma_terms12<false>(f[j & 1].w[0], xb[0], h);
+                    mma_terms12<false>(f[j & 1].w[1], xb[1], h);
+                    if (!(blk & 1)) {
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            const f32x4 w3 = *(NQ_AS3 const f32x4*)(par + 512 + 64 * mt);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) vpart = fmaf(w3[r], o.v[mt][r], vpart);
+                        }
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) spart = fmaf(w2.v[mt][r], fmaxf(h.v[mt][r], 0.f), spart);
+                    if (blk & 1) {                       // both halves of the head's hidden layer are in
+                        const f32x4 bb = *(NQ_AS3 const f32x4*)(PL16_PAR + blk * T16_FRAG + 768);
+                        const float sv = sum_g(spart) + bb[0], vv = sum_g(vpart) + bb[1];
+                        if (g == 0) {                    // device-scope stores: the reader may sit on another XCD (its own L2)
+                            __hip_atomic_store(pl.sc + (size_t)tok * 8 + (blk >> 1), sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(pl.sc + (size_t)np * 8 + (size_t)tok * 8 + (blk >> 1), vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        spart = 0.f;
+                        vpart = 0.f;
+                    }
+                }
+            }
+        }
+        NQ_STAMP(5);                                      // pooling blocks
+        // The clip's last workgroup to arrive pools over the clip's tokens (softmax of the scores, weighted sum of the values).  No
+        // fences (a device-scope release / acquire writes back and invalidates the XCD's whole L2: measured 26 us per launch):
+        // scores and values travel as device-scope stores and loads, ordered by "stores complete -> count -> loads".
+        VMCNT(0);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nwg = (tok_off[b + 1] - c0) >> 6;
+            *(NQ_AS3 int*)(0u) = __hip_atomic_fetch_add(pl.arrivals + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1;
+        }
+        __syncthreads();
+        if (*(NQ_AS3 const int*)(0u)) {
+            // every wave takes a quarter of the tokens and ALL heads: one round trip to memory for the 2 n_heads loads of a token
+            // (a loop over heads with a loop over tokens inside is a chain of dependent trips: measured 15 us), an online softmax
+            // per lane, then the lanes and the four waves merge their (max, denominator, numerator) triples
+            float m[8], d[8], u[8];
+#pragma unroll
+            for (int hd = 0; hd < 8; ++hd) { m[hd] = -INFINITY; d[hd] = 0.f; u[hd] = 0.f; }
+            for (int t = 64 * wave + lane; t < n; t += 256) {
+                const float* sc = pl.sc + (size_t)(c0 + t) * 8;
+                float sv[8], vv[8];
+#pragma unroll
+                for (int hd = 0; hd < 8; ++hd)
+                    if (hd < pl.n_heads) {
+                        sv[hd] = __hip_atomic_load(sc + hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vv[hd] = __hip_atomic_load(sc + (size_t)np * 8 + hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                for (int hd = 0; hd < 8; ++hd)
+                    if (hd < pl.n_heads) {
+                        const float mn = fmaxf(m[hd], sv[hd]);
+                        const float a = expf(m[hd] - mn), e = expf(sv[hd] - mn);
+                        d[hd] = fmaf(d[hd], a, e);
+                        u[hd] = fmaf(u[hd], a, e * vv[hd]);
+                        m[hd] = mn;
+                    }
+            }
+            __syncthreads();                             // (the flag at LDS 0 has been read by every wave)
+#pragma unroll
+            for (int hd = 0; hd < 8; ++hd)
+                if (hd < pl.n_heads) {
+                    const float mw = wave_max(m[hd]);
+                    const float a = m[hd] == -INFINITY ? 0.f : expf(m[hd] - mw);
+                    const float dw = wave_sum(d[hd] * a), uw = wave_sum(u[hd] * a);
+                    if (lane == 0) *(NQ_AS3 f32x4*)(16u * (wave * 8 + hd)) = f32x4{mw, dw, uw, 0.f};
+                }
+            __syncthreads();
+            if (threadIdx.x < pl.n_heads) {
+                float mm = -INFINITY;
+                f32x4 p[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { p[w] = *(NQ_AS3 const f32x4*)(16u * (w * 8 + threadIdx.x)); mm = fmaxf(mm, p[w][0]); }
+                float den = 0.f, num = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float a = p[w][0] == -INFINITY ? 0.f : expf(p[w][0] - mm);
+                    den = fmaf(p[w][1], a, den);
+                    num = fmaf(p[w][2], a, num);
+                }
+                pl.out[(size_t)b * pl.n_heads + threadIdx.x] = num / den;
+            }
+        }
+    } else if (lw_next) {
         VMCNT(0);
         __syncthreads();
         NQ_STAMP(5);                                      // next layer's Q / K / V fragments landed
@@ -515,29 +657,57 @@ __global__ __launch_bounds__(256, 1) void td16_layer_kernel(const int32_t* __res
 }
 
 // ws: 9 * np * 64 floats = two layer buffers of np * 576 bf16 each (Q: np * 192, K / V blocks: np * 384)
-extern "C" int nisqa_td_selfatt_bf16x6(const float* feat, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
-                                       int32_t total_tok_padded, int32_t n_layers, const float* td_w, const uint16_t* td_wx,
-                                       float* ws, float* x_out, void* stream) {
+// pool_wx16 != null: the last layer's launch carries the attention pooling as well (ws_pool: np * 16 floats + n_clips counters)
+static int td16_launch(const float* feat, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips, int32_t total_tok_padded,
+                       int32_t n_layers, const float* td_w, const uint16_t* td_wx, int32_t n_heads, const uint16_t* pool_wx16,
+                       float* ws, float* x_out, float* ws_pool, float* out, void* stream) {
     if (n_clips <= 0 || total_tok_padded <= 0 || (total_tok_padded & 63) || n_layers < 1 || !td_wx) return NISQA_ERR_ARG;
+    if (pool_wx16 && (n_heads < 1 || n_heads > 8 || !ws_pool || !out)) return NISQA_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int np = total_tok_padded;
     u16* lbuf[2] = {(u16*)ws, (u16*)ws + (size_t)np * 576};
     const int wgs = np / 64;
-    static std::atomic<bool> ok_p[64], ok_l[64];
-    if (nq_lds_opt_in((const void*)td16_proj_kernel, PJ_LDS, ok_p) || nq_lds_opt_in((const void*)td16_layer_kernel, LY_LDS, ok_l))
+    static std::atomic<bool> ok_p[64], ok_l[64], ok_lp[64];
+    if (nq_lds_opt_in((const void*)td16_proj_kernel, PJ_LDS, ok_p) || nq_lds_opt_in((const void*)td16_layer_kernel<false>, LY_LDS, ok_l) ||
+        nq_lds_opt_in((const void*)td16_layer_kernel<true>, LY_LDS + 16 * T16_FRAG, ok_lp))
         return NISQA_ERR_LAUNCH;
+    pool_args pl = {};
+    if (pool_wx16) pl = pool_args{n_heads, pool_wx16, ws_pool, (int32_t*)(ws_pool + (size_t)np * 16), out};
     NQ_LAUNCH_BEGIN();
     hipLaunchKernelGGL(td16_proj_kernel, dim3(wgs), dim3(256), PJ_LDS, st, feat, tok_off, n_wins, n_clips, np, td_w, td_wx, x_out,
-                       lbuf[0], lbuf[0] + (size_t)np * 192);
+                       lbuf[0], lbuf[0] + (size_t)np * 192, pl.arrivals);
     for (int l = 0; l < n_layers; ++l) {
         const float* lw = td_w + TD_LAYER0 + (size_t)l * TDL_FLOATS;
         const uint16_t* lwx = td_wx + TDX_LAYER0 + (size_t)l * TDXL_U16S;
         const bool more = l + 1 < n_layers;
         u16 *cur = lbuf[l & 1], *nxt = lbuf[(l & 1) ^ 1];
-        hipLaunchKernelGGL(td16_layer_kernel, dim3(wgs), dim3(256), LY_LDS, st, tok_off, n_wins, n_clips, np, lw, lwx,
-                           more ? lw + TDL_FLOATS : (const float*)nullptr, more ? lwx + TDXL_U16S : (const uint16_t*)nullptr,
-                           (const float*)x_out, (const u16*)cur, (const u16*)(cur + (size_t)np * 192), x_out, nxt,
-                           nxt + (size_t)np * 192);
+        if (!more && pool_wx16)
+            hipLaunchKernelGGL(td16_layer_kernel<true>, dim3(wgs), dim3(256), LY_LDS + 2 * n_heads * T16_FRAG, st, tok_off, n_wins, n_clips,
+                               np, lw, lwx, (const float*)nullptr, (const uint16_t*)nullptr, (const float*)x_out, (const u16*)cur,
+                               (const u16*)(cur + (size_t)np * 192), x_out, nxt, nxt + (size_t)np * 192, pl);
+        else
+            hipLaunchKernelGGL(td16_layer_kernel<false>, dim3(wgs), dim3(256), LY_LDS, st, tok_off, n_wins, n_clips, np, lw, lwx,
+                               more ? lw + TDL_FLOATS : (const float*)nullptr, more ? lwx + TDXL_U16S : (const uint16_t*)nullptr,
+                               (const float*)x_out, (const u16*)cur, (const u16*)(cur + (size_t)np * 192), x_out, nxt,
+                               nxt + (size_t)np * 192, pl);
     }
     return NQ_LAUNCH_STATUS();
+}
+
+extern "C" int nisqa_td_selfatt_bf16x6(const float* feat, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                                       int32_t total_tok_padded, int32_t n_layers, const float* td_w, const uint16_t* td_wx,
+                                       float* ws, float* x_out, void* stream) {
+    return td16_launch(feat, tok_off, n_wins, n_clips, total_tok_padded, n_layers, td_w, td_wx, 0, nullptr, ws, x_out, nullptr, nullptr,
+                       stream);
+}
+
+// self-attention and attention pooling of a batch in n_layers + 1 launches: pool_wx = the three-term pooling blob, whose 16-token
+// part (nisqa_amd/weights.py: pack_pool_att_t16) lies behind the n_heads blocks of nisqa_pool_att_bf16x6
+extern "C" int nisqa_td_pool_bf16x6(const float* feat, const int32_t* tok_off, const int32_t* n_wins, int32_t n_clips,
+                                    int32_t total_tok_padded, int32_t n_layers, const float* td_w, const uint16_t* td_wx,
+                                    int32_t n_heads, const uint16_t* pool_wx, float* ws, float* x_out, float* ws_pool, float* out,
+                                    void* stream) {
+    if (!pool_wx || n_heads < 1 || n_heads > 8) return NISQA_ERR_ARG;
+    return td16_launch(feat, tok_off, n_wins, n_clips, total_tok_padded, n_layers, td_w, td_wx, n_heads,
+                       pool_wx + (size_t)n_heads * PLX_U16S, ws, x_out, ws_pool, out, stream);
 }

@@ -361,7 +361,7 @@ class HipNisqa(object):
             _lib.check(self.lib.nisqa_cnn_adapt_segments(_ptr(x), L, _ptr(d['tok_off']), _ptr(d['n_wins']), B,
                                                          plan.total_tok, _ptr(self.cnn_w), _ptr(p3), _ptr(feat),
                                                          self._stream()), 'nisqa_cnn_adapt_segments')
-        return self.pool(self.td(feat, plan), plan)
+        return self.td_pool(feat, plan)
 
     # -- nisqa_tts.tar stages ------------------------------------------------------------------------
     def cnn_std(self, mel_tm, clip_floor, plan):
@@ -410,6 +410,21 @@ class HipNisqa(object):
                                                  plan.total_tok, self.n_layers, _ptr(self.td_w), _ptr(ws), _ptr(x),
                                                  self._stream()), 'nisqa_td_selfatt')
         return x
+
+    def td_pool(self, feat, plan):
+        """self-attention + attention pooling as the whole-batch forward runs them: in the three-term modes ONE chain of
+        n_layers + 1 launches (nisqa_td_pool_bf16x6), otherwise td() then pool()"""
+        if self.td_precision != 'bf16x6':
+            return self.pool(self.td(feat, plan), plan)
+        d = plan.to(self.device)
+        ws = torch.empty(plan.total_tok * 64 * 9, dtype=torch.float32, device=self.device)
+        wsp = torch.empty(plan.total_tok * 16 + plan.n_clips, dtype=torch.float32, device=self.device)
+        x = torch.zeros((plan.total_tok, 64), dtype=torch.float32, device=self.device)
+        out = torch.empty((plan.n_clips, self.n_heads), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.nisqa_td_pool_bf16x6(_ptr(feat), _ptr(d['tok_off']), _ptr(d['n_wins']), plan.n_clips, plan.total_tok,
+                                                 self.n_layers, _ptr(self.td_w), _ptr(self.td_wb), self.n_heads, _ptr(self.pool_wb),
+                                                 _ptr(ws), _ptr(x), _ptr(wsp), _ptr(out), self._stream()), 'nisqa_td_pool_bf16x6')
+        return out
 
     def pool(self, x, plan):
         d = plan.to(self.device)

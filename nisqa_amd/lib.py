@@ -60,6 +60,7 @@ SYMBOLS = {
     'nisqa_pool_att_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p]),
     'nisqa_td_selfatt_bf16x6': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p]),
     'nisqa_pool_att_bf16x6': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p]),
+    'nisqa_td_pool_bf16x6': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_i32, c_p, c_p, c_p, c_p, c_p, c_p]),
     'nisqa_pool_score_bf16': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_pool_score_bf16x6': (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
     'nisqa_pool_final': (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p, c_p, c_p]),

@@ -459,9 +459,32 @@ def pack_self_att_bf16(sd, n_layers, pfx='time_dependency.model.', terms=2):
 
 
 def pack_pool_att_bf16(sd, head_prefixes, terms=2):
+    """terms = 3: the blocks of pool_score_bf16x6_kernel followed by pack_pool_att_t16 (the pooling tail of td16_layer_kernel)"""
     sz = PLB_U16S if terms == 2 else PLX_U16S
     blob = np.zeros(len(head_prefixes) * sz, np.uint16)
     for h, p in enumerate(head_prefixes):
         fr = linear_a_fragments_bf16(_np(sd, p + 'linear1.weight'), chain=True, terms=terms)
         blob[h * sz: h * sz + fr.size] = fr
-    return blob
+    return blob if terms == 2 else np.concatenate([blob, pack_pool_att_t16(sd, head_prefixes)])
+
+
+def pack_pool_att_t16(sd, head_prefixes):
+    """PoolAttFF heads for the pooling tail of csrc/td16_bf16x6.hip: a head's linear1 [128][64] as two 64-row blocks of
+    linear_a_fragments_bf16_t16 (24 fragments of 1 KB each), all blocks first, then one 1 KB block of float32 per 64-row block:
+    b1[64] | w2[64] | w3[64] | b2, b3, 0 ... (the second block of a head repeats w3 / b2 / b3) -> uint16 [2 H * 12288 + 2 H * 512]"""
+    H = len(head_prefixes)
+    frags = np.zeros((2 * H, 24 * 512), np.uint16)
+    par = np.zeros((2 * H, 256), np.float32)
+    for h, p in enumerate(head_prefixes):
+        w1 = _np(sd, p + 'linear1.weight')
+        if tuple(w1.shape) != (128, 64):
+            raise NotImplementedError('HIP pooling kernel needs pool_att_h=128 on d=64')
+        fr = linear_a_fragments_bf16_t16(w1, chain=True, terms=3).reshape(2, -1)
+        for j in range(2):
+            frags[2 * h + j] = fr[j]
+            par[2 * h + j, 0:64] = _np(sd, p + 'linear1.bias')[64 * j:64 * j + 64]
+            par[2 * h + j, 64:128] = _np(sd, p + 'linear2.weight').reshape(-1)[64 * j:64 * j + 64]
+            par[2 * h + j, 128:192] = _np(sd, p + 'linear3.weight').reshape(-1)
+            par[2 * h + j, 192] = _np(sd, p + 'linear2.bias').reshape(-1)[0]
+            par[2 * h + j, 193] = _np(sd, p + 'linear3.bias').reshape(-1)[0]
+    return np.concatenate([frags.reshape(-1), par.reshape(-1).view(np.uint16)])

@@ -257,6 +257,34 @@ def test_network_stages_match_oracle_random_weights(eng_rand, batch):
     _stages_vs_oracle(eng_rand, dict(helpers.DIM_ARGS), helpers.random_state_dict(7, 'NISQA_DIM'), pcm, tf, to)
 
 
+@pytest.mark.parametrize('model', ['NISQA_DIM', 'NISQA'])
+def test_self_attention_chain_with_the_pooling_tail_is_exact_and_deterministic(model):
+    """nisqa_td_pool_bf16x6 (the last encoder layer's launch scores its tokens for every pooling head, the clip's last workgroup to
+    arrive does the softmax: csrc/td16_bf16x6.hip) against the two-call form (nisqa_td_selfatt_bf16x6, nisqa_pool_att_bf16x6) and
+    against the exact-fp32 kernels, on ragged batches -- one token, one key block, 1 300 tokens (the reference's ms_max_segments),
+    more workgroups than CUs -- for five heads and for one; the staging is LDS-DMA under explicit wait counts and the pooling
+    crosses workgroups through device-scope stores: the same batch 50 times must give the same bits."""
+    from nisqa_amd.engine import HipNisqa, BatchPlan
+    args = dict(helpers.DIM_ARGS) if model == 'NISQA_DIM' else dict(helpers.DIM_ARGS, model='NISQA')
+    sd = helpers.random_state_dict(7, model)
+    eng, eng32 = HipNisqa(args, sd, precision='bf16x6'), HipNisqa(args, sd, precision='f32')
+    rng = np.random.default_rng(5)
+    for nw in ([1], [1300, 900, 33, 64, 65, 1, 32], [247] * 64, list(rng.integers(1, 400, 96)), list(rng.integers(1, 40, 300))):
+        plan = BatchPlan.from_n_wins(np.asarray(nw, np.int64))
+        idx = torch.from_numpy(plan.token_index()).to(eng.device)
+        feat = torch.zeros((plan.total_tok, 384), device=eng.device)
+        feat[idx] = torch.randn((len(idx), 384), device=eng.device, generator=torch.Generator(eng.device).manual_seed(len(nw)))
+        x = eng.td(feat, plan)
+        two, fused = eng.pool(x, plan), eng.td_pool(feat, plan).clone()
+        x32 = eng32.td(feat, plan)
+        o32 = eng32.pool(x32, plan)
+        assert float((x[idx] - x32[idx]).abs().max()) < 2e-4
+        assert float((two - o32).abs().max()) < 1e-4 and float((fused - o32).abs().max()) < 1e-4
+        assert float((fused - two).abs().max()) < 1e-5
+        for _ in range(50):
+            assert torch.equal(eng.td_pool(feat, plan), fused) and torch.equal(eng.td(feat, plan)[idx], x[idx])
+
+
 @pytest.mark.parametrize('precision', PRECISIONS_SA)
 @pytest.mark.parametrize('name', ['dim_rand', 'mos_rand', 'dim_real', 'mos_real'])
 def test_end_to_end_matches_reference_fixture(name, precision):

@@ -155,7 +155,7 @@ def test_three_term_linear_fragments_hold_the_weights_exactly():
     heads = ['pool_layers.%d.model.' % h for h in range(5)]
     assert W.pack_self_att_bf16(sd, 2, terms=3).size == W.TDX_LAYER0 + 2 * W.TDXL_U16S
     assert W.pack_self_att_bf16(sd, 2).size == W.TDB_LAYER0 + 2 * W.TDBL_U16S
-    assert W.pack_pool_att_bf16(sd, heads, terms=3).size == 5 * W.PLX_U16S and W.pack_pool_att_bf16(sd, heads).size == 5 * W.PLB_U16S
+    assert W.pack_pool_att_bf16(sd, heads, terms=3).size == 5 * W.PLX_U16S + 10 * (24 * 512 + 512) and W.pack_pool_att_bf16(sd, heads).size == 5 * W.PLB_U16S
 
 
 def test_linear_fragments_roundtrip():

@@ -19,7 +19,7 @@ torch.cuda.synchronize()
 NAMES = {'proj': ['wait chunk 0', 'K-steps 0-3', 'wait chunk 1', 'K-steps 4-7', 'wait chunk 2', 'K-steps 8-11',
                   'LN + x store + wait QKV frags', 'Q / K / V GEMMs + stores'],
          'layer': ['attention loop', 'wait weights', 'out-proj + LN', 'feed-forward + LN + store',
-                   'wait next QKV frags', 'Q / K / V GEMMs + stores']}
+                   'wait next QKV frags | pooling blocks (last layer)', 'Q / K / V GEMMs + stores | arrival + pooling softmax']}
 LOOP = getattr(L, 'nisqa_debug_td16_loop_clock')
 LOOP.restype, LOOP.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]
 LOOP(None, 1)
