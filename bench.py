@@ -297,9 +297,12 @@ def init_dist(a):
 LAST_JOB_TIMING = {}          # nisqaModel.timing of the last predict_csv_job: seconds scoring / seconds writing the table
 
 
-def predict_csv_job(rank, world, dev, backend, clips, bs, distinct, workers, warmup, tmp_dir=None, tag='csv'):
+def predict_csv_job(rank, world, dev, backend, clips, bs, distinct, workers, warmup, tmp_dir=None, tag='csv', mode='predict_csv'):
     """BASELINE configs[2]: nisqaModel(predict_csv).predict() over `clips` rows of a CSV (`distinct` synthetic 10 s WAV files
-    on local disk, reused cyclically), ranks shard the CSV.  -> (seconds max over ranks, DataFrame on rank 0, description)."""
+    on local disk, reused cyclically), ranks shard the CSV.  -> (seconds max over ranks, DataFrame on rank 0, description).
+    mode='predict_dir' (BASELINE configs[1] as run_predict.py runs it): the same job over a DIRECTORY of `clips` *.wav names --
+    hard links to the `distinct` files (one inode each: the page cache holds `distinct` files, the directory listing, the RIFF
+    parse and the read of every name are real)."""
     import contextlib
     import io
     import shutil
@@ -314,6 +317,11 @@ def predict_csv_job(rank, world, dev, backend, clips, bs, distinct, workers, war
         for i in range(distinct):
             synth.write_wav(os.path.join(d, 'c%05d.wav' % i), synth.synth_pcm16(3000 + i, SECONDS), SR)
         pd.DataFrame({'deg': ['c%05d.wav' % (i % distinct) for i in range(clips)]}).to_csv(os.path.join(d, 'list.csv'), index=False)
+        if mode == 'predict_dir':
+            for sub, n in (('dir', clips), ('warm', max(1, warmup) * bs * world)):
+                os.makedirs(os.path.join(d, sub))
+                for i in range(n):
+                    os.link(os.path.join(d, 'c%05d.wav' % (i % distinct)), os.path.join(d, sub, 'f%06d.wav' % i))
         ck = dict(margs)
         ck.update({'pretrained_model': False, 'tr_bs_val': bs, 'tr_num_workers': workers})
         torch.save({'args': ck, 'model_state_dict': sd}, os.path.join(d, 'model.tar'))
@@ -324,6 +332,10 @@ def predict_csv_job(rank, world, dev, backend, clips, bs, distinct, workers, war
         torch.distributed.barrier()
 
     def args_for(csv):
+        if mode == 'predict_dir':
+            return {'mode': 'predict_dir', 'pretrained_model': os.path.join(d, 'model.tar'), 'deg': None,
+                    'data_dir': os.path.join(d, 'warm' if csv == 'warm.csv' else 'dir'), 'output_dir': None, 'csv_file': None,
+                    'csv_deg': None, 'num_workers': workers, 'bs': bs, 'ms_channel': None, 'tr_bs_val': bs, 'tr_num_workers': workers}
         return {'mode': 'predict_csv', 'pretrained_model': os.path.join(d, 'model.tar'), 'deg': None, 'data_dir': d,
                 'output_dir': None, 'csv_file': csv, 'csv_deg': 'deg', 'num_workers': workers, 'bs': bs,
                 'ms_channel': None, 'tr_bs_val': bs, 'tr_num_workers': workers}
@@ -410,6 +422,30 @@ def link_only_probe(dev, nbytes_per_copy=245_760_000, copies=24):
         e1.record(copy_stream)
     e1.synchronize()
     return nbytes_per_copy * copies / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def side_predict_dir(dev, cpu, link):
+    """configs[1] AS A USER RUNS IT (run_predict.py --mode predict_dir --bs 64, reference run_predict.py:20-39, NISQA_model.py:745-777):
+    nisqaModel(predict_dir, bs 64).predict() over a directory of 98 304 ten-second WAV files (64 inodes in the page cache, 98 304 names:
+    the size of the csv leg, so that the loop's fill and drain weigh the same in both),
+    file-fed and PCIe-inclusive like the csv leg; the contract `value` above is the same batch shape with the PCM already in HBM."""
+    clips, bs = 98304, 64
+    from nisqa_amd import ingest as _ing
+    from nisqa_amd import NISQA_lib as NL
+    dt, df, _ = predict_csv_job(0, 1, dev, None, clips, bs, 64, 0, 4, tag='side_dir', mode='predict_dir')
+    loop = dict(NL.LOOP_STATS)
+    timing = dict(LAST_JOB_TIMING)
+    gbs = clips * SECONDS * SR * 2 / dt / 1e9
+    return {'config': 'configs[1] predict_dir nisqa.tar bs=64, 1 GPU, a directory of %d *.wav names (hard links to 64 distinct 10 s files '
+                      'in the page cache), nisqaModel.predict() end to end incl. directory listing, DataFrame and the printed table; '
+                      'reader threads: the CPU budget (%d) - 3' % (clips, _ing.cpu_budget()),
+            'value': round(clips / dt, 1), 'unit': 'clips/s', 'seconds': round(dt, 3), 'pcie_inclusive': True,
+            'roofline': {'bound': 'pcie', 'kernel': 'H2D copy of the int16 PCM (SDMA, copy-only stream)', 'achieved': round(gbs, 2),
+                         'peak': PEAK_PCIE, 'unit': 'GB/s', 'frac': round(gbs / PEAK_PCIE, 4),
+                         'link_only_GBps': round(link, 2), 'frac_of_link_only': round(gbs / link, 4)},
+            'predict_s': round(timing.get('predict_s', float('nan')), 3), 'table_s': round(timing.get('table_s', float('nan')), 3),
+            'loop_host_s': {k: round(v, 3) for k, v in loop.items()},
+            'cpu_baseline': cpu and {k: cpu[k] for k in ('value', 'unit', 'cores', 'kind')}}
 
 
 def side_predict_csv(dev, cpu):
@@ -696,7 +732,7 @@ def main():
     ap.add_argument('--workers', type=int, default=16, help='predict_csv: native ingest threads per rank')
     ap.add_argument('--tmp-dir', default=None)
     ap.add_argument('--batch', type=int, default=BATCH, help='clips per step (experiments; the contract line is 64)')
-    ap.add_argument('--leg', default='all', choices=['all', 'main', 'tts', 'train', 'csv'],
+    ap.add_argument('--leg', default='all', choices=['all', 'main', 'tts', 'train', 'csv', 'dir'],
                     help='profiling runs: only this part (main = the contract workload without side legs)')
     ap.add_argument('--no-side', action='store_true', help='skip the side legs (configs[2], [3], [4])')
     a = ap.parse_args()
@@ -709,10 +745,11 @@ def main():
         return bench_predict_csv(a)
 
     rank, world, dev, backend = init_dist(a)
-    if a.leg in ('tts', 'train', 'csv'):                      # one side leg alone (rocprofv3 runs)
+    if a.leg in ('tts', 'train', 'csv', 'dir'):               # one side leg alone (rocprofv3 runs)
         pmc, _ = pmc_kernels()
         r = (side_tts(dev, max(1, a.steps // 4), not a.no_cpu_baseline, pmc, two_streams=not a.no_extras) if a.leg == 'tts' else
-             side_train(dev, a.steps, not a.no_cpu_baseline, pmc) if a.leg == 'train' else side_predict_csv(dev, None))
+             side_train(dev, a.steps, not a.no_cpu_baseline, pmc) if a.leg == 'train' else
+             side_predict_dir(dev, None, link_only_probe(dev)) if a.leg == 'dir' else side_predict_csv(dev, None))
         print(json.dumps({'leg': a.leg, **r}))
         return
     from nisqa_amd.engine import HipNisqa
@@ -924,7 +961,9 @@ def main():
             res['side'] = {}
             for name, fn in (('tts_mixed', lambda: side_tts(dev, 3, not a.no_cpu_baseline, pmc)),
                              ('train_step', lambda: side_train(dev, 30, not a.no_cpu_baseline, pmc)),
-                             ('predict_csv_1gpu', lambda: side_predict_csv(dev, res.get('cpu_baseline')))):
+                             ('predict_csv_1gpu', lambda: side_predict_csv(dev, res.get('cpu_baseline'))),
+                             ('predict_dir_bs64', lambda: side_predict_dir(dev, res.get('cpu_baseline'),
+                                                                           res['side']['predict_csv_1gpu']['roofline']['link_only_GBps']))):
                 t_leg = time.perf_counter()
                 try:
                     res['side'][name] = fn()
