@@ -391,14 +391,21 @@ def bench_predict_csv(a):
 
 
 # ---- side legs: the other BASELINE.json configurations on the driver-run line ---------------------------------------
-def _stage_events(n):
+def _stage_events(n, only_cnn=False):
+    """six events per step (all stage boundaries), or -- for a TIMED region -- only the two around the CNN kernel: an event record
+    costs ~5 us of stream time (profiles/r06_stage_event_cost.txt)"""
     ev = []
     for _ in range(n):
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        e = [torch.cuda.Event(enable_timing=True) if (not only_cnn or i in (1, 2)) else None for i in range(6)]
         for x in e:
-            x.record()
+            if x is not None:
+                x.record()
         ev.append(e)
     return ev
+
+
+def _stage_means(ev, names):
+    return {n: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i, n in enumerate(names) if ev[0][i] is not None and ev[0][i + 1] is not None}
 
 
 def link_only_probe(dev, nbytes_per_copy=245_760_000, copies=24):
@@ -776,18 +783,26 @@ def main():
     # (tools/probe_clock_ramp2.py: 0.746 against 0.718 ms per step; `steady` below is the cross-check).
     # NISQA_BENCH_PROBE_LAST=1 restores the old order (probe after the timed region).
     sus, probe_first = None, (not a.no_extras and os.environ.get('NISQA_BENCH_PROBE_LAST') != '1')
-    if probe_first:
-        sus = mfma_sustained(dev)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
     for st in streams:
         st.wait_stream(torch.cuda.current_stream(dev))
-    evs = []                                             # (created before the warm-up: no host work between it and the timed region)
+    # Events of the TIMED region: only the two around the dominant kernel (the roofline's live duration).  An event record costs
+    # stream time -- six per step read 60.5 k clips/s where the same steps without events read 62.2 k (profiles/
+    # r06_stage_event_cost.txt) --, so the other stage times come from a second pass of the same K steps right behind the timed
+    # region (evs_all, untimed).
+    evs, evs_all = [], []                                # (created before the warm-up: no host work between it and the timed region)
     for _ in range(a.steps):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         for x in e:
             x.record(streams[len(evs) % len(streams)])   # forces handle creation; re-recorded inside the library
+        evs_all.append(e)
+        e = [None] + [torch.cuda.Event(enable_timing=True) for _ in range(2)] + [None] * 3
+        for x in e[1:3]:
+            x.record(streams[len(evs) % len(streams)])
         evs.append(e)
+    if probe_first:                                      # (behind the event set-up: nothing but the warm-up steps between the probe and the timed region;
+        sus = mfma_sustained(dev)                        #  1.5 % more than with the 1 ms of event creation in between, same box)
     for i in range(max(a.warmup, len(streams))):
         with torch.cuda.stream(streams[i % len(streams)]):
             out = eng.forward_pcm(pcm, plan, SR)
@@ -817,8 +832,14 @@ def main():
         if os.environ.get('NISQA_BENCH_KO') != '1':           # knock-out builds (tools/ab_build.sh -DNQ_KO=..) compute garbage
             assert torch.isfinite(outs[-1]).all()
         names = ['mel', 'cnn_front', 'cnn_back', 'selfatt', 'pool']
-        stage_ms = {n: float(np.mean([evs[s][i].elapsed_time(evs[s][i + 1]) for s in range(a.steps)]))
+        for s in range(a.steps):                              # second pass, untimed: all six stage events
+            with torch.cuda.stream(streams[s % len(streams)]):
+                eng.forward_pcm(pcm, plan, SR, stage_events=evs_all[s])
+        torch.cuda.synchronize()
+        stage_ms = {n: float(np.mean([evs_all[s][i].elapsed_time(evs_all[s][i + 1]) for s in range(a.steps)]))
                     for i, n in enumerate(names)}
+        # the dominant kernel's launch duration: live, over the timed region itself
+        stage_ms['cnn_front'] = float(np.mean([evs[s][1].elapsed_time(evs[s][2]) for s in range(a.steps)]))
         pmc, pmc_file = pmc_kernels()
 
         def roofline_of(prec, ms_front):
@@ -860,8 +881,8 @@ def main():
         kern_tab = {}
         tdp = eng.td_precision
         for stage, ks in (('mel', ['mel_frame_kernel']), ('cnn', ['cnn_front_kernel', 'cnn_back_kernel'] if eng.precision == 'f32' else [CNN_KERNEL[eng.precision]]),
-                          ('selfatt', ['td_fused_bf16_kernel', 'td_proj_bf16_kernel', 'td_layer_bf16_kernel'] if tdp == 'bf16x3' else ['td_proj_bf16x6_kernel', 'td_layer_bf16x6_kernel'] if tdp == 'bf16x6' else ['td_proj_kernel', 'td_layer_kernel']),
-                          ('pool', ['pool_score_bf16_kernel', 'pool_final_kernel'] if tdp == 'bf16x3' else ['pool_score_bf16x6_kernel', 'pool_final_kernel'] if tdp == 'bf16x6' else ['pool_score_kernel', 'pool_final_kernel'])):
+                          ('selfatt', ['td_fused_bf16_kernel', 'td_proj_bf16_kernel', 'td_layer_bf16_kernel'] if tdp == 'bf16x3' else ['td16_proj_kernel', 'td16_layer_kernel'] if tdp == 'bf16x6' else ['td_proj_kernel', 'td_layer_kernel']),
+                          ('pool', ['pool_score_bf16_kernel', 'pool_final_kernel'] if tdp == 'bf16x3' else [] if tdp == 'bf16x6' else ['pool_score_kernel', 'pool_final_kernel'])):
             for kn in ks:
                 if kn in pmc:
                     tr, mu = pmc_derived(pmc[kn])
@@ -879,6 +900,9 @@ def main():
                        'parallelism': 'clip-sharded x%d, final all_gather of MOS rows' % world,
                        'collective_backend': backend, 'world_size_seen': world},
             'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
+            'stage_ms_note': 'cnn_front: HIP events around the dominant kernel inside the timed region (its live launch duration); the other '
+                             'stages: a second, untimed pass of the same steps with all six stage events (an event record costs ~5 us of '
+                             'stream time; selfatt carries the attention pooling since round 6: nisqa_td_pool_bf16x6)',
             'clock_state': ('the sustained-MFMA probe of roofline.peak_sustained (~100 ms of dense MFMA) ran before the warm-up steps: '
                             'the timed steps start at the loaded clock state (a short region behind an idle GPU measures 4 % low; '
                             'NISQA_BENCH_PROBE_LAST=1 restores the old order)') if probe_first else 'no load before the warm-up steps',
@@ -900,14 +924,18 @@ def main():
                 for _ in range(max(2, a.warmup)):
                     o2 = eng2.forward_pcm(pcm, plan, SR)
                 torch.cuda.synchronize()
-                ev2 = _stage_events(a.steps)
+                ev2, ev2_all = _stage_events(a.steps, only_cnn=other != 'f32'), _stage_events(a.steps)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for s_ in range(a.steps):
                     o2 = eng2.forward_pcm(pcm, plan, SR, stage_events=ev2[s_])
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t1
-                st2 = {n: float(np.mean([ev2[s_][i].elapsed_time(ev2[s_][i + 1]) for s_ in range(a.steps)])) for i, n in enumerate(names)}
+                for s_ in range(a.steps):                      # (untimed second pass: every stage)
+                    eng2.forward_pcm(pcm, plan, SR, stage_events=ev2_all[s_])
+                torch.cuda.synchronize()
+                st2 = _stage_means(ev2_all, names)
+                st2.update(_stage_means(ev2, names))           # the CNN kernels' durations from the timed pass
                 r2 = roofline_of(other, st2['cnn_front'])
                 res['value_' + other] = round(BATCH * a.steps / dt2, 2)
                 res[other] = {'precision': other, 'value': round(BATCH * a.steps / dt2, 2), 'unit': 'clips/s', 'steps': a.steps,
@@ -930,14 +958,14 @@ def main():
             for _ in range(50):
                 eng.forward_pcm(pcm, plan, SR)
             torch.cuda.synchronize()
-            ev3 = _stage_events(n3)
+            ev3 = _stage_events(n3, only_cnn=True)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for s_ in range(n3):
                 eng.forward_pcm(pcm, plan, SR, stage_events=ev3[s_])
             torch.cuda.synchronize()
             dt3 = time.perf_counter() - t1
-            st3 = {n: float(np.mean([ev3[s_][i].elapsed_time(ev3[s_][i + 1]) for s_ in range(n3)])) for i, n in enumerate(names)}
+            st3 = _stage_means(ev3, names)
             res['steady'] = {'value': round(BATCH * n3 / dt3, 2), 'unit': 'clips/s', 'steps': n3, 'warmup': 50,
                              'ms_per_step': round(1e3 * dt3 / n3, 4), 'stage_ms': {k: round(v, 4) for k, v in st3.items()},
                              'roofline_frac': roofline_of(eng.precision, st3['cnn_front'])['frac']}

@@ -264,7 +264,8 @@ typedef struct {
     int32_t n_layers; int32_t n_heads; int32_t seg_hop;
     /* optional profiling hook: NULL, or 6 caller-created hipEvent_t recorded on `stream` at the stage
      * boundaries of nisqa_predict_batch: [0] start, [1] after mel, [2] after the conv1-4 kernel,
-     * [3] after the conv5-6 kernel, [4] after self-attention, [5] after pooling */
+     * [3] after the conv5-6 kernel, [4] after self-attention, [5] after pooling; a NULL entry is skipped (an event record costs
+     * ~5 us of stream time: six of them 29 us of a 1.03 ms batch, profiles/r06_stage_event_cost.txt) */
     void* const* stage_events;
     const uint16_t* cnn_wb;  /* split-bf16 conv fragments, or NULL */
     int32_t cnn_mode;        /* 0 = exact fp32 MFMA kernels, 1 = split-bf16 kernels (needs cnn_wb, td_wb, pool_wb),

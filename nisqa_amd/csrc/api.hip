@@ -49,7 +49,7 @@ static int predict_batch(const void* pcm, bool pcm16, const int64_t* clip_off, c
     float* x = (float*)(w + p.x);
     float* pool = (float*)(w + p.pool);
     void* const* ev = model->stage_events;
-#define NQ_STAGE(i) do { if (ev && hipEventRecord((hipEvent_t)ev[i], (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH; } while (0)
+#define NQ_STAGE(i) do { if (ev && ev[i] && hipEventRecord((hipEvent_t)ev[i], (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH; } while (0)
     if (hipMemsetAsync(cmax, 0, (size_t)n_clips * 4, (hipStream_t)stream) != hipSuccess) return NISQA_ERR_LAUNCH;
     NQ_STAGE(0);
     int rc = pcm16 ? nisqa_mel_db_pcm16((const int16_t*)pcm, clip_off, frame_off, n_clips, total_frames, cfg, model->window,

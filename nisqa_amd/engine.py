@@ -273,7 +273,7 @@ class HipNisqa(object):
         out = torch.empty((plan.n_clips, self.n_heads), dtype=torch.float32, device=self.device)
         model = _lib.ModelDev.from_buffer_copy(mt['model'])
         if stage_events is not None:
-            arr = (ctypes.c_void_p * 6)(*[ctypes.c_void_p(e.cuda_event) for e in stage_events])
+            arr = (ctypes.c_void_p * 6)(*[ctypes.c_void_p(e.cuda_event if e is not None else None) for e in stage_events])
             model.stage_events = ctypes.cast(arr, ctypes.c_void_p)
         entry = self.lib.nisqa_predict_batch_pcm16 if pcm.dtype == torch.int16 else self.lib.nisqa_predict_batch
         rc = entry(_ptr(pcm), _ptr(d['clip_off']), _ptr(d['frame_off']), _ptr(d['tok_off']),
