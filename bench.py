@@ -30,10 +30,13 @@ Extra objects on the JSON line (DESIGN.md "Measurement"):
                       value_f32 at the top level, its own roofline (cnn_front_kernel against the fp32-MFMA peak, traffic and
                       mfma_util from the same PMC file).
   steady              the primary path again over >= 400 steps (the driver's 20-step run ends before the clocks settle).
+  overlap_2_streams, overlap_3_streams   the same steps alternated over 2 (the predict loop's form) / 3 streams, >= 200 steps, no events.
+  stage_ms            cnn_front from the two events of the timed region; the other stages from an untimed second pass (stage_ms_note).
   side                the other BASELINE.json configurations, each bounded to a few seconds, each with its own roofline
                       and cpu_baseline: predict_csv_1gpu (configs[2] through nisqaModel.predict(), WAV files on disk,
-                      PCIe-inclusive), tts_mixed (configs[3]: nisqa_tts.tar, mixed 3-30 s clips), train_step (configs[4]:
-                      forward + backward + Adam at bs 32).  `--leg main|tts|train|csv` runs one of them alone (profiling).
+                      PCIe-inclusive), predict_dir_bs64 (configs[1] as run_predict.py runs it: a directory of 98 304 names, bs 64, file-fed),
+                      tts_mixed (configs[3]: nisqa_tts.tar, mixed 3-30 s clips), train_step (configs[4]:
+                      forward + backward + Adam at bs 32).  `--leg main|tts|train|csv|dir` runs one of them alone (profiling).
   cpu_baseline        the CPU oracle (port of the reference path) at bs = 64 on this box's host cores, rank 0, N = 1.
 """
 import argparse
@@ -970,18 +973,22 @@ def main():
                              'ms_per_step': round(1e3 * dt3 / n3, 4), 'stage_ms': {k: round(v, 4) for k, v in st3.items()},
                              'roofline_frac': roofline_of(eng.precision, st3['cnn_front'])['frac']}
         if world == 1 and len(streams) == 1 and not a.no_extras:
-            # same steps alternated over 3 streams (what the predict loop does with 2): launches and copies overlap
-            st3 = [torch.cuda.Stream(device=dev) for _ in range(3)]
-            for i in range(3):
-                with torch.cuda.stream(st3[i]):
-                    eng.forward_pcm(pcm, plan, SR)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for s in range(a.steps):
-                with torch.cuda.stream(st3[s % 3]):
-                    eng.forward_pcm(pcm, plan, SR)
-            torch.cuda.synchronize()
-            res['overlap_3_streams'] = {'value': round(BATCH * a.steps / (time.perf_counter() - t1), 2), 'unit': 'clips/s'}
+            # the same steps alternated over 2 streams (what the predict loop does) and over 3: launches overlap, one batch's
+            # VALU-bound mel kernel runs next to another's MFMA-bound CNN kernel.  No events inside; >= 200 steps behind 4 per stream
+            # (a 20-step region on freshly created streams measures their start-up)
+            n_ov = max(200, a.steps)
+            for ns in (2, 3):
+                sts = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+                for i in range(4 * ns):
+                    with torch.cuda.stream(sts[i % ns]):
+                        eng.forward_pcm(pcm, plan, SR)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for s in range(n_ov):
+                    with torch.cuda.stream(sts[s % ns]):
+                        eng.forward_pcm(pcm, plan, SR)
+                torch.cuda.synchronize()
+                res['overlap_%d_streams' % ns] = {'value': round(BATCH * n_ov / (time.perf_counter() - t1), 2), 'unit': 'clips/s', 'steps': n_ov}
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(margs, sd)
         if world == 1 and a.leg == 'all' and not a.no_side and not a.no_extras:
