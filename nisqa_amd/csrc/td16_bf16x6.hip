@@ -26,6 +26,7 @@
 //                       KV [32-key block][ K: [jt 2][s 2][term 3][64][8] | V: [ft 4][term 3][64][8] ]   (24 KB per block)
 // K fragments are the producer's own D registers; a V fragment interleaves the two 16-token tiles of its block (8 bytes per lane
 // each).  The consumer copies a block linearly into LDS (double buffered, one barrier per block) and reads fragments at lane * 16.
+#include <type_traits>
 #include "common.hpp"
 #include "layout.hpp"
 #include "../../include/nisqa_hip.h"
@@ -199,13 +200,6 @@ NQ_DEV void dma_frags(const u16* __restrict__ src, unsigned dst, int wave, int l
         ii = ii + 1 == N ? 0 : ii + 1;
     }
 }
-// n = 1..3 fragment blocks of 24 KB (the layer kernel's asm requests); returns the requests per wave
-NQ_DEV int dma_blocks(const u16* __restrict__ src, unsigned dst, int n, int wave, int lane, int rot) {
-    if (n >= 3) dma_frags<18, true>(src, dst, wave, lane, rot);
-    else if (n == 2) dma_frags<12, true>(src, dst, wave, lane, rot);
-    else if (n == 1) dma_frags<6, true>(src, dst, wave, lane, rot);
-    return n >= 3 ? 18 : 6 * n;
-}
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 #define FENCE() asm volatile("" ::: "memory")
 
@@ -348,10 +342,12 @@ __global__ __launch_bounds__(256, 1) void td16_proj_kernel(const float* __restri
 #define LY_WFF2 (LY_WFF1 + T16_GEMM)
 #define LY_LDS (LY_WFF2 + T16_GEMM)                     /* 144 KB */
 // Pooling tail of the LAST layer (5 x PoolAttFF, NISQA_lib.py:1171-1183): a head's 64 -> 128 linear is two 64-row blocks of the same
-// fragment form; blocks travel three at a time, alternately into the ring and into the layer's own weight area (both free by
-// then); the fp32 vectors of every block (b1 | w2 | w3 | b2, b3: 1 KB) sit behind them
+// fragment form, read from L2 straight into the registers of the ONE wave that multiplies them; LDS holds the fp32 vectors of every
+// block (b1 | w2 | w3 | b2, b3: 1 KB each, behind the layer's own areas), the four tiles' activation terms and the partial scores
 #define PL16_PAR LY_LDS
 #define PL16_BLK_U16 (24 * 512)
+#define PL16_XT LY_RING                                 /* the four tiles' activation terms: [tile 4][s 2][term][1 KB] = 24 KB */
+#define PL16_SP (LY_RING + 4 * 2 * XT * T16_FRAG)       /* partial scores [block][64 tokens] */
 struct pool_args {
     int n_heads;
     const u16* wx;                                      // [2 n_heads][24 fragments] then [2 n_heads][256 floats]
@@ -488,11 +484,9 @@ __global__ __launch_bounds__(256, 1) void td16_layer_kernel(const int32_t* __res
     }
     for (; wb < 3; ++wb) dma_frags<6, true>(lwx + TDXL_OUT + (size_t)wb * (T16_GEMM / 2), LY_WOUT + wb * T16_GEMM, wave, lane, rot);
     FENCE();
-    // the next layer's Q / K / V fragments (last layer: the first three pooling blocks) go where the K / V blocks were (every wave is
-    // behind the loop's last barrier)
+    // the next layer's Q / K / V fragments go where the K / V blocks were (every wave is behind the loop's last barrier)
     if (POOL) {
-        const int rq = dma_blocks(pl.wx, LY_RING, nblk, wave, lane, rot);
-        if (rq == 18) VMCNT(18); else if (rq == 12) VMCNT(12); else VMCNT(6);
+        VMCNT(0);
     } else if (lw_next) { dma_frags<18, true>(lwx_next + TDXL_QKV, LY_RING, wave, lane, rot); VMCNT(18); } else { VMCNT(0); }
     __syncthreads();                                     // out / ff1 / ff2 fragments landed in every wave
     NQ_STAMP(2);
@@ -534,55 +528,99 @@ __global__ __launch_bounds__(256, 1) void td16_layer_kernel(const int32_t* __res
     }
     NQ_STAMP(4);                                          // feed-forward, residual, LayerNorm, x stored
     if constexpr (POOL) {
-        f32x4 xb[2][XT];
-        float vpart = 0.f;                                // linear3 of the head in hand over this lane's 16 features
-        if (active) { split8(o.v[0], o.v[1], xb[0]); split8(o.v[2], o.v[3], xb[1]); }
-        float spart = 0.f;
-        for (int b0 = 0, grp = 0; b0 < nblk; b0 += 3, ++grp) {
-            VMCNT(0);
-            __syncthreads();                             // blocks b0 .. b0 + 2 landed in every wave; every wave is done with the other area
-            const unsigned here = (grp & 1) ? LY_WOUT : LY_RING, there = (grp & 1) ? LY_RING : LY_WOUT;
-            dma_blocks(pl.wx + (size_t)(b0 + 3) * PL16_BLK_U16, there, nblk - b0 - 3, wave, lane, rot);
-            if (active) {
-                gemm_frags f[2];                          // block j + 1's fragments are requested under block j's products
-                frags_load(f[0], here, lane16);
+        // The 2 n_heads blocks are split over the four WAVES, every wave multiplies its blocks with all four token tiles of the
+        // workgroup: a weight fragment is then needed by ONE wave, so it comes from L2 straight into registers, and LDS carries only
+        // the tiles' activation terms (24 KB read once per wave).  With the blocks staged in LDS and every wave reading all of them
+        // (240 KB per wave) the LDS port was the limit: 26 k cycles for 7.7 k of MFMA work.
+        if (active) {                                    // (the ring is free since the loop's last barrier; the blocks' fp32 vectors landed with the weights)
+            f32x4 xb[2][XT];
+            split8(o.v[0], o.v[1], xb[0]);
+            split8(o.v[2], o.v[3], xb[1]);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int blk = b0 + j;
-                    if (blk >= nblk) break;
-                    const unsigned par = PL16_PAR + blk * T16_FRAG + 16 * g;
-                    tile16 h, w2;                        // (requested ahead of the prefetch: LDS reads return in order)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) { h.v[mt] = *(NQ_AS3 const f32x4*)(par + 64 * mt); w2.v[mt] = *(NQ_AS3 const f32x4*)(par + 256 + 64 * mt); }
-                    if (j + 1 < 3 && blk + 1 < nblk) frags_load(f[(j + 1) & 1], here + (j + 1) * T16_GEMM, lane16);
-                    mma_terms12<false>(f[j & 1].w[0], xb[0], h);
-                    mma_terms12<false>(f[j & 1].w[1], xb[1], h);
-                    if (!(blk & 1)) {
+                for (int t = 0; t < XT; ++t) *(NQ_AS3 f32x4*)(PL16_XT + ((wave * 2 + s) * XT + t) * T16_FRAG + lane16) = xb[s][t];
+            // linear3 of every head on this tile's tokens (the "value" the pooled softmax weights)
+            for (int hd = 0; hd < pl.n_heads; ++hd) {
+                const unsigned par = PL16_PAR + 2 * hd * T16_FRAG;
+                float vpart = 0.f;
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) {
-                            const f32x4 w3 = *(NQ_AS3 const f32x4*)(par + 512 + 64 * mt);
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x4 w3 = *(NQ_AS3 const f32x4*)(par + 512 + 64 * mt + 16 * g);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) vpart = fmaf(w3[r], o.v[mt][r], vpart);
-                        }
-                    }
-#pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) spart = fmaf(w2.v[mt][r], fmaxf(h.v[mt][r], 0.f), spart);
-                    if (blk & 1) {                       // both halves of the head's hidden layer are in
-                        const f32x4 bb = *(NQ_AS3 const f32x4*)(PL16_PAR + blk * T16_FRAG + 768);
-                        const float sv = sum_g(spart) + bb[0], vv = sum_g(vpart) + bb[1];
-                        if (g == 0) {                    // device-scope stores: the reader may sit on another XCD (its own L2)
-                            __hip_atomic_store(pl.sc + (size_t)tok * 8 + (blk >> 1), sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(pl.sc + (size_t)np * 8 + (size_t)tok * 8 + (blk >> 1), vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                        spart = 0.f;
-                        vpart = 0.f;
-                    }
+                    for (int r = 0; r < 4; ++r) vpart = fmaf(w3[r], o.v[mt][r], vpart);
                 }
+                const float vv = sum_g(vpart) + *(NQ_AS3 const float*)(par + 772);
+                if (g == 0) __hip_atomic_store(pl.sc + (size_t)np * 8 + (size_t)tok * 8 + hd, vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        NQ_STAMP(5);                                      // pooling blocks
+        const int nact = min(4, 2 * nkb - ((tok0 - c0) >> 4));          // active tiles of this workgroup (wave-uniform, >= 0)
+        __syncthreads();                                 // the tiles' terms are in LDS
+        NQ_STAMP(5);                                      // this tile's terms and values
+        if (nact > 0) {
+            // one fragment buffer: a K-step's 12 fragments are re-requested for the wave's NEXT block as soon as the four tiles have
+            // consumed them (half a block of MFMA work ahead of their use); the tiles' terms are read from LDS where they are used
+            gemm_frags f;
+            auto frags_global = [&](f32x4 (&w)[12], int blk, int s) {
+                const f32x4* src = (const f32x4*)(pl.wx + (size_t)blk * PL16_BLK_U16) + lane + s * 12 * 64;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) w[q] = src[q * 64];
+            };
+            if (wave < nblk) { frags_global(f.w[0], wave, 0); frags_global(f.w[1], wave, 1); }
+            // FULL: all four tiles active (every workgroup but a clip's last) -- straight-line code, the terms of a K-step's four
+            // tiles are requested together ahead of their products
+            auto blocks = [&](auto full) {
+                constexpr bool FULL = decltype(full)::value;
+                for (int blk = wave; blk < nblk; blk += 4) {
+                    const unsigned par = PL16_PAR + blk * T16_FRAG + 16 * g;
+                    tile16 h[4], w2;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const f32x4 b1 = *(NQ_AS3 const f32x4*)(par + 64 * mt);
+                        w2.v[mt] = *(NQ_AS3 const f32x4*)(par + 256 + 64 * mt);
+#pragma unroll
+                        for (int t4 = 0; t4 < 4; ++t4) h[t4].v[mt] = b1;
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        f32x4 xt[4][XT];
+#pragma unroll
+                        for (int t4 = 0; t4 < 4; ++t4)
+                            if (FULL || t4 < nact)
+#pragma unroll
+                                for (int t = 0; t < XT; ++t) xt[t4][t] = *(NQ_AS3 const f32x4*)(PL16_XT + ((t4 * 2 + s) * XT + t) * T16_FRAG + lane16);
+#pragma unroll
+                        for (int t4 = 0; t4 < 4; ++t4)
+                            if (FULL || t4 < nact) mma_terms12<false>(f.w[s], xt[t4], h[t4]);
+                        if (blk + 4 < nblk) frags_global(f.w[s], blk + 4, s);
+                    }
+#pragma unroll
+                    for (int t4 = 0; t4 < 4; ++t4) {
+                        if (FULL || t4 < nact) {
+                            float spart = 0.f;
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) spart = fmaf(w2.v[mt][r], fmaxf(h[t4].v[mt][r], 0.f), spart);
+                            spart = sum_g(spart);
+                            if (g == 0) *(NQ_AS3 float*)(PL16_SP + (blk * 64 + 16 * t4 + c) * 4) = spart;    // this half's share of the score
+                        }
+                    }
+                }
+            };
+            if (nact == 4) blocks(std::true_type{}); else blocks(std::false_type{});
+        }
+        NQ_STAMP(6);                                      // this wave's blocks x four tiles
+        __syncthreads();                                 // both halves of every head's hidden layer are in
+        for (int i = threadIdx.x; i < 64 * pl.n_heads; i += 256) {
+            const int hd = i >> 6, t = i & 63;
+            if ((t >> 4) < nact) {
+                const float sv = *(NQ_AS3 const float*)(PL16_SP + ((2 * hd) * 64 + t) * 4) + *(NQ_AS3 const float*)(PL16_SP + ((2 * hd + 1) * 64 + t) * 4) +
+                                 *(NQ_AS3 const float*)(PL16_PAR + 2 * hd * T16_FRAG + 768);
+                __hip_atomic_store(pl.sc + (size_t)(tok0 + t) * 8 + hd, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device scope: the reader may sit on another XCD
+            }
+        }
+        NQ_STAMP(7);                                      // barrier, scores stored
         // The clip's last workgroup to arrive pools over the clip's tokens (softmax of the scores, weighted sum of the values).  No
         // fences (a device-scope release / acquire writes back and invalidates the XCD's whole L2: measured 26 us per launch):
         // scores and values travel as device-scope stores and loads, ordered by "stores complete -> count -> loads".
@@ -652,7 +690,8 @@ __global__ __launch_bounds__(256, 1) void td16_layer_kernel(const int32_t* __res
     } else {
         NQ_STAMP(5);
     }
-    NQ_STAMP(6); NQ_STAMP(7); NQ_STAMP(8); NQ_STAMP(9); NQ_STAMP(10); NQ_STAMP(11);
+    if constexpr (!POOL) { NQ_STAMP(6); NQ_STAMP(7); }
+    NQ_STAMP(8); NQ_STAMP(9); NQ_STAMP(10); NQ_STAMP(11);
     NQ_STAMP_END(g_td16_layer_clk, (lw_next ? 0 : 16384) + blockIdx.x * 4 + wave);
 }
 

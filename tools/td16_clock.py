@@ -19,7 +19,8 @@ torch.cuda.synchronize()
 NAMES = {'proj': ['wait chunk 0', 'K-steps 0-3', 'wait chunk 1', 'K-steps 4-7', 'wait chunk 2', 'K-steps 8-11',
                   'LN + x store + wait QKV frags', 'Q / K / V GEMMs + stores'],
          'layer': ['attention loop', 'wait weights', 'out-proj + LN', 'feed-forward + LN + store',
-                   'wait next QKV frags | pooling blocks (last layer)', 'Q / K / V GEMMs + stores | arrival + pooling softmax']}
+                   'wait next QKV frags | last layer: own tile terms + values + barrier', 'Q / K / V GEMMs + stores | last layer: blocks x 4 tiles',
+                   'last layer: barrier + scores stored', 'last layer: arrival + pooling softmax']}
 LOOP = getattr(L, 'nisqa_debug_td16_loop_clock')
 LOOP.restype, LOOP.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]
 LOOP(None, 1)
