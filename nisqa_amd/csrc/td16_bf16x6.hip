@@ -1,12 +1,19 @@
-// Self-attention (Linear 384 -> 64 + LayerNorm, then the TransformerEncoder layers; reference nisqa/NISQA_lib.py:988-996,
-// 1025-1040) at fp32 OPERAND precision on the bf16 matrix pipe, round-6 form: 16-token tiles on v_mfma_f32_16x16x32_bf16, FOUR
-// waves = 64 tokens of ONE clip per workgroup, one workgroup per CU, every shared operand staged ONCE per workgroup in LDS.
+// Self-attention and attention pooling (Linear 384 -> 64 + LayerNorm, the TransformerEncoder layers, 5 x PoolAttFF; reference
+// nisqa/NISQA_lib.py:988-996, 1025-1040, 1171-1183) at fp32 OPERAND precision on the bf16 matrix pipe, round-6 form: 16-token tiles on
+// v_mfma_f32_16x16x32_bf16, FOUR waves = 64 tokens of ONE clip per workgroup, one workgroup per CU, n_layers + 1 launches:
+//   td16_proj_kernel          projection + LayerNorm + layer-0 Q / K / V
+//   td16_layer_kernel<false>  attention, out-projection, LayerNorm, feed-forward, LayerNorm, the NEXT layer's Q / K / V
+//   td16_layer_kernel<true>   the last layer, then every pooling head's scores for its own tokens; the clip's last workgroup to arrive
+//                             does the softmax over the clip's tokens (device-scope stores / loads, no fences)
 //
 // Why: the round 1-5 kernels ran one wave per 32-token tile -- 512 waves for 64 x 10 s on 1 024 SIMDs, a
 // dependent chain of ~700 32x32x16 MFMAs per layer and wave, every wave streaming the layer's 144 KB of weight fragments and its
-// clip's 196 KB of K / V through the vector-memory path.  Here a tile is half as wide (all 1 024 SIMDs work, every per-wave
-// chain -- MFMA and the VALU around it -- is half as long), and what the four waves of a workgroup share (weight fragments, the
-// clip's K / V blocks) is fetched from L2 once per workgroup and read from LDS as 1 KB conflict-free ds_read_b128 fragments.
+// clip's 196 KB of K / V through the vector-memory path, Q / K / V round trips through a [tokens][64] x 9 workspace, six launches.
+// Here a tile is half as wide (all 1 024 SIMDs work); the weight fragments the four waves share are fetched from L2 once per
+// workgroup (LDS-DMA) and read from LDS as 1 KB conflict-free ds_read_b128 fragments; what only ONE wave needs -- a key block of the
+// attention (the clip's key blocks are split over the waves, each wave attends with all four query tiles and the partial results
+// are merged through LDS), a weight block of the pooling (split over the waves the same way) -- goes from L2 straight into that
+// wave's registers.
 //
 // Operands: every fp32 operand as THREE bf16 terms (hi + mid + lo, an exact split) and the six products hh hm mh hl lh mm, fp32
 // accumulate, smallest products first -- the arithmetic of td_bf16x6.hip's round-5 kernels (softmax, LayerNorm, biases, residuals
@@ -25,7 +32,7 @@
 // buffer, bf16 units):  Q  [tile][s 2][term 3][64 lanes][8]          (B fragments of S^T = K Q^T, pre-scaled by 1/8)
 //                       KV [32-key block][ K: [jt 2][s 2][term 3][64][8] | V: [ft 4][term 3][64][8] ]   (24 KB per block)
 // K fragments are the producer's own D registers; a V fragment interleaves the two 16-token tiles of its block (8 bytes per lane
-// each).  The consumer copies a block linearly into LDS (double buffered, one barrier per block) and reads fragments at lane * 16.
+// each).  The consumer reads a fragment as one 16-byte load per lane (from LDS for Q, from L2 for K / V).
 #include <type_traits>
 #include "common.hpp"
 #include "layout.hpp"
@@ -52,14 +59,13 @@ NQ_DEV f32x4 mfma16(f32x4 a, f32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 // LDS fragment reads are plain loads (the compiler tracks them with lgkmcnt).  What it must NOT see is the LDS-DMA staging of the layer
-// kernel's K / V ring: hipcc orders every LDS read behind ALL outstanding LDS-DMA of the wave (s_waitcnt vmcnt(0): it cannot tell the
-// ring slots apart), i.e. the block being prefetched would have to land before the block in hand is read.  dma16_asm below issues the
-// request from inline asm, invisible to that bookkeeping; the protocol that makes a read safe is explicit (the issuing wave's vmcnt +
-// a workgroup barrier).  The compiler's own vmcnt waits for its global loads then count too few younger requests: they wait for more
-// than they need, never for less.
+// kernel: hipcc orders every LDS read behind ALL outstanding LDS-DMA of the wave (s_waitcnt vmcnt(0): it cannot tell the areas
+// apart), i.e. the next layer's fragments, requested early to travel under this layer's GEMMs, would have to land before those GEMMs
+// read their own.  dma16<true> below issues the request from inline asm, invisible to that bookkeeping; the protocol that makes a read
+// safe is explicit (the issuing wave's vmcnt + a workgroup barrier).  The compiler's own vmcnt waits for its global loads then count
+// too few younger requests: they wait for more than they need, never for less.
 template <int OFF>
 NQ_DEV f32x4 lds_rd(unsigned a) { return *(NQ_AS3 const f32x4*)(a + OFF); }
-NQ_DEV void lds_wait(f32x4 (&)[12]) {}
 NQ_DEV unsigned cvt_pk_bf16(float a, float b) {
     const f32x2_t v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
@@ -163,14 +169,13 @@ NQ_DEV void mma_terms12(const f32x4 (&w)[12], const f32x4 (&x)[XT], tile16& out)
             for (int mt = 0; mt < 4; ++mt)
                 out.v[mt] = SWAP ? mfma16(x[order - i], w[mt * XT + i], out.v[mt]) : mfma16(w[mt * XT + i], x[order - i], out.v[mt]);
 }
-// out += W in  (waits for the fragment reads of frags_load)
+// out += W in
 template <bool SWAP = false>
 NQ_DEV void chain_mma(gemm_frags& f, const tile16& in, tile16& out) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         f32x4 b[XT];
         split8(in.v[2 * s], in.v[2 * s + 1], b);
-        lds_wait(f.w[s]);
         mma_terms12<SWAP>(f.w[s], b, out);
     }
 }
@@ -315,7 +320,6 @@ __global__ __launch_bounds__(256, 1) void td16_proj_kernel(const float* __restri
                 f32x4 bt[XT];
                 const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
                 split8(valid ? fr[s][0] : z4, valid ? fr[s][1] : z4, bt);
-                lds_wait(w);
                 mma_terms12<false>(w, bt, acc);
             }
         }
@@ -334,13 +338,16 @@ __global__ __launch_bounds__(256, 1) void td16_proj_kernel(const float* __restri
     NQ_STAMP_END(g_td16_proj_clk, blockIdx.x * 4 + wave);
 }
 
-// LDS plan of the layer kernel: a ring of three K / V blocks (two in flight under the one being multiplied), then the layer's own
-// GEMMs; the next layer's Q / K / V fragments overwrite the ring behind the loop
+// LDS plan of the layer kernel: a 72 KB work area (the four tiles' Q fragments during the attention loop, the waves' partial results
+// behind it, then the next layer's Q / K / V fragments or the pooling tail's exchange), then the layer's own three GEMMs
 #define LY_RING 0u
 #define LY_WOUT (LY_RING + 3 * T16_KVBLK)               /* out-projection, feed-forward 1, feed-forward 2 */
 #define LY_WFF1 (LY_WOUT + T16_GEMM)
 #define LY_WFF2 (LY_WFF1 + T16_GEMM)
 #define LY_LDS (LY_WFF2 + T16_GEMM)                     /* 144 KB */
+#define LY_QT LY_RING                                   /* during the attention loop: the four tiles' Q fragments [tile][s 2][term][1 KB] = 24 KB */
+#define LY_PO LY_RING                                   /* behind it: the waves' partial outputs [wave][tile][ft 4][1 KB] = 64 KB ... */
+#define LY_PM (LY_RING + 64 * T16_FRAG)                 /* ... and (max, sum) pairs [wave][tile][64 lanes] = 8 KB */
 // Pooling tail of the LAST layer (5 x PoolAttFF, NISQA_lib.py:1171-1183): a head's 64 -> 128 linear is two 64-row blocks of the same
 // fragment form, read from L2 straight into the registers of the ONE wave that multiplies them; LDS holds the fp32 vectors of every
 // block (b1 | w2 | w3 | b2, b3: 1 KB each, behind the layer's own areas), the four tiles' activation terms and the partial scores
@@ -373,118 +380,166 @@ __global__ __launch_bounds__(256, 1) void td16_layer_kernel(const int32_t* __res
     const int wg = xcd_tile(blockIdx.x, gridDim.x), rot = blockIdx.x;
     const int tok0 = wg * 64;
     const int tile = wg * 4 + wave, tok = tile * 16 + c;
-    // this tile's Q fragments and residual rows do not depend on the clip: requested before the lookup
-    f32x4 q[2][XT];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int t = 0; t < XT; ++t) q[s][t] = *(const f32x4*)(qbuf + (size_t)tile * T16_QTILE_U16 + (s * XT + t) * 512 + lane * 8);
-    tile16 xr;
+    // the clip of this workgroup FIRST, by one vector load and a ballot per 64 clips (a binary search by scalar loads is a chain of
+    // log2(n_clips) trips to L2 at the head of everything: 2.5 k cycles of an 11 us kernel)
+    const int b = find_segment_wave(tok_off, n_clips, tok0, lane);
+    const int n = n_wins[b], c0 = tok_off[b];
+    tile16 xr;                                            // this tile's residual rows
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) xr.v[mt] = *(const f32x4*)(x_in + (size_t)tok * 64 + 16 * mt + 4 * g);
     FENCE();
-    const int b = find_segment(tok_off, n_clips, tok0);   // scalar loads
-    const int n = n_wins[b], c0 = tok_off[b];
     const int nkb = (n + 31) >> 5;                        // 32-key blocks of this clip
     const bool active = ((tok0 - c0) >> 4) + wave < 2 * nkb;
+    const int nact = min(4, 2 * nkb - ((tok0 - c0) >> 4));             // active tiles of this workgroup (wave-uniform)
     const u16* kvg = kvbuf + (size_t)(c0 >> 5) * T16_KVBLK_U16;
-    dma_frags<6, true>(kvg, LY_RING, wave, lane, 0);
-    if (nkb > 1) { dma_frags<6, true>(kvg + T16_KVBLK_U16, LY_RING + T16_KVBLK, wave, lane, 0); VMCNT(6); } else { VMCNT(0); }
-    __syncthreads();
-    // q and xr are older than block 0: they have landed.  The compiler does not know (it cannot see the asm requests) and would wait
-    // for them at their first use -- with a count that ignores the requests of iteration 0; here its wait costs block 1 at most.
-    asm volatile("" : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]), "+v"(xr.v[0]), "+v"(xr.v[1]),
-                 "+v"(xr.v[2]), "+v"(xr.v[3]));
-    NQ_STAMP(0);                                          // clip lookup, first K / V block landed
+    // The clip's key blocks are SPLIT OVER THE FOUR WAVES (wave w takes blocks w, w + 4, ...), every wave attends with all four query
+    // tiles of the workgroup: a K / V fragment is then needed by one wave only and comes from L2 straight into its registers (no ring,
+    // no barrier per block), the four tiles' Q fragments sit in LDS (24 KB, read per use), and the waves' partial (max, sum, output)
+    // triples are merged through LDS behind the loop.  With one tile per wave and every wave reading every block from LDS a block
+    // cost 2.8 k cycles for 0.77 k of MFMA work, nothing in a wave overlapping with anything.
+    dma_frags<6, true>(qbuf + (size_t)wg * 4 * T16_QTILE_U16, LY_QT, wave, lane, 0);
+    f32x4 kf[12], vf[12];                                  // K: [(jt * 2 + s) * XT + term], V: [ft * XT + term]
+    auto kv_global = [&](f32x4 (&w)[12], int kb, int half) {
+        const f32x4* src = (const f32x4*)(kvg + (size_t)kb * T16_KVBLK_U16) + lane + half * 12 * 64;
+#pragma unroll
+        for (int q = 0; q < 12; ++q) w[q] = src[q * 64];
+    };
+    if (wave < nkb) { kv_global(kf, wave, 0); kv_global(vf, wave, 1); }
+    FENCE();
+    // the layer's own weights (out-projection, feed-forward 1 and 2) behind the first block: they are not needed before the loop ends
+    for (int wb = 0; wb < 3; ++wb) dma_frags<6, true>(lwx + TDXL_OUT + (size_t)wb * (T16_GEMM / 2), LY_WOUT + wb * T16_GEMM, wave, lane, rot);
+    VMCNT(18);                                            // everything older than the 18 weight requests: Q fragments, first K / V block, xr
+    __syncthreads();                                     // Q fragments of every wave's share
+    NQ_STAMP(0);                                          // clip lookup, Q and the first K / V block landed
 
+    tile16 o4[4];
+    float m4[4], l4[4];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+        m4[t4] = -INFINITY;
+        l4[t4] = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) o4[t4].v[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float L2E = 1.44269504088896341f;
+    NQ_SUM_BEGIN();
+    // FULL: all four tiles active (every workgroup but a clip's last) -- straight-line code, the four tiles' chains interleave
+    auto attend = [&](auto full) {
+    constexpr bool FULL = decltype(full)::value;
+    for (int kb = wave; kb < nkb; kb += 4) {
+        // S^T = K Q^T of the two 16-key sub-tiles for every active query tile: one accumulator per product ORDER (independent chains),
+        // added smallest first
+        f32x4 st[4][2];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            if (FULL || t4 < nact) {
+                f32x4 q[2][XT];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int t = 0; t < XT; ++t) q[s][t] = *(NQ_AS3 const f32x4*)(LY_QT + ((t4 * 2 + s) * XT + t) * T16_FRAG + lane16);
+                f32x4 sa[2][XT];
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                    for (int k = 0; k < XT; ++k) sa[jt][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int order = XT - 1; order >= 0; --order)
+#pragma unroll
+                        for (int i = order; i >= 0; --i)
+#pragma unroll
+                            for (int jt = 0; jt < 2; ++jt) sa[jt][order] = mfma16(kf[(jt * 2 + s) * XT + i], q[s][order - i], sa[jt][order]);
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[t4][jt][r] = (sa[jt][2][r] + sa[jt][1][r]) + sa[jt][0][r];
+            }
+        }
+        if (kb + 4 < nkb) kv_global(kf, kb + 4, 0);       // (the K fragments are consumed: the next block's take their place)
+        NQ_SUM(1);                                       // S of the four tiles
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            if (FULL || t4 < nact) {
+                // online softmax over the keys (rows: key 32 kb + 16 jt + 4 g + r; a query's keys sit in the four lanes g = 0..3)
+                float mx = -INFINITY;
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (32 * kb + 16 * jt + 4 * g + r >= n) st[t4][jt][r] = -INFINITY;
+                        mx = fmaxf(mx, st[t4][jt][r]);
+                    }
+                mx = max_g(mx);
+                const float m_new = fmaxf(m4[t4], mx);
+                const float alpha = __builtin_amdgcn_exp2f((m4[t4] - m_new) * L2E);
+                float rs = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        st[t4][jt][r] = __builtin_amdgcn_exp2f((st[t4][jt][r] - m_new) * L2E);
+                        rs += st[t4][jt][r];
+                    }
+                l4[t4] = l4[t4] * alpha + rs;            // (per-lane partial sums: alpha is the same in the four lanes of a query)
+                m4[t4] = m_new;
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) o4[t4].v[ft] *= alpha;
+                f32x4 p[XT];
+                split8(st[t4][0], st[t4][1], p);
+                mma_terms12<false>(vf, p, o4[t4]);
+            }
+        }
+        if (kb + 4 < nkb) kv_global(vf, kb + 4, 1);
+        NQ_SUM(3);                                       // softmax, rescale, split, P V of the four tiles
+        NQ_SUM_COUNT(8, 1);
+    }
+    };
+    if (nact == 4) attend(std::true_type{}); else attend(std::false_type{});
+    NQ_SUM_END(g_td16_loop_clk, blockIdx.x * 4 + wave, lane == 0);
+    // merge: every wave leaves its (max, sum, output) of every tile in LDS, the wave that owns a tile combines the four
+    __syncthreads();                                     // (every wave is done with the Q fragments: the partials overlay them)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+        if (t4 < nact) {
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) *(NQ_AS3 f32x4*)(LY_PO + ((wave * 4 + t4) * 4 + ft) * T16_FRAG + lane16) = o4[t4].v[ft];
+            *(NQ_AS3 f32x2_t*)(LY_PM + (wave * 4 + t4) * 512 + lane * 8) = f32x2_t{m4[t4], l4[t4]};
+        }
+    }
+    __syncthreads();
     tile16 o;
+    float l = 0.f;
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) o.v[ft] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
-    const float L2E = 1.44269504088896341f;
-    int wb = 0;                                            // weight batches (out, ff1, ff2) travel under the first key blocks
-    unsigned slot = LY_RING, slot2 = LY_RING + 2 * T16_KVBLK;      // block kb, block kb + 2
-    NQ_SUM_BEGIN();
-    for (int kb = 0; kb < nkb; ++kb) {
-        int issued = 0;
-        if (kb + 2 < nkb) { dma_frags<6, true>(kvg + (size_t)(kb + 2) * T16_KVBLK_U16, slot2, wave, lane, 0); issued += 6; }
-        if (wb < 3) { dma_frags<6, true>(lwx + TDXL_OUT + (size_t)wb * (T16_GEMM / 2), LY_WOUT + wb * T16_GEMM, wave, lane, rot); issued += 6; ++wb; }
-        NQ_SUM(0);                                       // requests of block kb + 2 and a weight batch
-        if (active) {
-            // S^T = K Q^T for the two 16-key sub-tiles: one accumulator per product ORDER (independent chains), added smallest first
-            f32x4 kf[12], vf[12];                          // K: [(jt * 2 + s) * XT + term], V: [ft * XT + term]
-            frags_rd12<0>(kf, slot + lane16);
-            frags_rd12<0>(vf, slot + 12 * T16_FRAG + lane16);
-            lds_wait(kf);
-            f32x4 sa[2][XT];
+    if (active) {
+        f32x2_t ml[4];
+        float mm = -INFINITY;
 #pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int k = 0; k < XT; ++k) sa[jt][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int order = XT - 1; order >= 0; --order)
-#pragma unroll
-                    for (int i = order; i >= 0; --i)
-#pragma unroll
-                        for (int jt = 0; jt < 2; ++jt) sa[jt][order] = mfma16(kf[(jt * 2 + s) * XT + i], q[s][order - i], sa[jt][order]);
-            NQ_SUM(1);                                   // K / V fragment reads, S MFMAs issued
-            f32x4 st[2];
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) st[jt][r] = (sa[jt][2][r] + sa[jt][1][r]) + sa[jt][0][r];
-            NQ_SUM(2);                                   // S available
-            // online softmax over the keys (rows: key 32 kb + 16 jt + 4 g + r; a query's keys sit in the four lanes g = 0..3)
-            float mx = -INFINITY;
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (32 * kb + 16 * jt + 4 * g + r >= n) st[jt][r] = -INFINITY;
-                    mx = fmaxf(mx, st[jt][r]);
-                }
-            mx = max_g(mx);
-            const float m_new = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m - m_new) * L2E);
-            float rs = 0.f;
-#pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    st[jt][r] = __builtin_amdgcn_exp2f((st[jt][r] - m_new) * L2E);
-                    rs += st[jt][r];
-                }
-            l = l * alpha + rs;                          // (per-lane partial sums: alpha is the same in the four lanes of a query)
-            m = m_new;
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft) o.v[ft] *= alpha;
-            f32x4 p[XT];
-            split8(st[0], st[1], p);
-            NQ_SUM(3);                                   // softmax, rescale, split
-            lds_wait(vf);
-            mma_terms12<false>(vf, p, o);
-            NQ_SUM(4);                                   // P V MFMAs issued
+        for (int w = 0; w < 4; ++w) {
+            ml[w] = *(NQ_AS3 const f32x2_t*)(LY_PM + (w * 4 + wave) * 512 + lane * 8);
+            mm = fmaxf(mm, ml[w][0]);
         }
-        // block kb + 1 (requested one iteration ago) has landed once only this iteration's requests are outstanding
-        if (kb + 1 < nkb) { if (issued == 12) VMCNT(12); else if (issued == 6) VMCNT(6); else VMCNT(0); }
-        NQ_SUM(5);                                       // block kb + 1 landed
-        __syncthreads();                                 // ... in every wave; and every wave is done with block kb's slot
-        NQ_SUM(6);
-        NQ_SUM_COUNT(8, 1);
-        slot2 = slot;
-        slot = slot + T16_KVBLK == LY_RING + 3 * T16_KVBLK ? LY_RING : slot + T16_KVBLK;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = __builtin_amdgcn_exp2f((ml[w][0] - mm) * L2E);            // a wave without key blocks left max = -inf: weight 0
+            l = fmaf(ml[w][1], a, l);
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const f32x4 po = *(NQ_AS3 const f32x4*)(LY_PO + ((w * 4 + wave) * 4 + ft) * T16_FRAG + lane16);
+                o.v[ft] += po * a;
+            }
+        }
     }
-    NQ_SUM_END(g_td16_loop_clk, blockIdx.x * 4 + wave, lane == 0);
+    __syncthreads();                                     // every wave has read the partials: the area is free for the next fragments
     NQ_STAMP(1);                                          // attention over the clip's key blocks
     const int nblk = POOL ? 2 * pl.n_heads : 0;
     if constexpr (POOL) {                                 // the blocks' fp32 vectors: requested first, so that the wait below covers them
         for (int f = wave; f < nblk; f += 4) dma16<true>(pl.wx + (size_t)nblk * PL16_BLK_U16 + (size_t)f * 512 + lane * 8, PL16_PAR + f * T16_FRAG);
     }
-    for (; wb < 3; ++wb) dma_frags<6, true>(lwx + TDXL_OUT + (size_t)wb * (T16_GEMM / 2), LY_WOUT + wb * T16_GEMM, wave, lane, rot);
     FENCE();
-    // the next layer's Q / K / V fragments go where the K / V blocks were (every wave is behind the loop's last barrier)
+    // the next layer's Q / K / V fragments go where the partials were (every wave is behind the merge's last barrier)
     if (POOL) {
         VMCNT(0);
     } else if (lw_next) { dma_frags<18, true>(lwx_next + TDXL_QKV, LY_RING, wave, lane, rot); VMCNT(18); } else { VMCNT(0); }
@@ -554,7 +609,6 @@ __global__ __launch_bounds__(256, 1) void td16_layer_kernel(const int32_t* __res
                 if (g == 0) __hip_atomic_store(pl.sc + (size_t)np * 8 + (size_t)tok * 8 + hd, vv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        const int nact = min(4, 2 * nkb - ((tok0 - c0) >> 4));          // active tiles of this workgroup (wave-uniform, >= 0)
         __syncthreads();                                 // the tiles' terms are in LDS
         NQ_STAMP(5);                                      // this tile's terms and values
         if (nact > 0) {

@@ -43,6 +43,7 @@ out = (ctypes.c_ulonglong * 16)()
 assert LOOP(out, 0) == 0
 nb = max(1, out[8])
 print('attention loop, per key block and wave (%d block iterations):' % nb)
-for q, nm in enumerate(['requests (LDS-DMA)', 'K / V fragment reads + S MFMAs issued', 'S available (MFMA drain + sum)', 'softmax + rescale + split',
-                        'P V MFMAs issued', 'wait: next block landed', 'barrier']):
+for q, nm in enumerate(['', 'S of the four tiles (K fragments x Q fragments from LDS)', '', 'softmax + rescale + split + P V of the four tiles']):
+    if not nm:
+        continue
     print('    %-40s %8.0f' % (nm, out[q] / nb))
