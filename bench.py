@@ -884,7 +884,7 @@ def main():
         kern_tab = {}
         tdp = eng.td_precision
         for stage, ks in (('mel', ['mel_frame_kernel']), ('cnn', ['cnn_front_kernel', 'cnn_back_kernel'] if eng.precision == 'f32' else [CNN_KERNEL[eng.precision]]),
-                          ('selfatt', ['td_fused_bf16_kernel', 'td_proj_bf16_kernel', 'td_layer_bf16_kernel'] if tdp == 'bf16x3' else ['td16_proj_kernel', 'td16_layer_kernel'] if tdp == 'bf16x6' else ['td_proj_kernel', 'td_layer_kernel']),
+                          ('selfatt', ['td_fused_bf16_kernel', 'td_proj_bf16_kernel', 'td_layer_bf16_kernel'] if tdp == 'bf16x3' else ['td16_proj_kernel', 'td16_layer_kernel<false>', 'td16_layer_kernel<true>'] if tdp == 'bf16x6' else ['td_proj_kernel', 'td_layer_kernel']),
                           ('pool', ['pool_score_bf16_kernel', 'pool_final_kernel'] if tdp == 'bf16x3' else [] if tdp == 'bf16x6' else ['pool_score_kernel', 'pool_final_kernel'])):
             for kn in ks:
                 if kn in pmc:

@@ -2,7 +2,7 @@
 # Round profiles (run on the GPU box from the repo root): bench lines, rocprofv3 kernel stats and PMC passes for the
 # predict path (every precision form), the nisqa_tts.tar leg and the training step.  Output: gpurun_out/prof_rNN/ -> copy into profiles/.
 #   tools/collect_profiles.sh r03
-R=${1:-r05}
+R=${1:-r06}
 O=gpurun_out/prof_$R
 mkdir -p $O
 export TMPDIR=/tmp

@@ -26,7 +26,9 @@ def main():
         raise SystemExit('no counter_collection.csv under ' + ' '.join(dirs))
     t = pd.concat(frames)
     t = t[~t.Kernel_Name.str.contains('at::|rocclr|Cijk|vectorized_elementwise')]
-    t['k'] = t['_prefix'] + t.Kernel_Name.str.split('(').str[0].str.replace(r'^void ', '', regex=True).str.replace(r'<.*', '', regex=True)
+    base = t.Kernel_Name.str.split('(').str[0].str.replace(r'^void ', '', regex=True)
+    # template arguments are dropped, except for td16_layer_kernel: <false> is an encoder layer, <true> the last layer + the pooling tail
+    t['k'] = t['_prefix'] + base.where(base.str.startswith('td16_layer_kernel'), base.str.replace(r'<.*', '', regex=True))
     g = t.groupby(['k', 'Counter_Name'])['Counter_Value'].mean()
     n = t.groupby(['k', 'Counter_Name'])['Counter_Value'].count()
     kernels = {}
