@@ -153,6 +153,23 @@ def test_three_term_linear_fragments_hold_the_weights_exactly():
         assert len(cols) == 64 and {c_ for _, c_ in cols} == set(range(64))                # every column exactly once per row
     sd = synth.random_state_dict(7, 'NISQA_DIM')
     heads = ['pool_layers.%d.model.' % h for h in range(5)]
+    # the pooling tail of td16_layer_kernel<true>: per head two 64-row blocks of 24 fragments, then one 1 KB float block per 64-row block
+    t16 = W.pack_pool_att_t16(sd, heads)
+    assert t16.size == 10 * 24 * 512 + 10 * 512
+    par = t16[10 * 24 * 512:].view(np.float32).reshape(10, 256)
+    for h in (0, 3):
+        p_ = heads[h]
+        for j in range(2):
+            np.testing.assert_array_equal(par[2 * h + j, 0:64], sd[p_ + 'linear1.bias'].numpy()[64 * j:64 * j + 64])
+            np.testing.assert_array_equal(par[2 * h + j, 64:128], sd[p_ + 'linear2.weight'].numpy().reshape(-1)[64 * j:64 * j + 64])
+            np.testing.assert_array_equal(par[2 * h + j, 128:192], sd[p_ + 'linear3.weight'].numpy().reshape(-1))
+            assert par[2 * h + j, 192] == sd[p_ + 'linear2.bias'].numpy().reshape(-1)[0] and par[2 * h + j, 193] == sd[p_ + 'linear3.bias'].numpy().reshape(-1)[0]
+        fr = t16[:10 * 24 * 512].reshape(10, 2, 4, 3, 64, 8)          # [block][s][mt][term][lane][e]
+        w1 = sd[p_ + 'linear1.weight'].numpy()
+        tot = val(fr[:, :, :, 0]) + val(fr[:, :, :, 1]) + val(fr[:, :, :, 2])
+        for j, s_, mt, lane, e in [(0, 0, 0, 0, 0), (1, 1, 3, 63, 7), (1, 0, 2, 37, 5)]:
+            col = 16 * (2 * s_ + (e >> 2)) + 4 * (lane >> 4) + (e & 3)
+            assert tot[2 * h + j, s_, mt, lane, e] == np.float64(w1[64 * j + 16 * mt + (lane & 15), col])
     assert W.pack_self_att_bf16(sd, 2, terms=3).size == W.TDX_LAYER0 + 2 * W.TDXL_U16S
     assert W.pack_self_att_bf16(sd, 2).size == W.TDB_LAYER0 + 2 * W.TDBL_U16S
     assert W.pack_pool_att_bf16(sd, heads, terms=3).size == 5 * W.PLX_U16S + 10 * (24 * 512 + 512) and W.pack_pool_att_bf16(sd, heads).size == 5 * W.PLB_U16S
