@@ -114,10 +114,14 @@ class HipNisqa(object):
     """nisqa.tar / nisqa_mos_only.tar (CNN-SA-AP) on one MI355X."""
 
     def __init__(self, args, state_dict, device=None, precision=None):
-        """precision: 'bf16x6' (DEFAULT_PRECISION: every GEMM -- AdaptCNN / StandardCNN, self-attention, pooling -- with its fp32
-        operands as three bf16 terms, an exact split, and six MFMA products per term pair: the accuracy of 'f32' at 1.5-1.7 x its
-        rate), 'f32' (every GEMM on exact fp32 MFMA) or 'bf16x3' (two bf16 terms, three products: 16 of the 24 operand mantissa
-        bits, |dMOS| <= 5e-5, the fast mode); the environment variable NISQA_HIP_PRECISION overrides the default."""
+        """precision -- one of PRECISIONS, for every GEMM of the path (AdaptCNN / StandardCNN, self-attention, pooling):
+        'bf16x6' (DEFAULT_PRECISION, the bench contract line): fp32 operands as three bf16 terms, an exact split, six MFMA products per
+                 term pair -- the reference's operands bit for bit at 1.8 x the rate of 'f32';
+        'f32'    exact fp32 MFMA, the reference's own arithmetic;
+        'f16x4' / 'f16x3' (opt-in): the CNN on two f16 terms of the power-of-two-scaled tensors, four / three products (one fp32 ulp
+                 off for ~25 % of the operands; as close to float64 as 'f32' by measurement); self-attention and pooling as in 'bf16x6';
+        'bf16x3' (opt-in): two bf16 terms, three products: 16 of the 24 operand mantissa bits, |dMOS| <= 5e-5, the fast mode.
+        The environment variable NISQA_HIP_PRECISION overrides the default."""
         if not torch.cuda.is_available():
             raise RuntimeError('nisqa_amd: no GPU visible (torch.cuda.is_available() is False); '
                                'the HIP engine has no CPU fallback')
