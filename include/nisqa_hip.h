@@ -15,8 +15,10 @@
  *   - shapes: B clips; clip b has len[b] samples, T[b] = 1 + len[b]/hop frames and
  *     n[b] = ceil((T[b] - (seg_length-1)) / seg_hop) segments ("tokens");
  *       frame_off[B+1] = exclusive prefix sum of T          (int32)
- *       tok_off[B+1]   = exclusive prefix sum of round_up(n, 32)  (int32)  -- tokens are stored
- *                        PADDED to 32 per clip so attention tiles never straddle clips;
+ *       tok_off[B+1]   = exclusive prefix sum of round_up(n, 64)  (int32)  -- tokens are stored
+ *                        PADDED per clip so attention tiles never straddle clips: to 64 (a workgroup of the three-term kernels
+ *                        nisqa_td_selfatt_bf16x6 / nisqa_td_pool_bf16x6, i.e. of nisqa_predict_batch* in its default mode, holds
+ *                        64 tokens of ONE clip); the two-term and exact-fp32 kernels accept any multiple of 32;
  *     TT = frame_off[B], NP = tok_off[B].
  *   - the mel spectrogram is kept FRAME-MAJOR on the device: mel_tm[TT][n_mels]
  *     (the reference's per-clip array is its transpose, [n_mels][T]).
