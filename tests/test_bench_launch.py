@@ -56,3 +56,25 @@ def test_bench_predict_csv_gpus2_plain_python_one_json_line():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['config']['world_size_seen'] == 2 and d['scaling'] == 'strong'
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_contract_fields():
+    """One JSON line with the driver's contract keys, the roofline of the dominant kernel measured inside the timed region (only the
+    two events around the CNN kernel are recorded there: an event record costs stream time, profiles/r06_stage_event_cost.txt) and
+    the other stage times from the untimed second pass."""
+    r = _run(['--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-side'])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'stage_ms', 'stage_ms_note'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 2 and d['vs_baseline'] is None and d['dtype'].startswith('bf16x6')
+    roof = d['roofline']
+    assert roof['bound'] == 'mfma' and roof['unit'] == 'TFLOP/s' and abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    assert 0.02 < roof['frac'] < 0.2 and abs(roof['avg_launch_ms'] - d['stage_ms']['cnn_front']) < 1e-3
+    assert 0.5 * d['ms_per_step'] < d['stage_ms']['cnn_front'] < d['ms_per_step']          # the dominant kernel, and it fits the step
+    assert set(d['stage_ms']) == {'mel', 'cnn_front', 'cnn_back', 'selfatt', 'pool'}
+    assert d['overlap_2_streams']['steps'] >= 200 and d['steady']['steps'] >= 400
