@@ -235,13 +235,21 @@ class HipNisqa(object):
             return pcm
         ratio = float(self.ms_sr) / float(sr)
         if sr not in self._resample_tables:
-            self._resample_tables[sr] = torch.from_numpy(kaiser_best_table(ratio)).to(self.device)
+            # built once per source rate, on the default stream, and complete before any stream of the predict loop reads it (the
+            # loop alternates two kernel streams: a table uploaded on one of them would be unordered against the other)
+            ds = torch.cuda.default_stream(self.device)
+            with torch.cuda.stream(ds):
+                t = torch.from_numpy(kaiser_best_table(ratio)).to(self.device)
+            ds.synchronize()
+            self._resample_tables[sr] = t
         table = self._resample_tables[sr]
         lengths = np.asarray(lengths, dtype=np.int64).reshape(-1)
         n_out, valid = resampled_lengths(lengths, sr, self.ms_sr)
         offs = np.concatenate([np.concatenate([[0], np.cumsum(lengths)]), np.concatenate([[0], np.cumsum(n_out)]), valid]).astype(np.int64)
         assert pcm.numel() == int(lengths.sum()) and pcm.dtype in (torch.float32, torch.int16)
-        dev = torch.from_numpy(offs).to(self.device)
+        host = torch.empty(offs.shape, dtype=torch.int64, pin_memory=True)       # page-locked + non-blocking: a pageable copy would block the host
+        host.numpy()[...] = offs                                                   # until the stream has drained (caching host allocator: reuse is stream-safe)
+        dev = host.to(self.device, non_blocking=True)
         b = len(lengths)
         out = torch.empty(int(n_out.sum()), dtype=torch.float32, device=self.device)
         ws = torch.empty(max(8, self.lib.nisqa_resample_workspace_bytes(b, int(n_out.max()))), dtype=torch.uint8, device=self.device)
