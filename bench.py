@@ -693,13 +693,13 @@ def side_train(dev, steps, cpu_baseline_on, pmc):
                     names.append('t%02d.wav' % i)
                 targs = dict(args)
                 targs.update({'ms_sr': None, 'ms_fmax': synth.MOS_ARGS.get('ms_fmax', 20000), 'model': 'NISQA'})
-                r = ref_shim.reference_train_step(targs, sd, d, names, y[:, 0], bs, lr=1e-3, steps=1)
+                r = ref_shim.reference_train_step(targs, sd, d, names, y[:, 0], bs, lr=1e-3, steps=2)
                 ref_base = {'value': round(bs / r['seconds'][-1], 3), 'unit': 'clips/s', 'cores': int(torch.get_num_threads()),
                             'kind': 'reference-torch + oracle-mel',
-                            'sample': 'ONE step of the reference\'s own loop at bs = %d x 10 s (%d segments; SpeechQualityDataset -> DataLoader -> '
+                            'sample': 'the SECOND of two steps of the reference\'s own loop (the first one carries DataLoader start-up, table construction and the first Adam state: %.1f s) at bs = %d x 10 s (%d segments; SpeechQualityDataset -> DataLoader -> '
                                       'NISQA.forward in train mode -> biasLoss.get_loss -> backward -> Adam.step, NISQA_model.py:96-152), device '
                                       'cpu, %d torch threads, %.1f s, loss %.4f; librosa served by oracle/mel.py (mel stage parity unpinned)'
-                                      % (bs, r['segments'], int(torch.get_num_threads()), r['seconds'][-1], r['loss'])}
+                                      % (r['seconds'][0], bs, r['segments'], int(torch.get_num_threads()), r['seconds'][-1], r['loss'])}
             except Exception as e:                            # noqa: BLE001  (the port below still gives a baseline)
                 ref_base = {'error': '%s: %s' % (type(e).__name__, e)}
             finally:

@@ -175,7 +175,11 @@ def reference_train_step(args, state_dict, data_dir, files, labels, bs, lr=1e-3,
     it = iter(dl)
     for _ in range(steps):
         t0 = time.perf_counter()
-        xb, yb, (idx, n_wins) = next(it)
+        try:
+            xb, yb, (idx, n_wins) = next(it)
+        except StopIteration:                              # the next epoch over the same files, as the reference's loop would
+            it = iter(dl)
+            xb, yb, (idx, n_wins) = next(it)
         y_hat = model(xb, n_wins)
         loss = bias.get_loss(yb, y_hat, idx)
         loss.backward()
