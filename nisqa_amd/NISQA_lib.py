@@ -359,8 +359,15 @@ def batch_policy(eng, ds, indices, bs):
     """Length-aware batches for the predict loop (ingest.LengthAware): --bs is a lower bound, batches are cut by
     segments / clips / staged bytes after sorting a window of items by length."""
     lstm = getattr(eng, 'arch', 0) == 1
+    # Large jobs get larger batches: an H2D copy carries ~80 us that does not scale with its size (64 MB copies run at 53 GB/s inside
+    # the loop where 245 MB copies run at 56), but a job needs a few hundred batches to keep the pipeline's fill and drain small --
+    # so the floor grows with the job, 1 x (<= 25 k items) ... 4 x (>= 100 k items) of MIN_TOKENS_SA.  Measured on a directory of
+    # 98 304 ten-second files at --bs 64: 48.5 k clips/s (1 x) / 50.0-50.9 k (2 x) / 50.3-51.2 k (4 x); on 32 768 files 4 x is the
+    # slowest (128 batches).  Rows do not depend on the batch composition (tested).
+    n_items = len(indices)
+    scale = min(4, max(1, n_items // (384 * 66)))
     return _ingest.LengthAware(indices, bs, lambda f, r: tokens_of(ds, f, r),
-                               min_tokens=0 if lstm else int(os.environ.get('NISQA_MIN_TOKENS', MIN_TOKENS_SA)),
+                               min_tokens=0 if lstm else int(os.environ.get('NISQA_MIN_TOKENS', MIN_TOKENS_SA * scale)),
                                min_clips=int(os.environ.get('NISQA_MIN_CLIPS', MIN_CLIPS_LSTM)) if lstm else 1,
                                byte_cap=int(os.environ.get('NISQA_BATCH_BYTES', BATCH_BYTE_CAP)))
 

@@ -1716,3 +1716,29 @@ def test_big_endian_pcm16_never_takes_the_verbatim_int16_path(tmp_path):
         ing.ring.release_after(staged.slot, None)
     finally:
         ing.close()
+
+
+def test_batch_floor_grows_with_the_job():
+    """batch_policy: the work floor of a batch is MIN_TOKENS_SA for jobs up to ~25 k items and grows to 4 x for jobs of 100 k and more
+    (an H2D copy carries a fixed cost; a job still needs a few hundred batches to pipeline); --bs stays a lower bound, the LSTM
+    architecture keeps its own clip floor, NISQA_MIN_TOKENS overrides."""
+    from nisqa_amd import NISQA_lib as NL
+
+    class Eng(object):
+        arch = 0
+
+    class Ds(object):
+        seg_length, seg_hop_length, max_length = 15, 4, 1300
+        ms_n_fft, ms_hop_length, ms_sr = 4096, 0.01, None
+    for n, want in ((1000, 1), (25343, 1), (25344, 1), (50688, 2), (98304, 3), (101376, 4), (10 ** 6, 4)):
+        pol = NL.batch_policy(Eng(), Ds(), range(n), 64)
+        assert pol.min_tokens == NL.MIN_TOKENS_SA * want and pol.bs == 64 and pol.min_clips == 1, (n, pol.min_tokens)
+    lstm = Eng()
+    lstm.arch = 1
+    pol = NL.batch_policy(lstm, Ds(), range(10 ** 6), 1)
+    assert pol.min_tokens == 0 and pol.min_clips == NL.MIN_CLIPS_LSTM
+    os.environ['NISQA_MIN_TOKENS'] = '777'
+    try:
+        assert NL.batch_policy(Eng(), Ds(), range(10 ** 6), 1).min_tokens == 777
+    finally:
+        del os.environ['NISQA_MIN_TOKENS']
