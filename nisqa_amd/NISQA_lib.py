@@ -12,6 +12,7 @@ Out of scope here (raise NotImplementedError): training, NISQA_DE,
 alternative blocks no shipped checkpoint uses.
 """
 import os
+import sys
 import time
 from contextlib import nullcontext as _nullcontext
 
@@ -410,6 +411,14 @@ def _predict(model, ds, bs, dev, num_workers, on_rows=None):
         bounds = _dist.balanced_bounds(tok, world)
         lo, hi = bounds[rank]
     loop_err, ing, copy_events = None, None, []
+    # Three Python threads share the interpreter lock here: this one (enqueue, results, table cells), the producer (staging) and the
+    # helper that probes and cuts the NEXT window of 16 384 files -- 20 ms of pure Python per window.  With CPython's default 5 ms
+    # switch interval the helper holds the lock in 5 ms slices while the other two need it for microseconds every batch: the copy
+    # stream ran dry for 2 x 6-8 ms at every window boundary (rocprofv3 --memory-copy-trace: 85 of 1 735 ms on the csv leg, 135 of
+    # 1 794 on the directory leg).  A 0.1 ms interval for the duration of the loop hands the lock over before a copy's worth of
+    # time has passed.
+    switch_interval = sys.getswitchinterval()
+    sys.setswitchinterval(min(switch_interval, float(os.environ.get('NISQA_LOOP_SWITCH_INTERVAL', '1e-4'))))
     T = {'queue_wait': 0.0, 'enqueue': 0.0, 'result_wait': 0.0}
     try:
         bs = max(1, int(bs))
@@ -504,6 +513,7 @@ def _predict(model, ds, bs, dev, num_workers, on_rows=None):
         # closing all_gather
         loop_err = e
     finally:
+        sys.setswitchinterval(switch_interval)
         LOOP_STATS.clear()
         LOOP_STATS.update(T)
         if ing is not None:

@@ -643,7 +643,18 @@ def test_nisqa_model_predict_dir_and_csv_plumbing(tmp_path, wav_dir, capsys):
     assert m.args['dim'] is True and m.args['ms_seg_hop_length'] == 4 and m.args['name'] == 'rand_dim'
     assert len(m.ds_val) == 5 and list(m.ds_val.df.columns) == ['deg']
     m.model._engine = FakeEngine(5)
+    import sys as _sys
+    seen_interval = []
+    real_forward = m.model._engine.forward_audio if hasattr(m.model._engine, 'forward_audio') else None
+    before = _sys.getswitchinterval()
+    if real_forward is not None:                                     # inside the loop the interpreter's switch interval is short ...
+        def spy(*a, **k):
+            seen_interval.append(_sys.getswitchinterval())
+            return real_forward(*a, **k)
+        m.model._engine.forward_audio = spy
     df = m.predict()
+    assert _sys.getswitchinterval() == before                        # ... and restored behind it (NISQA_lib._predict)
+    assert not seen_interval or max(seen_interval) <= 1.0001e-4
     assert list(df.columns) == ['deg', 'mos_pred', 'noi_pred', 'dis_pred', 'col_pred', 'loud_pred', 'model']
     csv = pd.read_csv(out_dir / 'NISQA_results.csv')
     assert list(csv.columns) == list(df.columns) and len(csv) == 5 and (csv['model'] == 'rand_dim').all()
