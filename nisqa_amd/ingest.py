@@ -323,10 +323,13 @@ class Ingest(object):
         self.thread.start()
 
     # -- producer side ---------------------------------------------------------------------------------
-    def _probe(self, idx, stats=None):
+    def _probe(self, idx, stats=None, chunk=None):
         """RIFF headers of items ``idx`` -> (names, encoded paths, header records as a numpy structured array).  stats: the
         dict the 'paths' / 'probe' seconds are added to (the helper thread of _planned passes its own: two threads never
-        write self.stats)."""
+        write self.stats).  chunk: headers per native call.  The native pool runs ONE job at a time (csrc/ingest.cpp: Pool::run), so a
+        probe of 16 384 headers in one call keeps the readers that stage the batches in hand out of the pool for its whole 20 ms --
+        the copy stream ran dry for 5-15 ms at every window boundary (rocprofv3 --memory-copy-trace); in chunks of 1 024 the reads
+        wait 1.3 ms at most."""
         ds, L, n = self.ds, self.lib, len(idx)
         T, t0 = self.stats if stats is None else stats, time.perf_counter()
         if self._col is not None:                                  # the column as it was when this loop started
@@ -339,7 +342,15 @@ class Ingest(object):
         infos = (_lib.WavInfo * n)()
         t1 = time.perf_counter()
         T['paths'] += t1 - t0
-        rc = L.nisqa_ingest_probe(paths, n, infos, self.workers)
+        if chunk is None or n <= chunk:
+            rc = L.nisqa_ingest_probe(paths, n, infos, self.workers)
+        else:
+            rc = 0
+            for s in range(0, n, chunk):
+                m = min(chunk, n - s)
+                rc += L.nisqa_ingest_probe(ctypes.cast(ctypes.byref(paths, s * ctypes.sizeof(ctypes.c_char_p)), ctypes.POINTER(ctypes.c_char_p)),
+                                           m, ctypes.cast(ctypes.byref(infos, s * ctypes.sizeof(_lib.WavInfo)), ctypes.POINTER(_lib.WavInfo)),
+                                           self.workers)
         T['probe'] += time.perf_counter() - t1
         if rc:
             bad = next(k for k in range(n) if infos[k].status != _lib.WAV_OK)
@@ -417,7 +428,7 @@ class Ingest(object):
                 if self.stop.is_set():
                     box[w] = ('stop', None, loc)
                     return
-                names, enc, info = self._probe(wins[w], loc)
+                names, enc, info = self._probe(wins[w], loc, chunk=None if w == 0 else 1024)    # (w >= 1: in the background, under window w - 1's staging)
                 # the window's batches are cut HERE, on the helper thread: sorting and walking 16 384 items in Python is
                 # 10-20 ms during which the producer staged nothing and the link ran dry once per window
                 fast = _verbatim_i16(info)
